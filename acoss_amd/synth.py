@@ -1,0 +1,108 @@
+"""
+Seeded synthetic feature generators.  Real covers80 /
+DA-TACOS feature files are not available offline, so the benchmark and the
+parity tests run on shape-matched synthetic chroma:
+
+  * rand_set   -- the THROUGHPUT set: i.i.d. U[0,1) frames, each divided by its
+                  max (look-alike of HPCP's per-frame max normalisation), fed
+                  to similarity() as already-pooled features.
+  * cover_set  -- the PARITY set: every work is a piecewise-constant chord
+                  sequence; each version applies a circular bin shift, a tempo
+                  warp and fresh noise, so that cliques are recoverable and MAP
+                  is meaningful.
+"""
+import numpy as np
+
+NBINS = 12
+
+
+def _frame_max_normalise(x):
+    mx = x.max(axis=1, keepdims=True)
+    mx[mx == 0] = 1
+    return (x / mx).astype(np.float32)
+
+
+def pack(tracks):
+    """list of (T_i, dim) arrays -> (frames (sum T, dim) f32, offsets (n+1) int64)."""
+    lens = np.array([t.shape[0] for t in tracks], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    frames = np.ascontiguousarray(np.concatenate(tracks, axis=0), dtype=np.float32)
+    return frames, offsets
+
+
+def rand_set(n_tracks, T=2000, seed=1234):
+    rng = np.random.default_rng(seed)
+    tracks = [_frame_max_normalise(rng.random((T, NBINS))) for _ in range(n_tracks)]
+    frames, offsets = pack(tracks)
+    return dict(frames=frames, offsets=offsets, labels=[str(i) for i in range(n_tracks)])
+
+
+def _triads():
+    t = np.zeros((24, NBINS))
+    for root in range(12):
+        for k, third in enumerate((4, 3)):
+            v = np.zeros(NBINS)
+            v[root] = 1.0
+            v[(root + third) % 12] = 0.8
+            v[(root + 7) % 12] = 0.9
+            t[2 * root + k] = v
+    return t
+
+
+def cover_set(n_works=None, versions=5, seed=4321, t_range=(300, 600), clique_sizes=None):
+    """clique_sizes overrides (n_works, versions).  Returns frames/offsets/labels."""
+    rng = np.random.default_rng(seed)
+    tri = _triads()
+    if clique_sizes is None:
+        clique_sizes = [versions] * n_works
+    tracks, labels = [], []
+    for w, nv in enumerate(clique_sizes):
+        T = int(rng.integers(t_range[0], t_range[1] + 1))
+        chords = []
+        c = int(rng.integers(0, 24))
+        while len(chords) < T:
+            seg = int(rng.integers(4, 17))
+            chords += [c] * seg
+            c = (c + int(rng.choice([-5, -2, 2, 5, 7, 1]))) % 24
+        base = tri[np.array(chords[:T])]
+        for _ in range(nv):
+            shift = int(rng.integers(0, 12))
+            fac = float(rng.uniform(0.8, 1.25))
+            Tv = max(32, int(round(T * fac)))
+            pos = np.linspace(0, T - 1, Tv)
+            lo = np.floor(pos).astype(int)
+            hi = np.minimum(lo + 1, T - 1)
+            fr = (pos - lo)[:, None]
+            x = (1 - fr) * base[lo] + fr * base[hi]
+            x = np.roll(x, shift, axis=1) + 0.05 * rng.random((Tv, NBINS))
+            tracks.append(_frame_max_normalise(x))
+            labels.append("w%d" % w)
+    frames, offsets = pack(tracks)
+    return dict(frames=frames, offsets=offsets, labels=labels)
+
+
+COVERS80_CLIQUES = [2] * 77 + [3] * 2 + [4]   # 164 tracks / 80 works (covers80_annotations.csv)
+
+
+def covers80_shaped(seed=4321, t_range=(300, 600)):
+    return cover_set(clique_sizes=COVERS80_CLIQUES, seed=seed, t_range=t_range)
+
+
+def simple_raw_set(n_works, versions=3, seed=4321, t0_range=(15000, 25000)):
+    """Raw (un-pooled) chroma for SiMPle: T0 frames so that WIN/SKIP pooling gives 150-250."""
+    return cover_set(n_works=n_works, versions=versions, seed=seed, t_range=t0_range)
+
+
+def earlyfusion_set(n_tracks, seed=4321, nb_range=(300, 500)):
+    """Block features with the shapes of earlyfusion_traile.py:100-154."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_tracks):
+        nb = int(rng.integers(nb_range[0], nb_range[1] + 1))
+        mf = rng.standard_normal((nb, 650)).astype(np.float32)
+        mf /= np.linalg.norm(mf, axis=1, keepdims=True)
+        out.append(dict(mfccs=mf.astype(np.float32),
+                        ssms=(2 * rng.random((nb, 1225))).astype(np.float32),
+                        chromas=rng.random((nb, 480)).astype(np.float32),
+                        chroma_med=rng.random(12)))
+    return out

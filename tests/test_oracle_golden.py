@@ -1,0 +1,141 @@
+"""
+CPU suite, part 1: the oracle against the golden vectors captured from the
+reference itself (tests/golden/make_goldens.py).  Bit-exact where the reference
+is integer / index work, tight fp tolerance where BLAS order may differ.
+"""
+import numpy as np
+import pytest
+
+import oracle
+
+
+# ---------------------------------------------------------------- EarlyFusion kernels
+def test_get_csm_matches_reference(golden):
+    g = golden("ef_kernels")
+    for k in ("1", "2"):
+        X, Y = g["csm_X" + k], g["csm_Y" + k]
+        np.testing.assert_allclose(oracle.get_csm(X, Y), g["csm_e_" + k], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(oracle.get_csm_cosine(X, Y), g["csm_c_" + k], rtol=2e-5, atol=2e-6)
+
+
+def test_get_oti_matches_reference(golden):
+    g = golden("ef_kernels")
+    got = [oracle.get_oti(a, b) for a, b in zip(g["oti_C1"], g["oti_C2"])]
+    assert got == list(g["oti_out"])
+    assert got[5] == 3 and got[4] == 0        # known answers: e0 vs e3 -> 3; all-tie -> first
+
+
+def test_blocked_oti_matches_reference(golden):
+    g = golden("ef_kernels")
+    out = oracle.get_csm_blocked_oti(g["boti_X"], g["boti_Y"], g["boti_C1"], g["boti_C2"])
+    np.testing.assert_allclose(out, g["boti_out"], rtol=2e-5, atol=2e-6)
+
+
+def test_csm_to_binary_matches_reference(golden):
+    g = golden("ef_kernels")
+    D = g["bin_D"]
+    for kap, tag in ((0, "0"), (0.1, "0p1"), (0.4, "0p4"), (2, "2")):
+        ref = g["bin_out_" + tag]
+        got = oracle.csm_to_binary(D, kap)
+        assert np.array_equal(got, ref)
+        if kap != 0:
+            assert got.dtype == np.uint8 and np.all(got.sum(1) == oracle.binary_k(kap, D.shape[1]))
+    assert np.array_equal(oracle.csm_to_binary(g["bin_dec"], 0.4), g["bin_dec_out"])
+
+
+def test_smith_waterman_matches_reference(golden):
+    g = golden("ef_kernels")
+    names = [k for k in g.files if k.startswith("sw_B_") or k.startswith("swk_B_")]
+    assert len(names) >= 30
+    for name in names:
+        B = g[name]
+        ref = float(g[name.replace("_B_", "_out_")])
+        got = oracle.sw_constrained(B)
+        assert abs(got - ref) < 1e-9, name
+        # the integer-tenths DP (what the HIP kernel runs) is the same number
+        assert oracle.sw_constrained_i32(B) == int(round(ref * 10)), name
+
+
+def test_smith_waterman_known_answers(golden):
+    g = golden("ef_kernels")
+    ka = {"eye8": 5.0, "ones8": 5.0, "zeros8": 0.0, "eye3": 0.0, "eye10_gap1": 4.3, "eye10_gap2": 3.3}
+    for name, val in ka.items():
+        assert abs(float(g["swk_out_" + name]) - val) < 1e-12      # SURVEY 8c known answers
+        assert abs(oracle.sw_constrained(g["swk_B_" + name]) - val) < 1e-12
+    assert int(g["sw_nonbinary_raises"]) == 1
+    with pytest.raises(IOError):
+        oracle.sw_constrained(2 * np.ones((8, 8), np.uint8))
+
+
+def test_wcsm_matches_reference(golden):
+    g = golden("ef_kernels")
+    np.testing.assert_allclose(oracle.get_wcsm(g["wcsm_C"], 10, 10), g["wcsm_out"], rtol=1e-5, atol=1e-7)
+
+
+def test_earlyfusion_chain_matches_reference(golden):
+    g = golden("ef_chain")
+    for pk in (0, 1):
+        f1 = {s: g["p%d_f1_%s" % (pk, s)] for s in ("mfccs", "ssms", "chromas", "chroma_med")}
+        f2 = {s: g["p%d_f2_%s" % (pk, s)] for s in ("mfccs", "ssms", "chromas", "chroma_med")}
+        scores, inter = oracle.earlyfusion_pair(f1, f2, kappa=0.1, K=10)
+        for s in ("mfccs", "ssms", "chromas"):
+            np.testing.assert_allclose(inter["csms"][s], g["p%d_csm_%s" % (pk, s)], rtol=5e-5, atol=5e-5)
+        np.testing.assert_allclose(inter["fused"], g["p%d_fused" % pk], rtol=1e-4, atol=1e-6)
+        ref = g["p%d_scores" % pk]
+        got = np.array([scores[s] for s in ("mfccs", "ssms", "chromas", "early")])
+        # SW on the reference's own CSMs must be exact; on recomputed CSMs allow borderline flips
+        for k, s in enumerate(("mfccs", "ssms", "chromas")):
+            exact = oracle.sw_constrained(oracle.csm_to_binary(g["p%d_csm_%s" % (pk, s)], 0.1))
+            assert abs(exact - ref[k]) < 1e-9
+        exact = oracle.sw_constrained(oracle.csm_to_binary(g["p%d_fused" % pk], 0.1))
+        assert abs(exact - ref[3]) < 1e-9
+        assert np.all(np.abs(got - ref) <= 2.0), (got, ref)
+        assert ref.max() > 5.0      # the fixture has real alignments in it
+
+
+# ---------------------------------------------------------------- SiMPle
+def test_simple_smooth_and_features(golden):
+    g = golden("simple")
+    np.testing.assert_allclose(oracle.simple_smooth(g["smooth_in"]), g["smooth_out"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(oracle.simple_features(g["feat_in"]), g["feat_out"], rtol=1e-10, atol=1e-12)
+
+
+def test_simple_oti_and_sim(golden):
+    g = golden("simple")
+    for k in range(6):
+        A, B = g["sim_A_%d" % k], g["sim_B_%d" % k]
+        Bo, shift = oracle.simple_oti(A, B)
+        assert shift == int(g["oti_shift_%d" % k])
+        assert np.array_equal(Bo, g["oti_B_%d" % k])
+        ref = float(g["sim_out_%d" % k])
+        assert abs(oracle.simple_sim(A, Bo) - ref) <= 1e-12 * max(1.0, abs(ref))
+
+
+# ---------------------------------------------------------------- harness
+def _cliques_from(g, tag):
+    return [[int(t) for t in s.split(",")] for s in g["cliques_" + tag]]
+
+
+def test_all_pairs_order():
+    from itertools import combinations, permutations
+    assert [tuple(p) for p in oracle.all_pairs(7, True)] == list(combinations(range(7), 2))
+    assert [tuple(p) for p in oracle.all_pairs(7, False)] == list(permutations(range(7), 2))
+
+
+def test_eval_statistics_matches_reference(golden):
+    g = golden("harness")
+    for tag in ("sym", "asym"):
+        D = g["D_" + tag]
+        res = oracle.eval_statistics(D, _cliques_from(g, tag), topsidx=(1, 2, 5), stable=True)
+        got = np.array(list(res[:4]) + list(res[4]))
+        np.testing.assert_allclose(got, g["stats_" + tag], rtol=1e-12)
+    # symmetric run: D was mirrored by D += D.T (algorithm_template.py:189-191)
+    assert np.array_equal(g["D_sym"], g["D_sym"].T)
+    assert np.all(np.diag(g["D_sym"]) == 0)
+
+
+def test_snf_matches_reference(golden):
+    g = golden("snf")
+    Ws, F = oracle.snf_fuse(list(g["Ds"]), K=5, niters=4, reg_diag=1)
+    np.testing.assert_allclose(np.stack(Ws), g["Ws"], rtol=1e-12)
+    np.testing.assert_allclose(F, g["F"], rtol=1e-10, atol=1e-12)
