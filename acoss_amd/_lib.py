@@ -1,0 +1,203 @@
+"""
+ctypes binding of libacx.so (C ABI: include/acx.h).  This is the ONLY compute path of
+the package: there is no CPU fallback.  If the shared library is missing, or no gfx950
+device is present, the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libacx.so")
+
+ACX_OK = 0
+ACX_ERR_INVALID = -1
+ACX_ERR_HIP = -2
+ACX_ERR_NOMEM = -3
+ACX_ERR_STATE = -4
+ACX_ERR_SHORT = -5
+ACX_ERR_UNSUPPORTED = -6
+
+EXPORTS = [
+    "acx_abi_version", "acx_create", "acx_destroy", "acx_last_error", "acx_set_scratch_limit",
+    "acx_upload_pool", "acx_serra09_default_params", "acx_serra09_pairs", "acx_serra09_debug_pair",
+    "acx_serra09_embed_len", "acx_profile_enable", "acx_profile_reset", "acx_profile_count",
+    "acx_profile_get", "acx_debug_sqrt",
+]
+
+
+class AcxError(RuntimeError):
+    """A libacx call failed (HIP error, missing device, out of device memory ...)."""
+
+
+class Serra09Params(ctypes.Structure):
+    """acx_serra09_params (include/acx.h); defaults = Serra09 ctor, rqa_serra09.py:31-32."""
+    _fields_ = [
+        ("m", ctypes.c_int32), ("tau", ctypes.c_int32), ("kappa", ctypes.c_float),
+        ("oti", ctypes.c_int32), ("gamma_o", ctypes.c_float), ("gamma_e", ctypes.c_float),
+        ("embed_full", ctypes.c_int32), ("pct_mode", ctypes.c_int32), ("oti_target", ctypes.c_int32),
+        ("dp_start", ctypes.c_int32), ("inclusive", ctypes.c_int32), ("dmax", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libacx.so and declare the prototypes.  Raises ImportError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libacx.so is not built (%s). Build it with `make -C acoss_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    fp = ctypes.POINTER(ctypes.c_float)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    lp = ctypes.POINTER(ctypes.c_int64)
+    pp = ctypes.POINTER(Serra09Params)
+    vp = ctypes.c_void_p
+    L.acx_abi_version.restype = ctypes.c_int
+    L.acx_create.restype = vp
+    L.acx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.acx_destroy.restype = None
+    L.acx_destroy.argtypes = [vp]
+    L.acx_last_error.restype = ctypes.c_char_p
+    L.acx_last_error.argtypes = [vp]
+    L.acx_set_scratch_limit.argtypes = [vp, ctypes.c_int64]
+    L.acx_upload_pool.argtypes = [vp, fp, lp, ctypes.c_int32, ctypes.c_int32]
+    L.acx_serra09_default_params.restype = None
+    L.acx_serra09_default_params.argtypes = [pp]
+    L.acx_serra09_pairs.argtypes = [vp, ip, ctypes.c_int64, pp, fp]
+    L.acx_serra09_debug_pair.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, pp, fp, fp, fp, fp, fp, ip, fp, ip]
+    L.acx_serra09_embed_len.restype = ctypes.c_int32
+    L.acx_serra09_embed_len.argtypes = [ctypes.c_int32, pp]
+    L.acx_profile_enable.argtypes = [vp, ctypes.c_int]
+    L.acx_profile_reset.argtypes = [vp]
+    L.acx_profile_count.argtypes = [vp]
+    L.acx_profile_get.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_double), lp, lp]
+    L.acx_debug_sqrt.argtypes = [vp, fp, ctypes.c_int64, fp]
+    _lib = L
+    return L
+
+
+def serra09_params(m=9, tau=1, kappa=0.095, oti=True, gamma_o=0.5, gamma_e=0.5, embed_full=0,
+                   pct_mode=0, oti_target=0, dp_start=2, inclusive=1, dmax=0):
+    return Serra09Params(int(m), int(tau), float(kappa), int(bool(oti)), float(gamma_o), float(gamma_e),
+                         int(embed_full), int(pct_mode), int(oti_target), int(dp_start), int(inclusive), int(dmax))
+
+
+def _fptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+class Context(object):
+    """One libacx context = one GPU.  Single-owner (one host thread)."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        err = ctypes.c_int(0)
+        self._h = self._L.acx_create(int(device), ctypes.byref(err))
+        if not self._h:
+            msg = self._L.acx_last_error(None)
+            raise AcxError("acx_create(device=%d) failed (%d): %s"
+                           % (device, err.value, msg.decode() if msg else "?"))
+        self.device = int(device)
+        self.n_tracks = 0
+        self.lengths = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.acx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == ACX_OK:
+            return
+        msg = self._L.acx_last_error(self._h)
+        msg = msg.decode() if msg else "error %d" % rc
+        if rc == ACX_ERR_INVALID:
+            raise ValueError(msg)
+        if rc == ACX_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        if rc == ACX_ERR_NOMEM:
+            raise MemoryError(msg)
+        # ACX_ERR_SHORT mirrors essentia's exception for inputs shorter than the stack
+        raise AcxError(msg)
+
+    def set_scratch_limit(self, nbytes):
+        self._check(self._L.acx_set_scratch_limit(self._h, int(nbytes)))
+
+    def upload_pool(self, frames, offsets):
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if frames.ndim != 2 or offsets.ndim != 1 or offsets[-1] != frames.shape[0]:
+            raise ValueError("upload_pool: frames must be (sum T, dim) and offsets (n+1,) with offsets[-1] == sum T")
+        self._check(self._L.acx_upload_pool(self._h, _fptr(frames),
+                                            offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                            len(offsets) - 1, frames.shape[1]))
+        self.n_tracks = len(offsets) - 1
+        self.lengths = np.diff(offsets)
+
+    def serra09_pairs(self, pairs, params=None):
+        p = params or serra09_params()
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        out = np.empty(len(pairs), np.float32)
+        self._check(self._L.acx_serra09_pairs(self._h, pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                              len(pairs), ctypes.byref(p), _fptr(out)))
+        return out
+
+    def serra09_embed_len(self, T, params=None):
+        p = params or serra09_params()
+        return int(self._L.acx_serra09_embed_len(int(T), ctypes.byref(p)))
+
+    def serra09_debug_pair(self, i, j, params=None):
+        p = params or serra09_params()
+        Mq = self.serra09_embed_len(self.lengths[i], p)
+        Mr = self.serra09_embed_len(self.lengths[j], p)
+        if Mq <= 0 or Mr <= 0:
+            Mq = Mr = 1
+        d2 = np.empty((Mq, Mr), np.float32)
+        eq, tq = np.empty(Mq, np.float32), np.empty(Mq, np.float32)
+        er, tr = np.empty(Mr, np.float32), np.empty(Mr, np.float32)
+        oti = ctypes.c_int32(0)
+        score = ctypes.c_float(0)
+        dims = (ctypes.c_int32 * 2)()
+        self._check(self._L.acx_serra09_debug_pair(self._h, int(i), int(j), ctypes.byref(p), _fptr(d2),
+                                                   _fptr(eq), _fptr(er), _fptr(tq), _fptr(tr),
+                                                   ctypes.byref(oti), ctypes.byref(score), dims))
+        assert (dims[0], dims[1]) == (Mq, Mr)
+        return dict(d2=d2, eps_q=eq, eps_r=er, thr_q=tq, thr_r=tr, oti=int(oti.value), score=float(score.value))
+
+    def profile_enable(self, on=True):
+        self._check(self._L.acx_profile_enable(self._h, int(bool(on))))
+
+    def profile_reset(self):
+        self._check(self._L.acx_profile_reset(self._h))
+
+    def profile(self):
+        out = {}
+        for k in range(self._L.acx_profile_count(self._h)):
+            name = ctypes.create_string_buffer(64)
+            ms = ctypes.c_double(0)
+            n = ctypes.c_int64(0)
+            cells = ctypes.c_int64(0)
+            self._check(self._L.acx_profile_get(self._h, k, name, 64, ctypes.byref(ms), ctypes.byref(n),
+                                                ctypes.byref(cells)))
+            out[name.value.decode()] = dict(ms=ms.value, launches=n.value, cells=cells.value)
+        return out
+
+    def debug_sqrt(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        self._check(self._L.acx_debug_sqrt(self._h, _fptr(x), x.size, _fptr(out)))
+        return out

@@ -1,0 +1,489 @@
+// libacx.so -- host side of the C ABI declared in include/acx.h.
+//
+// Owns the HIP device state (stream, packed feature pool in HBM, per-batch scratch arena)
+// and drives the kernels of serra09_kernels.hpp over batches of track pairs.  No torch, no
+// CPU fallback: if the device or a launch fails the call returns an error code.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/acx.h"
+#include "serra09_kernels.hpp"
+
+using acx::PairDesc;
+
+namespace {
+
+std::string g_create_error;
+
+struct KStat {
+    const char *name;
+    double ms;
+    int64_t launches;
+    int64_t cells;
+};
+enum { KS_OTI = 0, KS_CSM, KS_SEL, KS_QMAX, KS_COUNT };
+
+struct PendingEvent {
+    hipEvent_t a, b;
+    int stat;
+    int64_t cells;
+};
+
+}  // namespace
+
+struct acx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // pool
+    float *d_frames = nullptr;
+    int64_t *d_toff = nullptr;
+    float *d_gch = nullptr;
+    std::vector<int64_t> h_off;
+    int32_t n_tracks = 0, dim = 0;
+    // scratch (grow-only)
+    float *d_scratch = nullptr; size_t scratch_cap = 0;   // floats
+    float *d_thr = nullptr;     size_t thr_cap = 0;
+    PairDesc *d_pd = nullptr;   size_t pd_cap = 0;
+    float *d_out = nullptr;     size_t out_cap = 0;
+    int64_t scratch_limit = 0;                            // bytes
+    size_t total_mem = 0;
+    // profiling
+    bool prof = false;
+    KStat stats[KS_COUNT] = {{"oti_kernel", 0, 0, 0}, {"csm_tile_kernel", 0, 0, 0},
+                             {"rowsel_kernel", 0, 0, 0}, {"qmax_kernel", 0, 0, 0}};
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(acx_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define ACX_HIP(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(ctx, ACX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int ensure(acx_ctx *c, T *&ptr, size_t &cap, size_t need)
+{
+    if (need <= cap) return ACX_OK;
+    if (ptr) { ACX_HIP(c, hipFree(ptr)); ptr = nullptr; cap = 0; }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, need * sizeof(T));
+    if (e != hipSuccess)
+        return fail(c, ACX_ERR_NOMEM, "hipMalloc of " + std::to_string(need * sizeof(T)) + " bytes failed: " + hipGetErrorString(e));
+    ptr = static_cast<T *>(p);
+    cap = need;
+    return ACX_OK;
+}
+
+hipEvent_t get_event(acx_ctx *c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    acx_ctx *c; int stat; int64_t cells; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(acx_ctx *c_, int stat_, int64_t cells_) : c(c_), stat(stat_), cells(cells_)
+    {
+        if (c->prof) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope()
+    {
+        if (c->prof) { (void)hipEventRecord(b, c->stream); c->pending.push_back({a, b, stat, cells}); }
+    }
+};
+
+void drain_profile(acx_ctx *c)
+{
+    for (auto &p : c->pending) {
+        float ms = 0.0f;
+        (void)hipEventSynchronize(p.b);
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->stats[p.stat].ms += ms;
+            c->stats[p.stat].launches += 1;
+            c->stats[p.stat].cells += p.cells;
+        }
+        c->event_pool.push_back(p.a);
+        c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int embed_len(int T, const acx_serra09_params &p)
+{
+    int span = p.embed_full ? (p.m - 1) * p.tau : p.m * p.tau;
+    int L = T - span;
+    if (L <= 0) return 0;
+    return (L + p.tau - 1) / p.tau;
+}
+
+int check_params(acx_ctx *c, const acx_serra09_params &p)
+{
+    if (p.m < 1 || p.m > acx::MAX_M) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: m must be in 1..16 on the device");
+    if (p.tau != 1) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: tau != 1 is not implemented on the device");
+    if (!(p.kappa >= 0.0f && p.kappa <= 1.0f)) return fail(c, ACX_ERR_INVALID, "serra09: kappa must be in [0, 1]");
+    if (p.dp_start != 2 && p.dp_start != 3) return fail(c, ACX_ERR_INVALID, "serra09: dp_start must be 2 or 3");
+    if (p.pct_mode < 0 || p.pct_mode > 3) return fail(c, ACX_ERR_INVALID, "serra09: pct_mode must be 0..3");
+    if (p.oti_target != 0 && p.oti_target != 1) return fail(c, ACX_ERR_INVALID, "serra09: oti_target must be 0 or 1");
+    if (p.dmax != 0) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: Dmax (chen17) is not implemented on the device yet");
+    if (!(p.gamma_o >= 0.0f) || !(p.gamma_e >= 0.0f)) return fail(c, ACX_ERR_INVALID, "serra09: gammas must be >= 0");
+    return ACX_OK;
+}
+
+template <int M>
+void launch_csm(acx_ctx *c, dim3 grid, int tiles_x, int oti_target)
+{
+    hipLaunchKernelGGL((acx::csm_tile_kernel<M>), grid, dim3(256), 0, c->stream,
+                       c->d_frames, c->d_toff, c->d_pd, c->d_scratch, tiles_x, oti_target);
+}
+
+void launch_csm_m(acx_ctx *c, int m, dim3 grid, int tiles_x, int oti_target)
+{
+    switch (m) {
+#define ACX_CASE(M_) case M_: launch_csm<M_>(c, grid, tiles_x, oti_target); break;
+        ACX_CASE(1) ACX_CASE(2) ACX_CASE(3) ACX_CASE(4) ACX_CASE(5) ACX_CASE(6) ACX_CASE(7) ACX_CASE(8)
+        ACX_CASE(9) ACX_CASE(10) ACX_CASE(11) ACX_CASE(12) ACX_CASE(13) ACX_CASE(14) ACX_CASE(15) ACX_CASE(16)
+#undef ACX_CASE
+    }
+}
+
+template <int NG>
+void launch_qmax(acx_ctx *c, int B, bool eqg, float go, float ge, int dp_start)
+{
+    if (eqg)
+        hipLaunchKernelGGL((acx::qmax_kernel<NG, true>), dim3(B), dim3(64), 0, c->stream,
+                           c->d_pd, c->d_scratch, c->d_thr, c->d_out, go, ge, dp_start);
+    else
+        hipLaunchKernelGGL((acx::qmax_kernel<NG, false>), dim3(B), dim3(64), 0, c->stream,
+                           c->d_pd, c->d_scratch, c->d_thr, c->d_out, go, ge, dp_start);
+}
+
+struct DebugOut {
+    float *d2, *epsq, *epsr, *thrq, *thrr;
+    int32_t *oti;
+    int32_t *dims;
+};
+
+// Runs the chain over `K` pairs in scratch-sized batches.
+int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params &p, float *out,
+                const DebugOut *dbg)
+{
+    if (!c->d_frames) return fail(c, ACX_ERR_STATE, "serra09: feature pool not uploaded (acx_upload_pool)");
+    if (c->dim != acx::NBIN) return fail(c, ACX_ERR_INVALID, "serra09: pool dim must be 12");
+    int rc = check_params(c, p);
+    if (rc != ACX_OK) return rc;
+    ACX_HIP(c, hipSetDevice(c->device));
+
+    int64_t limit = c->scratch_limit;
+    if (limit <= 0) {
+        const char *env = getenv("ACX_SCRATCH_GB");
+        if (env && atof(env) > 0) limit = (int64_t)(atof(env) * (double)(1ull << 30));
+        else limit = (int64_t)(0.40 * (double)c->total_mem);
+    }
+    const int64_t limit_floats = limit / 4;
+
+    std::vector<PairDesc> pd;
+    int64_t k0 = 0;
+    while (k0 < K) {
+        pd.clear();
+        int64_t used = 0, used_thr = 0;
+        int maxMq = 0, maxMr = 0, maxRows = 0, maxNe = 0;
+        int64_t cells = 0;
+        int64_t k = k0;
+        for (; k < K && pd.size() < 65535; ++k) {
+            const int qi = pairs[2 * k], ri = pairs[2 * k + 1];
+            if (qi < 0 || ri < 0 || qi >= c->n_tracks || ri >= c->n_tracks)
+                return fail(c, ACX_ERR_INVALID, "serra09: track index out of range in pair " + std::to_string(k));
+            PairDesc d;
+            d.q = qi; d.r = ri;
+            d.Tq = (int)(c->h_off[qi + 1] - c->h_off[qi]);
+            d.Tr = (int)(c->h_off[ri + 1] - c->h_off[ri]);
+            d.Mq = embed_len(d.Tq, p);
+            d.Mr = embed_len(d.Tr, p);
+            if (d.Mq <= 0 || d.Mr <= 0)
+                return fail(c, ACX_ERR_SHORT, "serra09: track shorter than the delay-embedding stack (pair " + std::to_string(k) + ")");
+            const int Ne = d.Mr - (p.dp_start == 3 ? 1 : 0);
+            if (Ne > 2048 || d.Mq > 2048 || d.Mr > 2048)
+                return fail(c, ACX_ERR_UNSUPPORTED, "serra09: tracks with more than 2048 embedded frames are not supported on the device yet");
+            d.oti = 0;
+            d.pitchD = round_up(d.Mr, 64);
+            d.pitchT = round_up(d.Mq, 64);
+            d.pad_ = 0;
+            const int64_t need = (int64_t)d.Mq * d.pitchD + (int64_t)d.Mr * d.pitchT;
+            if (need > limit_floats)
+                return fail(c, ACX_ERR_NOMEM, "serra09: one pair does not fit the scratch limit");
+            if (used + need > limit_floats) break;
+            d.offD = used;
+            d.offT = used + (int64_t)d.Mq * d.pitchD;
+            d.offX = used_thr;
+            used += need;
+            used_thr += 2 * ((int64_t)d.pitchD + d.pitchT);
+            maxMq = std::max(maxMq, d.Mq);
+            maxMr = std::max(maxMr, d.Mr);
+            maxRows = std::max(maxRows, d.Mq + d.Mr);
+            maxNe = std::max(maxNe, Ne);
+            cells += (int64_t)d.Mq * d.Mr;
+            pd.push_back(d);
+        }
+        const int B = (int)pd.size();
+        if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)used)) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)used_thr)) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_pd, c->pd_cap, (size_t)B)) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)B)) != ACX_OK) return rc;
+        ACX_HIP(c, hipMemcpyAsync(c->d_pd, pd.data(), sizeof(PairDesc) * B, hipMemcpyHostToDevice, c->stream));
+
+        {   // K0
+            ProfScope ps(c, KS_OTI, cells);
+            hipLaunchKernelGGL(acx::oti_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream,
+                               c->d_pd, B, c->d_gch, p.oti, p.oti_target);
+        }
+        {   // K1
+            const int tiles_x = (maxMr + 63) / 64, tiles_y = (maxMq + 63) / 64;
+            ProfScope ps(c, KS_CSM, cells);
+            launch_csm_m(c, p.m, dim3(tiles_x * tiles_y, B), tiles_x, p.oti_target);
+        }
+        {   // K2
+            ProfScope ps(c, KS_SEL, cells);
+            const int maxN = std::max(maxMq, maxMr);   // longest row of D2 / D2T in the batch
+            const dim3 g((maxRows + 3) / 4, B);
+#define ACX_SEL(V4_) hipLaunchKernelGGL((acx::rowsel_kernel<V4_>), g, dim3(256), 0, c->stream, \
+                                        c->d_pd, c->d_scratch, c->d_thr, p.kappa, p.pct_mode, p.inclusive)
+            if (maxN <= 512) ACX_SEL(2);
+            else if (maxN <= 1024) ACX_SEL(4);
+            else ACX_SEL(8);
+#undef ACX_SEL
+        }
+        {   // K3
+            const int NG = (maxNe + 511) / 512;
+            const bool eqg = p.gamma_o == p.gamma_e;
+            ProfScope ps(c, KS_QMAX, cells);
+            switch (NG) {
+            case 0: case 1: launch_qmax<1>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
+            case 2: launch_qmax<2>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
+            case 3: launch_qmax<3>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
+            default: launch_qmax<4>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
+            }
+        }
+        ACX_HIP(c, hipGetLastError());
+        ACX_HIP(c, hipMemcpyAsync(out + k0, c->d_out, sizeof(float) * B, hipMemcpyDeviceToHost, c->stream));
+        ACX_HIP(c, hipStreamSynchronize(c->stream));
+        drain_profile(c);
+
+        if (dbg && B >= 1) {
+            PairDesc d;
+            ACX_HIP(c, hipMemcpy(&d, c->d_pd, sizeof(PairDesc), hipMemcpyDeviceToHost));
+            if (dbg->oti) *dbg->oti = d.oti;
+            if (dbg->dims) { dbg->dims[0] = d.Mq; dbg->dims[1] = d.Mr; }
+            if (dbg->d2)
+                ACX_HIP(c, hipMemcpy2D(dbg->d2, sizeof(float) * d.Mr, c->d_scratch + d.offD, sizeof(float) * d.pitchD,
+                                       sizeof(float) * d.Mr, d.Mq, hipMemcpyDeviceToHost));
+            const float *X = c->d_thr + d.offX;
+            if (dbg->thrq) ACX_HIP(c, hipMemcpy(dbg->thrq, X, sizeof(float) * d.Mq, hipMemcpyDeviceToHost));
+            if (dbg->thrr) ACX_HIP(c, hipMemcpy(dbg->thrr, X + d.pitchT, sizeof(float) * d.Mr, hipMemcpyDeviceToHost));
+            if (dbg->epsq) ACX_HIP(c, hipMemcpy(dbg->epsq, X + d.pitchT + d.pitchD, sizeof(float) * d.Mq, hipMemcpyDeviceToHost));
+            if (dbg->epsr) ACX_HIP(c, hipMemcpy(dbg->epsr, X + 2 * d.pitchT + d.pitchD, sizeof(float) * d.Mr, hipMemcpyDeviceToHost));
+        }
+        k0 = k;
+    }
+    return ACX_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int acx_abi_version(void) { return ACX_ABI_VERSION; }
+
+acx_ctx *acx_create(int device, int *err)
+{
+    auto bad = [&](int code, const std::string &msg) -> acx_ctx * {
+        g_create_error = msg;
+        if (err) *err = code;
+        return nullptr;
+    };
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return bad(ACX_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= n) return bad(ACX_ERR_INVALID, "device index out of range");
+    if ((e = hipSetDevice(device)) != hipSuccess) return bad(ACX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bad(ACX_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return bad(ACX_ERR_HIP, std::string("libacx is built for gfx950 only; device is ") + prop.gcnArchName);
+    acx_ctx *c = new acx_ctx();
+    c->device = device;
+    c->total_mem = prop.totalGlobalMem;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c;
+        return bad(ACX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    if (err) *err = ACX_OK;
+    return c;
+}
+
+void acx_destroy(acx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drain_profile(c);
+    for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
+    if (c->d_frames) (void)hipFree(c->d_frames);
+    if (c->d_toff) (void)hipFree(c->d_toff);
+    if (c->d_gch) (void)hipFree(c->d_gch);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_thr) (void)hipFree(c->d_thr);
+    if (c->d_pd) (void)hipFree(c->d_pd);
+    if (c->d_out) (void)hipFree(c->d_out);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *acx_last_error(const acx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int acx_set_scratch_limit(acx_ctx *c, int64_t bytes)
+{
+    if (!c) return ACX_ERR_INVALID;
+    c->scratch_limit = bytes < 0 ? 0 : bytes;
+    return ACX_OK;
+}
+
+int acx_upload_pool(acx_ctx *c, const float *frames, const int64_t *offsets, int32_t n_tracks, int32_t dim)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!frames || !offsets || n_tracks <= 0 || dim <= 0) return fail(c, ACX_ERR_INVALID, "upload_pool: bad argument");
+    if (offsets[0] != 0) return fail(c, ACX_ERR_INVALID, "upload_pool: offsets[0] must be 0");
+    for (int i = 0; i < n_tracks; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(c, ACX_ERR_INVALID, "upload_pool: offsets must be non-decreasing");
+    ACX_HIP(c, hipSetDevice(c->device));
+    if (c->d_frames) { (void)hipFree(c->d_frames); c->d_frames = nullptr; }
+    if (c->d_toff) { (void)hipFree(c->d_toff); c->d_toff = nullptr; }
+    if (c->d_gch) { (void)hipFree(c->d_gch); c->d_gch = nullptr; }
+    const int64_t total = offsets[n_tracks];
+    c->h_off.assign(offsets, offsets + n_tracks + 1);
+    c->n_tracks = n_tracks;
+    c->dim = dim;
+    ACX_HIP(c, hipMalloc((void **)&c->d_frames, sizeof(float) * std::max<int64_t>(1, total) * dim));
+    ACX_HIP(c, hipMalloc((void **)&c->d_toff, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIP(c, hipMemcpy(c->d_frames, frames, sizeof(float) * total * dim, hipMemcpyHostToDevice));
+    ACX_HIP(c, hipMemcpy(c->d_toff, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    if (dim == acx::NBIN) {
+        // global chroma profile per track: sequential f32 sum over frames, divided by its max
+        // (arithmetic spec step 1; O(sum T) host work done once per pool)
+        std::vector<float> g((size_t)n_tracks * acx::NBIN);
+        for (int t = 0; t < n_tracks; ++t) {
+            float acc[acx::NBIN];
+            for (int b = 0; b < acx::NBIN; ++b) acc[b] = 0.0f;
+            const float *x = frames + offsets[t] * dim;
+            const int64_t T = offsets[t + 1] - offsets[t];
+            for (int64_t f = 0; f < T; ++f)
+                for (int b = 0; b < acx::NBIN; ++b) acc[b] = acc[b] + x[f * acx::NBIN + b];
+            float mx = acc[0];
+            for (int b = 1; b < acx::NBIN; ++b) if (acc[b] > mx) mx = acc[b];
+            for (int b = 0; b < acx::NBIN; ++b) g[(size_t)t * acx::NBIN + b] = (mx > 0.0f) ? acc[b] / mx : acc[b];
+        }
+        ACX_HIP(c, hipMalloc((void **)&c->d_gch, sizeof(float) * g.size()));
+        ACX_HIP(c, hipMemcpy(c->d_gch, g.data(), sizeof(float) * g.size(), hipMemcpyHostToDevice));
+    }
+    return ACX_OK;
+}
+
+void acx_serra09_default_params(acx_serra09_params *p)
+{
+    if (!p) return;
+    p->m = 9; p->tau = 1; p->kappa = 0.095f; p->oti = 1; p->gamma_o = 0.5f; p->gamma_e = 0.5f;
+    p->embed_full = 0; p->pct_mode = 0; p->oti_target = 0; p->dp_start = 2; p->inclusive = 1; p->dmax = 0;
+}
+
+int32_t acx_serra09_embed_len(int32_t T, const acx_serra09_params *p)
+{
+    if (!p || p->m < 1 || p->tau < 1) return 0;
+    return embed_len(T, *p);
+}
+
+int acx_serra09_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params *params, float *out)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (K < 0 || (K > 0 && (!pairs || !out)) || !params) return fail(c, ACX_ERR_INVALID, "serra09_pairs: bad argument");
+    if (K == 0) return ACX_OK;
+    return run_serra09(c, pairs, K, *params, out, nullptr);
+}
+
+int acx_serra09_debug_pair(acx_ctx *c, int32_t i, int32_t j, const acx_serra09_params *params,
+                           float *d2, float *epsq, float *epsr, float *thrq, float *thrr,
+                           int32_t *oti, float *score, int32_t *dims)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!params) return fail(c, ACX_ERR_INVALID, "serra09_debug_pair: bad argument");
+    int32_t pr[2] = {i, j};
+    float s = 0.0f;
+    DebugOut dbg{d2, epsq, epsr, thrq, thrr, oti, dims};
+    int rc = run_serra09(c, pr, 1, *params, &s, &dbg);
+    if (rc == ACX_OK && score) *score = s;
+    return rc;
+}
+
+int acx_profile_enable(acx_ctx *c, int on)
+{
+    if (!c) return ACX_ERR_INVALID;
+    c->prof = on != 0;
+    return ACX_OK;
+}
+int acx_profile_reset(acx_ctx *c)
+{
+    if (!c) return ACX_ERR_INVALID;
+    for (auto &s : c->stats) { s.ms = 0; s.launches = 0; s.cells = 0; }
+    return ACX_OK;
+}
+int acx_profile_count(const acx_ctx *c) { return c ? KS_COUNT : 0; }
+int acx_profile_get(acx_ctx *c, int idx, char *name, int name_len, double *ms, int64_t *launches, int64_t *cells)
+{
+    if (!c || idx < 0 || idx >= KS_COUNT) return ACX_ERR_INVALID;
+    if (name && name_len > 0) { strncpy(name, c->stats[idx].name, name_len - 1); name[name_len - 1] = 0; }
+    if (ms) *ms = c->stats[idx].ms;
+    if (launches) *launches = c->stats[idx].launches;
+    if (cells) *cells = c->stats[idx].cells;
+    return ACX_OK;
+}
+
+int acx_debug_sqrt(acx_ctx *c, const float *in, int64_t n, float *out)
+{
+    if (!c || !in || !out || n <= 0) return ACX_ERR_INVALID;
+    ACX_HIP(c, hipSetDevice(c->device));
+    float *d_in = nullptr, *d_o = nullptr;
+    ACX_HIP(c, hipMalloc((void **)&d_in, sizeof(float) * n));
+    ACX_HIP(c, hipMalloc((void **)&d_o, sizeof(float) * n));
+    ACX_HIP(c, hipMemcpy(d_in, in, sizeof(float) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(acx::sqrt_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, d_o, n);
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    ACX_HIP(c, hipMemcpy(out, d_o, sizeof(float) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    (void)hipFree(d_o);
+    return ACX_OK;
+}
+
+}  // extern "C"

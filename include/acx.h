@@ -1,0 +1,136 @@
+/*
+ * acx.h -- C ABI of libacx.so, the MI355X (gfx950) all-pairwise cover-song
+ * similarity engine behind acoss's CoverAlgorithm.similarity()/all_pairwise().
+ *
+ * The reference (furkanyesiler/acoss) is pure Python and has NO FFI of its own;
+ * its only native boundary on this path is essentia's Python wrapper
+ * (acoss/algorithms/rqa_serra09.py:60-67).  Each entry point below therefore
+ * cites the reference INTERFACE it replaces; INTEGRATION.md shows the ctypes
+ * binding a maintainer adds on the acoss side.
+ *
+ * Conventions
+ *   - plain C types only; every host buffer is caller-allocated and
+ *     caller-owned; the library owns device memory inside acx_ctx; no pointer
+ *     outlives a call except the context.
+ *   - every call returns ACX_OK (0) or a negative ACX_ERR_* code; the message
+ *     is available from acx_last_error().  Nothing falls back to the CPU.
+ *   - a context is single-owner (one host thread per context / per GPU).
+ */
+#ifndef ACX_H
+#define ACX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACX_ABI_VERSION 1
+
+enum {
+    ACX_OK = 0,
+    ACX_ERR_INVALID = -1,      /* bad argument (NULL, index out of range, dim != expected)  */
+    ACX_ERR_HIP = -2,          /* a HIP runtime call failed / no gfx950 device              */
+    ACX_ERR_NOMEM = -3,        /* device scratch cannot hold even one pair                  */
+    ACX_ERR_STATE = -4,        /* pool not uploaded                                         */
+    ACX_ERR_SHORT = -5,        /* a track is shorter than the delay-embedding stack (essentia
+                                  raises EssentiaException there)                           */
+    ACX_ERR_UNSUPPORTED = -6   /* parameter combination not implemented on the device       */
+};
+
+typedef struct acx_ctx acx_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Create a context on HIP device `device`.  Returns NULL and sets *err on failure. */
+acx_ctx *acx_create(int device, int *err);
+void acx_destroy(acx_ctx *ctx);
+/* Last error message of this context (ctx == NULL: of the last failed acx_create). */
+const char *acx_last_error(const acx_ctx *ctx);
+int acx_abi_version(void);
+/* Upper bound (bytes) for the per-batch device scratch; 0 restores the default
+ * (env ACX_SCRATCH_GB, else 40 % of device memory). */
+int acx_set_scratch_limit(acx_ctx *ctx, int64_t bytes);
+
+/* ---- feature pool ------------------------------------------------------- */
+
+/*
+ * Upload the packed feature pool: `frames` is row-major (sum_i T_i, dim) f32,
+ * track i occupies rows offsets[i] .. offsets[i+1].  Replaces the per-track
+ * feature cache of the reference (Serra09.load_features -> self.all_feats,
+ * rqa_serra09.py:44-53): tracks are ALREADY pooled (x40 median) when uploaded.
+ * dim must be 12 for the chroma algorithms.  Copies to HBM; the host buffers may
+ * be released on return.
+ */
+int acx_upload_pool(acx_ctx *ctx, const float *frames, const int64_t *offsets,
+                    int32_t n_tracks, int32_t dim);
+
+/* ---- Serra09 (OTI + delay embedding + CSM + mutual-kappa + Qmax) --------- */
+
+/* Mirrors the constructor arguments of Serra09 (rqa_serra09.py:31-32) that reach
+ * essentia (rqa_serra09.py:60-64), plus the switchable recalled-essentia details
+ * documented in oracle/acx_oracle.c. */
+typedef struct {
+    int32_t m;           /* frameStackSize,   default 9      */
+    int32_t tau;         /* frameStackStride, default 1 (device: 1 only) */
+    float kappa;         /* binarizePercentile, default 0.095 */
+    int32_t oti;         /* default 1 */
+    float gamma_o;       /* disOnset, default 0.5 */
+    float gamma_e;       /* disExtension, default 0.5 */
+    int32_t embed_full;  /* 0: M = T - m*tau   1: M = T - (m-1)*tau */
+    int32_t pct_mode;    /* 0 linear  1 essentia d0+d1  2 lower  3 nearest */
+    int32_t oti_target;  /* 0 rotate reference  1 rotate query */
+    int32_t dp_start;    /* 2 or 3 */
+    int32_t inclusive;   /* 1: d <= eps  0: d < eps */
+    int32_t dmax;        /* 0 Qmax ('serra09')  1 Dmax ('chen17') */
+} acx_serra09_params;
+
+void acx_serra09_default_params(acx_serra09_params *p);
+
+/*
+ * Scores for K (query, reference) track-index pairs: out[k] = max of the Qmax
+ * matrix for pair (pairs[2k], pairs[2k+1]) -- exactly the scalar that
+ * Serra09.similarity() stores into Ds[key][i][j] (rqa_serra09.py:55-69), for a
+ * whole (K,2) idxs array in one call instead of one essentia round trip per pair.
+ * pairs, out: host memory.  The pool must be uploaded.
+ */
+int acx_serra09_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K,
+                      const acx_serra09_params *params, float *out);
+
+/*
+ * One pair with intermediates, for parity tests (every pointer may be NULL):
+ *   d2   (Mq*Mr) squared embedded distances (the ChromaCrossSimilarity distance
+ *        matrix before sqrt, rqa_serra09.py:66)
+ *   epsq (Mq), epsr (Mr)   the kappa-percentile thresholds on d = sqrt(d2)
+ *   thrq (Mq), thrr (Mr)   the same thresholds moved to the d2 domain
+ *                          (largest f32 x with sqrt(x) <=/< eps)
+ *   oti, score, dims[2] = {Mq, Mr}
+ */
+int acx_serra09_debug_pair(acx_ctx *ctx, int32_t i, int32_t j,
+                           const acx_serra09_params *params,
+                           float *d2, float *epsq, float *epsr,
+                           float *thrq, float *thrr,
+                           int32_t *oti, float *score, int32_t *dims);
+
+/* Number of embedded frames for a pooled length T (0 if too short). */
+int32_t acx_serra09_embed_len(int32_t T, const acx_serra09_params *params);
+
+/* ---- measurement -------------------------------------------------------- */
+
+/* Per-kernel timing with HIP events recorded on the library's own stream around
+ * every launch (bench.py's roofline leg).  Off by default. */
+int acx_profile_enable(acx_ctx *ctx, int on);
+int acx_profile_reset(acx_ctx *ctx);
+int acx_profile_count(const acx_ctx *ctx);
+/* kernel `idx`: name (NUL-terminated into name[name_len]), accumulated
+ * milliseconds, launches, and the number of pair-cells (Mq*Mr summed) it covered. */
+int acx_profile_get(acx_ctx *ctx, int idx, char *name, int name_len,
+                    double *ms, int64_t *launches, int64_t *cells);
+
+/* device-side sqrt probe used by the parity tests (must be correctly rounded) */
+int acx_debug_sqrt(acx_ctx *ctx, const float *in, int64_t n, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACX_H */

@@ -1,0 +1,172 @@
+"""
+GPU parity tests (run with -m gpu on a real MI355X): the HIP Serra09 chain, called through
+the C ABI (libacx.so via ctypes), against the CPU oracle on the same seeded inputs.
+
+Bar: BIT-EXACT.  The oracle's default "tree" arithmetic is the arithmetic spec of the
+kernels (per-frame fmaf chains == v_mfma_f32_16x16x4_f32, doubling-tree window sums, f32
+percentile interpolation), so every intermediate (distances, thresholds, recurrence plot)
+and the final Qmax score must be identical.  Against the oracle's "seq108" arithmetic
+(sequential 108-dim inner products as essentia is recalled to do) the stated tolerance is:
+scores within +-2.0 and identical MAP / MR.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from acoss_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle():
+    import oracle
+    return oracle
+
+
+def _track(d, i):
+    return d["frames"][d["offsets"][i]:d["offsets"][i + 1]]
+
+
+def _compare_pair(ctx, d, i, j, gp, op, tag=""):
+    oracle = _oracle()
+    g = ctx.serra09_debug_pair(i, j, gp)
+    s, it = oracle.serra09_pair(_track(d, i), _track(d, j), op, want_intermediates=True)
+    assert g["oti"] == it["oti"], "%s oti %d vs %d" % (tag, g["oti"], it["oti"])
+    dg = np.sqrt(g["d2"])
+    nbad = int(np.sum(dg != it["d"]))
+    assert nbad == 0, "%s distances differ in %d / %d cells, max |diff| %g" % (
+        tag, nbad, dg.size, float(np.max(np.abs(dg - it["d"]))))
+    bq = np.nonzero(g["eps_q"] != it["eps_q"])[0]
+    br = np.nonzero(g["eps_r"] != it["eps_r"])[0]
+    assert len(bq) == 0, "%s row thresholds differ at %s: %s vs %s" % (tag, bq[:5], g["eps_q"][bq[:5]], it["eps_q"][bq[:5]])
+    assert len(br) == 0, "%s col thresholds differ at %s: %s vs %s" % (tag, br[:5], g["eps_r"][br[:5]], it["eps_r"][br[:5]])
+    incl = bool(op.inclusive)
+    if incl:
+        Rg = (g["d2"] <= g["thr_q"][:, None]) & (g["d2"] <= g["thr_r"][None, :])
+    else:
+        Rg = (g["d2"] <= g["thr_q"][:, None]) & (g["d2"] <= g["thr_r"][None, :])
+    assert np.array_equal(Rg.astype(np.uint8), it["R"]), "%s recurrence plot differs in %d cells" % (
+        tag, int(np.sum(Rg.astype(np.uint8) != it["R"])))
+    assert g["score"] == s, "%s score %r vs %r" % (tag, g["score"], s)
+    return g, it
+
+
+def test_device_sqrt_is_correctly_rounded(ctx):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.random(200000).astype(np.float32) * 100,
+                        np.float32(2.0) ** rng.integers(-60, 60, 20000).astype(np.float32) * rng.random(20000).astype(np.float32),
+                        np.array([0.0, 1e-45, 1e-40, 1.0, 4.0, 3.4e38], np.float32)])
+    assert np.array_equal(ctx.debug_sqrt(x), np.sqrt(x))
+
+
+def test_intermediates_bit_exact_small(ctx):
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    d = synth.cover_set(n_works=3, versions=2, seed=21, t_range=(40, 150))
+    ctx.upload_pool(d["frames"], d["offsets"])
+    n = len(d["offsets"]) - 1
+    for i in range(n):
+        for j in range(n):
+            if i != j:
+                _compare_pair(ctx, d, i, j, _lib.serra09_params(), oracle.serra09_params(), "pair(%d,%d)" % (i, j))
+
+
+def test_intermediates_bit_exact_ragged_and_large(ctx):
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    rng = np.random.default_rng(5)
+    lens = [10, 11, 64 + 9, 65 + 9, 128 + 9, 513 + 9, 700, 1033, 2000]
+    tracks = [synth._frame_max_normalise(rng.random((T, 12))) for T in lens]
+    frames, offsets = synth.pack(tracks)
+    d = dict(frames=frames, offsets=offsets)
+    ctx.upload_pool(frames, offsets)
+    for (i, j) in [(0, 1), (1, 0), (0, 8), (2, 3), (3, 4), (4, 2), (5, 6), (6, 5), (7, 5), (8, 7), (7, 8)]:
+        _compare_pair(ctx, d, i, j, _lib.serra09_params(), oracle.serra09_params(), "len(%d,%d)" % (lens[i], lens[j]))
+
+
+def test_full_size_pair_2000(ctx):
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    d = synth.rand_set(3, T=2000, seed=1234)
+    ctx.upload_pool(d["frames"], d["offsets"])
+    g, it = _compare_pair(ctx, d, 0, 1, _lib.serra09_params(), oracle.serra09_params(), "T=2000")
+    assert g["d2"].shape == (1991, 1991)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(pct_mode=1), dict(pct_mode=2), dict(pct_mode=3), dict(inclusive=0), dict(dp_start=3),
+    dict(embed_full=1), dict(oti=False), dict(oti_target=1), dict(gamma_o=1.0, gamma_e=0.25),
+    dict(gamma_o=0.25, gamma_e=1.5), dict(m=4), dict(m=12), dict(m=16), dict(m=1), dict(kappa=0.3),
+    dict(kappa=0.0), dict(kappa=1.0),
+])
+def test_parameter_switches_bit_exact(ctx, kw):
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    d = synth.cover_set(n_works=2, versions=2, seed=33, t_range=(70, 200))
+    ctx.upload_pool(d["frames"], d["offsets"])
+    for (i, j) in [(0, 1), (2, 1), (3, 0)]:
+        _compare_pair(ctx, d, i, j, _lib.serra09_params(**kw), oracle.serra09_params(**kw), "%s (%d,%d)" % (kw, i, j))
+
+
+def test_all_pairs_scores_and_map(ctx):
+    """covers80-shaped plumbing case at reduced track length: every pair bit-exact, and the
+    MAP / MR of the resulting matrix identical to the oracle's (tree) and to seq108's."""
+    from acoss_amd import synth
+    oracle = _oracle()
+    d = synth.cover_set(clique_sizes=[2] * 10 + [3, 3, 4], seed=4321, t_range=(60, 140))
+    n = len(d["offsets"]) - 1
+    ctx.upload_pool(d["frames"], d["offsets"])
+    pairs = oracle.all_pairs(n, True).astype(np.int32)
+    got = ctx.serra09_pairs(pairs)
+    ref = oracle.serra09_pairs(d["frames"], d["offsets"], pairs)
+    assert np.array_equal(got, ref), "scores differ for %d / %d pairs" % (int(np.sum(got != ref)), len(ref))
+    ref108 = oracle.serra09_pairs(d["frames"], d["offsets"], pairs, oracle.serra09_params(arith="seq108"))
+    assert np.max(np.abs(got - ref108)) <= 2.0
+    cl = {}
+    for i, l in enumerate(d["labels"]):
+        cl.setdefault(l, []).append(i)
+    stats = []
+    for sc in (got, ref, ref108):
+        D = np.zeros((n, n), np.float32)
+        D[pairs[:, 0], pairs[:, 1]] = sc
+        D += D.T
+        D = oracle.serra09_normalize_by_length(D, np.diff(d["offsets"]))
+        stats.append(oracle.eval_statistics(D, list(cl.values()), topsidx=(1, 10)))
+    assert stats[0][:4] == stats[1][:4]
+    assert abs(stats[0][3] - stats[2][3]) <= 1e-4 and stats[0][0] == stats[2][0]
+
+
+def test_batching_is_invisible(ctx):
+    """A tiny scratch limit forces many batches; results must not change."""
+    from acoss_amd import synth
+    oracle = _oracle()
+    d = synth.cover_set(n_works=4, versions=2, seed=8, t_range=(50, 90))
+    n = len(d["offsets"]) - 1
+    ctx.upload_pool(d["frames"], d["offsets"])
+    pairs = oracle.all_pairs(n, False).astype(np.int32)       # ordered pairs, both orientations
+    a = ctx.serra09_pairs(pairs)
+    ctx.set_scratch_limit(3 * 90 * 128 * 4 * 2)
+    b = ctx.serra09_pairs(pairs)
+    ctx.set_scratch_limit(0)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, oracle.serra09_pairs(d["frames"], d["offsets"], pairs))
+
+
+def test_error_behaviour(ctx):
+    from acoss_amd import synth, _lib
+    rng = np.random.default_rng(1)
+    tracks = [synth._frame_max_normalise(rng.random((T, 12))) for T in (9, 40)]
+    frames, offsets = synth.pack(tracks)
+    ctx.upload_pool(frames, offsets)
+    with pytest.raises(_lib.AcxError):                      # essentia raises on inputs shorter than the stack
+        ctx.serra09_pairs(np.array([[0, 1]], np.int32))
+    with pytest.raises(NotImplementedError):
+        ctx.serra09_pairs(np.array([[1, 1]], np.int32), _lib.serra09_params(tau=2))
+    with pytest.raises(ValueError):
+        ctx.serra09_pairs(np.array([[1, 7]], np.int32))
+    assert ctx.serra09_pairs(np.zeros((0, 2), np.int32)).shape == (0,)
