@@ -1,0 +1,232 @@
+"""
+CoverAlgorithm: the harness every cover-id algorithm subclasses.  Mirrors the interface
+of acoss/algorithms/algorithm_template.py (ctor :30-62, load_features :71-95,
+get_all_clique_ids :97-119, similarity :121-140, all_pairwise :142-192,
+cleanup_memmap :194-203, getEvalStatistics :205-290) so that user subclasses written
+against acoss keep working, while device-backed subclasses hand the WHOLE pair list to
+libacx in a few calls.
+
+Differences from the reference, all deliberate:
+  * the pair list is a numpy (K,2) array, not a Python list of tuples (1.1e8 tuples at
+    N = 15 000 would need > 10 GB);
+  * getEvalStatistics is vectorised (the reference's N x N Python double loop takes
+    hours at N = 15 000) and uses a STABLE argsort so that ties have one defined order;
+  * cleanup_memmap really removes the memmap files (the reference calls rmtree on a file
+    and always fails);
+  * the distance matrices are saved as <prefix>_Ds.npz (no deepdish/h5py offline);
+  * under torch.distributed (one process per GPU) all_pairwise shards the pair list over
+    the ranks and performs one all-gather of the scores.
+"""
+import os
+import warnings
+
+import numpy as np
+
+from .. import dist as _dist
+from ..featurestore import load_track
+from ..utils import create_dataset_filepaths
+
+__all__ = ["CoverAlgorithm"]
+
+
+class CoverAlgorithm(object):
+    """
+    Attributes
+    ----------
+    filepaths: list(string)   paths of all feature files of the dataset
+    cliques: {label: set(int)}  cover cliques, indexing into filepaths
+    N: int
+    Ds: {similarity type: (N, N) float32 memmap}   pairwise similarity matrices
+    """
+
+    # how many chunks all_pairwise cuts the pair list into before calling similarity();
+    # 45 is what the reference does (algorithm_template.py:172); device-backed subclasses
+    # override this with 1 (whole list per call).
+    n_chunks = 45
+
+    def __init__(self, dataset_csv, name="Serra09", datapath="features_benchmark", shortname="full",
+                 cachedir="cache", similarity_types=["main"]):
+        self.name = name
+        self.shortname = shortname
+        self.cachedir = cachedir
+        self.filepaths = create_dataset_filepaths(dataset_csv, root_audio_dir=datapath, file_format=".h5")
+        self.cliques = {}
+        self.N = len(self.filepaths)
+        if not os.path.exists(cachedir):
+            os.makedirs(cachedir, exist_ok=True)
+        self.Ds = {}
+        for s in similarity_types:
+            self.Ds[s] = np.memmap(self._dmat_path(s), shape=(self.N, self.N), mode="w+", dtype="float32")
+        print("Initialized %s algorithm on %i songs in dataset %s" % (name, self.N, shortname))
+
+    # ------------------------------------------------------------------ files / caches
+    def get_cacheprefix(self):
+        return "%s/%s_%s" % (self.cachedir, self.name, self.shortname)
+
+    def _dmat_path(self, s):
+        rank, _ = _dist.world()
+        # one process per GPU: every rank keeps its own memmap (rank 0 owns the reference's file name)
+        return "%s_%s_dmat%s" % (self.get_cacheprefix(), s, "" if rank == 0 else ".rank%d" % rank)
+
+    def _register_label(self, i, label):
+        self.cliques.setdefault(label, set()).add(int(i))
+
+    def load_features(self, i):
+        """Feature dict of track i; records its clique (feats['label']) as a side effect."""
+        feats = load_track(self.filepaths[i])
+        self._register_label(i, feats["label"])
+        return feats
+
+    def get_all_clique_ids(self, verbose=False):
+        """Clique membership of every track, cached in <prefix>_clique_info.txt ("i,label")."""
+        path = "%s_clique_info.txt" % self.get_cacheprefix()
+        if not os.path.exists(path):
+            with open(path, "w") as fout:
+                for i in range(len(self.filepaths)):
+                    feats = CoverAlgorithm.load_features(self, i)
+                    if verbose:
+                        print(i)
+                    fout.write("%i,%s\n" % (i, feats["label"]))
+        else:
+            with open(path) as fin:
+                for line in fin:
+                    i, label = line.split(",", 1)
+                    self._register_label(int(i), label.strip())
+
+    # ------------------------------------------------------------------ pairwise
+    def similarity(self, idxs):
+        """idxs: (K,2) int array.  Writes Ds[type][i, j] for every row; the return value is
+        ignored.  The base class stores zeros."""
+        idxs = np.asarray(idxs)
+        self.Ds["main"][idxs[:, 0], idxs[:, 1]] = 0.0
+
+    @staticmethod
+    def pair_list(N, symmetric):
+        """(K,2) int64 array in itertools.combinations / permutations order
+        (algorithm_template.py:168-171)."""
+        if symmetric:
+            i, j = np.triu_indices(N, 1)
+        else:
+            i, j = np.nonzero(~np.eye(N, dtype=bool))
+        return np.stack([i, j], axis=1).astype(np.int64)
+
+    def all_pairwise(self, parallel=0, n_cores=12, symmetric=False, precomputed=False):
+        """All pairwise comparisons.  `parallel` / `n_cores` are accepted for signature
+        compatibility; the fan-out unit here is the GPU (one process per GPU under
+        torch.distributed), not joblib workers."""
+        npz = "%s_Ds.npz" % self.get_cacheprefix()
+        if precomputed:
+            with np.load(npz) as z:
+                for s in z.files:
+                    if s in self.Ds:
+                        self.Ds[s][:] = z[s]
+                    else:
+                        self.Ds[s] = z[s]
+            self.get_all_clique_ids()
+            return
+        pairs = self.pair_list(self.N, symmetric)
+        rank, ws = _dist.world()
+        lo, hi = _dist.shard_bounds(len(pairs), rank, ws)
+        mine = pairs[lo:hi]
+        for chunk in np.array_split(mine, max(1, min(self.n_chunks, len(mine)))):
+            if len(chunk):
+                self.similarity(chunk)
+        if ws > 1:
+            keys = list(self.Ds.keys())
+            local = np.stack([np.asarray(self.Ds[s][mine[:, 0], mine[:, 1]]) for s in keys], axis=1)
+            full = _dist.gather_scores(local, len(pairs))
+            for c, s in enumerate(keys):
+                self.Ds[s][pairs[:, 0], pairs[:, 1]] = full[:, c]
+        if not self.cliques:
+            self.get_all_clique_ids()
+        if symmetric:
+            for s in self.Ds:
+                self.Ds[s] += self.Ds[s].T
+        if rank == 0:
+            np.savez(npz, **{s: np.asarray(self.Ds[s]) for s in self.Ds})
+
+    def cleanup_memmap(self):
+        """Remove the memmap files behind the similarity matrices."""
+        for s in list(self.Ds.keys()):
+            path = self._dmat_path(s)
+            if isinstance(self.Ds[s], np.memmap):
+                self.Ds[s].flush()
+            try:
+                if os.path.exists(path):
+                    os.remove(path)
+            except OSError:
+                print("Could not clean-up automatically.")
+
+    # ------------------------------------------------------------------ evaluation
+    def getEvalStatistics(self, similarity_type, topsidx=[1, 10, 100, 1000]):
+        """MR, MRR, MDR, MAP and Top-k of one similarity matrix; appends a row to
+        results_<shortname>_<name>.csv.  Same definitions as the reference (:205-290),
+        including MRR's division by ALL N songs and the %.3g CSV format."""
+        D = np.array(self.Ds[similarity_type], dtype=np.float32)
+        MR, MRR, MDR, MAP, tops = eval_statistics(D, [sorted(self.cliques[s]) for s in self.cliques], topsidx)
+        print("%s %s STATS\n-------------------------\nMR = %.3g\nMRR = %.3g\nMDR = %.3g\nMAP = %.3g"
+              % (self.name, similarity_type, MR, MRR, MDR, MAP))
+        for t, v in zip(topsidx, tops):
+            print("Top-%i: %i" % (t, v))
+        resultsfile = "results_%s_%s.csv" % (self.shortname, self.name)
+        if not os.path.exists(resultsfile):
+            with open(resultsfile, "w") as fout:
+                fout.write("name, MR, MRR, MDR, MAP")
+                for t in topsidx:
+                    fout.write(",Top-%i" % t)
+                fout.write("\n")
+        with open(resultsfile, "a") as fout:
+            fout.write("%s_%s," % (self.name, similarity_type))
+            fout.write("%.3g, %.3g, %.3g, %.3g" % (MR, MRR, MDR, MAP))
+            for t in tops:
+                fout.write(", %.3g" % t)
+            fout.write("\n")
+        return MR, MRR, MDR, MAP, tops
+
+
+def eval_statistics(D, cliques, topsidx=(1, 10, 100, 1000), row_block=1024):
+    """Vectorised evaluation.  `cliques`: list of lists of track indices (dict insertion
+    order).  Rows are reordered so that cliques are contiguous, largest first; the
+    diagonal is -inf; every row is sorted by descending score with a STABLE sort; for every
+    song of a clique of size >= 2 the 1-based ranks of its clique mates are collected."""
+    D = np.array(D, dtype=np.float32)
+    N = D.shape[0]
+    Ks = np.array([len(c) for c in cliques])
+    order = np.argsort(-Ks, kind="stable")
+    Ks = Ks[order]
+    cl = [list(cliques[i]) for i in order]
+    idx = np.array([t for c in cl for t in c], dtype=np.int64)
+    D = D[idx, :][:, idx]
+    np.fill_diagonal(D, -np.inf)
+    starts = np.concatenate([[0], np.cumsum(Ks)])[:-1]
+    row_start = np.repeat(starts, Ks)            # first column of the row's own clique
+    row_K = np.repeat(Ks, Ks)
+    n_eval = int(np.sum(Ks[Ks >= 2]))            # cliques are sorted: evaluated rows come first
+    ranks = np.full(N, np.nan)
+    allmap = np.full(N, np.nan)
+    for r0 in range(0, n_eval, row_block):
+        r1 = min(n_eval, r0 + row_block)
+        srt = np.argsort(-D[r0:r1], axis=1, kind="stable")
+        member = (srt >= row_start[r0:r1, None]) & (srt < (row_start[r0:r1] + row_K[r0:r1])[:, None])
+        rr, kk = np.nonzero(member)              # row-major: per row, ascending rank position
+        # the last member of every row is the song itself (-inf sorts last): drop it
+        first = np.concatenate([[0], np.cumsum(row_K[r0:r1])])[:-1]
+        last = first + row_K[r0:r1] - 1
+        keep = np.ones(len(rr), dtype=bool)
+        keep[last] = False
+        pos = (kk + 1)[keep].astype(np.float64)
+        rows = rr[keep]
+        within = np.arange(len(rr)) - np.repeat(first, row_K[r0:r1])
+        num = (within + 1)[keep].astype(np.float64)
+        ranks[r0:r1] = pos[np.searchsorted(rows, np.arange(r1 - r0))]
+        sums = np.bincount(rows, weights=num / pos, minlength=r1 - r0)
+        allmap[r0:r1] = sums / (row_K[r0:r1] - 1)
+    if n_eval == 0:
+        warnings.warn("no clique with at least two songs")
+    MAP = float(np.nanmean(allmap)) if n_eval else float("nan")
+    ranks = ranks[~np.isnan(ranks)]
+    MR = float(np.mean(ranks)) if len(ranks) else float("nan")
+    MRR = float(1.0 / N * np.sum(1.0 / ranks))
+    MDR = float(np.median(ranks)) if len(ranks) else float("nan")
+    tops = np.array([np.sum(ranks <= t) for t in topsidx], dtype=np.float64)
+    return MR, MRR, MDR, MAP, tops

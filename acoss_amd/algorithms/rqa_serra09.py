@@ -1,0 +1,107 @@
+"""
+Serra09: cross recurrence quantification (Serra, Serra & Andrzejak 2009, NJP 11 093017).
+Drop-in for acoss/algorithms/rqa_serra09.py: same constructor, load_features(i),
+similarity(idxs), normalize_by_length().  The per-pair arithmetic that the reference
+delegates to essentia (ChromaCrossSimilarity + CoverSongSimilarity, rqa_serra09.py:60-67)
+runs in libacx's HIP kernels for ALL rows of `idxs` in one call.
+"""
+import numpy as np
+
+from .. import _lib
+from .algorithm_template import CoverAlgorithm
+
+__all__ = ["Serra09", "pool_median"]
+
+
+def pool_median(chroma, fac):
+    """Median over consecutive blocks of `fac` frames (the last block may be shorter):
+    what librosa.util.sync(chroma.T, arange(0, T, fac), aggregate=np.median).T yields at
+    rqa_serra09.py:51.  (T0, d) -> (ceil(T0 / fac), d), dtype preserved."""
+    chroma = np.asarray(chroma)
+    T0 = chroma.shape[0]
+    nfull = T0 // fac
+    parts = []
+    if nfull:
+        parts.append(np.median(chroma[:nfull * fac].reshape(nfull, fac, -1), axis=1))
+    if T0 > nfull * fac:
+        parts.append(np.median(chroma[nfull * fac:], axis=0, keepdims=True))
+    return np.concatenate(parts, axis=0).astype(chroma.dtype, copy=False)
+
+
+class Serra09(CoverAlgorithm):
+    """
+    Attributes (as in the reference): chroma_type, downsample_fac, all_feats, oti, kappa,
+    tau, m.  Extra keyword `device` selects the GPU (default: LOCAL_RANK or 0); `engine`
+    holds further switches of the essentia-recalled details (acx_serra09_params).
+    """
+    n_chunks = 1      # the whole pair list goes to the GPU in one similarity() call
+
+    def __init__(self, dataset_csv, datapath, chroma_type='hpcp', shortname='benchmark',
+                 oti=True, kappa=0.095, tau=1, m=9, downsample_fac=40, device=None, engine=None):
+        self.oti = oti
+        self.kappa = kappa
+        self.tau = tau
+        self.m = m
+        self.chroma_type = chroma_type
+        self.downsample_fac = downsample_fac
+        self.all_feats = {}
+        self._device = device
+        self._engine = dict(engine or {})
+        self._ctx = None
+        self._pool_ready = False
+        CoverAlgorithm.__init__(self, dataset_csv=dataset_csv, name="Serra09", datapath=datapath,
+                                shortname=shortname)
+
+    # ------------------------------------------------------------------ features
+    def load_features(self, i):
+        if i not in self.all_feats:
+            feats = CoverAlgorithm.load_features(self, i)
+            self.all_feats[i] = pool_median(feats[self.chroma_type], self.downsample_fac)
+        return self.all_feats[i]
+
+    def set_pooled_features(self, tracks, labels=None):
+        """Inject already-pooled (T_i, 12) chroma for every track (synthetic benchmarks,
+        or features prepared elsewhere) instead of reading feature files."""
+        assert len(tracks) == self.N
+        self.all_feats = {i: np.ascontiguousarray(t, dtype=np.float32) for i, t in enumerate(tracks)}
+        if labels is not None:
+            for i, l in enumerate(labels):
+                self._register_label(i, l)
+        self._pool_ready = False
+
+    # ------------------------------------------------------------------ device
+    def _params(self):
+        return _lib.serra09_params(m=self.m, tau=self.tau, kappa=self.kappa, oti=self.oti, **self._engine)
+
+    def _context(self):
+        if self._ctx is None:
+            import os
+            dev = self._device
+            if dev is None:
+                dev = int(os.environ.get("LOCAL_RANK", "0"))
+            self._ctx = _lib.Context(dev)
+        if not self._pool_ready:
+            tracks = [np.ascontiguousarray(self.load_features(i), dtype=np.float32) for i in range(self.N)]
+            lens = np.array([t.shape[0] for t in tracks], dtype=np.int64)
+            offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            self._ctx.upload_pool(np.concatenate(tracks, axis=0), offsets)
+            self._pool_ready = True
+        return self._ctx
+
+    def similarity(self, idxs):
+        idxs = np.asarray(idxs).reshape(-1, 2)
+        if len(idxs) == 0:
+            return
+        scores = self._context().serra09_pairs(idxs.astype(np.int32), self._params())
+        for key in self.Ds.keys():
+            self.Ds[key][idxs[:, 0], idxs[:, 1]] = scores
+
+    def normalize_by_length(self):
+        """Non-symmetric normalisation: D[i, j] /= sqrt(T_j), T_j the pooled length
+        (rqa_serra09.py:71-83; the reciprocal of the paper's distance, so larger = closer)."""
+        norm = np.sqrt(np.array([self.load_features(j).shape[0] for j in range(self.N)], dtype=np.float64))
+        for key in self.Ds.keys():
+            D = self.Ds[key]
+            for j0 in range(0, self.N, 2048):
+                j1 = min(self.N, j0 + 2048)
+                D[:, j0:j1] = (D[:, j0:j1] / norm[None, j0:j1]).astype(np.float32)

@@ -1,0 +1,39 @@
+"""
+Host utilities mirroring the two helpers of acoss/utils.py that sit on the benchmark
+path: create_dataset_filepaths (utils.py:87-102) and log (utils.py:24-35).
+"""
+import logging
+import os
+
+import pandas as pd
+
+__all__ = ["create_dataset_filepaths", "log"]
+
+
+def log(log_file):
+    """Logger with a file and a console handler (same format as the reference).  Handlers
+    are attached once per log file, so repeated calls do not duplicate output."""
+    logger = logging.getLogger("acoss_amd.%s" % os.path.basename(log_file))
+    logger.setLevel(logging.DEBUG)
+    if not logger.handlers:
+        fmt = logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+        fh = logging.FileHandler(log_file)
+        fh.setFormatter(fmt)
+        logger.addHandler(fh)
+        ch = logging.StreamHandler()
+        ch.setFormatter(fmt)
+        logger.addHandler(ch)
+    return logger
+
+
+def create_dataset_filepaths(dataset_csv, root_audio_dir, file_format=".mp3"):
+    """CSV with exactly the columns work_id, track_id -> root + work_id/track_id + ext.
+    Like the reference, `root_audio_dir` is string-concatenated (it must end with '/'),
+    and any other column raises IOError."""
+    table = pd.read_csv(dataset_csv)
+    for col in table.columns.tolist():
+        if col not in ("work_id", "track_id"):
+            raise IOError("Wrong input dataset csv annotation file '%s'. Expected a csv file with the "
+                          "columns of key 'work_id', 'track_id'" % dataset_csv)
+    return [root_audio_dir + str(w) + "/" + str(t) + file_format
+            for w, t in zip(table["work_id"], table["track_id"])]

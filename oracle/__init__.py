@@ -383,7 +383,7 @@ def eval_statistics(D, cliques, topsidx=(1, 10, 100, 1000), stable=True):
     N = D.shape[0]
     cl = [list(c) for c in cliques]
     Ks = np.array([len(c) for c in cl])
-    order = np.argsort(-Ks)
+    order = np.argsort(-Ks, kind="stable")   # reference: default sort (:222); equal-size cliques may come in any order
     Ks = Ks[order]
     cl = [cl[i] for i in order]
     idx = np.array([t for c in cl for t in c], dtype=int)

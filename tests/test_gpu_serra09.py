@@ -170,3 +170,41 @@ def test_error_behaviour(ctx):
     with pytest.raises(ValueError):
         ctx.serra09_pairs(np.array([[1, 7]], np.int32))
     assert ctx.serra09_pairs(np.zeros((0, 2), np.int32)).shape == (0,)
+
+
+def test_benchmark_end_to_end_from_feature_files(tmp_path, monkeypatch):
+    """benchmark(algorithm="Serra09") over per-track feature files: raw chroma is pooled x40
+    on load, every pair goes through libacx, D is mirrored and length-normalised, and the
+    statistics equal the oracle's on the same data (configs[1] plumbing at reduced length)."""
+    import acoss_amd
+    from acoss_amd import synth
+    from acoss_amd.featurestore import save_track
+    oracle = _oracle()
+    d = synth.cover_set(clique_sizes=[2, 2, 3, 2, 1, 1], seed=99, t_range=(45, 90))
+    n = len(d["offsets"]) - 1
+    root = str(tmp_path) + "/feat/"
+    with open(tmp_path / "ds.csv", "w") as f:
+        f.write("work_id,track_id\n")
+        for i in range(n):
+            pooled = _track(d, i)
+            raw = np.repeat(pooled, 40, axis=0)[: 40 * len(pooled) - 7 * (i % 3)]   # ragged last segment
+            save_track(root + "%s/t%d.h5" % (d["labels"][i], i),
+                       {"label": d["labels"][i], "track_id": "t%d" % i, "hpcp": raw})
+            f.write("%s,t%d\n" % (d["labels"][i], i))
+    monkeypatch.chdir(tmp_path)
+    res = acoss_amd.benchmark(str(tmp_path / "ds.csv"), root, feature_type="hpcp", algorithm="Serra09",
+                              shortname="toy")
+    pairs = oracle.all_pairs(n, True).astype(np.int32)
+    sc = oracle.serra09_pairs(d["frames"], d["offsets"], pairs)
+    D = np.zeros((n, n), np.float32)
+    D[pairs[:, 0], pairs[:, 1]] = sc
+    D += D.T
+    D = oracle.serra09_normalize_by_length(D, np.diff(d["offsets"]))
+    cl = {}
+    for i, l in enumerate(d["labels"]):
+        cl.setdefault(l, []).append(i)
+    want = oracle.eval_statistics(D, list(cl.values()))
+    got = res["main"]
+    assert got[:4] == want[:4] and np.array_equal(got[4], want[4])
+    assert np.array_equal(np.load("cache/Serra09_toy_Ds.npz")["main"] / 1.0, np.load("cache/Serra09_toy_Ds.npz")["main"])
+    assert open("results_toy_Serra09.csv").read().startswith("name, MR, MRR, MDR, MAP,Top-1,Top-10,Top-100,Top-1000")
