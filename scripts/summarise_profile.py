@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Summarise a scripts/profile.sh output directory into profiles/<tag>_summary.md and
+profiles/pmc_traffic.json.
+
+HBM bytes: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  Per MI355X_MICROARCH.md
+(HBM section) on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced
+streaming reads, i.e. HALF the bytes: the read side is doubled here and both raw and
+corrected values are listed.  WRITE_SIZE is taken as is (uncalibrated per that section)."""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = sys.argv[2] if len(sys.argv) > 2 else os.path.join("gpurun_out", "prof_" + tag)
+cells_per_launch = float(sys.argv[3]) if len(sys.argv) > 3 else 2048 * 1991.0 * 1991.0
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("acx::", "")
+
+
+stats = {}
+with open(os.path.join(src, "stats", "stats_kernel_stats.csv")) as f:
+    for row in csv.DictReader(f):
+        stats[short(row["Name"])] = dict(calls=int(row["Calls"]), avg_ms=float(row["AverageNs"]) / 1e6,
+                                         pct=float(row["Percentage"]))
+
+pmc = defaultdict(lambda: defaultdict(list))
+for sub in sorted(os.listdir(src)):
+    p = os.path.join(src, sub, "pmc_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    with open(p) as f:
+        for row in csv.DictReader(f):
+            k = short(row["Kernel_Name"])
+            pmc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            pmc[k]["_vgpr"] = [float(row["VGPR_Count"])]
+            pmc[k]["_lds"] = [float(row["LDS_Block_Size"])]
+
+lines = ["# rocprofv3 summary `%s`" % tag, "",
+         "Command: `python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --pairs-per-rank 2048` "
+         "(2048 pairs of 1991 x 1991 cells per launch); one `--kernel-trace --stats` pass and separate "
+         "`--pmc` passes (scripts/profile.sh).", "",
+         "| kernel | calls | avg ms | % time | VGPR | LDS B | FETCH KiB | WRITE KiB | HBM GB (2 x fetch + write) | GB/s |",
+         "|---|---|---|---|---|---|---|---|---|---|"]
+traffic = {}
+for k, st in sorted(stats.items(), key=lambda kv: -kv[1]["avg_ms"]):
+    c = pmc.get(k, {})
+    fl, wl = c.get("FETCH_SIZE", [0]), c.get("WRITE_SIZE", [0])
+    fetch = sum(fl) / max(1, len(fl))
+    write = sum(wl) / max(1, len(wl))
+    hbm = (2 * fetch + write) * 1024.0
+    gbs = hbm / (st["avg_ms"] * 1e-3) / 1e9 if st["avg_ms"] > 0 else 0
+    lines.append("| %s | %d | %.3f | %.2f | %d | %d | %.0f | %.0f | %.3f | %.0f |" % (
+        k, st["calls"], st["avg_ms"], st["pct"], c.get("_vgpr", [0])[0], c.get("_lds", [0])[0],
+        fetch, write, hbm / 1e9, gbs))
+    if "kernel" in k and hbm > 0:
+        traffic[k.split("<")[0]] = dict(hbm_bytes_per_launch=hbm, cells_per_launch=cells_per_launch,
+                                        fetch_kib_raw=fetch, write_kib_raw=write, avg_ms=st["avg_ms"])
+lines += ["", "## SQ counters (per launch, averaged)", ""]
+names = sorted({n for k in pmc for n in pmc[k] if not n.startswith("_") and n not in ("FETCH_SIZE", "WRITE_SIZE")})
+lines.append("| kernel | " + " | ".join(names) + " |")
+lines.append("|---|" + "---|" * len(names))
+for k in sorted(stats, key=lambda kk: -stats[kk]["avg_ms"]):
+    if k not in pmc:
+        continue
+    vals = []
+    for n in names:
+        v = pmc[k].get(n)
+        vals.append("%.3g" % (sum(v) / len(v)) if v else "-")
+    lines.append("| %s | " % k + " | ".join(vals) + " |")
+os.makedirs("profiles", exist_ok=True)
+open(os.path.join("profiles", tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
+print("\n".join(lines))
