@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libacx.so")
+LIB_PATH = os.environ.get("ACX_LIB") or os.path.join(_HERE, "csrc", "libacx.so")   # ACX_LIB: development A/B builds
 
 ACX_OK = 0
 ACX_ERR_INVALID = -1

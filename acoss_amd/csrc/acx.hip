@@ -28,7 +28,7 @@ struct KStat {
     int64_t launches;
     int64_t cells;
 };
-enum { KS_OTI = 0, KS_CSM, KS_SEL, KS_QMAX, KS_COUNT };
+enum { KS_OTI = 0, KS_NORMS, KS_BAND, KS_CSM, KS_SEL, KS_QMAX, KS_COUNT };
 
 struct PendingEvent {
     hipEvent_t a, b;
@@ -57,8 +57,8 @@ struct acx_ctx {
     size_t total_mem = 0;
     // profiling
     bool prof = false;
-    KStat stats[KS_COUNT] = {{"oti_kernel", 0, 0, 0}, {"csm_tile_kernel", 0, 0, 0},
-                             {"rowsel_kernel", 0, 0, 0}, {"qmax_kernel", 0, 0, 0}};
+    KStat stats[KS_COUNT] = {{"oti_kernel", 0, 0, 0}, {"norms_kernel", 0, 0, 0}, {"band_kernel", 0, 0, 0},
+                             {"csm_tile_kernel", 0, 0, 0}, {"rowsel_kernel", 0, 0, 0}, {"qmax_kernel", 0, 0, 0}};
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
 };
@@ -162,11 +162,48 @@ void launch_csm_m(acx_ctx *c, int m, dim3 grid, int tiles_x, int oti_target)
 {
     switch (m) {
 #define ACX_CASE(M_) case M_: launch_csm<M_>(c, grid, tiles_x, oti_target); break;
+#ifdef ACX_FAST_BUILD
+        ACX_CASE(9)
+#else
         ACX_CASE(1) ACX_CASE(2) ACX_CASE(3) ACX_CASE(4) ACX_CASE(5) ACX_CASE(6) ACX_CASE(7) ACX_CASE(8)
         ACX_CASE(9) ACX_CASE(10) ACX_CASE(11) ACX_CASE(12) ACX_CASE(13) ACX_CASE(14) ACX_CASE(15) ACX_CASE(16)
+#endif
 #undef ACX_CASE
     }
 }
+
+template <int M>
+void launch_band(acx_ctx *c, int B, int maxM, const acx_serra09_params &p)
+{
+    const dim3 grid((maxM + acx::BAND - 1) / acx::BAND, B, 2);
+    const int ndata = (maxM + acx::BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
+#define ACX_BAND(V4_) hipLaunchKernelGGL((acx::band_kernel<M, V4_>), grid, dim3(acx::BAND_THREADS), 0, c->stream, c->d_frames, \
+                                         c->d_toff, c->d_pd, c->d_scratch, c->d_thr, p.kappa, p.pct_mode,       \
+                                         p.inclusive, p.oti_target)
+    if (ndata <= 8) ACX_BAND(2);
+    else if (ndata <= 16) ACX_BAND(4);
+    else ACX_BAND(8);
+#undef ACX_BAND
+}
+
+template <int M>
+void launch_norms(acx_ctx *c, int B, int maxRows, int oti_target)
+{
+    hipLaunchKernelGGL((acx::norms_kernel<M>), dim3((maxRows + 255) / 256, B), dim3(256), 0, c->stream,
+                       c->d_frames, c->d_toff, c->d_pd, c->d_thr, oti_target);
+}
+
+#ifdef ACX_FAST_BUILD   /* development builds: only the default stack size */
+#define ACX_M_SWITCH(m_, CALL) switch (m_) { case 9: CALL(9); break; }
+#else
+#define ACX_M_SWITCH(m_, CALL)                                                                      \
+    switch (m_) {                                                                                   \
+        case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break;     \
+        case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;     \
+        case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
+        case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break; \
+    }
+#endif
 
 template <int NG>
 void launch_qmax(acx_ctx *c, int B, bool eqg, float go, float ge, int dp_start)
@@ -202,6 +239,8 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
         else limit = (int64_t)(0.40 * (double)c->total_mem);
     }
     const int64_t limit_floats = limit / 4;
+    const char *pipe = getenv("ACX_PIPELINE");
+    const bool v1 = pipe && strcmp(pipe, "v1") == 0;     // A/B switch: materialised D2 + D2T pipeline
 
     std::vector<PairDesc> pd;
     int64_t k0 = 0;
@@ -224,13 +263,13 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             if (d.Mq <= 0 || d.Mr <= 0)
                 return fail(c, ACX_ERR_SHORT, "serra09: track shorter than the delay-embedding stack (pair " + std::to_string(k) + ")");
             const int Ne = d.Mr - (p.dp_start == 3 ? 1 : 0);
-            if (Ne > 2048 || d.Mq > 2048 || d.Mr > 2048)
-                return fail(c, ACX_ERR_UNSUPPORTED, "serra09: tracks with more than 2048 embedded frames are not supported on the device yet");
+            if (Ne > 2041 || d.Mq > 2041 || d.Mr > 2041)
+                return fail(c, ACX_ERR_UNSUPPORTED, "serra09: tracks with more than 2041 embedded frames are not supported on the device yet");
             d.oti = 0;
             d.pitchD = round_up(d.Mr, 64);
             d.pitchT = round_up(d.Mq, 64);
             d.pad_ = 0;
-            const int64_t need = (int64_t)d.Mq * d.pitchD + (int64_t)d.Mr * d.pitchT;
+            const int64_t need = (int64_t)d.Mq * d.pitchD + (v1 ? (int64_t)d.Mr * d.pitchT : 0);
             if (need > limit_floats)
                 return fail(c, ACX_ERR_NOMEM, "serra09: one pair does not fit the scratch limit");
             if (used + need > limit_floats) break;
@@ -238,7 +277,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             d.offT = used + (int64_t)d.Mq * d.pitchD;
             d.offX = used_thr;
             used += need;
-            used_thr += 2 * ((int64_t)d.pitchD + d.pitchT);
+            used_thr += 3 * ((int64_t)d.pitchD + d.pitchT);
             maxMq = std::max(maxMq, d.Mq);
             maxMr = std::max(maxMr, d.Mr);
             maxRows = std::max(maxRows, d.Mq + d.Mr);
@@ -258,21 +297,36 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             hipLaunchKernelGGL(acx::oti_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream,
                                c->d_pd, B, c->d_gch, p.oti, p.oti_target);
         }
-        {   // K1
-            const int tiles_x = (maxMr + 63) / 64, tiles_y = (maxMq + 63) / 64;
-            ProfScope ps(c, KS_CSM, cells);
-            launch_csm_m(c, p.m, dim3(tiles_x * tiles_y, B), tiles_x, p.oti_target);
-        }
-        {   // K2
-            ProfScope ps(c, KS_SEL, cells);
-            const int maxN = std::max(maxMq, maxMr);   // longest row of D2 / D2T in the batch
-            const dim3 g((maxRows + 3) / 4, B);
+        if (v1) {
+            {   // K1 (v1): tiles -> D2 and D2T
+                const int tiles_x = (maxMr + 63) / 64, tiles_y = (maxMq + 63) / 64;
+                ProfScope ps(c, KS_CSM, cells);
+                launch_csm_m(c, p.m, dim3(tiles_x * tiles_y, B), tiles_x, p.oti_target);
+            }
+            {   // K2 (v1): row selection on D2 and D2T
+                ProfScope ps(c, KS_SEL, cells);
+                const int maxN = std::max(maxMq, maxMr);
+                const dim3 g((maxRows + 3) / 4, B);
 #define ACX_SEL(V4_) hipLaunchKernelGGL((acx::rowsel_kernel<V4_>), g, dim3(256), 0, c->stream, \
                                         c->d_pd, c->d_scratch, c->d_thr, p.kappa, p.pct_mode, p.inclusive)
-            if (maxN <= 512) ACX_SEL(2);
-            else if (maxN <= 1024) ACX_SEL(4);
-            else ACX_SEL(8);
+                if (maxN <= 512) ACX_SEL(2);
+                else if (maxN <= 1024) ACX_SEL(4);
+                else ACX_SEL(8);
 #undef ACX_SEL
+            }
+        } else {
+            {   // K0b: embedded norms
+                ProfScope ps(c, KS_NORMS, cells);
+#define ACX_CALL(M_) launch_norms<M_>(c, B, maxRows, p.oti_target)
+                ACX_M_SWITCH(p.m, ACX_CALL)
+#undef ACX_CALL
+            }
+            {   // K1': fused band kernel, both roles
+                ProfScope ps(c, KS_BAND, cells);
+#define ACX_CALL(M_) launch_band<M_>(c, B, std::max(maxMq, maxMr), p)
+                ACX_M_SWITCH(p.m, ACX_CALL)
+#undef ACX_CALL
+            }
         }
         {   // K3
             const int NG = (maxNe + 511) / 512;

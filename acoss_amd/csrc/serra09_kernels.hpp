@@ -262,29 +262,44 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Wave64 reductions / inclusive scan on the DPP crossbar (row_shr 1,2,4,8 inside each row of
+// 16 lanes, then row_bcast15 / row_bcast31 across rows; lanes without a source keep `idn`).
+// One VALU op per step instead of an LDS-crossbar ds_bpermute round trip.
+template <typename Op>
+__device__ __forceinline__ int wave_scan_bits(int v, int idn, Op op)
+{
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return v;       // inclusive scan; lane 63 holds the total
+}
+struct OpMinF { __device__ int operator()(int a, int b) const { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); } };
+struct OpMaxF { __device__ int operator()(int a, int b) const { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); } };
+struct OpAddI { __device__ int operator()(int a, int b) const { return a + b; } };
+
 __device__ __forceinline__ float wave_min(float v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    const int r = wave_scan_bits(__float_as_int(v), __float_as_int(__builtin_inff()), OpMinF());
+    return __int_as_float(__builtin_amdgcn_readlane(r, 63));
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    const int r = wave_scan_bits(__float_as_int(v), __float_as_int(-__builtin_inff()), OpMaxF());
+    return __int_as_float(__builtin_amdgcn_readlane(r, 63));
 }
 __device__ __forceinline__ int wave_sum_i(int v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return __builtin_amdgcn_readlane(wave_scan_bits(v, 0, OpAddI()), 63);
 }
+__device__ __forceinline__ int wave_incl_scan_i(int v) { return wave_scan_bits(v, 0, OpAddI()); }
 
 // histogram slot of logical bin b: one pad word per 32 bins, so that neighbouring bins sit
 // in neighbouring banks (atomics) AND the scan, where lane L reads bins 32L..32L+31, is
 // conflict-free ((33 L + e) mod 32 distinct over L).
-constexpr int SEL_SLOTS = SEL_BINS + SEL_BINS / 32;
+constexpr int SEL_SLOTS = SEL_BINS + SEL_BINS / 32 + 16;   // + the dummy slot hslot(SEL_BINS), padded to 16
 __device__ __forceinline__ int hslot(int b) { return b + (b >> 5); }
 
 struct SelectResult { float value; int cnt_le; float next; };
@@ -296,6 +311,143 @@ struct SelectResult { float value; int cnt_le; float next; };
 // SEL_BINS linear bins, descend into the bin holding rank k, until it holds <= 64
 // elements, which are ranked directly.  If want_next, also returns #(v <= result) and
 // min{v > result} (+inf if none).
+template <int NV>
+__device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], int k, unsigned *hist, float *cand,
+                                                         unsigned *counter, int lane, bool want_next)
+{
+    const float INF = __builtin_inff();
+    float mn = INF, mx = -INF;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        mn = fminf(mn, x[t]);
+        mx = fmaxf(mx, (x[t] == INF) ? -INF : x[t]);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    int below = 0;           // elements strictly below the active range [mn, mx]
+    float result = mn;
+#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 1
+    return SelectResult{mn + mx, 0, INF};
+#endif
+    for (int iter = 0; iter < 64; ++iter) {
+        if (!(mn < mx)) { result = mn; break; }
+        const float scale = (float)SEL_BINS / (mx - mn);
+        for (int b = lane * 4; b < SEL_SLOTS; b += 256)
+            *reinterpret_cast<uint4 *>(hist + b) = make_uint4(0, 0, 0, 0);
+        if (lane == 0) *counter = 0u;
+        wave_lds_fence();
+        // Histogram, branch-free: elements outside the active range (the +inf pads, and in later
+        // narrowing rounds everything outside [mn, mx]) are routed to a dummy slot, so the NV
+        // LDS atomics of a lane issue back to back.
+        int bins[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            int b = (int)((x[t] - mn) * scale);
+            b = b > SEL_BINS - 1 ? SEL_BINS - 1 : b;
+            const bool in = x[t] >= mn && x[t] <= mx;
+            bins[t] = in ? b : SEL_BINS;          // SEL_BINS = dummy
+        }
+#pragma unroll
+        for (int t = 0; t < NV; ++t)
+            __hip_atomic_fetch_add(&hist[hslot(bins[t])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wave_lds_fence();
+#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 2
+        return SelectResult{(float)hist[lane] + (float)bins[3], 0, INF};
+#endif
+        // scan: lane owns bins [32*lane, 32*lane+32)
+        int hv[32];
+        int lsum = 0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) { hv[e] = (int)hist[33 * lane + e]; lsum += hv[e]; }
+        const int incl = wave_incl_scan_i(lsum);
+        const int target = k - below;                 // rank inside the active set
+        const unsigned long long m = __ballot(incl > target);
+        const int L = __ffsll((long long)m) - 1;      // first lane whose inclusive sum exceeds target
+        const int excl = incl - lsum;
+        int binsel_v = 0, cum_v = 0, cnt_v = 0;
+        {
+            int run = excl;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const bool here = cnt_v == 0 && run + hv[e] > target;
+                binsel_v = here ? 32 * lane + e : binsel_v;
+                cum_v = here ? run : cum_v;
+                cnt_v = here ? hv[e] : cnt_v;
+                run += hv[e];
+            }
+        }
+        // wave-uniform (SGPR) copies of lane L's findings
+        const int binsel = __builtin_amdgcn_readlane(binsel_v, L);
+        const int cum = __builtin_amdgcn_readlane(cum_v, L);
+        const int cnt = __builtin_amdgcn_readlane(cnt_v, L);
+#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 3
+        return SelectResult{(float)(binsel + cum + cnt) + (float)bins[3], 0, INF};
+#endif
+        if (cnt <= 64) {
+            // append the bin's elements (<= 64) to cand[] (order irrelevant), rank, pick.  Only
+            // a handful of the NV register slots hold a hit in any lane: a wave-uniform ballot
+            // skips the others.
+#if !(defined(ACX_SEL_STOP) && ACX_SEL_STOP == 41)
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const bool hit = bins[t] == binsel;
+                if (__ballot(hit) != 0ull) {
+                    if (hit) {
+                        unsigned pos = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        cand[pos & 63u] = x[t];
+                    }
+                }
+            }
+#endif
+            wave_lds_fence();
+            const float mine = (lane < cnt) ? cand[lane] : INF;
+            int rank = 0;
+#pragma unroll 1
+            for (int t = 0; t < cnt; ++t) {      // cnt is an SGPR: scalar loop, no LDS traffic
+#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 42
+                break;
+#endif
+                const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), t));
+                rank += (o < mine || (o == mine && t < lane)) ? 1 : 0;
+            }
+            const int want = target - cum;
+            const unsigned long long hitm = __ballot(lane < cnt && rank == want);
+            const int src = __ffsll((long long)hitm) - 1;
+            result = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), src));
+            wave_lds_fence();
+            break;
+        }
+        // narrow to the bin's own value range and iterate
+        float nmn = INF, nmx = -INF;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            if (bins[t] == binsel) { nmn = fminf(nmn, x[t]); nmx = fmaxf(nmx, x[t]); }
+        }
+        below += cum;
+        mn = wave_min(nmn);
+        mx = wave_max(nmx);
+        result = mn;
+        wave_lds_fence();
+    }
+    SelectResult res{result, 0, INF};
+#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 4
+    return res;
+#endif
+    if (want_next) {
+        int cle = 0;
+        float nx = INF;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            cle += (x[t] <= result) ? 1 : 0;
+            nx = fminf(nx, (x[t] > result) ? x[t] : INF);
+        }
+        res.cnt_le = wave_sum_i(cle);
+        res.next = wave_min(nx);
+    }
+    return res;
+}
+
+// row in HBM -> registers (V4 back-to-back 16-byte loads per lane), then select
 template <int V4>
 __device__ __forceinline__ SelectResult wave_select(const float *__restrict__ v, int n, int pitch, int k,
                                                     unsigned *hist, float *cand, unsigned *counter,
@@ -314,115 +466,7 @@ __device__ __forceinline__ SelectResult wave_select(const float *__restrict__ v,
         x[4 * q + 2] = (j + 2 < n) ? t.z : INF;
         x[4 * q + 3] = (j + 3 < n) ? t.w : INF;
     }
-    float mn = INF, mx = -INF;
-#pragma unroll
-    for (int t = 0; t < NV; ++t) {
-        mn = fminf(mn, x[t]);
-        mx = fmaxf(mx, (x[t] == INF) ? -INF : x[t]);
-    }
-    mn = wave_min(mn);
-    mx = wave_max(mx);
-    int below = 0;           // elements strictly below the active range [mn, mx]
-    float result = mn;
-    for (int iter = 0; iter < 64; ++iter) {
-        if (!(mn < mx)) { result = mn; break; }
-        const float scale = (float)SEL_BINS / (mx - mn);
-        for (int b = lane * 4; b < SEL_SLOTS; b += 256)
-            *reinterpret_cast<uint4 *>(hist + b) = make_uint4(0, 0, 0, 0);
-        if (lane == 0) *counter = 0u;
-        wave_lds_fence();
-#pragma unroll
-        for (int t = 0; t < NV; ++t) {
-            if (x[t] >= mn && x[t] <= mx) {
-                int b = (int)((x[t] - mn) * scale);
-                b = b > SEL_BINS - 1 ? SEL_BINS - 1 : b;
-                __hip_atomic_fetch_add(&hist[hslot(b)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        wave_lds_fence();
-        // scan: lane owns bins [32*lane, 32*lane+32)
-        int hv[32];
-        int lsum = 0;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) { hv[e] = (int)hist[33 * lane + e]; lsum += hv[e]; }
-        int incl = lsum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        const int target = k - below;                 // rank inside the active set
-        const unsigned long long m = __ballot(incl > target);
-        const int L = __ffsll((long long)m) - 1;      // first lane whose inclusive sum exceeds target
-        const int excl = incl - lsum;
-        int binsel = 0, cum = 0, cnt = 0;
-        if (lane == L) {
-            int run = excl;
-#pragma unroll
-            for (int e = 0; e < 32; ++e) {
-                if (cnt == 0 && run + hv[e] > target) { binsel = 32 * lane + e; cum = run; cnt = hv[e]; }
-                run += hv[e];
-            }
-        }
-        binsel = __shfl(binsel, L, 64);
-        cum = __shfl(cum, L, 64);
-        cnt = __shfl(cnt, L, 64);
-        if (cnt <= 64) {
-            // append the bin's elements (<= 64) to cand[] (order irrelevant), rank, pick
-#pragma unroll
-            for (int t = 0; t < NV; ++t) {
-                if (x[t] >= mn && x[t] <= mx) {
-                    int b = (int)((x[t] - mn) * scale);
-                    b = b > SEL_BINS - 1 ? SEL_BINS - 1 : b;
-                    if (b == binsel) {
-                        unsigned pos = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        cand[pos & 63u] = x[t];
-                    }
-                }
-            }
-            wave_lds_fence();
-            const float mine = (lane < cnt) ? cand[lane] : INF;
-            int rank = 0;
-            for (int t = 0; t < cnt; ++t) {
-                const float o = cand[t];
-                rank += (o < mine || (o == mine && t < lane)) ? 1 : 0;
-            }
-            const int want = target - cum;
-            const unsigned long long hit = __ballot(lane < cnt && rank == want);
-            const int src = __ffsll((long long)hit) - 1;
-            result = __shfl(mine, src, 64);
-            wave_lds_fence();
-            break;
-        }
-        // narrow to the bin's own value range and iterate
-        float nmn = INF, nmx = -INF;
-#pragma unroll
-        for (int t = 0; t < NV; ++t) {
-            if (x[t] >= mn && x[t] <= mx) {
-                int b = (int)((x[t] - mn) * scale);
-                b = b > SEL_BINS - 1 ? SEL_BINS - 1 : b;
-                if (b == binsel) { nmn = fminf(nmn, x[t]); nmx = fmaxf(nmx, x[t]); }
-            }
-        }
-        below += cum;
-        mn = wave_min(nmn);
-        mx = wave_max(nmx);
-        result = mn;
-        wave_lds_fence();
-    }
-    SelectResult res{result, 0, INF};
-    if (want_next) {
-        int cle = 0;
-        float nx = INF;
-#pragma unroll
-        for (int t = 0; t < NV; ++t) {
-            cle += (x[t] <= result) ? 1 : 0;
-            if (x[t] > result) nx = fminf(nx, x[t]);
-        }
-        res.cnt_le = wave_sum_i(cle);
-        res.next = wave_min(nx);
-    }
-    return res;
+    return wave_select_regs<NV>(x, k, hist, cand, counter, lane, want_next);
 }
 
 // largest f32 x with sqrt(x) <= eps (inclusive) or sqrt(x) < eps (exclusive); -1 if none
@@ -510,6 +554,334 @@ __global__ __launch_bounds__(256) void rowsel_kernel(const PairDesc *__restrict_
     if (lane == 0) {
         float *X = thr + P.offX;
         const int o = side ? P.pitchT + row : row;
+        X[o] = d2_threshold(eps, inclusive);
+        X[P.pitchT + P.pitchD + o] = eps;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K0b: embedded squared norms of every track of every pair (tiny): xx_i = tree over m frame
+// norms, each a 12-term fmaf chain over the (rotated) bins.  Written behind the thresholds
+// in the threshold arena: [.. 2 (pitchT + pitchD) ..][nq: pitchT][nr: pitchD].
+// ------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ pool,
+                                                    const int64_t *__restrict__ toff,
+                                                    const PairDesc *__restrict__ pd,
+                                                    float *__restrict__ thr, int oti_target)
+{
+    const PairDesc P = pd[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;     // 0 .. Mq + Mr
+    if (e >= P.Mq + P.Mr) return;
+    const bool isr = e >= P.Mq;
+    const int i = isr ? e - P.Mq : e;
+    const float *f = pool + toff[isr ? P.r : P.q] * NBIN + (size_t)i * NBIN;
+    const int rot = (isr == (oti_target == 0)) ? P.oti : 0;
+    float s[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        float v[NBIN];
+#pragma unroll
+        for (int c = 0; c < NBIN; ++c) v[c] = f[k * NBIN + c];
+        // chain over the ROTATED bin order: rotated[c'] = src[(c' - rot) mod 12]
+        float acc = 0.0f;
+        for (int cp = 0; cp < NBIN; ++cp) {
+            int c = cp - rot; if (c < 0) c += NBIN;
+            float x = v[0];
+#pragma unroll
+            for (int q = 1; q < NBIN; ++q) x = (c == q) ? v[q] : x;
+            acc = fmaf(x, x, acc);
+        }
+        s[k] = acc;
+    }
+    float *N = thr + P.offX + 2 * (P.pitchT + P.pitchD);
+    N[isr ? P.pitchT + i : i] = tree_sum<M>(s);
+}
+
+// ------------------------------------------------------------------------------------
+// K1': fused band kernel.  One workgroup (8 waves) owns a band of 8 rows of the embedded
+// distance matrix; the band is cut into tiles of 64 columns and WAVE w sweeps tiles
+// w, w+8, w+16, ... on its own -- there is no workgroup barrier inside the sweep:
+//   * the wave stages the tile's column frames into its private LDS slab (bin-major,
+//     un-rotated: the OTI rotation is applied by picking the operand ROW of the MFMA, so the
+//     k-order of the fmaf chain is still the rotated bin order of the arithmetic spec);
+//   * the (8+m-1) x (64+7+m-1) frame Gram is built on the matrix cores
+//     (v_mfma_f32_16x16x4_f32, K = 12 in 3 k-steps; row-frame operands stay in registers for
+//     the whole band) and parked in the wave's LDS slab;
+//   * lane c walks the 8 cells (a, c + a), a = 0..7, down one diagonal: m+7 LDS reads give
+//     all 8 window sums (doubling-tree subterms are shared between the cells); tile t
+//     therefore covers, for band row a, the 64 columns 64 t - 7 + a ...;
+//   * distances go (role 0) to the row-major D2 matrix in HBM, and into registers.
+// After the sweep the 8 waves exchange their pieces through LDS so that wave w holds band
+// row w completely (32 values per lane) and runs the exact percentile selection on it.
+// role 0: rows = query frames  -> writes D2 + the row thresholds.
+// role 1: rows = reference frames, columns = query frames (the transposed problem, same
+//         bits) -> writes only the column thresholds.  D2 is never re-read for thresholds
+//         and its transpose is never materialised.
+// ------------------------------------------------------------------------------------
+constexpr int BAND = 8;
+constexpr int BAND_THREADS = 512;   // 8 waves
+
+template <int M>
+struct BandGeom {
+    static constexpr int NRT = (BAND + M - 1 + 15) / 16;            // 16-row MFMA tiles of row frames
+    static constexpr int NCT = (64 + BAND - 1 + M - 1 + 15) / 16;   // 16-col MFMA tiles of column frames
+    static constexpr int AROWS = 16 * NRT;
+    static constexpr int BW = 16 * NCT;
+    static constexpr int AP = (AROWS % 32 == 16) ? AROWS : AROWS + 16;   // pitch % 32 == 16: the two
+    static constexpr int BP = (BW % 32 == 16) ? BW : BW + 16;            // k-halves hit different banks
+    static constexpr int SP = BW + 1;
+    static constexpr int WAVE_FLOATS = NBIN * BP + AROWS * SP + BW;  // Bs + S + column norms
+};
+
+// eps from the selected order statistics (oracle percentile_f32)
+__device__ __forceinline__ float percentile_eps(const SelectResult &sr, int pct_mode, int ilo, int ihi,
+                                                float kf, float fl, float ce)
+{
+    if (!(pct_mode == 0 || pct_mode == 1)) return __builtin_sqrtf(sr.value);
+    float shi = sr.value;
+    if (ihi != ilo && sr.cnt_le <= ihi) shi = sr.next;     // rank ihi is the next distinct value
+    const float dlo = __builtin_sqrtf(sr.value), dhi = __builtin_sqrtf(shi);
+    if (pct_mode == 0 && ihi == ilo) return dlo;
+    const float d0 = __fmul_rn(dlo, __fsub_rn(ce, kf));
+    const float d1 = __fmul_rn(dhi, __fsub_rn(kf, fl));
+    return __fadd_rn(d0, d1);
+}
+
+template <int M, int V4>
+__global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__restrict__ pool,
+                                                            const int64_t *__restrict__ toff,
+                                                            const PairDesc *__restrict__ pd,
+                                                            float *__restrict__ scratch,
+                                                            float *__restrict__ thr,
+                                                            float kappa, int pct_mode, int inclusive, int oti_target)
+{
+    using G = BandGeom<M>;
+    constexpr int NV = 4 * V4;           // values per lane of a complete row
+    constexpr int NSTEP = NV / 8;        // tiles per wave
+    constexpr int ROWP = 64 * NV + 4;    // exchange pitch (floats)
+    constexpr int SWEEP_FLOATS = NBIN * G::AP + 8 * G::WAVE_FLOATS;
+    constexpr int XCH_FLOATS = BAND * ROWP;
+    constexpr int SEL_FLOATS = 8 * SEL_SLOTS + 8 * 64 + 8;
+    constexpr int LDS_A = SWEEP_FLOATS > XCH_FLOATS ? SWEEP_FLOATS : XCH_FLOATS;
+    constexpr int LDS_FLOATS = LDS_A > SEL_FLOATS ? LDS_A : SEL_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+
+    const PairDesc P = pd[blockIdx.y];
+    const int role = blockIdx.z;
+    const int MA = role ? P.Mr : P.Mq, MB = role ? P.Mq : P.Mr;
+    const int TA = role ? P.Tr : P.Tq, TB = role ? P.Tq : P.Tr;
+    const int i0 = blockIdx.x * BAND;
+    if (i0 >= MA) return;     // block-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *fa = pool + toff[role ? P.r : P.q] * NBIN;
+    const float *fb = pool + toff[role ? P.q : P.r] * NBIN;
+    const bool rows_are_ref = role == 1;
+    const int rota = (rows_are_ref == (oti_target == 0)) ? P.oti : 0;
+    const int rotb = (rows_are_ref == (oti_target == 0)) ? 0 : P.oti;
+    const float *NRM = thr + P.offX + 2 * (P.pitchT + P.pitchD);
+    const float *nrow = role ? NRM + P.pitchT : NRM;   // embedded norms of the row track
+    const float *ncol = role ? NRM : NRM + P.pitchT;
+    const float INF = __builtin_inff();
+
+    float *As = smem;
+    float *Bw = smem + NBIN * G::AP + wave * G::WAVE_FLOATS;   // this wave's slab
+    float *Sw = Bw + NBIN * G::BP;
+    float *Yw = Sw + G::AROWS * G::SP;
+
+    // ---- stage the band's row frames once (bin-major, un-rotated)
+    for (int idx = tid; idx < G::AROWS * 3; idx += BAND_THREADS) {
+        const int a = idx / 3, part = idx - 3 * a;
+        const int f = i0 + a;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < TA) v = *reinterpret_cast<const float4 *>(fa + (size_t)f * NBIN + 4 * part);
+        As[(4 * part + 0) * G::AP + a] = v.x;
+        As[(4 * part + 1) * G::AP + a] = v.y;
+        As[(4 * part + 2) * G::AP + a] = v.z;
+        As[(4 * part + 3) * G::AP + a] = v.w;
+    }
+    __syncthreads();
+    // MFMA operands: position k of the chain holds rotated bin k = source bin (k - rot) mod 12
+    const int lr = lane & 15, lk = lane >> 4;
+    float areg[G::NRT][3];
+    int browoff[3];
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+        int ka = 4 * kb + lk - rota; if (ka < 0) ka += NBIN;
+        int kbb = 4 * kb + lk - rotb; if (kbb < 0) kbb += NBIN;
+        browoff[kb] = kbb * G::BP;
+#pragma unroll
+        for (int ta = 0; ta < G::NRT; ++ta) areg[ta][kb] = As[ka * G::AP + 16 * ta + lr];
+    }
+    float xrow[BAND];
+#pragma unroll
+    for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : 0.0f;
+
+    const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= NV by dispatch
+    const int pitchD = P.pitchD;
+    float *D = scratch + P.offD + (size_t)i0 * pitchD;
+
+    float xv[BAND][NSTEP];
+#pragma unroll
+    for (int a = 0; a < BAND; ++a)
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) xv[a][st] = INF;
+
+    // prefetch registers: the tile's BW column frames (lane = frame, 3 bin-quads; frames
+    // 64.. of the tile on the low lanes) + up to 2 column norms
+    constexpr int NF4 = 3 * ((G::BW + 63) / 64);
+    float4 pf[NF4];
+    float pn[2];
+    auto prefetch = [&](int tile) {
+        const int base = 64 * tile - (BAND - 1);
+#pragma unroll
+        for (int q = 0; q < NF4; ++q) {
+            const int a = lane + 64 * (q / 3), part = q % 3;
+            const int f = base + a;
+            pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile < ntiles && a < G::BW && f >= 0 && f < TB)
+                pf[q] = *reinterpret_cast<const float4 *>(fb + (size_t)f * NBIN + 4 * part);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = base + lane + 64 * q;
+            pn[q] = (tile < ntiles && lane + 64 * q < G::BW && j >= 0 && j < MB) ? ncol[j] : 0.0f;
+        }
+    };
+    prefetch(wave);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        const int tile = wave + 8 * st;
+        if (tile < ntiles) {      // wave-uniform
+            const int base = 64 * tile - (BAND - 1);
+            // ---- prefetched frames -> LDS slab
+#pragma unroll
+            for (int q = 0; q < NF4; ++q) {
+                const int a = lane + 64 * (q / 3), part = q % 3;
+                if (a < G::BW) {
+                    Bw[(4 * part + 0) * G::BP + a] = pf[q].x;
+                    Bw[(4 * part + 1) * G::BP + a] = pf[q].y;
+                    Bw[(4 * part + 2) * G::BP + a] = pf[q].z;
+                    Bw[(4 * part + 3) * G::BP + a] = pf[q].w;
+                }
+            }
+            Yw[lane] = pn[0];
+            if (lane + 64 < G::BW) Yw[lane + 64] = pn[1];
+            wave_lds_fence();
+            if (st + 1 < NSTEP) prefetch(tile + 8);
+            // ---- frame Gram on the matrix cores
+#ifndef ACX_ABL_NOGRAM
+#pragma unroll
+            for (int tb = 0; tb < G::NCT; ++tb) {
+                float bv[3];
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb) bv[kb] = Bw[browoff[kb] + 16 * tb + lr];
+#pragma unroll
+                for (int ta = 0; ta < G::NRT; ++ta) {
+                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int kb = 0; kb < 3; ++kb)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ta][kb], bv[kb], acc, 0, 0, 0);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        Sw[(16 * ta + 4 * lk + reg) * G::SP + 16 * tb + lr] = acc[reg];
+                }
+            }
+#endif
+            wave_lds_fence();
+            // ---- diagonal walk: 8 cells per lane
+            float sv[M + BAND - 1];
+#pragma unroll
+            for (int u = 0; u < M + BAND - 1; ++u) sv[u] = Sw[u * G::SP + lane + u];
+            float dv[BAND];
+#pragma unroll
+            for (int a = 0; a < BAND; ++a) {
+                const float xy = tree_sum<M>(sv + a);
+                const float nc_ = Yw[lane + a];
+                const float t1 = 2.0f * xy;
+                // query-side norm first: (xx - 2xy) + yy
+                float t3 = role ? ((nc_ - t1) + xrow[a]) : ((xrow[a] - t1) + nc_);
+                if (!(t3 > 0.0f)) t3 = 0.0f;
+                dv[a] = t3;
+            }
+            const int j0 = base + lane;                       // column of the lane's first cell
+            const bool interior = base >= 0 && base + 64 + BAND - 1 <= MB && i0 + BAND <= MA;   // wave-uniform
+            if (interior) {
+#pragma unroll
+                for (int a = 0; a < BAND; ++a) xv[a][st] = dv[a];
+#ifndef ACX_ABL_NOSTORE
+                if (role == 0) {
+                    float *Dl = D + j0;
+#pragma unroll
+                    for (int a = 0; a < BAND; ++a) Dl[a * pitchD + a] = dv[a];
+                }
+#endif
+            } else {
+#pragma unroll
+                for (int a = 0; a < BAND; ++a) {
+                    const int j = j0 + a;
+                    const bool rowok = (i0 + a) < MA;
+                    const bool ok = rowok && j >= 0 && j < MB;
+                    const float v = ok ? dv[a] : INF;
+                    xv[a][st] = v;
+                    if (role == 0 && rowok && j >= 0 && j < pitchD) D[a * pitchD + j] = v;
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+    // role 0: +inf into the pad columns [MB, pitchD) of the band's rows (K3 reads whole 8-column groups)
+    if (role == 0) {
+        const int npad = pitchD - MB;
+        for (int idx = tid; idx < BAND * npad; idx += BAND_THREADS) {
+            const int a = idx / npad, j = MB + idx - a * npad;
+            if (i0 + a < MA) D[a * pitchD + j] = INF;
+        }
+    }
+    __syncthreads();     // all slabs dead -> reuse LDS as the exchange buffer
+    // ---- exchange: element (tile, lane) of band row a -> X[a][64 tile + lane]
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        const int tile = wave + 8 * st;
+#pragma unroll
+        for (int a = 0; a < BAND; ++a) smem[a * ROWP + 64 * tile + lane] = xv[a][st];
+    }
+    __syncthreads();
+    float xr[NV];
+#pragma unroll
+    for (int q = 0; q < V4; ++q) {
+        const float4 t = *reinterpret_cast<const float4 *>(smem + wave * ROWP + 256 * q + 4 * lane);
+        xr[4 * q + 0] = t.x; xr[4 * q + 1] = t.y; xr[4 * q + 2] = t.z; xr[4 * q + 3] = t.w;
+    }
+    __syncthreads();     // exchange buffer dead -> reuse as histograms
+
+    // ---- exact percentile selection: wave w owns band row w
+    const int row = i0 + wave;
+    if (row >= MA) return;
+#ifdef ACX_ABL_NOSELECT
+    if (lane == 0) { float acc_ = 0; for (int e = 0; e < NV; ++e) acc_ += xr[e]; thr[P.offX + (role ? P.pitchT + row : row)] = acc_; }
+    return;
+#endif
+    unsigned *hist = reinterpret_cast<unsigned *>(smem) + wave * SEL_SLOTS;
+    float *cand = smem + 8 * SEL_SLOTS + wave * 64;
+    unsigned *counter = reinterpret_cast<unsigned *>(smem) + 8 * SEL_SLOTS + 8 * 64 + wave;
+    const int n = MB;
+    const float kf = (n > 1) ? __fmul_rn((float)(n - 1), kappa) : __fmul_rn((float)n, kappa);
+    const float fl = floorf(kf), ce = ceilf(kf);
+    int ilo = (int)fl, ihi = (int)ce;
+    ilo = ilo < 0 ? 0 : (ilo > n - 1 ? n - 1 : ilo);
+    ihi = ihi < 0 ? 0 : (ihi > n - 1 ? n - 1 : ihi);
+    int k = ilo;
+    if (pct_mode == 3) {
+        k = (int)floorf(__fadd_rn(kf, 0.5f));
+        k = k > n - 1 ? n - 1 : k;
+    }
+    const bool interp = (pct_mode == 0 || pct_mode == 1);
+    const SelectResult sr = wave_select_regs<NV>(xr, k, hist, cand, counter, lane, interp);
+    const float eps = percentile_eps(sr, pct_mode, ilo, ihi, kf, fl, ce);
+    if (lane == 0) {
+        float *X = thr + P.offX;
+        const int o = role ? P.pitchT + row : row;
         X[o] = d2_threshold(eps, inclusive);
         X[P.pitchT + P.pitchD + o] = eps;
     }

@@ -40,7 +40,10 @@ M_STACK = 9
 # algorithmic bytes per matrix cell by kernel (DESIGN.md "Roofline model"; SURVEY.md 8d:
 # 10 B/cell = f32 distance matrix written once + read once, 1-byte recurrence matrix
 # written once + read once)
-ALGO_BYTES_PER_CELL = {"csm_tile_kernel": 4.0, "rowsel_kernel": 4.0, "qmax_kernel": 2.0, "oti_kernel": 0.0}
+# band_kernel = distance matrix + both threshold passes fused (it replaces the v1 pair
+# csm_tile_kernel 4 B/cell + rowsel_kernel 4 B/cell); qmax_kernel = recurrence plot + DP.
+ALGO_BYTES_PER_CELL = {"band_kernel": 8.0, "csm_tile_kernel": 4.0, "rowsel_kernel": 4.0, "qmax_kernel": 2.0,
+                       "oti_kernel": 0.0, "norms_kernel": 0.0}
 
 
 def chain_bytes_per_pair(Tq, Tr, m=M_STACK):
@@ -124,7 +127,7 @@ def main():
         cells_per_launch = kst["cells"] / launches
         avg_ms = kst["ms"] / launches
         algo_bytes = ALGO_BYTES_PER_CELL[kname] * cells_per_launch
-        if kname == "csm_tile_kernel":
+        if kname in ("csm_tile_kernel", "band_kernel"):
             algo_bytes += 48.0 * 2 * T_FRAMES * (cells_per_launch / float((T_FRAMES - M_STACK) ** 2))
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
