@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace acx {
 
@@ -629,9 +630,10 @@ struct BandGeom {
     static constexpr int AROWS = 16 * NRT;
     static constexpr int BW = 16 * NCT;
     static constexpr int AP = (AROWS % 32 == 16) ? AROWS : AROWS + 16;   // pitch % 32 == 16: the two
-    static constexpr int BP = (BW % 32 == 16) ? BW : BW + 16;            // k-halves hit different banks
     static constexpr int SP = BW + 1;
-    static constexpr int WAVE_FLOATS = NBIN * BP + AROWS * SP + BW;  // Bs + S + column norms
+    static constexpr int NPIECE = (BW * 3 + 63) / 64;               // 16-byte LDS-DMA pieces per lane per tile
+    static constexpr int BFLOATS = 256 * NPIECE;                    // frame-major column-frame slab (DMA image)
+    static constexpr int WAVE_FLOATS = BFLOATS + AROWS * SP + 2 * BW;  // frames + S + column norms (x2)
 };
 
 // eps from the selected order statistics (oracle percentile_f32)
@@ -673,7 +675,8 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     const int TA = role ? P.Tr : P.Tq, TB = role ? P.Tq : P.Tr;
     const int i0 = blockIdx.x * BAND;
     if (i0 >= MA) return;     // block-uniform
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: everything derived from it is scalar
     const float *fa = pool + toff[role ? P.r : P.q] * NBIN;
     const float *fb = pool + toff[role ? P.q : P.r] * NBIN;
     const bool rows_are_ref = role == 1;
@@ -685,9 +688,9 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     const float INF = __builtin_inff();
 
     float *As = smem;
-    float *Bw = smem + NBIN * G::AP + wave * G::WAVE_FLOATS;   // this wave's slab
-    float *Sw = Bw + NBIN * G::BP;
-    float *Yw = Sw + G::AROWS * G::SP;
+    float *Bw = smem + NBIN * G::AP + wave * G::WAVE_FLOATS;   // this wave's slab: frames (frame-major)
+    float *Sw = Bw + G::BFLOATS;                               // Gram tile
+    float *Yw = Sw + G::AROWS * G::SP;                         // column norms, double-buffered
 
     // ---- stage the band's row frames once (bin-major, un-rotated)
     for (int idx = tid; idx < G::AROWS * 3; idx += BAND_THREADS) {
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     for (int kb = 0; kb < 3; ++kb) {
         int ka = 4 * kb + lk - rota; if (ka < 0) ka += NBIN;
         int kbb = 4 * kb + lk - rotb; if (kbb < 0) kbb += NBIN;
-        browoff[kb] = kbb * G::BP;
+        browoff[kb] = kbb + lr * NBIN;       // frame-major slab: element (frame, bin) at frame*12 + bin
 #pragma unroll
         for (int ta = 0; ta < G::NRT; ++ta) areg[ta][kb] = As[ka * G::AP + 16 * ta + lr];
     }
@@ -727,83 +730,104 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) xv[a][st] = INF;
 
-    // prefetch registers: the tile's BW column frames (lane = frame, 3 bin-quads; frames
-    // 64.. of the tile on the low lanes) + up to 2 column norms
-    constexpr int NF4 = 3 * ((G::BW + 63) / 64);
-    float4 pf[NF4];
-    float pn[2];
-    auto prefetch = [&](int tile) {
+    // Column frames + norms of a tile go HBM/L2 -> LDS by LDS-DMA (global_load_lds): the slab is
+    // a straight image of the frame memory (lane-linear 16-byte pieces), no VGPR round trip and
+    // no ds_write.  Pieces of frames outside the track are skipped (their cells are masked).
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto dma_tile = [&](int tile, int ybuf) {
+        if (tile >= ntiles) return;
         const int base = 64 * tile - (BAND - 1);
+        const float *src = fb + (ptrdiff_t)base * NBIN + 4 * lane;
+        const float *nsrc = ncol + base + lane;
+        float *ydst = Yw + ybuf * G::BW;
+        if (base >= 0 && base + G::BW <= TB && base + G::BW <= MB) {      // wave-uniform: all frames exist
 #pragma unroll
-        for (int q = 0; q < NF4; ++q) {
-            const int a = lane + 64 * (q / 3), part = q % 3;
-            const int f = base + a;
-            pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tile < ntiles && a < G::BW && f >= 0 && f < TB)
-                pf[q] = *reinterpret_cast<const float4 *>(fb + (size_t)f * NBIN + 4 * part);
-        }
+            for (int q = 0; q < G::NPIECE; ++q)
+                if (64 * q + 64 <= G::BW * 3 || lane + 64 * q < G::BW * 3)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(src + 256 * q), (lds_void *)(Bw + 256 * q), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)nsrc, (lds_void *)ydst, 4, 0, 0);
+            if (G::BW > 64 && lane + 64 < G::BW)
+                __builtin_amdgcn_global_load_lds((glb_void *)(nsrc + 64), (lds_void *)(ydst + 64), 4, 0, 0);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int j = base + lane + 64 * q;
-            pn[q] = (tile < ntiles && lane + 64 * q < G::BW && j >= 0 && j < MB) ? ncol[j] : 0.0f;
+            for (int q = 0; q < G::NPIECE; ++q) {
+                const int pidx = lane + 64 * q;
+                const int f = base + pidx / 3;
+                if (pidx < G::BW * 3 && f >= 0 && f < TB)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(src + 256 * q), (lds_void *)(Bw + 256 * q), 16, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int idx = lane + 64 * q;
+                const int j = base + idx;
+                if (idx < G::BW && j >= 0 && j < MB)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(nsrc + 64 * q), (lds_void *)(ydst + 64 * q), 4, 0, 0);
+            }
         }
     };
-    prefetch(wave);
+    dma_tile(wave, 0);
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
         const int tile = wave + 8 * st;
         if (tile < ntiles) {      // wave-uniform
             const int base = 64 * tile - (BAND - 1);
-            // ---- prefetched frames -> LDS slab
-#pragma unroll
-            for (int q = 0; q < NF4; ++q) {
-                const int a = lane + 64 * (q / 3), part = q % 3;
-                if (a < G::BW) {
-                    Bw[(4 * part + 0) * G::BP + a] = pf[q].x;
-                    Bw[(4 * part + 1) * G::BP + a] = pf[q].y;
-                    Bw[(4 * part + 2) * G::BP + a] = pf[q].z;
-                    Bw[(4 * part + 3) * G::BP + a] = pf[q].w;
-                }
-            }
-            Yw[lane] = pn[0];
-            if (lane + 64 < G::BW) Yw[lane + 64] = pn[1];
+            const float *Yt = Yw + (st & 1) * G::BW;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's DMA has landed
             wave_lds_fence();
-            if (st + 1 < NSTEP) prefetch(tile + 8);
             // ---- frame Gram on the matrix cores
 #ifndef ACX_ABL_NOGRAM
+            {
+                // all column tiles in flight at once: operand loads first, then the MFMA chains
+                // interleaved k-step-major so that no MFMA waits on its predecessor
+                float bv[G::NCT][3];
 #pragma unroll
-            for (int tb = 0; tb < G::NCT; ++tb) {
-                float bv[3];
+                for (int tb = 0; tb < G::NCT; ++tb)
 #pragma unroll
-                for (int kb = 0; kb < 3; ++kb) bv[kb] = Bw[browoff[kb] + 16 * tb + lr];
+                    for (int kb = 0; kb < 3; ++kb) bv[tb][kb] = Bw[browoff[kb] + 16 * NBIN * tb];
+                f32x4 acc[G::NRT][G::NCT];
 #pragma unroll
-                for (int ta = 0; ta < G::NRT; ++ta) {
-                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int ta = 0; ta < G::NRT; ++ta)
 #pragma unroll
-                    for (int kb = 0; kb < 3; ++kb)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ta][kb], bv[kb], acc, 0, 0, 0);
+                    for (int tb = 0; tb < G::NCT; ++tb) acc[ta][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        Sw[(16 * ta + 4 * lk + reg) * G::SP + 16 * tb + lr] = acc[reg];
-                }
+                for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                    for (int ta = 0; ta < G::NRT; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < G::NCT; ++tb)
+                            acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ta][kb], bv[tb][kb], acc[ta][tb], 0, 0, 0);
+#pragma unroll
+                for (int ta = 0; ta < G::NRT; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < G::NCT; ++tb)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            Sw[(16 * ta + 4 * lk + reg) * G::SP + 16 * tb + lr] = acc[ta][tb][reg];
             }
 #endif
             wave_lds_fence();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operand reads done: slab is free
+            if (st + 1 < NSTEP) dma_tile(tile + 8, (st + 1) & 1);
             // ---- diagonal walk: 8 cells per lane
             float sv[M + BAND - 1];
 #pragma unroll
             for (int u = 0; u < M + BAND - 1; ++u) sv[u] = Sw[u * G::SP + lane + u];
             float dv[BAND];
+            auto dist = [&](auto role_tag) {
+                constexpr bool R1 = decltype(role_tag)::value;
 #pragma unroll
-            for (int a = 0; a < BAND; ++a) {
-                const float xy = tree_sum<M>(sv + a);
-                const float nc_ = Yw[lane + a];
-                const float t1 = 2.0f * xy;
-                // query-side norm first: (xx - 2xy) + yy
-                float t3 = role ? ((nc_ - t1) + xrow[a]) : ((xrow[a] - t1) + nc_);
-                if (!(t3 > 0.0f)) t3 = 0.0f;
-                dv[a] = t3;
-            }
+                for (int a = 0; a < BAND; ++a) {
+                    const float xy = tree_sum<M>(sv + a);
+                    const float nc_ = Yt[lane + a];
+                    const float t1 = 2.0f * xy;
+                    // query-side norm first: (xx - 2xy) + yy
+                    float t3 = R1 ? ((nc_ - t1) + xrow[a]) : ((xrow[a] - t1) + nc_);
+                    if (!(t3 > 0.0f)) t3 = 0.0f;
+                    dv[a] = t3;
+                }
+            };
+            if (role) dist(std::true_type()); else dist(std::false_type());   // block-uniform
             const int j0 = base + lane;                       // column of the lane's first cell
             const bool interior = base >= 0 && base + 64 + BAND - 1 <= MB && i0 + BAND <= MA;   // wave-uniform
             if (interior) {
