@@ -23,7 +23,7 @@ EXPORTS = [
     "acx_abi_version", "acx_create", "acx_destroy", "acx_last_error", "acx_set_scratch_limit",
     "acx_upload_pool", "acx_serra09_default_params", "acx_serra09_pairs", "acx_serra09_debug_pair",
     "acx_serra09_embed_len", "acx_profile_enable", "acx_profile_reset", "acx_profile_count",
-    "acx_profile_get", "acx_debug_sqrt",
+    "acx_profile_get", "acx_debug_sqrt", "acx_upload_pool_f64", "acx_simple_pairs",
 ]
 
 
@@ -80,6 +80,9 @@ def load():
     L.acx_profile_get.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_double), lp, lp]
     L.acx_debug_sqrt.argtypes = [vp, fp, ctypes.c_int64, fp]
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.acx_upload_pool_f64.argtypes = [vp, dp, lp, ctypes.c_int32, ctypes.c_int32]
+    L.acx_simple_pairs.argtypes = [vp, ip, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, dp]
     _lib = L
     return L
 
@@ -147,6 +150,24 @@ class Context(object):
                                             len(offsets) - 1, frames.shape[1]))
         self.n_tracks = len(offsets) - 1
         self.lengths = np.diff(offsets)
+
+    def upload_pool_f64(self, frames, offsets):
+        """SiMPle features: (sum n_i, 12) f64 time-major + offsets."""
+        frames = np.ascontiguousarray(frames, dtype=np.float64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if frames.ndim != 2 or offsets.ndim != 1 or offsets[-1] != frames.shape[0]:
+            raise ValueError("upload_pool_f64: frames must be (sum n, 12) and offsets (n+1,)")
+        self._check(self._L.acx_upload_pool_f64(self._h, frames.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                len(offsets) - 1, frames.shape[1]))
+
+    def simple_pairs(self, pairs, sslen=10, oti=True):
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        out = np.empty(len(pairs), np.float64)
+        self._check(self._L.acx_simple_pairs(self._h, pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                             len(pairs), int(sslen), int(bool(oti)),
+                                             out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return out
 
     def serra09_pairs(self, pairs, params=None):
         p = params or serra09_params()

@@ -15,6 +15,7 @@
 
 #include "../../include/acx.h"
 #include "serra09_kernels.hpp"
+#include "simple_kernels.hpp"
 
 using acx::PairDesc;
 
@@ -28,7 +29,7 @@ struct KStat {
     int64_t launches;
     int64_t cells;
 };
-enum { KS_OTI = 0, KS_NORMS, KS_BAND, KS_CSM, KS_SEL, KS_QMAX, KS_COUNT };
+enum { KS_OTI = 0, KS_NORMS, KS_BAND, KS_CSM, KS_SEL, KS_QMAX, KS_SIMPLE, KS_COUNT };
 
 struct PendingEvent {
     hipEvent_t a, b;
@@ -48,6 +49,14 @@ struct acx_ctx {
     float *d_gch = nullptr;
     std::vector<int64_t> h_off;
     int32_t n_tracks = 0, dim = 0;
+    // f64 pool (SiMPle)
+    double *d_frames64 = nullptr;
+    int64_t *d_toff64 = nullptr;
+    double *d_prof64 = nullptr;
+    std::vector<int64_t> h_off64;
+    int32_t n_tracks64 = 0;
+    int32_t *d_pairs = nullptr; size_t pairs_cap = 0;
+    double *d_out64 = nullptr;  size_t out64_cap = 0;
     // scratch (grow-only)
     float *d_scratch = nullptr; size_t scratch_cap = 0;   // floats
     float *d_thr = nullptr;     size_t thr_cap = 0;
@@ -58,7 +67,8 @@ struct acx_ctx {
     // profiling
     bool prof = false;
     KStat stats[KS_COUNT] = {{"oti_kernel", 0, 0, 0}, {"norms_kernel", 0, 0, 0}, {"band_kernel", 0, 0, 0},
-                             {"csm_tile_kernel", 0, 0, 0}, {"rowsel_kernel", 0, 0, 0}, {"qmax_kernel", 0, 0, 0}};
+                             {"csm_tile_kernel", 0, 0, 0}, {"rowsel_kernel", 0, 0, 0}, {"qmax_kernel", 0, 0, 0},
+                             {"simple_kernel", 0, 0, 0}};
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
 };
@@ -365,6 +375,15 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
 
 }  // namespace
 
+template <int L>
+int launch_simple(acx_ctx *c, int n, size_t smem, int oti)
+{
+    auto kern = acx::simple_kernel<L>;
+    ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(n), dim3(256), smem, c->stream, c->d_frames64, c->d_toff64, c->d_prof64, c->d_pairs, c->d_out64, oti);
+    return ACX_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
@@ -413,6 +432,11 @@ void acx_destroy(acx_ctx *c)
     if (c->d_thr) (void)hipFree(c->d_thr);
     if (c->d_pd) (void)hipFree(c->d_pd);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_frames64) (void)hipFree(c->d_frames64);
+    if (c->d_toff64) (void)hipFree(c->d_toff64);
+    if (c->d_prof64) (void)hipFree(c->d_prof64);
+    if (c->d_pairs) (void)hipFree(c->d_pairs);
+    if (c->d_out64) (void)hipFree(c->d_out64);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -499,6 +523,79 @@ int acx_serra09_debug_pair(acx_ctx *c, int32_t i, int32_t j, const acx_serra09_p
     int rc = run_serra09(c, pr, 1, *params, &s, &dbg);
     if (rc == ACX_OK && score) *score = s;
     return rc;
+}
+
+int acx_upload_pool_f64(acx_ctx *c, const double *frames, const int64_t *offsets, int32_t n_tracks, int32_t dim)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!frames || !offsets || n_tracks <= 0 || dim != 12) return fail(c, ACX_ERR_INVALID, "upload_pool_f64: bad argument (dim must be 12)");
+    if (offsets[0] != 0) return fail(c, ACX_ERR_INVALID, "upload_pool_f64: offsets[0] must be 0");
+    for (int i = 0; i < n_tracks; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(c, ACX_ERR_INVALID, "upload_pool_f64: offsets must be non-decreasing");
+    ACX_HIP(c, hipSetDevice(c->device));
+    if (c->d_frames64) { (void)hipFree(c->d_frames64); c->d_frames64 = nullptr; }
+    if (c->d_toff64) { (void)hipFree(c->d_toff64); c->d_toff64 = nullptr; }
+    if (c->d_prof64) { (void)hipFree(c->d_prof64); c->d_prof64 = nullptr; }
+    const int64_t total = offsets[n_tracks];
+    c->h_off64.assign(offsets, offsets + n_tracks + 1);
+    c->n_tracks64 = n_tracks;
+    // per-track chroma profile: sum over time (np.sum(seq, 1), simple_silva.py:46-47)
+    std::vector<double> prof((size_t)n_tracks * 12, 0.0);
+    for (int t = 0; t < n_tracks; ++t)
+        for (int64_t f = offsets[t]; f < offsets[t + 1]; ++f)
+            for (int b = 0; b < 12; ++b) prof[(size_t)t * 12 + b] += frames[f * 12 + b];
+    ACX_HIP(c, hipMalloc((void **)&c->d_frames64, sizeof(double) * std::max<int64_t>(1, total) * 12));
+    ACX_HIP(c, hipMalloc((void **)&c->d_toff64, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIP(c, hipMalloc((void **)&c->d_prof64, sizeof(double) * prof.size()));
+    ACX_HIP(c, hipMemcpy(c->d_frames64, frames, sizeof(double) * total * 12, hipMemcpyHostToDevice));
+    ACX_HIP(c, hipMemcpy(c->d_toff64, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    ACX_HIP(c, hipMemcpy(c->d_prof64, prof.data(), sizeof(double) * prof.size(), hipMemcpyHostToDevice));
+    return ACX_OK;
+}
+
+int acx_simple_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, int32_t sslen, int32_t oti, double *out)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (K < 0 || (K > 0 && (!pairs || !out))) return fail(c, ACX_ERR_INVALID, "simple_pairs: bad argument");
+    if (K == 0) return ACX_OK;
+    if (!c->d_frames64) return fail(c, ACX_ERR_STATE, "simple_pairs: f64 feature pool not uploaded (acx_upload_pool_f64)");
+    if (sslen < 1 || sslen > acx::SIMPLE_MAXL) return fail(c, ACX_ERR_UNSUPPORTED, "simple_pairs: SSLEN must be in 1..16 on the device");
+    ACX_HIP(c, hipSetDevice(c->device));
+    int maxn = 0;
+    for (int64_t k = 0; k < K; ++k) {
+        for (int s = 0; s < 2; ++s) {
+            const int t = pairs[2 * k + s];
+            if (t < 0 || t >= c->n_tracks64) return fail(c, ACX_ERR_INVALID, "simple_pairs: track index out of range in pair " + std::to_string(k));
+            const int n = (int)(c->h_off64[t + 1] - c->h_off64[t]);
+            if (n < sslen) return fail(c, ACX_ERR_SHORT, "simple_pairs: track shorter than SSLEN (pair " + std::to_string(k) + ")");
+            if (n > acx::SIMPLE_MAXN) return fail(c, ACX_ERR_UNSUPPORTED, "simple_pairs: tracks with more than 512 pooled frames are not supported on the device yet");
+            maxn = std::max(maxn, n);
+        }
+    }
+    const size_t smem = 32 + sizeof(double) * ((size_t)2 * maxn * 12 + 3 * (size_t)maxn);
+    const int64_t chunk = 1 << 22;
+    int rc;
+    if ((rc = ensure(c, c->d_pairs, c->pairs_cap, (size_t)2 * std::min(K, chunk))) != ACX_OK) return rc;
+    if ((rc = ensure(c, c->d_out64, c->out64_cap, (size_t)std::min(K, chunk))) != ACX_OK) return rc;
+    for (int64_t k0 = 0; k0 < K; k0 += chunk) {
+        const int n = (int)std::min(chunk, K - k0);
+        ACX_HIP(c, hipMemcpyAsync(c->d_pairs, pairs + 2 * k0, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, c->stream));
+        {
+            ProfScope ps(c, KS_SIMPLE, n);
+            switch (sslen) {
+#define ACX_L(L_) case L_: rc = launch_simple<L_>(c, n, smem, oti); break;
+                ACX_L(1) ACX_L(2) ACX_L(3) ACX_L(4) ACX_L(5) ACX_L(6) ACX_L(7) ACX_L(8)
+                ACX_L(9) ACX_L(10) ACX_L(11) ACX_L(12) ACX_L(13) ACX_L(14) ACX_L(15) ACX_L(16)
+#undef ACX_L
+            }
+            if (rc != ACX_OK) return rc;
+        }
+        ACX_HIP(c, hipGetLastError());
+        ACX_HIP(c, hipMemcpyAsync(out + k0, c->d_out64, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        ACX_HIP(c, hipStreamSynchronize(c->stream));
+        drain_profile(c);
+    }
+    return ACX_OK;
 }
 
 int acx_profile_enable(acx_ctx *c, int on)

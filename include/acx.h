@@ -115,6 +115,27 @@ int acx_serra09_debug_pair(acx_ctx *ctx, int32_t i, int32_t j,
 /* Number of embedded frames for a pooled length T (0 if too short). */
 int32_t acx_serra09_embed_len(int32_t T, const acx_serra09_params *params);
 
+/* ---- SiMPle (similarity matrix profile) ---------------------------------- */
+
+/*
+ * Pool of SiMPle features in f64: `frames` is row-major (sum_i n_i, 12), TIME-major --
+ * frame t of track i is the column t of what Simple.load_features(i) returns
+ * (simple_silva.py:34-43: WIN/SKIP mean pooling + Hann smoothing + L2 column norm, done by
+ * the host).  Independent of the f32 pool of acx_upload_pool.
+ */
+int acx_upload_pool_f64(acx_ctx *ctx, const double *frames, const int64_t *offsets,
+                        int32_t n_tracks, int32_t dim);
+
+/*
+ * out[k] = -median(matrix profile) of the ORDERED pair (pairs[2k], pairs[2k+1]): OTI of the
+ * second track toward the first, then simple_sim -- the value Simple.similarity() stores into
+ * Ds['main'][i, j] (simple_silva.py:45-54, 68-126).  f64 like the reference.  sslen = SSLEN
+ * (default 10, <= 16); tracks need sslen <= n_i <= 512 pooled frames.  oti = 0 skips the
+ * transposition (Simple.simple_sim alone, simple_silva.py:68).
+ */
+int acx_simple_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, int32_t sslen, int32_t oti,
+                     double *out);
+
 /* ---- measurement -------------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on the library's own stream around

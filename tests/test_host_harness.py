@@ -154,3 +154,22 @@ def test_benchmark_rejects_unknown_algorithm(tmp_path, monkeypatch):
     with pytest.raises(NotImplementedError):
         acoss_amd.benchmark("x.csv", "feat/", algorithm="FTM2D")
     assert "Serra09" in acoss_amd.algorithm_names and "SiMPle" in acoss_amd.algorithm_names
+
+
+def test_simple_host_feature_prep_matches_reference(golden, tmp_path, monkeypatch):
+    """Simple.load_features / smooth / oti (host side of a11-a12) against the goldens captured
+    from the reference class (simple_silva.py:34-66)."""
+    from acoss_amd.algorithms.simple_silva import Simple
+    g = golden("simple")
+    csv, root = _toy_dataset(tmp_path, ["w"])
+    save_track(root + "w/t0.h5", {"label": "w", "track_id": "t0", "hpcp": g["feat_in"]})
+    monkeypatch.chdir(tmp_path)
+    s = Simple(csv, root, chroma_type="hpcp", shortname="toy")
+    assert (s.name, s.SSLEN, s.WIN, s.SKIP) == ("SiMPle", 10, 200, 100)
+    np.testing.assert_allclose(s.smooth(g["smooth_in"]), g["smooth_out"], rtol=1e-12, atol=1e-14)
+    f = s.load_features(0)
+    np.testing.assert_allclose(f, g["feat_out"], rtol=1e-10, atol=1e-12)
+    assert s.load_features(0) is f                      # cached (the reference re-reads per pair)
+    for k in range(6):
+        Bo, order = s.oti(g["sim_A_%d" % k], g["sim_B_%d" % k])
+        assert int(order[-1]) == int(g["oti_shift_%d" % k]) and np.array_equal(Bo, g["oti_B_%d" % k])
