@@ -24,11 +24,17 @@ EXPORTS = [
     "acx_upload_pool", "acx_serra09_default_params", "acx_serra09_pairs", "acx_serra09_debug_pair",
     "acx_serra09_embed_len", "acx_profile_enable", "acx_profile_reset", "acx_profile_count",
     "acx_profile_get", "acx_debug_sqrt", "acx_upload_pool_f64", "acx_simple_pairs",
+    "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
 ]
 
 
 class AcxError(RuntimeError):
     """A libacx call failed (HIP error, missing device, out of device memory ...)."""
+
+
+class EfParams(ctypes.Structure):
+    """acx_ef_params (include/acx.h); defaults = EarlyFusion ctor, earlyfusion_traile.py:44-45."""
+    _fields_ = [("kappa", ctypes.c_double), ("K", ctypes.c_int32)]
 
 
 class Serra09Params(ctypes.Structure):
@@ -83,6 +89,11 @@ def load():
     dp = ctypes.POINTER(ctypes.c_double)
     L.acx_upload_pool_f64.argtypes = [vp, dp, lp, ctypes.c_int32, ctypes.c_int32]
     L.acx_simple_pairs.argtypes = [vp, ip, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, dp]
+    ep = ctypes.POINTER(EfParams)
+    L.acx_ef_upload_pool.argtypes = [vp, fp, fp, fp, dp, lp, ctypes.c_int32, ip]
+    L.acx_earlyfusion_pairs.argtypes = [vp, ip, ctypes.c_int64, ep, fp]
+    L.acx_ef_debug_pair.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ep, fp, fp, fp, ip]
+    L.acx_sw_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, fp]
     _lib = L
     return L
 
@@ -168,6 +179,50 @@ class Context(object):
                                              len(pairs), int(sslen), int(bool(oti)),
                                              out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return out
+
+    def ef_upload_pool(self, tracks):
+        """tracks: list of dicts with mfccs (nb,650), ssms (nb,1225), chromas (nb,480) f32 and
+        chroma_med (12,) -- the block features of EarlyFusion.load_features."""
+        nb = np.array([t["mfccs"].shape[0] for t in tracks], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
+        mats = [np.ascontiguousarray(np.concatenate([t[k] for t in tracks], axis=0), dtype=np.float32)
+                for k in ("mfccs", "ssms", "chromas")]
+        med = np.ascontiguousarray(np.stack([np.asarray(t["chroma_med"], dtype=np.float64) for t in tracks]))
+        dims = (ctypes.c_int32 * 3)(*[m.shape[1] for m in mats])
+        self._check(self._L.acx_ef_upload_pool(self._h, _fptr(mats[0]), _fptr(mats[1]), _fptr(mats[2]),
+                                               med.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                               offs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(tracks), dims))
+        self.ef_blocks = nb
+
+    def earlyfusion_pairs(self, pairs, kappa=0.1, K=10):
+        """(n, 4) scores: mfccs, ssms, chromas, early."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        out = np.empty((len(pairs), 4), np.float32)
+        p = EfParams(float(kappa), int(K))
+        self._check(self._L.acx_earlyfusion_pairs(self._h, pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                  len(pairs), ctypes.byref(p), _fptr(out)))
+        return out
+
+    def ef_debug_pair(self, i, j, kappa=0.1, K=10):
+        M, N = int(self.ef_blocks[i]), int(self.ef_blocks[j])
+        csm = np.empty((3, M, N), np.float32)
+        fused = np.empty((M, N), np.float32)
+        sc = np.empty(4, np.float32)
+        oti = ctypes.c_int32(0)
+        p = EfParams(float(kappa), int(K))
+        self._check(self._L.acx_ef_debug_pair(self._h, int(i), int(j), ctypes.byref(p), _fptr(csm), _fptr(fused),
+                                              _fptr(sc), ctypes.byref(oti)))
+        return dict(csm=csm, fused=fused, scores=sc, oti=int(oti.value))
+
+    def sw_binary(self, B):
+        B = np.ascontiguousarray(B, dtype=np.uint8)
+        sc = ctypes.c_float(0)
+        rc = self._L.acx_sw_binary(self._h, B.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), B.shape[0], B.shape[1],
+                                   ctypes.byref(sc))
+        if rc == ACX_ERR_INVALID and b"Non-binary" in (self._L.acx_last_error(self._h) or b""):
+            raise IOError("Non-binary elements found in input")       # alignment_tools.py:23
+        self._check(rc)
+        return float(sc.value)
 
     def serra09_pairs(self, pairs, params=None):
         p = params or serra09_params()

@@ -16,6 +16,7 @@
 #include "../../include/acx.h"
 #include "serra09_kernels.hpp"
 #include "simple_kernels.hpp"
+#include "ef_kernels.hpp"
 
 using acx::PairDesc;
 
@@ -29,7 +30,7 @@ struct KStat {
     int64_t launches;
     int64_t cells;
 };
-enum { KS_OTI = 0, KS_NORMS, KS_BAND, KS_CSM, KS_SEL, KS_QMAX, KS_SIMPLE, KS_COUNT };
+enum { KS_OTI = 0, KS_NORMS, KS_BAND, KS_CSM, KS_SEL, KS_QMAX, KS_SIMPLE, KS_EFGEMM, KS_EFSTAT, KS_EFFUSE, KS_EFSW, KS_COUNT };
 
 struct PendingEvent {
     hipEvent_t a, b;
@@ -57,6 +58,15 @@ struct acx_ctx {
     int32_t n_tracks64 = 0;
     int32_t *d_pairs = nullptr; size_t pairs_cap = 0;
     double *d_out64 = nullptr;  size_t out64_cap = 0;
+    // EarlyFusion pool
+    float *d_ef[3] = {nullptr, nullptr, nullptr};
+    float *d_efn[2] = {nullptr, nullptr};
+    double *d_efmed = nullptr;
+    int64_t *d_efoff = nullptr;
+    std::vector<int64_t> h_efoff;
+    int32_t ef_ntracks = 0;
+    int32_t ef_dims[3] = {0, 0, 0};
+    acx::EfPair *d_efpd = nullptr; size_t efpd_cap = 0;
     // scratch (grow-only)
     float *d_scratch = nullptr; size_t scratch_cap = 0;   // floats
     float *d_thr = nullptr;     size_t thr_cap = 0;
@@ -68,7 +78,8 @@ struct acx_ctx {
     bool prof = false;
     KStat stats[KS_COUNT] = {{"oti_kernel", 0, 0, 0}, {"norms_kernel", 0, 0, 0}, {"band_kernel", 0, 0, 0},
                              {"csm_tile_kernel", 0, 0, 0}, {"rowsel_kernel", 0, 0, 0}, {"qmax_kernel", 0, 0, 0},
-                             {"simple_kernel", 0, 0, 0}};
+                             {"simple_kernel", 0, 0, 0}, {"ef_gemm_kernel", 0, 0, 0}, {"ef_rowstat_kernel", 0, 0, 0},
+                             {"ef_fuse_kernel", 0, 0, 0}, {"sw_kernel", 0, 0, 0}};
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
 };
@@ -375,6 +386,141 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------
+// EarlyFusion driver
+// ---------------------------------------------------------------------------------------
+struct EfDebug { float *csm, *fused; int32_t *oti; };
+
+int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, float *out, const EfDebug *dbg,
+           const float *ext_matrix, int extM, int extN)
+{
+    using acx::EfPair;
+    if (!ext_matrix && !c->d_ef[0]) return fail(c, ACX_ERR_STATE, "earlyfusion: block-feature pool not uploaded (acx_ef_upload_pool)");
+    if (!(p.kappa >= 0.0)) return fail(c, ACX_ERR_INVALID, "earlyfusion: kappa must be >= 0");
+    if (p.K < 1) return fail(c, ACX_ERR_INVALID, "earlyfusion: K must be >= 1");
+    ACX_HIP(c, hipSetDevice(c->device));
+    int64_t limit = c->scratch_limit;
+    if (limit <= 0) {
+        const char *env = getenv("ACX_SCRATCH_GB");
+        if (env && atof(env) > 0) limit = (int64_t)(atof(env) * (double)(1ull << 30));
+        else limit = (int64_t)(0.40 * (double)c->total_mem);
+    }
+    const int64_t limit_floats = limit / 4;
+    std::vector<EfPair> pd;
+    int rc;
+    int64_t k0 = 0;
+    while (k0 < K) {
+        pd.clear();
+        int64_t used = 0, used_s = 0, cells = 0;
+        int maxM = 0, maxN = 0;
+        int64_t k = k0;
+        for (; k < K && pd.size() < 65535; ++k) {
+            EfPair d;
+            if (ext_matrix) {
+                d.q = d.r = 0; d.M = extM; d.N = extN;
+            } else {
+                d.q = pairs[2 * k]; d.r = pairs[2 * k + 1];
+                if (d.q < 0 || d.r < 0 || d.q >= c->ef_ntracks || d.r >= c->ef_ntracks)
+                    return fail(c, ACX_ERR_INVALID, "earlyfusion: track index out of range in pair " + std::to_string(k));
+                d.M = (int)(c->h_efoff[d.q + 1] - c->h_efoff[d.q]);
+                d.N = (int)(c->h_efoff[d.r + 1] - c->h_efoff[d.r]);
+            }
+            if (d.M < 1 || d.N < 1) return fail(c, ACX_ERR_SHORT, "earlyfusion: track without blocks (pair " + std::to_string(k) + ")");
+            if (d.M > acx::EF_MAXNB || d.N > acx::EF_MAXNB)
+                return fail(c, ACX_ERR_UNSUPPORTED, "earlyfusion: tracks with more than 512 blocks are not supported on the device yet");
+            d.oti = 0;
+            d.pitchC = round_up(d.N, 64);
+            d.pitchT = round_up(d.M, 64);
+            // csm_to_binary (cross_recurrence.py:149-154): kappa == 0 -> all ones; kappa < 1 ->
+            // int(round(kappa * ncols)) (numpy: half to even, in f64); else kappa neighbours
+            if (p.kappa == 0.0) d.kbin = d.N;
+            else if (p.kappa < 1.0) d.kbin = (int)std::nearbyint(p.kappa * (double)d.N);
+            else d.kbin = (int)p.kappa;
+            const int64_t need = (int64_t)4 * d.M * d.pitchC + (int64_t)3 * d.N * d.pitchT;
+            if (need > limit_floats) return fail(c, ACX_ERR_NOMEM, "earlyfusion: one pair does not fit the scratch limit");
+            if (used + need > limit_floats) break;
+            d.offC = used;
+            d.offS = used_s;
+            used += need;
+            used_s += 4 * (2 * (int64_t)d.pitchT + d.pitchC);
+            maxM = std::max(maxM, d.M);
+            maxN = std::max(maxN, d.N);
+            cells += (int64_t)d.M * d.N;
+            pd.push_back(d);
+        }
+        const int B = (int)pd.size();
+        if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)used)) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)used_s)) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_efpd, c->efpd_cap, (size_t)B)) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)4 * B)) != ACX_OK) return rc;
+        ACX_HIP(c, hipMemcpyAsync(c->d_efpd, pd.data(), sizeof(EfPair) * B, hipMemcpyHostToDevice, c->stream));
+        const int rows_g = (std::max(maxM, maxN) + 3) / 4;
+        if (ext_matrix) {
+            // test entry: the caller's matrix is "feature 0", threshold = kbin smallest per row
+            ACX_HIP(c, hipMemcpy2DAsync(c->d_scratch, sizeof(float) * pd[0].pitchC, ext_matrix, sizeof(float) * extN,
+                                        sizeof(float) * extN, extM, hipMemcpyHostToDevice, c->stream));
+        } else {
+            hipLaunchKernelGGL(acx::ef_oti_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream, c->d_efpd, B, c->d_efmed);
+            {
+                const int tiles_x = (maxN + 63) / 64, tiles_y = (maxM + 63) / 64;
+                ProfScope ps(c, KS_EFGEMM, cells);
+                hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 3), dim3(256), 0, c->stream,
+                                   c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
+                                   c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x);
+            }
+        }
+        const int nfeat = ext_matrix ? 1 : 3;
+        {
+            ProfScope ps(c, KS_EFSTAT, cells);
+            hipLaunchKernelGGL(acx::ef_rowstat_kernel, dim3(rows_g, B, nfeat), dim3(256), 0, c->stream,
+                               c->d_efpd, c->d_scratch, c->d_thr, 0, p.K);
+            if (!ext_matrix)
+                hipLaunchKernelGGL(acx::ef_rowstat_kernel, dim3(rows_g, B, 3), dim3(256), 0, c->stream,
+                                   c->d_efpd, c->d_scratch, c->d_thr, 1, p.K);
+        }
+        {
+            ProfScope ps(c, KS_EFSW, cells);
+            hipLaunchKernelGGL(acx::sw_kernel, dim3(B, nfeat), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
+        }
+        if (!ext_matrix) {
+            {
+                ProfScope ps(c, KS_EFFUSE, cells);
+                hipLaunchKernelGGL(acx::ef_fuse_kernel, dim3(maxM, B), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr);
+            }
+            {
+                ProfScope ps(c, KS_EFSTAT, 0);
+                hipLaunchKernelGGL(acx::ef_rowstat_kernel, dim3(rows_g, B, 1), dim3(256), 0, c->stream,
+                                   c->d_efpd, c->d_scratch, c->d_thr, 2, p.K);
+            }
+            {
+                ProfScope ps(c, KS_EFSW, 0);
+                hipLaunchKernelGGL(acx::sw_kernel, dim3(B, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 3);
+            }
+        }
+        ACX_HIP(c, hipGetLastError());
+        ACX_HIP(c, hipMemcpyAsync(out + 4 * k0, c->d_out, sizeof(float) * 4 * B, hipMemcpyDeviceToHost, c->stream));
+        ACX_HIP(c, hipStreamSynchronize(c->stream));
+        drain_profile(c);
+        if (dbg && B >= 1) {
+            EfPair d;
+            ACX_HIP(c, hipMemcpy(&d, c->d_efpd, sizeof(EfPair), hipMemcpyDeviceToHost));
+            if (dbg->oti) *dbg->oti = d.oti;
+            for (int sft = 0; sft < 3 && dbg->csm; ++sft)
+                ACX_HIP(c, hipMemcpy2D(dbg->csm + (size_t)sft * d.M * d.N, sizeof(float) * d.N,
+                                       c->d_scratch + d.offC + (int64_t)sft * d.M * d.pitchC, sizeof(float) * d.pitchC,
+                                       sizeof(float) * d.N, d.M, hipMemcpyDeviceToHost));
+            if (dbg->fused)
+                ACX_HIP(c, hipMemcpy2D(dbg->fused, sizeof(float) * d.N,
+                                       c->d_scratch + d.offC + (int64_t)3 * d.M * d.pitchC + (int64_t)3 * d.N * d.pitchT,
+                                       sizeof(float) * d.pitchC, sizeof(float) * d.N, d.M, hipMemcpyDeviceToHost));
+        }
+        k0 = k;
+        if (ext_matrix) break;
+    }
+    return ACX_OK;
+}
+
 template <int L>
 int launch_simple(acx_ctx *c, int n, size_t smem, int oti)
 {
@@ -437,6 +583,11 @@ void acx_destroy(acx_ctx *c)
     if (c->d_prof64) (void)hipFree(c->d_prof64);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_out64) (void)hipFree(c->d_out64);
+    for (int k = 0; k < 3; ++k) if (c->d_ef[k]) (void)hipFree(c->d_ef[k]);
+    for (int k = 0; k < 2; ++k) if (c->d_efn[k]) (void)hipFree(c->d_efn[k]);
+    if (c->d_efmed) (void)hipFree(c->d_efmed);
+    if (c->d_efoff) (void)hipFree(c->d_efoff);
+    if (c->d_efpd) (void)hipFree(c->d_efpd);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -595,6 +746,117 @@ int acx_simple_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, int32_t sslen,
         ACX_HIP(c, hipStreamSynchronize(c->stream));
         drain_profile(c);
     }
+    return ACX_OK;
+}
+
+int acx_ef_upload_pool(acx_ctx *c, const float *mfccs, const float *ssms, const float *chromas,
+                       const double *chroma_med, const int64_t *offsets, int32_t n_tracks, const int32_t *dims)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!mfccs || !ssms || !chromas || !chroma_med || !offsets || !dims || n_tracks <= 0)
+        return fail(c, ACX_ERR_INVALID, "ef_upload_pool: bad argument");
+    if (dims[0] < 1 || dims[1] < 1 || dims[2] < 12 || dims[2] % 12 != 0)
+        return fail(c, ACX_ERR_INVALID, "ef_upload_pool: dims must be positive and dims[2] a multiple of 12");
+    if (offsets[0] != 0) return fail(c, ACX_ERR_INVALID, "ef_upload_pool: offsets[0] must be 0");
+    for (int i = 0; i < n_tracks; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(c, ACX_ERR_INVALID, "ef_upload_pool: offsets must be non-decreasing");
+    ACX_HIP(c, hipSetDevice(c->device));
+    for (int k = 0; k < 3; ++k) if (c->d_ef[k]) { (void)hipFree(c->d_ef[k]); c->d_ef[k] = nullptr; }
+    for (int k = 0; k < 2; ++k) if (c->d_efn[k]) { (void)hipFree(c->d_efn[k]); c->d_efn[k] = nullptr; }
+    if (c->d_efmed) { (void)hipFree(c->d_efmed); c->d_efmed = nullptr; }
+    if (c->d_efoff) { (void)hipFree(c->d_efoff); c->d_efoff = nullptr; }
+    const int64_t nb = offsets[n_tracks];
+    c->h_efoff.assign(offsets, offsets + n_tracks + 1);
+    c->ef_ntracks = n_tracks;
+    for (int k = 0; k < 3; ++k) c->ef_dims[k] = dims[k];
+    const float *src[3] = {mfccs, ssms, chromas};
+    // squared row norms of the Euclidean features (np.sum(X**2, 1), cross_recurrence.py:46) and
+    // unit-norm chroma rows (X / XNorm with zero norms -> 1, :66-71), once per pool
+    std::vector<float> cn((size_t)nb * dims[2]);
+    for (int64_t b = 0; b < nb; ++b) {
+        double acc = 0.0;
+        for (int k = 0; k < dims[2]; ++k) { double v = chromas[b * dims[2] + k]; acc += v * v; }
+        float nr = (float)std::sqrt(acc);
+        if (nr == 0.0f) nr = 1.0f;
+        for (int k = 0; k < dims[2]; ++k) cn[(size_t)b * dims[2] + k] = chromas[b * dims[2] + k] / nr;
+    }
+    src[2] = cn.data();
+    for (int k = 0; k < 3; ++k) {
+        ACX_HIP(c, hipMalloc((void **)&c->d_ef[k], sizeof(float) * std::max<int64_t>(1, nb) * dims[k]));
+        ACX_HIP(c, hipMemcpy(c->d_ef[k], src[k], sizeof(float) * nb * dims[k], hipMemcpyHostToDevice));
+    }
+    for (int k = 0; k < 2; ++k) {
+        std::vector<float> nrm((size_t)nb);
+        for (int64_t b = 0; b < nb; ++b) {
+            double acc = 0.0;      // f64 accumulation: as close as numpy's pairwise f32 sum gets to exact
+            const float *x = src[k] + b * dims[k];
+            for (int e = 0; e < dims[k]; ++e) acc += (double)x[e] * (double)x[e];
+            nrm[(size_t)b] = (float)acc;
+        }
+        ACX_HIP(c, hipMalloc((void **)&c->d_efn[k], sizeof(float) * std::max<int64_t>(1, nb)));
+        ACX_HIP(c, hipMemcpy(c->d_efn[k], nrm.data(), sizeof(float) * nb, hipMemcpyHostToDevice));
+    }
+    ACX_HIP(c, hipMalloc((void **)&c->d_efmed, sizeof(double) * 12 * n_tracks));
+    ACX_HIP(c, hipMemcpy(c->d_efmed, chroma_med, sizeof(double) * 12 * n_tracks, hipMemcpyHostToDevice));
+    ACX_HIP(c, hipMalloc((void **)&c->d_efoff, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIP(c, hipMemcpy(c->d_efoff, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    return ACX_OK;
+}
+
+int acx_earlyfusion_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params *params, float *out)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (K < 0 || (K > 0 && (!pairs || !out)) || !params) return fail(c, ACX_ERR_INVALID, "earlyfusion_pairs: bad argument");
+    if (K == 0) return ACX_OK;
+    return run_ef(c, pairs, K, *params, out, nullptr, nullptr, 0, 0);
+}
+
+int acx_ef_debug_pair(acx_ctx *c, int32_t i, int32_t j, const acx_ef_params *params, float *csm, float *fused,
+                      float *scores, int32_t *oti)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!params) return fail(c, ACX_ERR_INVALID, "ef_debug_pair: bad argument");
+    int32_t pr[2] = {i, j};
+    float sc[4] = {0, 0, 0, 0};
+    EfDebug dbg{csm, fused, oti};
+    int rc = run_ef(c, pr, 1, *params, sc, &dbg, nullptr, 0, 0);
+    if (rc == ACX_OK && scores) for (int k = 0; k < 4; ++k) scores[k] = sc[k];
+    return rc;
+}
+
+int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *score)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!B || !score || M < 1 || N < 1) return fail(c, ACX_ERR_INVALID, "sw_binary: bad argument");
+    if (M > acx::EF_MAXNB || N > acx::EF_MAXNB) return fail(c, ACX_ERR_UNSUPPORTED, "sw_binary: matrices larger than 512 are not supported on the device yet");
+    std::vector<float> Cm((size_t)M * N);
+    for (size_t k = 0; k < Cm.size(); ++k) {
+        if (B[k] > 1) return fail(c, ACX_ERR_INVALID, "Non-binary elements found in input");
+        Cm[k] = B[k] ? 0.0f : 1.0f;         // B = [C <= threshold] with threshold 0
+    }
+    // run the DP on this matrix with per-row thresholds 0: the row-stat kernel would select by
+    // rank, so the thresholds are written directly
+    acx_ef_params p{1.0, 1};
+    float sc[4] = {0, 0, 0, 0};
+    acx::EfPair d;
+    d.q = d.r = 0; d.M = M; d.N = N; d.oti = 0; d.pitchC = round_up(N, 64); d.pitchT = round_up(M, 64); d.kbin = 0;
+    d.offC = 0; d.offS = 0;
+    int rc;
+    ACX_HIP(c, hipSetDevice(c->device));
+    if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)M * d.pitchC)) != ACX_OK) return rc;
+    if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)4 * (2 * d.pitchT + d.pitchC))) != ACX_OK) return rc;
+    if ((rc = ensure(c, c->d_efpd, c->efpd_cap, (size_t)1)) != ACX_OK) return rc;
+    if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)4)) != ACX_OK) return rc;
+    ACX_HIP(c, hipMemcpyAsync(c->d_efpd, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+    ACX_HIP(c, hipMemcpy2DAsync(c->d_scratch, sizeof(float) * d.pitchC, Cm.data(), sizeof(float) * N, sizeof(float) * N, M,
+                                hipMemcpyHostToDevice, c->stream));
+    ACX_HIP(c, hipMemsetAsync(c->d_thr, 0, sizeof(float) * M, c->stream));
+    hipLaunchKernelGGL(acx::sw_kernel, dim3(1, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
+    ACX_HIP(c, hipGetLastError());
+    ACX_HIP(c, hipMemcpyAsync(sc, c->d_out, sizeof(float) * 4, hipMemcpyDeviceToHost, c->stream));
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    (void)p;
+    *score = sc[0];
     return ACX_OK;
 }
 

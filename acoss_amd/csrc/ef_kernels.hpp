@@ -1,0 +1,354 @@
+// EarlyFusion per-pair device kernels for gfx950 (reference:
+// acoss/algorithms/earlyfusion_traile.py:157-198 and the L2 utilities it calls).
+//
+//   E1 ef_gemm_kernel   the three cross-similarity matrices of a pair as f32 MFMA GEMMs
+//                       (v_mfma_f32_16x16x4_f32, K = 650 / 1225 / 480) with the epilogue of
+//                       get_csm (cross_recurrence.py:30-48: sqrt(max(0, |x|^2+|y|^2-2xy))) or
+//                       get_csm_cosine after the blocked OTI roll (:53-73, :105-134: rows are
+//                       pre-normalised at upload, the roll is a permutation of the k index);
+//                       writes C and C^T
+//   E2 ef_rowstat_kernel one wave per row: the k-th smallest value of the row (threshold of
+//                       csm_to_binary, :136-161) and the mean of the K smallest
+//                       (getWCSM, similarity_fusion.py:46-50); on C^T rows = column stats
+//   E3 ef_fuse_kernel   fused = exp(-(W_mfcc + W_ssm + W_chroma)),
+//                       W = exp(-C^2 / (2 (0.5 (r_i + c_j + C)/3)^2))   (similarity_fusion.py:51-54,
+//                       earlyfusion_traile.py:178-182)
+//   E4 sw_kernel        constrained Smith-Waterman (alignment_tools.py:26-46) as an exact
+//                       integer DP in tenths (+10 / -10 / -7), binarising on the fly
+//                       (B_ij = C_ij <= t_i), one wave per matrix, row sweep with the two
+//                       previous rows in registers
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "serra09_kernels.hpp"
+
+namespace acx {
+
+constexpr int EF_MAXNB = 512;     // blocks per track supported on the device
+
+struct EfPair {
+    int32_t q, r;          // track indices
+    int32_t M, N;          // blocks of q / r
+    int32_t oti;           // get_oti(chroma_med_q, chroma_med_r)
+    int32_t pitchC;        // row pitch of C (multiple of 64, >= N)
+    int32_t pitchT;        // row pitch of C^T (multiple of 64, >= M)
+    int32_t kbin;          // neighbours per row of csm_to_binary (host: int(round(kappa * N)), half-to-even)
+    int64_t offC;          // float offset of the pair's matrices: [C x3][C^T x3][F]
+    int64_t offS;          // float offset of the pair's vectors:
+                           //   per feature s<3: [t rows][r rows][c cols]; then [t rows of F]
+};
+
+__device__ __forceinline__ int64_t ef_c_off(const EfPair &P, int s) { return P.offC + (int64_t)s * P.M * P.pitchC; }
+__device__ __forceinline__ int64_t ef_ct_off(const EfPair &P, int s)
+{
+    return P.offC + (int64_t)3 * P.M * P.pitchC + (int64_t)s * P.N * P.pitchT;
+}
+__device__ __forceinline__ int64_t ef_f_off(const EfPair &P)
+{
+    return P.offC + (int64_t)3 * P.M * P.pitchC + (int64_t)3 * P.N * P.pitchT;
+}
+// vectors: feature s: t at +0, r at +pitchT, c at +2 pitchT (size pitchC); stride per feature
+__device__ __forceinline__ int64_t ef_s_stride(const EfPair &P) { return 2 * (int64_t)P.pitchT + P.pitchC; }
+
+// ---- OTI of the pair (cross_recurrence.py:75-103): argmax_s sum(roll(C1, s) * C2), f64, first max
+__global__ void ef_oti_kernel(EfPair *pd, int B, const double *__restrict__ med)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const double *c1 = med + (size_t)12 * pd[p].q, *c2 = med + (size_t)12 * pd[p].r;
+    int best = 0;
+    double bestv = 0.0;
+    for (int s = 0; s < 12; ++s) {
+        double acc = 0.0;
+        for (int c = 0; c < 12; ++c) acc += c1[(c - s + 12) % 12] * c2[c];
+        if (s == 0 || acc > bestv) { bestv = acc; best = s; }
+    }
+    pd[p].oti = best;
+}
+
+// ------------------------------------------------------------------------------------
+// E1: C[i][j] = epilogue( sum_k A[i][perm(k)] * B[j][k] ), 64 x 64 tile per workgroup,
+// 4 waves as 2 x 2, each wave 32 x 32 = 2 x 2 MFMA tiles, BK = 16.
+// feat: 0 mfcc (euclid), 1 ssm (euclid), 2 chroma (cosine, A rolled by oti).
+// ------------------------------------------------------------------------------------
+constexpr int EF_BK = 16;
+constexpr int EF_LP = 80;      // LDS pitch (k-major, 64 rows + pad; 80 % 32 == 16)
+
+__global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ feat0, const float *__restrict__ feat1,
+                                                      const float *__restrict__ feat2,
+                                                      const float *__restrict__ nrm0, const float *__restrict__ nrm1,
+                                                      const int64_t *__restrict__ boff,
+                                                      const EfPair *__restrict__ pd, float *__restrict__ scratch,
+                                                      int K0, int K1, int K2, int tiles_x)
+{
+    __shared__ float As[EF_BK * EF_LP];
+    __shared__ float Bs[EF_BK * EF_LP];
+    const EfPair P = pd[blockIdx.y];
+    const int s = blockIdx.z;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int i0 = ty * 64, j0 = tx * 64;
+    if (i0 >= P.M || j0 >= P.N) return;
+    const int K = s == 0 ? K0 : (s == 1 ? K1 : K2);
+    const float *F = s == 0 ? feat0 : (s == 1 ? feat1 : feat2);
+    const float *A = F + boff[P.q] * K, *Bm = F + boff[P.r] * K;
+    const int rot = (s == 2) ? P.oti : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: thread -> (row = tid / 4, 4 consecutive k = 4 * (tid % 4))
+    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    for (int k0 = 0; k0 < K; k0 += EF_BK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + sk + e;
+            float va = 0.f, vb = 0.f;
+            if (k < K) {
+                if (i0 + srow < P.M) {
+                    int ka = k;
+                    if (rot) { const int c = k % 12; int cs = c - rot; if (cs < 0) cs += 12; ka = k - c + cs; }
+                    va = A[(size_t)(i0 + srow) * K + ka];
+                }
+                if (j0 + srow < P.N) vb = Bm[(size_t)(j0 + srow) * K + k];
+            }
+            As[(sk + e) * EF_LP + srow] = va;
+            Bs[(sk + e) * EF_LP + srow] = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < EF_BK / 4; ++kb) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = As[(4 * kb + lk) * EF_LP + 32 * wr + 16 * a + lr];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bv[b] = Bs[(4 * kb + lk) * EF_LP + 32 * wc + 16 * b + lr];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue + stores (C row-major and C^T)
+    const float *nrm = s == 0 ? nrm0 : nrm1;
+    float *C = scratch + ef_c_off(P, s);
+    float *CT = scratch + ef_ct_off(P, s);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = i0 + 32 * wr + 16 * a + 4 * lk + reg;
+                const int j = j0 + 32 * wc + 16 * b + lr;
+                if (i < P.M && j < P.N) {
+                    const float dot = acc[a][b][reg];
+                    float v;
+                    if (s == 2) {
+                        v = 1.0f - dot;
+                    } else {
+                        const float nx = nrm[boff[P.q] + i], ny = nrm[boff[P.r] + j];
+                        float t = (nx + ny) - 2.0f * dot;
+                        if (t < 0.0f) t = 0.0f;
+                        v = __builtin_sqrtf(t);
+                    }
+                    C[(size_t)i * P.pitchC + j] = v;
+                    CT[(size_t)j * P.pitchT + i] = v;
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------
+// E2: per-row statistics of a matrix with rows <= 512 long.  mode 0 (C rows): threshold
+// t_i = the kb-th smallest (k = round(kappa n), kappa < 1; kappa >= 1: k = kappa; k = 0 or
+// kappa == 0 handled by the host) and r_i = mean of the kw smallest; mode 1 (C^T rows):
+// only the mean (= column statistic c_j); mode 2 (F rows): only the threshold.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float mean_k_smallest(const float (&x)[8], int kw, float vk, int lane)
+{
+    // vk = kw-th smallest (rank kw-1).  sum of elements < vk, plus (kw - count) * vk: exact
+    // whatever the ties.
+    float acc = 0.0f;
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bool lt = x[t] < vk;
+        acc += lt ? x[t] : 0.0f;
+        cnt += lt ? 1 : 0;
+    }
+    // deterministic wave sum (DPP scan order)
+    const int tot = wave_sum_i(cnt);
+    float s = acc;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    (void)lane;
+    return (s + (float)(kw - tot) * vk) / (float)kw;
+}
+
+__global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
+                                                         float *__restrict__ stat, int mode, int kw)
+{
+    __shared__ __attribute__((aligned(16))) unsigned hist[4][SEL_SLOTS];
+    __shared__ float cand[4][64];
+    __shared__ unsigned counter[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const EfPair P = pd[blockIdx.y];
+    const int s = blockIdx.z;                         // feature (mode 2: always 0)
+    const int nrows = mode == 1 ? P.N : P.M;
+    const int n = mode == 1 ? P.M : P.N;              // row length
+    const int pitch = mode == 1 ? P.pitchT : P.pitchC;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= nrows) return;
+    const int64_t base = mode == 0 ? ef_c_off(P, s) : (mode == 1 ? ef_ct_off(P, s) : ef_f_off(P));
+    const float *v = scratch + base + (size_t)row * pitch;
+    float x[8];
+    const float INF = __builtin_inff();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = 256 * q + 4 * lane;
+        float4 t = make_float4(INF, INF, INF, INF);
+        if (j < pitch) t = *reinterpret_cast<const float4 *>(v + j);
+        x[4 * q + 0] = (j + 0 < n) ? t.x : INF;
+        x[4 * q + 1] = (j + 1 < n) ? t.y : INF;
+        x[4 * q + 2] = (j + 2 < n) ? t.z : INF;
+        x[4 * q + 3] = (j + 3 < n) ? t.w : INF;
+    }
+    float *S = stat + P.offS + (mode == 2 ? 3 * ef_s_stride(P) : s * ef_s_stride(P));
+    if (mode != 1) {
+        const int kb = P.kbin;
+        float t;
+        if (kb <= 0) t = -INF;                         // no neighbours: empty rows
+        else if (kb >= n) t = INF;
+        else t = wave_select_regs<8>(x, kb - 1, hist[wave], cand[wave], &counter[wave], lane, false).value;
+        if (lane == 0) S[row] = t;
+    }
+    if (mode != 2) {
+        const int kk = kw < n ? kw : n;
+        const float vk = wave_select_regs<8>(x, kk - 1, hist[wave], cand[wave], &counter[wave], lane, false).value;
+        const float m = mean_k_smallest(x, kk, vk, lane);
+        if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// E3: fused = exp(-(W0 + W1 + W2)), elementwise over the pair's M x N cells
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ef_fuse_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
+                                                      const float *__restrict__ stat)
+{
+    const EfPair P = pd[blockIdx.y];
+    const int i = blockIdx.x;
+    if (i >= P.M) return;
+    float *F = scratch + ef_f_off(P) + (size_t)i * P.pitchC;
+    float r[3];
+    const float *c[3];
+    const float *C[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const float *S = stat + P.offS + s * ef_s_stride(P);
+        r[s] = S[P.pitchT + i];
+        c[s] = S + 2 * P.pitchT;
+        C[s] = scratch + ef_c_off(P, s) + (size_t)i * P.pitchC;
+    }
+    for (int j = threadIdx.x; j < P.N; j += 256) {
+        float wsum = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const float cv = C[s][j];
+            float eps = (r[s] + c[s][j]) + cv;
+            eps = eps / 3.0f;
+            const float h = 0.5f * eps;
+            const float den = 2.0f * (h * h);
+            const float w = expf(-(cv * cv) / den);
+            wsum += w;
+        }
+        F[j] = expf(-wsum);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// E4: constrained Smith-Waterman, exact in integer tenths.  With T[i][j] = S[i+1][j+1] of the
+// reference and U = T + delta(B) (delta = 0 if B else -7):
+//   T[i][j] = max(0, mv(B[i][j]) + max(U[i-1][j-1], U[i-2][j-1], U[i-1][j-2])),  i, j >= 2,
+//   i <= M-2, j <= N-2;  T = 0 (and U = delta(B)) in rows / columns 0, 1;  score = max T / 10.
+// One wave per matrix; lane owns 8 contiguous columns (N <= 512).  B_ij = C_ij <= t_i.
+// src: 0..2 = feature CSM, 3 = fused matrix.  out[pair * 4 + src].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
+                                                const float *__restrict__ stat, float *__restrict__ out, int src_base)
+{
+    const int lane = threadIdx.x;
+    const EfPair P = pd[blockIdx.x];
+    const int src = src_base + blockIdx.y;
+    const int M = P.M, N = P.N, pitch = P.pitchC;
+    const float *C = scratch + (src < 3 ? ef_c_off(P, src) : ef_f_off(P));
+    const float *thr = stat + P.offS + src * ef_s_stride(P);
+    float result = 0.0f;
+    if (M >= 4 && N >= 4) {
+        int U1[8], U2[8];          // U of rows i-1, i-2
+        const int prev = (lane + 63) & 63;
+        const int j0 = 8 * lane;
+        // rows 0 and 1: T = 0, U = delta(B)
+        auto load_b = [&](int row, bool (&b)[8]) {
+            const float t = thr[row];
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (j0 < pitch) {
+                const float4 *p = reinterpret_cast<const float4 *>(C + (size_t)row * pitch + j0);
+                v0 = p[0];
+                v1 = p[1];
+            }
+            const float d[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = (j0 + e < N) && (d[e] <= t);
+        };
+        bool b[8];
+        load_b(0, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) U2[e] = b[e] ? 0 : -7;
+        load_b(1, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) U1[e] = b[e] ? 0 : -7;
+        int best = 0;
+        for (int i = 2; i <= M - 2; ++i) {
+            load_b(i, b);
+            const int l1a = __shfl(U1[7], prev, 64), l1b = __shfl(U1[6], prev, 64), l2a = __shfl(U2[7], prev, 64);
+            int Tn[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c2 = (e >= 1) ? U1[e - 1] : l1a;                        // U[i-1][j-1]
+                const int c3 = (e >= 1) ? U2[e - 1] : l2a;                        // U[i-2][j-1]
+                const int c4 = (e >= 2) ? U1[e - 2] : (e == 1 ? l1a : l1b);       // U[i-1][j-2]
+                int mx = c2 > c3 ? c2 : c3;
+                mx = mx > c4 ? mx : c4;
+                int t = (b[e] ? 10 : -10) + mx;
+                t = t > 0 ? t : 0;
+                const int j = j0 + e;
+                if (j < 2) t = 0;                  // columns 0, 1 (lane 0 only; its shuffled inputs are unused)
+                Tn[e] = t;
+                if (j <= N - 2) best = best > t ? best : t;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                U2[e] = U1[e];
+                U1[e] = Tn[e] + (b[e] ? 0 : -7);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int t = __shfl_xor(best, o, 64);
+            best = best > t ? best : t;
+        }
+        result = (float)best / 10.0f;
+    }
+    if (lane == 0) out[(size_t)blockIdx.x * 4 + src] = result;
+}
+
+}  // namespace acx

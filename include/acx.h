@@ -136,6 +136,40 @@ int acx_upload_pool_f64(acx_ctx *ctx, const double *frames, const int64_t *offse
 int acx_simple_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, int32_t sslen, int32_t oti,
                      double *out);
 
+/* ---- EarlyFusion (Tralie 2017) per-pair chain ---------------------------- */
+
+/*
+ * Block features of every track, as EarlyFusion.load_features() builds them
+ * (earlyfusion_traile.py:100-154): for track i, blocks offsets[i] .. offsets[i+1];
+ * mfccs (sum nb, dims[0]=650), ssms (sum nb, dims[1]=1225), chromas (sum nb, dims[2]=480,
+ * 40 frames x 12 bins, bin fastest) f32 row-major, chroma_med (n_tracks, 12) f64.
+ */
+int acx_ef_upload_pool(acx_ctx *ctx, const float *mfccs, const float *ssms, const float *chromas,
+                       const double *chroma_med, const int64_t *offsets, int32_t n_tracks,
+                       const int32_t *dims);
+
+typedef struct {
+    double kappa;     /* csm_to_binary neighbourhood (EarlyFusion ctor kappa = 0.1)  */
+    int32_t K;        /* getWCSM neighbours (ctor K = 10)                            */
+} acx_ef_params;
+
+/*
+ * out[4k .. 4k+3] = Smith-Waterman scores (mfccs, ssms, chromas, early) of pair
+ * (pairs[2k], pairs[2k+1]) -- what EarlyFusion.similarity() stores into
+ * Ds['mfccs'|'ssms'|'chromas'|'early'][i, j] (earlyfusion_traile.py:157-198).
+ */
+int acx_earlyfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const acx_ef_params *params,
+                          float *out);
+
+/* One pair with intermediates (tests): csm (3, M, N), fused (M, N), scores (4); any may be NULL. */
+int acx_ef_debug_pair(acx_ctx *ctx, int32_t i, int32_t j, const acx_ef_params *params,
+                      float *csm, float *fused, float *scores, int32_t *oti);
+
+/* smith_waterman_constrained (alignment_tools.py:26-46) of one binary (M, N) uint8 matrix on
+ * the device DP (tests against the reference goldens).  Non-{0,1} input -> ACX_ERR_INVALID
+ * (the reference raises IOError). */
+int acx_sw_binary(acx_ctx *ctx, const uint8_t *B, int32_t M, int32_t N, float *score);
+
 /* ---- measurement -------------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on the library's own stream around
