@@ -72,6 +72,7 @@ struct acx_ctx {
     float *d_thr = nullptr;     size_t thr_cap = 0;
     PairDesc *d_pd = nullptr;   size_t pd_cap = 0;
     float *d_out = nullptr;     size_t out_cap = 0;
+    unsigned long long *d_bits = nullptr; size_t bits_cap = 0;   // recurrence bitmaps (u64 words)
     int64_t scratch_limit = 0;                            // bytes
     size_t total_mem = 0;
     // profiling
@@ -194,13 +195,13 @@ void launch_csm_m(acx_ctx *c, int m, dim3 grid, int tiles_x, int oti_target)
 }
 
 template <int M>
-void launch_band(acx_ctx *c, int B, int maxM, const acx_serra09_params &p)
+void launch_band(acx_ctx *c, int B, int maxRows, int maxCols, const acx_serra09_params &p, int role, int write_d2)
 {
-    const dim3 grid((maxM + acx::BAND - 1) / acx::BAND, B, 2);
-    const int ndata = (maxM + acx::BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
-#define ACX_BAND(V4_) hipLaunchKernelGGL((acx::band_kernel<M, V4_>), grid, dim3(acx::BAND_THREADS), 0, c->stream, c->d_frames, \
-                                         c->d_toff, c->d_pd, c->d_scratch, c->d_thr, p.kappa, p.pct_mode,       \
-                                         p.inclusive, p.oti_target)
+    const dim3 grid((maxRows + acx::BAND - 1) / acx::BAND, B, 1);
+    const int ndata = (maxCols + acx::BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
+#define ACX_BAND(V4_) hipLaunchKernelGGL((acx::band_kernel<M, V4_>), grid, dim3(acx::BAND_THREADS), 0, c->stream,     \
+                                         c->d_frames, c->d_toff, c->d_pd, c->d_scratch, c->d_thr, c->d_bits, p.kappa, \
+                                         p.pct_mode, p.inclusive, p.oti_target, role, write_d2)
     if (ndata <= 8) ACX_BAND(2);
     else if (ndata <= 16) ACX_BAND(4);
     else ACX_BAND(8);
@@ -267,7 +268,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
     int64_t k0 = 0;
     while (k0 < K) {
         pd.clear();
-        int64_t used = 0, used_thr = 0;
+        int64_t used = 0, used_thr = 0, used_bits = 0;
         int maxMq = 0, maxMr = 0, maxRows = 0, maxNe = 0;
         int64_t cells = 0;
         int64_t k = k0;
@@ -289,13 +290,16 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             d.oti = 0;
             d.pitchD = round_up(d.Mr, 64);
             d.pitchT = round_up(d.Mq, 64);
-            d.pad_ = 0;
-            const int64_t need = (int64_t)d.Mq * d.pitchD + (v1 ? (int64_t)d.Mr * d.pitchT : 0);
+            d.nw = (d.Mr + acx::BAND - 1 + 63) / 64;
+            const bool want_d2 = v1 || dbg != nullptr;      // the band pipeline keeps D2 out of HBM
+            const int64_t need = (want_d2 ? (int64_t)d.Mq * d.pitchD : 0) + (v1 ? (int64_t)d.Mr * d.pitchT : 0);
+            const int64_t need_bits = v1 ? 0 : (int64_t)d.Mq * d.nw;
             if (need > limit_floats)
                 return fail(c, ACX_ERR_NOMEM, "serra09: one pair does not fit the scratch limit");
-            if (used + need > limit_floats) break;
+            if (used + need + 2 * (used_bits + need_bits) > limit_floats) break;
             d.offD = used;
-            d.offT = used + (int64_t)d.Mq * d.pitchD;
+            d.offT = v1 ? used + (int64_t)d.Mq * d.pitchD : used_bits;
+            used_bits += need_bits;
             d.offX = used_thr;
             used += need;
             used_thr += 3 * ((int64_t)d.pitchD + d.pitchT);
@@ -307,7 +311,8 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             pd.push_back(d);
         }
         const int B = (int)pd.size();
-        if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)used)) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)std::max<int64_t>(used, 1))) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_bits, c->bits_cap, (size_t)std::max<int64_t>(used_bits, 1))) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)used_thr)) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_pd, c->pd_cap, (size_t)B)) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)B)) != ACX_OK) return rc;
@@ -342,22 +347,34 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                 ACX_M_SWITCH(p.m, ACX_CALL)
 #undef ACX_CALL
             }
-            {   // K1': fused band kernel, both roles
+            {   // K1': fused band kernel; role 1 (column thresholds) first, then role 0 (row
+                // thresholds + recurrence bitmap, which needs the column thresholds)
                 ProfScope ps(c, KS_BAND, cells);
-#define ACX_CALL(M_) launch_band<M_>(c, B, std::max(maxMq, maxMr), p)
+#define ACX_CALL(M_) launch_band<M_>(c, B, maxMr, maxMq, p, 1, 0)
+                ACX_M_SWITCH(p.m, ACX_CALL)
+#undef ACX_CALL
+#define ACX_CALL(M_) launch_band<M_>(c, B, maxMq, maxMr, p, 0, dbg ? 1 : 0)
                 ACX_M_SWITCH(p.m, ACX_CALL)
 #undef ACX_CALL
             }
         }
         {   // K3
-            const int NG = (maxNe + 511) / 512;
             const bool eqg = p.gamma_o == p.gamma_e;
             ProfScope ps(c, KS_QMAX, cells);
-            switch (NG) {
-            case 0: case 1: launch_qmax<1>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
-            case 2: launch_qmax<2>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
-            case 3: launch_qmax<3>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
-            default: launch_qmax<4>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
+            if (v1) {
+                const int NG = (maxNe + 511) / 512;
+                switch (NG) {
+                case 0: case 1: launch_qmax<1>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
+                case 2: launch_qmax<2>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
+                case 3: launch_qmax<3>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
+                default: launch_qmax<4>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
+                }
+            } else if (eqg) {
+                hipLaunchKernelGGL((acx::qmax_bits_kernel<true>), dim3(B), dim3(64), 0, c->stream,
+                                   c->d_pd, c->d_bits, c->d_out, p.gamma_o, p.gamma_e, p.dp_start);
+            } else {
+                hipLaunchKernelGGL((acx::qmax_bits_kernel<false>), dim3(B), dim3(64), 0, c->stream,
+                                   c->d_pd, c->d_bits, c->d_out, p.gamma_o, p.gamma_e, p.dp_start);
             }
         }
         ACX_HIP(c, hipGetLastError());
@@ -578,6 +595,7 @@ void acx_destroy(acx_ctx *c)
     if (c->d_thr) (void)hipFree(c->d_thr);
     if (c->d_pd) (void)hipFree(c->d_pd);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_bits) (void)hipFree(c->d_bits);
     if (c->d_frames64) (void)hipFree(c->d_frames64);
     if (c->d_toff64) (void)hipFree(c->d_toff64);
     if (c->d_prof64) (void)hipFree(c->d_prof64);

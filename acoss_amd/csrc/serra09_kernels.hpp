@@ -41,8 +41,10 @@ struct PairDesc {
     int32_t oti;           // filled by K0
     int32_t pitchD;        // row pitch of D2  (floats, multiple of 64, >= Mr)
     int32_t pitchT;        // row pitch of D2T (floats, multiple of 64, >= Mq)
-    int32_t pad_;
-    int64_t offD, offT;    // float offsets into the scratch arena
+    int32_t nw;            // 64-bit words per row of the recurrence bitmap (band pipeline)
+    int64_t offD, offT;    // offD: float offset of D2 in the scratch arena (v1 / debug);
+                           // offT: v1: float offset of D2^T; band pipeline: u64-word offset of the
+                           // pair's recurrence bitmap (Mq rows x nw words) in the bit arena
     int64_t offX;          // float offset into the threshold arena:
                            //   [thr rows: pitchT][thr cols: pitchD][eps rows: pitchT][eps cols: pitchD]
 };
@@ -656,7 +658,9 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
                                                             const PairDesc *__restrict__ pd,
                                                             float *__restrict__ scratch,
                                                             float *__restrict__ thr,
-                                                            float kappa, int pct_mode, int inclusive, int oti_target)
+                                                            unsigned long long *__restrict__ bits,
+                                                            float kappa, int pct_mode, int inclusive, int oti_target,
+                                                            int role, int write_d2)
 {
     using G = BandGeom<M>;
     constexpr int NV = 4 * V4;           // values per lane of a complete row
@@ -670,7 +674,6 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
 
     const PairDesc P = pd[blockIdx.y];
-    const int role = blockIdx.z;
     const int MA = role ? P.Mr : P.Mq, MB = role ? P.Mq : P.Mr;
     const int TA = role ? P.Tr : P.Tq, TB = role ? P.Tq : P.Tr;
     const int i0 = blockIdx.x * BAND;
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #pragma unroll
                 for (int a = 0; a < BAND; ++a) xv[a][st] = dv[a];
 #ifndef ACX_ABL_NOSTORE
-                if (role == 0) {
+                if (write_d2) {
                     float *Dl = D + j0;
 #pragma unroll
                     for (int a = 0; a < BAND; ++a) Dl[a * pitchD + a] = dv[a];
@@ -848,14 +851,14 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
                     const bool ok = rowok && j >= 0 && j < MB;
                     const float v = ok ? dv[a] : INF;
                     xv[a][st] = v;
-                    if (role == 0 && rowok && j >= 0 && j < pitchD) D[a * pitchD + j] = v;
+                    if (write_d2 && rowok && j >= 0 && j < pitchD) D[a * pitchD + j] = v;
                 }
             }
             wave_lds_fence();
         }
     }
-    // role 0: +inf into the pad columns [MB, pitchD) of the band's rows (K3 reads whole 8-column groups)
-    if (role == 0) {
+    // debug / v1 consumers: +inf into the pad columns [MB, pitchD) of the band's rows
+    if (write_d2) {
         const int npad = pitchD - MB;
         for (int idx = tid; idx < BAND * npad; idx += BAND_THREADS) {
             const int a = idx / npad, j = MB + idx - a * npad;
@@ -871,12 +874,9 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
         for (int a = 0; a < BAND; ++a) smem[a * ROWP + 64 * tile + lane] = xv[a][st];
     }
     __syncthreads();
-    float xr[NV];
+    float xr[NV];      // xr[t] = cell of column 64 t - 7 + wave + lane of band row `wave`
 #pragma unroll
-    for (int q = 0; q < V4; ++q) {
-        const float4 t = *reinterpret_cast<const float4 *>(smem + wave * ROWP + 256 * q + 4 * lane);
-        xr[4 * q + 0] = t.x; xr[4 * q + 1] = t.y; xr[4 * q + 2] = t.z; xr[4 * q + 3] = t.w;
-    }
+    for (int t = 0; t < NV; ++t) xr[t] = smem[wave * ROWP + 64 * t + lane];
     __syncthreads();     // exchange buffer dead -> reuse as histograms
 
     // ---- exact percentile selection: wave w owns band row w
@@ -903,12 +903,120 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     const bool interp = (pct_mode == 0 || pct_mode == 1);
     const SelectResult sr = wave_select_regs<NV>(xr, k, hist, cand, counter, lane, interp);
     const float eps = percentile_eps(sr, pct_mode, ilo, ihi, kf, fl, ce);
+    const float thr_row = d2_threshold(eps, inclusive);
+    float *X = thr + P.offX;
     if (lane == 0) {
-        float *X = thr + P.offX;
         const int o = role ? P.pitchT + row : row;
-        X[o] = d2_threshold(eps, inclusive);
+        X[o] = thr_row;
         X[P.pitchT + P.pitchD + o] = eps;
     }
+    // ---- role 0 (the column thresholds of the pair are already there): binarise the row the
+    // wave still holds in registers and emit it as a bitmap -- word t = columns
+    // [64 t - 7 + (row & 7), +64).  256 bytes per row instead of 8 KB of f32.
+    if (role == 0 && bits) {
+        const float *tc = X + P.pitchT;                  // column thresholds (d2 domain)
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int j = 64 * t - (BAND - 1) + wave + lane;
+            const float tcj = (j >= 0 && j < MB) ? tc[j] : -1.0f;
+            const unsigned long long m = __ballot(xr[t] <= fminf(thr_row, tcj));
+            mine = (lane == t) ? m : mine;
+        }
+        if (lane < P.nw) bits[P.offT + (size_t)row * P.nw + lane] = (lane < NV) ? mine : 0ull;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K3b: Qmax on the recurrence bitmap (band pipeline).  One wave per pair; lane owns the 32
+// contiguous columns [32 lane, +32); Q rows i-1 / i-2 live in registers (updated in place,
+// descending column order); the row's 32 recurrence bits of a lane are one funnel shift of two
+// dwords of the row bitmap (the bitmap of row i starts at column (i & 7) - 7).
+// ------------------------------------------------------------------------------------
+template <bool EQG>
+__global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restrict__ pd,
+                                                       const unsigned long long *__restrict__ bits,
+                                                       float *__restrict__ out, float go, float ge, int dp_start)
+{
+    const int lane = threadIdx.x;
+    const PairDesc P = pd[blockIdx.x];
+    int Me = P.Mq, Ne = P.Mr;
+    if (dp_start == 3) { Me -= 1; Ne -= 1; }
+    const int ndw = 2 * P.nw;                                   // dwords per row
+    const unsigned *rows = reinterpret_cast<const unsigned *>(bits + P.offT);
+    // columns of this lane that exist (and are >= 2: the first two columns of Q stay 0)
+    unsigned colmask = 0u;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const int j = 32 * lane + e;
+        if (j >= 2 && j < Ne) colmask |= (1u << e);
+    }
+    float Q1[32], Q2[32];
+    float P1[EQG ? 1 : 32], P2[EQG ? 1 : 32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        Q1[e] = 0.0f; Q2[e] = 0.0f;
+        if constexpr (!EQG) { P1[e] = 0.0f; P2[e] = 0.0f; }
+    }
+    float best = 0.0f;
+    const int prev = (lane + 63) & 63;
+    const bool has0 = lane < ndw, has1 = lane + 1 < ndw;
+
+    auto load_row = [&](int i, unsigned &d0, unsigned &d1) {
+        d0 = 0u; d1 = 0u;
+        if (i < Me) {
+            const unsigned *r = rows + (size_t)i * ndw;
+            if (has0) d0 = r[lane];
+            if (has1) d1 = r[lane + 1];
+        }
+    };
+    // One DP row: QA = row i-1, QB = row i-2 (overwritten with row i)
+    auto dp_row = [&](int i, unsigned d0, unsigned d1, float (&QA)[32], float (&QB)[32],
+                      float (&PA)[EQG ? 1 : 32], float (&PB)[EQG ? 1 : 32]) {
+        const int sh = (BAND - 1) - (i & (BAND - 1));           // bit position of column 0 in the row bitmap
+        const unsigned w = __builtin_amdgcn_alignbit(d1, d0, sh) & colmask;
+        float l1a = wave_shfl(QA[31], prev), l1b = wave_shfl(QA[30], prev), l2a = wave_shfl(QB[31], prev);
+        float p1a = 0.f, p1b = 0.f, p2a = 0.f;
+        if constexpr (!EQG) {
+            p1a = wave_shfl(PA[31], prev); p1b = wave_shfl(PA[30], prev); p2a = wave_shfl(PB[31], prev);
+        }
+        if (lane == 0) { l1a = 0.f; l1b = 0.f; l2a = 0.f; p1a = 0.f; p1b = 0.f; p2a = 0.f; }
+#pragma unroll
+        for (int e = 31; e >= 0; --e) {
+            const bool r = (w >> e) & 1u;
+            const float c2 = (e >= 1) ? QA[e - 1] : l1a;                          // (i-1, j-1)
+            const float c3 = (e >= 1) ? QB[e - 1] : l2a;                          // (i-2, j-1)
+            const float c4 = (e >= 2) ? QA[e - 2] : (e == 1 ? l1a : l1b);         // (i-1, j-2)
+            const float mx = fmaxf(fmaxf(c2, c3), c4);
+            float vgap;
+            if constexpr (EQG) {
+                vgap = fmaxf(mx - go, 0.0f);
+            } else {
+                const float a2 = (e >= 1) ? PA[e - 1] : p1a;
+                const float a3 = (e >= 1) ? PB[e - 1] : p2a;
+                const float a4 = (e >= 2) ? PA[e - 2] : (e == 1 ? p1a : p1b);
+                vgap = fmaxf(fmaxf(fmaxf(a2, a3), a4), 0.0f);
+            }
+            float q = r ? (mx + 1.0f) : vgap;
+            if (!((colmask >> e) & 1u)) q = 0.0f;      // columns 0, 1 and columns right of the matrix
+            QB[e] = q;
+            if constexpr (!EQG) PB[e] = q - (r ? go : ge);
+            best = fmaxf(best, q);
+        }
+    };
+
+    unsigned a0, a1, b0, b1, c0, c1, d0, d1;
+    load_row(2, a0, a1); load_row(3, b0, b1); load_row(4, c0, c1); load_row(5, d0, d1);
+    for (int i = 2; i < Me; i += 4) {
+        // rows i .. i+3; row i+S reads QA = row i+S-1, QB = row i+S-2 and overwrites QB
+        unsigned n0, n1;
+        if (i < Me) { load_row(i + 4, n0, n1); dp_row(i, a0, a1, Q1, Q2, P1, P2); a0 = n0; a1 = n1; }
+        if (i + 1 < Me) { load_row(i + 5, n0, n1); dp_row(i + 1, b0, b1, Q2, Q1, P2, P1); b0 = n0; b1 = n1; }
+        if (i + 2 < Me) { load_row(i + 6, n0, n1); dp_row(i + 2, c0, c1, Q1, Q2, P1, P2); c0 = n0; c1 = n1; }
+        if (i + 3 < Me) { load_row(i + 7, n0, n1); dp_row(i + 3, d0, d1, Q2, Q1, P2, P1); d0 = n0; d1 = n1; }
+    }
+    best = wave_max(best);
+    if (lane == 0) out[blockIdx.x] = best;
 }
 
 // ------------------------------------------------------------------------------------
