@@ -347,12 +347,14 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                 ACX_M_SWITCH(p.m, ACX_CALL)
 #undef ACX_CALL
             }
-            {   // K1': fused band kernel; role 1 (column thresholds) first, then role 0 (row
-                // thresholds + recurrence bitmap, which needs the column thresholds)
+            {   // K1' role 1: rows = reference frames -> column thresholds
                 ProfScope ps(c, KS_BAND, cells);
 #define ACX_CALL(M_) launch_band<M_>(c, B, maxMr, maxMq, p, 1, 0)
                 ACX_M_SWITCH(p.m, ACX_CALL)
 #undef ACX_CALL
+            }
+            {   // K1' role 0: rows = query frames -> row thresholds + recurrence bitmap (needs role 1)
+                ProfScope ps(c, KS_BAND, cells);
 #define ACX_CALL(M_) launch_band<M_>(c, B, maxMq, maxMr, p, 0, dbg ? 1 : 0)
                 ACX_M_SWITCH(p.m, ACX_CALL)
 #undef ACX_CALL

@@ -31,7 +31,10 @@ constexpr int NBIN = 12;       // chroma bins
 constexpr int TILE = 64;       // output tile edge of K1
 constexpr int STILE = 80;      // S tile edge (TILE + 16 halo): supports m <= 17
 constexpr int SPITCH = 81;
-constexpr int SEL_BINS = 2048; // histogram bins of K2
+#ifndef ACX_SEL_BINS
+#define ACX_SEL_BINS 2048
+#endif
+constexpr int SEL_BINS = ACX_SEL_BINS; // histogram bins of the percentile selection
 constexpr int MAX_M = 16;
 
 struct PairDesc {

@@ -40,9 +40,11 @@ M_STACK = 9
 # algorithmic bytes per matrix cell by kernel (DESIGN.md "Roofline model"; SURVEY.md 8d:
 # 10 B/cell = f32 distance matrix written once + read once, 1-byte recurrence matrix
 # written once + read once)
-# band_kernel = distance matrix + both threshold passes fused (it replaces the v1 pair
-# csm_tile_kernel 4 B/cell + rowsel_kernel 4 B/cell); qmax_kernel = recurrence plot + DP.
-ALGO_BYTES_PER_CELL = {"band_kernel": 8.0, "csm_tile_kernel": 4.0, "rowsel_kernel": 4.0, "qmax_kernel": 2.0,
+# band_kernel is launched twice per batch (role 1: column thresholds, role 0: row thresholds +
+# recurrence bitmap); each launch carries one 4 B/cell pass over the distance matrix of the
+# model (write / read-back), together the 8 B/cell of v1's csm_tile_kernel + rowsel_kernel;
+# qmax_kernel = the DP over the recurrence plot.
+ALGO_BYTES_PER_CELL = {"band_kernel": 4.0, "csm_tile_kernel": 4.0, "rowsel_kernel": 4.0, "qmax_kernel": 2.0,
                        "oti_kernel": 0.0, "norms_kernel": 0.0}
 
 
