@@ -302,11 +302,16 @@ __device__ __forceinline__ int wave_sum_i(int v)
 }
 __device__ __forceinline__ int wave_incl_scan_i(int v) { return wave_scan_bits(v, 0, OpAddI()); }
 
-// histogram slot of logical bin b: one pad word per 32 bins, so that neighbouring bins sit
-// in neighbouring banks (atomics) AND the scan, where lane L reads bins 32L..32L+31, is
-// conflict-free ((33 L + e) mod 32 distinct over L).
-constexpr int SEL_SLOTS = SEL_BINS + SEL_BINS / 32 + 16;   // + the dummy slot hslot(SEL_BINS), padded to 16
-__device__ __forceinline__ int hslot(int b) { return b + (b >> 5); }
+// histogram slot of logical bin b of an SB-bin histogram: one pad word per BPL = SB/64 bins,
+// so that neighbouring bins sit in neighbouring banks (atomics) AND the scan, where lane L
+// reads bins BPL*L .. BPL*L+BPL-1, is conflict-free (((BPL+1) L + e) mod 32 distinct over L).
+template <int SB> struct SelGeom {
+    static constexpr int BPL = SB / 64;                    // bins per lane in the scan
+    static constexpr int SLOTS = SB + 64 + 16;             // + pads + the dummy slot, padded to 16
+    static_assert(SB % 128 == 0, "bins per lane must be even");
+    __device__ static __forceinline__ int slot(int b) { return b + b / BPL; }
+};
+constexpr int SEL_SLOTS = SelGeom<SEL_BINS>::SLOTS;
 
 struct SelectResult { float value; int cnt_le; float next; };
 
@@ -317,10 +322,12 @@ struct SelectResult { float value; int cnt_le; float next; };
 // SEL_BINS linear bins, descend into the bin holding rank k, until it holds <= 64
 // elements, which are ranked directly.  If want_next, also returns #(v <= result) and
 // min{v > result} (+inf if none).
-template <int NV>
+template <int NV, int SB = SEL_BINS>
 __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], int k, unsigned *hist, float *cand,
                                                          unsigned *counter, int lane, bool want_next)
 {
+    using SG = SelGeom<SB>;
+    constexpr int BPL = SG::BPL;
     const float INF = __builtin_inff();
     float mn = INF, mx = -INF;
 #pragma unroll
@@ -337,8 +344,8 @@ __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], i
 #endif
     for (int iter = 0; iter < 64; ++iter) {
         if (!(mn < mx)) { result = mn; break; }
-        const float scale = (float)SEL_BINS / (mx - mn);
-        for (int b = lane * 4; b < SEL_SLOTS; b += 256)
+        const float scale = (float)SB / (mx - mn);
+        for (int b = lane * 4; b < SG::SLOTS; b += 256)
             *reinterpret_cast<uint4 *>(hist + b) = make_uint4(0, 0, 0, 0);
         if (lane == 0) *counter = 0u;
         wave_lds_fence();
@@ -349,22 +356,22 @@ __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], i
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             int b = (int)((x[t] - mn) * scale);
-            b = b > SEL_BINS - 1 ? SEL_BINS - 1 : b;
+            b = b > SB - 1 ? SB - 1 : b;
             const bool in = x[t] >= mn && x[t] <= mx;
-            bins[t] = in ? b : SEL_BINS;          // SEL_BINS = dummy
+            bins[t] = in ? b : SB;                // SB = dummy
         }
 #pragma unroll
         for (int t = 0; t < NV; ++t)
-            __hip_atomic_fetch_add(&hist[hslot(bins[t])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&hist[SG::slot(bins[t])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         wave_lds_fence();
 #if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 2
         return SelectResult{(float)hist[lane] + (float)bins[3], 0, INF};
 #endif
-        // scan: lane owns bins [32*lane, 32*lane+32)
-        int hv[32];
+        // scan: lane owns bins [BPL*lane, BPL*lane+BPL)
+        int hv[BPL];
         int lsum = 0;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) { hv[e] = (int)hist[33 * lane + e]; lsum += hv[e]; }
+        for (int e = 0; e < BPL; ++e) { hv[e] = (int)hist[(BPL + 1) * lane + e]; lsum += hv[e]; }
         const int incl = wave_incl_scan_i(lsum);
         const int target = k - below;                 // rank inside the active set
         const unsigned long long m = __ballot(incl > target);
@@ -374,9 +381,9 @@ __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], i
         {
             int run = excl;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) {
+            for (int e = 0; e < BPL; ++e) {
                 const bool here = cnt_v == 0 && run + hv[e] > target;
-                binsel_v = here ? 32 * lane + e : binsel_v;
+                binsel_v = here ? BPL * lane + e : binsel_v;
                 cum_v = here ? run : cum_v;
                 cnt_v = here ? hv[e] : cnt_v;
                 run += hv[e];
@@ -503,6 +510,180 @@ __device__ __forceinline__ float d2_threshold(float eps, int inclusive)
         }
         return c;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Fast path of the band kernel's selection: ONE histogram pass, order statistics k and k+1
+// together.  The row lives in registers (NV values per lane, cells outside the matrix are
+// +inf).  Returns false when the pass cannot decide (more than 64 candidates in the target
+// bins, degenerate value range): the caller then runs the generic narrowing selection.
+//   * range: integer min / max on the f32 bit patterns (d2 >= +0, so the patterns order like
+//     the values); the max runs on bits + 0x00800000, which makes +inf negative;
+//   * bin = (x - mn) * scale, monotone in x, so the histogram is a monotone partition and
+//     ranks are exact whatever the rounding; three VALU ops per value give the LDS byte
+//     address of the bin (sub, mul, cvt, and_or); +inf lands in the top slot, which no finite
+//     value reaches;
+//   * lane L owns BINS/64 consecutive bins in the scan; the two target bins are then located
+//     with one more LDS read by 2 x 16 lanes; their members (<= 64) are gathered with an
+//     address compare and ranked directly.
+// `hist_addr` = LDS byte address of this wave's zeroed BINS-dword histogram, aligned to its
+// size; `cand` = 64 floats of scratch LDS private to the wave.
+// ------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+// compile-time loop: f(std::integral_constant<int, I>()) for I = B .. E-1
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>());
+        static_for<B + 1, E>(f);
+    }
+}
+// (lo, hi)[lane LANE] = the two halves of a wave-uniform 64-bit mask, other lanes keep theirs.
+// gfx950 needs 2 wait states between a VALU write of an SGPR (the ballot) and a VALU read of it;
+// the compiler does not track that hazard into inline asm, hence the s_nop.
+template <int LANE>
+__device__ __forceinline__ void writelane_mask(unsigned &lo, unsigned &hi, unsigned long long m)
+{
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi) : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "n"(LANE));
+}
+
+struct OpMinU { __device__ int operator()(int a, int b) const { return (unsigned)a < (unsigned)b ? a : b; } };
+struct OpMaxI { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
+
+template <int NV, int BINS>
+__device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bool want_next, unsigned hist_addr,
+                                                 float *cand, int lane, float &slo, float &shi)
+{
+    constexpr int BPL = BINS / 64;          // bins per lane in the scan
+    constexpr int NQ = BPL / 4;             // 16-byte pieces per lane
+    static_assert(BPL >= 4 && BPL <= 16 && (BPL & (BPL - 1)) == 0, "BINS must be 256, 512 or 1024");
+    const float INF = __builtin_inff();
+    // ---- value range over the finite cells
+    unsigned mnu = 0xFFFFFFFFu;
+    int mxb = (int)0x80000000;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const unsigned b = __float_as_uint(x[t]);
+        mnu = b < mnu ? b : mnu;
+        const int bb = (int)(b + 0x00800000u);
+        mxb = bb > mxb ? bb : mxb;
+    }
+    mnu = (unsigned)__builtin_amdgcn_readlane(wave_scan_bits((int)mnu, -1, OpMinU()), 63);
+    mxb = __builtin_amdgcn_readlane(wave_scan_bits(mxb, (int)0x80000000, OpMaxI()), 63);
+    const float mn = __uint_as_float(mnu);
+    const float mx = __uint_as_float((unsigned)mxb - 0x00800000u);
+    if (mxb < 0) return false;                       // no finite cell at all
+    if (!(mn < mx)) { slo = mn; shi = mn; return true; }   // every finite cell equal
+    const float range = mx - mn;
+    if (!(range >= 1e-30f) || !(range <= 1e30f)) return false;
+    const float scale4 = (4.0f * ((float)BINS - 1.5f)) * __builtin_amdgcn_rcpf(range);
+    // ---- histogram
+    unsigned off[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const float y = (x[t] - mn) * scale4;
+        unsigned q;
+        asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(y));        // saturating: +inf -> 0xffffffff
+        off[t] = (q & (unsigned)(4 * (BINS - 1))) | hist_addr;
+    }
+#pragma unroll
+    for (int t = 0; t < NV; ++t)
+        __hip_atomic_fetch_add((lds_u32 *)off[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    wave_lds_fence();
+    // ---- scan: lane owns bins [BPL lane, +BPL); pieces read in a staggered order (conflict-free)
+    int lsum = 0;
+    {
+        const int rot = (NQ > 1) ? ((lane >> (NQ == 2 ? 3 : 2)) & (NQ - 1)) : 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int piece = (q + rot) & (NQ - 1);
+            const u32x4 h = *(const lds_u32x4 *)(hist_addr + (unsigned)(lane * BPL + 4 * piece) * 4u);
+            lsum += (int)(h.x + h.y) + (int)(h.z + h.w);
+        }
+    }
+    const int incl = wave_incl_scan_i(lsum);
+    const int L1 = __ffsll((long long)__ballot(incl > k)) - 1;
+    const int L2 = want_next ? __ffsll((long long)__ballot(incl > k + 1)) - 1 : L1;
+    if (L1 < 0 || L2 < 0) return false;              // cannot happen (k < n <= finite count + pads)
+    const int ex1 = __builtin_amdgcn_readlane(incl - lsum, L1);
+    const int ex2 = __builtin_amdgcn_readlane(incl - lsum, L2);
+    // second level: lanes 0..15 look at lane L1's bins, lanes 16..31 at lane L2's
+    const int e = lane & 15;
+    const bool lo16 = lane < 16;
+    int c = 0;
+    if (lane < 32 && e < BPL)
+        c = (int)*(const lds_u32 *)(hist_addr + (unsigned)((lo16 ? L1 : L2) * BPL + e) * 4u);
+    int P = c;                                        // inclusive prefix inside each row of 16 lanes
+    P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, false);
+    P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, false);
+    P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xf, 0xf, false);
+    if (BPL > 8) P += __builtin_amdgcn_update_dpp(0, P, 0x118, 0xf, 0xf, false);
+    const int l1 = __ffsll((long long)__ballot(lo16 && e < BPL && ex1 + P > k)) - 1;
+    if (l1 < 0) return false;
+    const int cnt1 = __builtin_amdgcn_readlane(c, l1);
+    const int cum1 = ex1 + __builtin_amdgcn_readlane(P, l1) - cnt1;
+    const int bin1 = L1 * BPL + l1;
+    int bin2 = bin1, ncand = cnt1;
+    if (want_next) {
+        const int l2 = __ffsll((long long)__ballot(!lo16 && lane < 32 && e < BPL && ex2 + P > k + 1)) - 1;
+        if (l2 < 0) return false;
+        bin2 = L2 * BPL + (l2 - 16);
+        if (bin2 != bin1) ncand += __builtin_amdgcn_readlane(c, l2);    // the bins between are empty
+    }
+    if (ncand > 64 || bin2 >= BINS - 1) return false;
+    // ---- gather the members of [bin1, bin2]
+    const unsigned a1 = hist_addr + 4u * (unsigned)bin1, span = 4u * (unsigned)(bin2 - bin1);
+    int n = 0;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const bool hit = (off[t] - a1) <= span;
+        const unsigned long long m = __ballot(hit);
+        if (m != 0ull) {
+            if (hit) {
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                cand[(n + (int)pos) & 63] = x[t];
+            }
+            n += __popcll(m);
+        }
+    }
+    wave_lds_fence();
+    // ---- rank them
+    const float mine = (lane < ncand) ? cand[lane] : INF;
+    int rank = 0;
+#pragma unroll 1
+    for (int t = 0; t < ncand; ++t) {
+        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), t));
+        rank += (o < mine || (o == mine && t < lane)) ? 1 : 0;
+    }
+    const int want = k - cum1;
+    const int s1 = __ffsll((long long)__ballot(lane < ncand && rank == want)) - 1;
+    if (s1 < 0) return false;
+    slo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), s1));
+    shi = slo;
+    if (want_next) {
+        const int s2 = __ffsll((long long)__ballot(lane < ncand && rank == want + 1)) - 1;
+        if (s2 < 0) return false;
+        shi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), s2));
+    }
+    wave_lds_fence();
+    return true;
+}
+
+// eps from the two order statistics d2_(ilo) <= d2_(ihi) (oracle percentile_f32)
+__device__ __forceinline__ float percentile_eps2(float slo, float shi, int pct_mode, int ilo, int ihi,
+                                                 float kf, float fl, float ce)
+{
+    if (!(pct_mode == 0 || pct_mode == 1)) return __builtin_sqrtf(slo);
+    const float dlo = __builtin_sqrtf(slo), dhi = __builtin_sqrtf(shi);
+    if (pct_mode == 0 && ihi == ilo) return dlo;
+    const float d0 = __fmul_rn(dlo, __fsub_rn(ce, kf));
+    const float d1 = __fmul_rn(dhi, __fsub_rn(kf, fl));
+    return __fadd_rn(d0, d1);
 }
 
 template <int V4>
@@ -635,7 +816,7 @@ struct BandGeom {
     static constexpr int AROWS = 16 * NRT;
     static constexpr int BW = 16 * NCT;
     static constexpr int AP = (AROWS % 32 == 16) ? AROWS : AROWS + 16;   // pitch % 32 == 16: the two
-    static constexpr int SP = BW + 1;
+    static constexpr int SP = BW + 4;                              // S pitch: 16-byte aligned rows; 84 % 32 = 20 keeps the 16-byte tile stores conflict-free
     static constexpr int NPIECE = (BW * 3 + 63) / 64;               // 16-byte LDS-DMA pieces per lane per tile
     static constexpr int BFLOATS = 256 * NPIECE;                    // frame-major column-frame slab (DMA image)
     static constexpr int WAVE_FLOATS = BFLOATS + AROWS * SP + 2 * BW;  // frames + S + column norms (x2)
@@ -668,13 +849,21 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     using G = BandGeom<M>;
     constexpr int NV = 4 * V4;           // values per lane of a complete row
     constexpr int NSTEP = NV / 8;        // tiles per wave
-    constexpr int ROWP = 64 * NV + 4;    // exchange pitch (floats)
-    constexpr int SWEEP_FLOATS = NBIN * G::AP + 8 * G::WAVE_FLOATS;
-    constexpr int XCH_FLOATS = BAND * ROWP;
-    constexpr int SEL_FLOATS = 8 * SEL_SLOTS + 8 * 64 + 8;
-    constexpr int LDS_A = SWEEP_FLOATS > XCH_FLOATS ? SWEEP_FLOATS : XCH_FLOATS;
-    constexpr int LDS_FLOATS = LDS_A > SEL_FLOATS ? LDS_A : SEL_FLOATS;
-    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    constexpr int ROWP = 64 * NV;        // exchange pitch (floats): row a = [wave w'][lane][step]
+#ifdef ACX_FBINS
+    constexpr int FBINS = ACX_FBINS;
+#else
+    constexpr int FBINS = NV >= 32 ? 512 : 256;                 // bins of the fast selection
+#endif
+    constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
+    constexpr int SWEEP_FLOATS = 8 * G::WAVE_FLOATS;            // (the row-frame stage As aliases the slabs)
+    static_assert(NBIN * G::AP <= 8 * G::WAVE_FLOATS, "row-frame stage must fit");
+    constexpr int HIST_OFF = BAND * ROWP;                       // fast histograms sit behind the exchange rows
+    constexpr int TAIL_FLOATS = HIST_OFF + 8 * FBINS;
+    constexpr int LDS_FLOATS = SWEEP_FLOATS > TAIL_FLOATS ? SWEEP_FLOATS : TAIL_FLOATS;
+    static_assert(SelGeom<GBINS>::SLOTS + 64 + 4 <= ROWP, "generic selection must fit the wave's own exchange row");
+    static_assert((HIST_OFF * 4) % (FBINS * 4) == 0, "fast histograms must be aligned to their size");
+    __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
 
     const PairDesc P = pd[blockIdx.y];
     const int MA = role ? P.Mr : P.Mq, MB = role ? P.Mq : P.Mr;
@@ -694,8 +883,8 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     const float INF = __builtin_inff();
 
     float *As = smem;
-    float *Bw = smem + NBIN * G::AP + wave * G::WAVE_FLOATS;   // this wave's slab: frames (frame-major)
-    float *Sw = Bw + G::BFLOATS;                               // Gram tile
+    float *Bw = smem + wave * G::WAVE_FLOATS;                  // this wave's slab: frames (frame-major)
+    float *Sw = Bw + G::BFLOATS;                               // Gram tile, [row frame][column frame], pitch SP
     float *Yw = Sw + G::AROWS * G::SP;                         // column norms, double-buffered
 
     // ---- stage the band's row frames once (bin-major, un-rotated)
@@ -725,6 +914,7 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     float xrow[BAND];
 #pragma unroll
     for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : 0.0f;
+    __syncthreads();     // As is dead (operands are in registers): its LDS now belongs to the slabs
 
     const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= NV by dispatch
     const int pitchD = P.pitchD;
@@ -781,7 +971,9 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
             const float *Yt = Yw + (st & 1) * G::BW;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's DMA has landed
             wave_lds_fence();
-            // ---- frame Gram on the matrix cores
+            // ---- frame Gram on the matrix cores.  The COLUMN frames are the MFMA's row operand, so a
+            // lane ends up with four consecutive column frames of one row frame: one 16-byte LDS store
+            // per 16x16 tile (products commute, the k order is unchanged: same bits).
 #ifndef ACX_ABL_NOGRAM
             {
                 // all column tiles in flight at once: operand loads first, then the MFMA chains
@@ -802,14 +994,12 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
                     for (int ta = 0; ta < G::NRT; ++ta)
 #pragma unroll
                         for (int tb = 0; tb < G::NCT; ++tb)
-                            acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ta][kb], bv[tb][kb], acc[ta][tb], 0, 0, 0);
+                            acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[tb][kb], areg[ta][kb], acc[ta][tb], 0, 0, 0);
 #pragma unroll
                 for (int ta = 0; ta < G::NRT; ++ta)
 #pragma unroll
                     for (int tb = 0; tb < G::NCT; ++tb)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg)
-                            Sw[(16 * ta + 4 * lk + reg) * G::SP + 16 * tb + lr] = acc[ta][tb][reg];
+                        *reinterpret_cast<f32x4 *>(Sw + (16 * ta + lr) * G::SP + 16 * tb + 4 * lk) = acc[ta][tb];
             }
 #endif
             wave_lds_fence();
@@ -868,19 +1058,39 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
             if (i0 + a < MA) D[a * pitchD + j] = INF;
         }
     }
-    __syncthreads();     // all slabs dead -> reuse LDS as the exchange buffer
-    // ---- exchange: element (tile, lane) of band row a -> X[a][64 tile + lane]
+    __syncthreads();     // all slabs dead -> reuse LDS as the exchange rows + the fast histograms
+    // ---- exchange: wave w hands its NSTEP cells of band row a to X[a][w][lane][0..NSTEP) -- one
+    // 16-byte store per row; the order of a row's cells is irrelevant to the selection, only the
+    // bitmap below needs to know that element w' * NSTEP + st sits in tile w' + 8 st.
 #pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {
-        const int tile = wave + 8 * st;
+    for (int a = 0; a < BAND; ++a) {
+        float *dst = smem + a * ROWP + (wave * 64 + lane) * NSTEP;
+        if constexpr (NSTEP == 4) *reinterpret_cast<float4 *>(dst) = make_float4(xv[a][0], xv[a][1], xv[a][2], xv[a][3]);
+        else if constexpr (NSTEP == 2) *reinterpret_cast<float2 *>(dst) = make_float2(xv[a][0], xv[a][1]);
+        else dst[0] = xv[a][0];
+    }
+    {   // zero this wave's fast histogram
+        float *h = smem + HIST_OFF + wave * FBINS;
 #pragma unroll
-        for (int a = 0; a < BAND; ++a) smem[a * ROWP + 64 * tile + lane] = xv[a][st];
+        for (int q = 0; q < FBINS / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    float xr[NV];      // xr[t] = cell of column 64 t - 7 + wave + lane of band row `wave`
+    float xr[NV];      // xr[w' * NSTEP + st] = cell of column 64 (w' + 8 st) - 7 + wave + lane of band row `wave`
 #pragma unroll
-    for (int t = 0; t < NV; ++t) xr[t] = smem[wave * ROWP + 64 * t + lane];
-    __syncthreads();     // exchange buffer dead -> reuse as histograms
+    for (int w = 0; w < 8; ++w) {
+        const float *src = smem + wave * ROWP + (w * 64 + lane) * NSTEP;
+        if constexpr (NSTEP == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src);
+            xr[4 * w + 0] = v.x; xr[4 * w + 1] = v.y; xr[4 * w + 2] = v.z; xr[4 * w + 3] = v.w;
+        } else if constexpr (NSTEP == 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(src);
+            xr[2 * w + 0] = v.x; xr[2 * w + 1] = v.y;
+        } else {
+            xr[w] = src[0];
+        }
+    }
+    // From here on the waves are independent: wave w owns exchange row w (its cells are in
+    // registers now) as private scratch, and its own fast histogram.
 
     // ---- exact percentile selection: wave w owns band row w
     const int row = i0 + wave;
@@ -889,9 +1099,6 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     if (lane == 0) { float acc_ = 0; for (int e = 0; e < NV; ++e) acc_ += xr[e]; thr[P.offX + (role ? P.pitchT + row : row)] = acc_; }
     return;
 #endif
-    unsigned *hist = reinterpret_cast<unsigned *>(smem) + wave * SEL_SLOTS;
-    float *cand = smem + 8 * SEL_SLOTS + wave * 64;
-    unsigned *counter = reinterpret_cast<unsigned *>(smem) + 8 * SEL_SLOTS + 8 * 64 + wave;
     const int n = MB;
     const float kf = (n > 1) ? __fmul_rn((float)(n - 1), kappa) : __fmul_rn((float)n, kappa);
     const float fl = floorf(kf), ce = ceilf(kf);
@@ -904,8 +1111,22 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
         k = k > n - 1 ? n - 1 : k;
     }
     const bool interp = (pct_mode == 0 || pct_mode == 1);
-    const SelectResult sr = wave_select_regs<NV>(xr, k, hist, cand, counter, lane, interp);
-    const float eps = percentile_eps(sr, pct_mode, ilo, ihi, kf, fl, ce);
+    float *myrow = smem + wave * ROWP;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row has left LDS
+    float slo, shi;
+    const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + HIST_OFF + wave * FBINS);
+    bool done = false;
+#ifndef ACX_NO_FASTSEL
+    done = wave_select_fast<NV, FBINS>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi);
+#endif
+    if (!done) {
+        unsigned *ghist = reinterpret_cast<unsigned *>(myrow) + 64;
+        unsigned *counter = reinterpret_cast<unsigned *>(myrow) + 64 + SelGeom<GBINS>::SLOTS;
+        const SelectResult sr = wave_select_regs<NV, GBINS>(xr, k, ghist, myrow, counter, lane, interp);
+        slo = sr.value;
+        shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
+    }
+    const float eps = percentile_eps2(slo, shi, pct_mode, ilo, ihi, kf, fl, ce);
     const float thr_row = d2_threshold(eps, inclusive);
     float *X = thr + P.offX;
     if (lane == 0) {
@@ -918,15 +1139,17 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     // [64 t - 7 + (row & 7), +64).  256 bytes per row instead of 8 KB of f32.
     if (role == 0 && bits) {
         const float *tc = X + P.pitchT;                  // column thresholds (d2 domain)
-        unsigned long long mine = 0ull;
-#pragma unroll
-        for (int t = 0; t < NV; ++t) {
-            const int j = 64 * t - (BAND - 1) + wave + lane;
+        unsigned mlo = 0u, mhi = 0u;
+        static_for<0, NV>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            constexpr int tile = idx / NSTEP + 8 * (idx % NSTEP);
+            const int j = 64 * tile - (BAND - 1) + wave + lane;
             const float tcj = (j >= 0 && j < MB) ? tc[j] : -1.0f;
-            const unsigned long long m = __ballot(xr[t] <= fminf(thr_row, tcj));
-            mine = (lane == t) ? m : mine;
-        }
-        if (lane < P.nw) bits[P.offT + (size_t)row * P.nw + lane] = (lane < NV) ? mine : 0ull;
+            const unsigned long long m = __ballot(xr[idx] <= fminf(thr_row, tcj));
+            writelane_mask<tile>(mlo, mhi, m);
+        });
+        if (lane < P.nw)
+            bits[P.offT + (size_t)row * P.nw + lane] = (lane < NV) ? (((unsigned long long)mhi << 32) | mlo) : 0ull;
     }
 }
 

@@ -89,6 +89,27 @@ def test_intermediates_bit_exact_ragged_and_large(ctx):
         _compare_pair(ctx, d, i, j, _lib.serra09_params(), oracle.serra09_params(), "len(%d,%d)" % (lens[i], lens[j]))
 
 
+def test_ties_and_degenerate_rows(ctx):
+    """Heavy exact ties (piecewise-constant tracks without noise, repeated frames, an all-equal
+    track): the histogram selection's candidate bins overflow and the generic narrowing path /
+    the all-equal shortcut must give the oracle's thresholds bit for bit."""
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    rng = np.random.default_rng(77)
+    protos = synth._frame_max_normalise(rng.random((5, 12)))
+    def steps(T, seg):
+        idx = np.repeat(rng.integers(0, len(protos), T // seg + 1), seg)[:T]
+        return protos[idx].astype(np.float32)
+    tracks = [steps(300, 7), steps(257, 3), np.repeat(protos[:1], 120, axis=0).astype(np.float32),
+              steps(900, 40), synth._frame_max_normalise(rng.random((400, 12))), steps(2000, 25)]
+    frames, offsets = synth.pack(tracks)
+    d = dict(frames=frames, offsets=offsets)
+    ctx.upload_pool(frames, offsets)
+    for (i, j) in [(0, 1), (1, 0), (2, 0), (0, 2), (2, 2), (3, 4), (4, 3), (3, 0), (5, 3), (3, 5), (5, 5)]:
+        for kw in (dict(), dict(pct_mode=2), dict(kappa=0.5)):
+            _compare_pair(ctx, d, i, j, _lib.serra09_params(**kw), oracle.serra09_params(**kw), "ties(%d,%d) %s" % (i, j, kw))
+
+
 def test_full_size_pair_2000(ctx):
     from acoss_amd import synth, _lib
     oracle = _oracle()
