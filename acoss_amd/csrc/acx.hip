@@ -903,6 +903,19 @@ int acx_profile_get(acx_ctx *c, int idx, char *name, int name_len, double *ms, i
     return ACX_OK;
 }
 
+#ifdef ACX_TIMING
+/* development builds only: read (and optionally clear) band_kernel's per-phase clock totals */
+int acx_debug_timing(acx_ctx *c, unsigned long long *out32, int reset)
+{
+    ACX_HIP(c, hipMemcpyFromSymbol(out32, HIP_SYMBOL(acx::acx_tim), sizeof(unsigned long long) * 32));
+    if (reset) {
+        unsigned long long z[32] = {0};
+        ACX_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(acx::acx_tim), z, sizeof(z)));
+    }
+    return ACX_OK;
+}
+#endif
+
 int acx_debug_sqrt(acx_ctx *c, const float *in, int64_t n, float *out)
 {
     if (!c || !in || !out || n <= 0) return ACX_ERR_INVALID;

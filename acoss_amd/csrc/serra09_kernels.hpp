@@ -482,34 +482,31 @@ __device__ __forceinline__ SelectResult wave_select(const float *__restrict__ v,
     return wave_select_regs<NV>(x, k, hist, cand, counter, lane, want_next);
 }
 
-// largest f32 x with sqrt(x) <= eps (inclusive) or sqrt(x) < eps (exclusive); -1 if none
+// largest f32 x with sqrtf(x) <= eps (inclusive) or sqrtf(x) < eps (exclusive); -1 if none.
+// Closed form (no search): sqrtf is correctly rounded, so sqrtf(x) <= e  <=>  sqrt(x) < m, or
+// sqrt(x) == m and the tie rounds to e (e's significand even), where m is the midpoint of e and
+// the next float above it.  m and m*m are exact in f64 (25 x 25 significant bits), hence the
+// threshold is the largest float below m*m -- or m*m itself in the tie case.  "< eps" is
+// "<= the float just below eps".
 __device__ __forceinline__ float d2_threshold(float eps, int inclusive)
 {
     if (!(eps >= 0.0f)) return -1.0f;
     if (eps == __builtin_inff()) return eps;
-    float c = __fmul_rn(eps, eps);
-    if (inclusive) {
-        for (int it = 0; it < 8 && __builtin_sqrtf(c) > eps; ++it)
-            c = __int_as_float(__float_as_int(c) - 1);
-        if (__builtin_sqrtf(c) > eps) return -1.0f;
-        for (int it = 0; it < 8; ++it) {
-            float up = __int_as_float(__float_as_int(c) + 1);
-            if (__builtin_sqrtf(up) <= eps) c = up; else break;
-        }
-        return c;
-    } else {
+    float e = eps;
+    if (!inclusive) {
         if (eps == 0.0f) return -1.0f;
-        for (int it = 0; it < 8 && !(__builtin_sqrtf(c) < eps); ++it) {
-            if (c == 0.0f) return -1.0f;
-            c = __int_as_float(__float_as_int(c) - 1);
-        }
-        if (!(__builtin_sqrtf(c) < eps)) return -1.0f;
-        for (int it = 0; it < 8; ++it) {
-            float up = __int_as_float(__float_as_int(c) + 1);
-            if (__builtin_sqrtf(up) < eps) c = up; else break;
-        }
-        return c;
+        e = __uint_as_float(__float_as_uint(eps) - 1u);
     }
+    if (__float_as_uint(e) >= 0x7f7fffffu) return e;            // FLT_MAX: every finite x qualifies
+    const float en = __uint_as_float(__float_as_uint(e) + 1u);
+    const double m = ((double)e + (double)en) * 0.5;
+    const double m2 = m * m;
+    float c = (float)m2;                                        // round to nearest
+    if ((double)c >= m2) {
+        const bool tie = (double)c == m2 && (__float_as_uint(e) & 1u) == 0u;
+        if (!tie) c = __uint_as_float(__float_as_uint(c) - 1u);  // m2 > 0, so c > 0 here
+    }
+    return c;
 }
 
 // ------------------------------------------------------------------------------------
@@ -555,10 +552,17 @@ __device__ __forceinline__ void writelane_mask(unsigned &lo, unsigned &hi, unsig
 struct OpMinU { __device__ int operator()(int a, int b) const { return (unsigned)a < (unsigned)b ? a : b; } };
 struct OpMaxI { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
 
+#ifdef ACX_TIMING
+#define ACX_TS(k) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (tsel) tsel[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ACX_TS(k) do { } while (0)
+#endif
 template <int NV, int BINS>
 __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bool want_next, unsigned hist_addr,
-                                                 float *cand, int lane, float &slo, float &shi)
+                                                 float *cand, int lane, float &slo, float &shi,
+                                                 unsigned long long *tsel = nullptr)
 {
+    ACX_TS(0);
     constexpr int BPL = BINS / 64;          // bins per lane in the scan
     constexpr int NQ = BPL / 4;             // 16-byte pieces per lane
     static_assert(BPL >= 4 && BPL <= 16 && (BPL & (BPL - 1)) == 0, "BINS must be 256, 512 or 1024");
@@ -580,21 +584,29 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
     if (mxb < 0) return false;                       // no finite cell at all
     if (!(mn < mx)) { slo = mn; shi = mn; return true; }   // every finite cell equal
     const float range = mx - mn;
-    if (!(range >= 1e-30f) || !(range <= 1e30f)) return false;
+    // y = fma(x, scale4, off4) is monotone in x; the rounding of off4 shifts every y by the same
+    // amount, at most 2^-24 * mn * scale4 -- kept below one quarter-bin unit by the guard (the top
+    // half bin is spare), so no finite value can reach the top slot or wrap the address mask
+    if (!(range >= 1e-30f) || !(range <= 1e30f) || !(mn <= 2048.0f * range)) return false;
     const float scale4 = (4.0f * ((float)BINS - 1.5f)) * __builtin_amdgcn_rcpf(range);
+    const float off4 = -(mn * scale4);
+    ACX_TS(1);
     // ---- histogram
     unsigned off[NV];
+    unsigned vmask = (unsigned)(4 * (BINS - 1));
+    asm volatile("" : "+v"(vmask));                 // keep the mask in a VGPR: v_and_or_b32 q, vmask, s_base
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
-        const float y = (x[t] - mn) * scale4;
+        const float y = __builtin_fmaf(x[t], scale4, off4);
         unsigned q;
-        asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(y));        // saturating: +inf -> 0xffffffff
-        off[t] = (q & (unsigned)(4 * (BINS - 1))) | hist_addr;
+        asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(y));        // saturating: +inf -> 0xffffffff, y < 0 -> 0
+        off[t] = (q & vmask) | hist_addr;
     }
 #pragma unroll
     for (int t = 0; t < NV; ++t)
         __hip_atomic_fetch_add((lds_u32 *)off[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     wave_lds_fence();
+    ACX_TS(2);
     // ---- scan: lane owns bins [BPL lane, +BPL); pieces read in a staggered order (conflict-free)
     int lsum = 0;
     {
@@ -636,29 +648,56 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
         if (bin2 != bin1) ncand += __builtin_amdgcn_readlane(c, l2);    // the bins between are empty
     }
     if (ncand > 64 || bin2 >= BINS - 1) return false;
+    ACX_TS(3);
     // ---- gather the members of [bin1, bin2]
     const unsigned a1 = hist_addr + 4u * (unsigned)bin1, span = 4u * (unsigned)(bin2 - bin1);
     int n = 0;
-#pragma unroll
-    for (int t = 0; t < NV; ++t) {
-        const bool hit = (off[t] - a1) <= span;
-        const unsigned long long m = __ballot(hit);
+    auto put = [&](unsigned long long m, bool hit, float v) {
         if (m != 0ull) {
             if (hit) {
                 const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                cand[(n + (int)pos) & 63] = x[t];
+                cand[(n + (int)pos) & 63] = v;
             }
             n += __popcll(m);
         }
+    };
+    static_assert(NV % 4 == 0, "gather works in groups of 4");
+    if (span == 0u) {
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            const bool h0 = off[t] == a1, h1 = off[t + 1] == a1, h2 = off[t + 2] == a1, h3 = off[t + 3] == a1;
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            if ((m0 | m1 | m2 | m3) != 0ull) {       // most groups hold no member of the target bin
+                put(m0, h0, x[t]); put(m1, h1, x[t + 1]); put(m2, h2, x[t + 2]); put(m3, h3, x[t + 3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            const bool h0 = (off[t] - a1) <= span, h1 = (off[t + 1] - a1) <= span;
+            const bool h2 = (off[t + 2] - a1) <= span, h3 = (off[t + 3] - a1) <= span;
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            if ((m0 | m1 | m2 | m3) != 0ull) {
+                put(m0, h0, x[t]); put(m1, h1, x[t + 1]); put(m2, h2, x[t + 2]); put(m3, h3, x[t + 3]);
+            }
+        }
     }
     wave_lds_fence();
+    ACX_TS(4);
     // ---- rank them
-    const float mine = (lane < ncand) ? cand[lane] : INF;
+    // every lane reads the candidates as LDS broadcasts, four per 16-byte read; slots beyond
+    // ncand are padded with +inf first so that no tail test is needed
+    if (lane >= ncand) cand[lane] = INF;
+    wave_lds_fence();
+    const float mine = cand[lane];
     int rank = 0;
 #pragma unroll 1
-    for (int t = 0; t < ncand; ++t) {
-        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), t));
-        rank += (o < mine || (o == mine && t < lane)) ? 1 : 0;
+    for (int t = 0; t < ncand; t += 4) {
+        const float4 o = *reinterpret_cast<const float4 *>(cand + t);
+        rank += (o.x < mine || (o.x == mine && t + 0 < lane)) ? 1 : 0;
+        rank += (o.y < mine || (o.y == mine && t + 1 < lane)) ? 1 : 0;
+        rank += (o.z < mine || (o.z == mine && t + 2 < lane)) ? 1 : 0;
+        rank += (o.w < mine || (o.w == mine && t + 3 < lane)) ? 1 : 0;
     }
     const int want = k - cum1;
     const int s1 = __ffsll((long long)__ballot(lane < ncand && rank == want)) - 1;
@@ -671,6 +710,7 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
         shi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), s2));
     }
     wave_lds_fence();
+    ACX_TS(5);
     return true;
 }
 
@@ -809,6 +849,15 @@ __global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ po
 constexpr int BAND = 8;
 constexpr int BAND_THREADS = 512;   // 8 waves
 
+// Development aid (-DACX_TIMING): per-phase shader-clock totals of band_kernel, summed over all
+// waves into acx_tim[] (slot 31 = number of waves).  Not compiled into the product library.
+#ifdef ACX_TIMING
+__device__ unsigned long long acx_tim[32];
+#define ACX_T(k) do { tstamp[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ACX_T(k) do { } while (0)
+#endif
+
 template <int M>
 struct BandGeom {
     static constexpr int NRT = (BAND + M - 1 + 15) / 16;            // 16-row MFMA tiles of row frames
@@ -857,7 +906,6 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #endif
     constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
     constexpr int SWEEP_FLOATS = 8 * G::WAVE_FLOATS;            // (the row-frame stage As aliases the slabs)
-    static_assert(NBIN * G::AP <= 8 * G::WAVE_FLOATS, "row-frame stage must fit");
     constexpr int HIST_OFF = BAND * ROWP;                       // fast histograms sit behind the exchange rows
     constexpr int TAIL_FLOATS = HIST_OFF + 8 * FBINS;
     constexpr int LDS_FLOATS = SWEEP_FLOATS > TAIL_FLOATS ? SWEEP_FLOATS : TAIL_FLOATS;
@@ -881,51 +929,20 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     const float *nrow = role ? NRM + P.pitchT : NRM;   // embedded norms of the row track
     const float *ncol = role ? NRM : NRM + P.pitchT;
     const float INF = __builtin_inff();
+#ifdef ACX_TIMING
+    unsigned long long tstamp[16];
+    unsigned long long tsub[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 16; ++q) tstamp[q] = 0;
+#endif
+    ACX_T(0);
 
-    float *As = smem;
     float *Bw = smem + wave * G::WAVE_FLOATS;                  // this wave's slab: frames (frame-major)
     float *Sw = Bw + G::BFLOATS;                               // Gram tile, [row frame][column frame], pitch SP
     float *Yw = Sw + G::AROWS * G::SP;                         // column norms, double-buffered
-
-    // ---- stage the band's row frames once (bin-major, un-rotated)
-    for (int idx = tid; idx < G::AROWS * 3; idx += BAND_THREADS) {
-        const int a = idx / 3, part = idx - 3 * a;
-        const int f = i0 + a;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < TA) v = *reinterpret_cast<const float4 *>(fa + (size_t)f * NBIN + 4 * part);
-        As[(4 * part + 0) * G::AP + a] = v.x;
-        As[(4 * part + 1) * G::AP + a] = v.y;
-        As[(4 * part + 2) * G::AP + a] = v.z;
-        As[(4 * part + 3) * G::AP + a] = v.w;
-    }
-    __syncthreads();
-    // MFMA operands: position k of the chain holds rotated bin k = source bin (k - rot) mod 12
-    const int lr = lane & 15, lk = lane >> 4;
-    float areg[G::NRT][3];
-    int browoff[3];
-#pragma unroll
-    for (int kb = 0; kb < 3; ++kb) {
-        int ka = 4 * kb + lk - rota; if (ka < 0) ka += NBIN;
-        int kbb = 4 * kb + lk - rotb; if (kbb < 0) kbb += NBIN;
-        browoff[kb] = kbb + lr * NBIN;       // frame-major slab: element (frame, bin) at frame*12 + bin
-#pragma unroll
-        for (int ta = 0; ta < G::NRT; ++ta) areg[ta][kb] = As[ka * G::AP + 16 * ta + lr];
-    }
-    float xrow[BAND];
-#pragma unroll
-    for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : 0.0f;
-    __syncthreads();     // As is dead (operands are in registers): its LDS now belongs to the slabs
+    float *As = smem + 7 * G::WAVE_FLOATS + G::BFLOATS;        // row-frame stage: aliases wave 7's Gram tile
+    static_assert(NBIN * G::AP <= G::AROWS * G::SP, "row-frame stage must fit a Gram tile");
 
     const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= NV by dispatch
-    const int pitchD = P.pitchD;
-    float *D = scratch + P.offD + (size_t)i0 * pitchD;
-
-    float xv[BAND][NSTEP];
-#pragma unroll
-    for (int a = 0; a < BAND; ++a)
-#pragma unroll
-        for (int st = 0; st < NSTEP; ++st) xv[a][st] = INF;
-
     // Column frames + norms of a tile go HBM/L2 -> LDS by LDS-DMA (global_load_lds): the slab is
     // a straight image of the frame memory (lane-linear 16-byte pieces), no VGPR round trip and
     // no ds_write.  Pieces of frames outside the track are skipped (their cells are masked).
@@ -963,14 +980,60 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
         }
     };
     dma_tile(wave, 0);
+
+    // ---- stage the band's row frames once (bin-major, un-rotated)
+    for (int idx = tid; idx < G::AROWS * 3; idx += BAND_THREADS) {
+        const int a = idx / 3, part = idx - 3 * a;
+        const int f = i0 + a;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < TA) v = *reinterpret_cast<const float4 *>(fa + (size_t)f * NBIN + 4 * part);
+        As[(4 * part + 0) * G::AP + a] = v.x;
+        As[(4 * part + 1) * G::AP + a] = v.y;
+        As[(4 * part + 2) * G::AP + a] = v.z;
+        As[(4 * part + 3) * G::AP + a] = v.w;
+    }
+    __syncthreads();
+    // MFMA operands: position k of the chain holds rotated bin k = source bin (k - rot) mod 12
+    const int lr = lane & 15, lk = lane >> 4;
+    float areg[G::NRT][3];
+    int browoff[3];
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+        int ka = 4 * kb + lk - rota; if (ka < 0) ka += NBIN;
+        int kbb = 4 * kb + lk - rotb; if (kbb < 0) kbb += NBIN;
+        browoff[kb] = kbb + lr * NBIN;       // frame-major slab: element (frame, bin) at frame*12 + bin
+#pragma unroll
+        for (int ta = 0; ta < G::NRT; ++ta) areg[ta][kb] = As[ka * G::AP + 16 * ta + lr];
+    }
+    float xrow[BAND];
+#pragma unroll
+    for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : 0.0f;
+    __syncthreads();     // As is dead (operands are in registers): wave 7 may write its Gram tile
+    ACX_T(1);
+
+    const int pitchD = P.pitchD;
+    float *D = scratch + P.offD + (size_t)i0 * pitchD;
+
+    float xv[BAND][NSTEP];
+#pragma unroll
+    for (int a = 0; a < BAND; ++a)
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) xv[a][st] = INF;
+
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
         const int tile = wave + 8 * st;
         if (tile < ntiles) {      // wave-uniform
             const int base = 64 * tile - (BAND - 1);
             const float *Yt = Yw + (st & 1) * G::BW;
+#ifdef ACX_TIMING
+            const unsigned long long ta0 = __builtin_readcyclecounter();
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's DMA has landed
             wave_lds_fence();
+#ifdef ACX_TIMING
+            const unsigned long long ta1 = __builtin_readcyclecounter();
+#endif
             // ---- frame Gram on the matrix cores.  The COLUMN frames are the MFMA's row operand, so a
             // lane ends up with four consecutive column frames of one row frame: one 16-byte LDS store
             // per 16x16 tile (products commute, the k order is unchanged: same bits).
@@ -1004,6 +1067,9 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #endif
             wave_lds_fence();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operand reads done: slab is free
+#ifdef ACX_TIMING
+            const unsigned long long ta2 = __builtin_readcyclecounter();
+#endif
             if (st + 1 < NSTEP) dma_tile(tile + 8, (st + 1) & 1);
             // ---- diagonal walk: 8 cells per lane
             float sv[M + BAND - 1];
@@ -1016,9 +1082,9 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
                 for (int a = 0; a < BAND; ++a) {
                     const float xy = tree_sum<M>(sv + a);
                     const float nc_ = Yt[lane + a];
-                    const float t1 = 2.0f * xy;
-                    // query-side norm first: (xx - 2xy) + yy
-                    float t3 = R1 ? ((nc_ - t1) + xrow[a]) : ((xrow[a] - t1) + nc_);
+                    // query-side norm first: (xx - 2xy) + yy.  2 * xy is exact, so the fused
+                    // multiply-add rounds once exactly where the spec's subtraction does.
+                    float t3 = R1 ? (__builtin_fmaf(-2.0f, xy, nc_) + xrow[a]) : (__builtin_fmaf(-2.0f, xy, xrow[a]) + nc_);
                     if (!(t3 > 0.0f)) t3 = 0.0f;
                     dv[a] = t3;
                 }
@@ -1048,8 +1114,16 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
                 }
             }
             wave_lds_fence();
+#ifdef ACX_TIMING
+            {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long ta3 = __builtin_readcyclecounter();
+                tsub[0] += ta1 - ta0; tsub[1] += ta2 - ta1; tsub[2] += ta3 - ta2;
+            }
+#endif
         }
     }
+    ACX_T(2);
     // debug / v1 consumers: +inf into the pad columns [MB, pitchD) of the band's rows
     if (write_d2) {
         const int npad = pitchD - MB;
@@ -1059,6 +1133,7 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
         }
     }
     __syncthreads();     // all slabs dead -> reuse LDS as the exchange rows + the fast histograms
+    ACX_T(3);
     // ---- exchange: wave w hands its NSTEP cells of band row a to X[a][w][lane][0..NSTEP) -- one
     // 16-byte store per row; the order of a row's cells is irrelevant to the selection, only the
     // bitmap below needs to know that element w' * NSTEP + st sits in tile w' + 8 st.
@@ -1074,7 +1149,9 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #pragma unroll
         for (int q = 0; q < FBINS / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    ACX_T(4);
     __syncthreads();
+    ACX_T(5);
     float xr[NV];      // xr[w' * NSTEP + st] = cell of column 64 (w' + 8 st) - 7 + wave + lane of band row `wave`
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
@@ -1113,11 +1190,18 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     const bool interp = (pct_mode == 0 || pct_mode == 1);
     float *myrow = smem + wave * ROWP;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row has left LDS
+    ACX_T(6);
     float slo, shi;
     const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + HIST_OFF + wave * FBINS);
     bool done = false;
 #ifndef ACX_NO_FASTSEL
+#ifdef ACX_TIMING
+    unsigned long long tsel[6] = {0, 0, 0, 0, 0, 0};
+    done = wave_select_fast<NV, FBINS>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, tsel);
+    if (lane == 0 && done && tsel[5] && (blockIdx.x & 31) == 5) for (int q = 0; q < 5; ++q) atomicAdd(&acx_tim[20 + q], tsel[q + 1] - tsel[q]);
+#else
     done = wave_select_fast<NV, FBINS>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi);
+#endif
 #endif
     if (!done) {
         unsigned *ghist = reinterpret_cast<unsigned *>(myrow) + 64;
@@ -1126,8 +1210,13 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
         slo = sr.value;
         shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
     }
+    ACX_T(7);
     const float eps = percentile_eps2(slo, shi, pct_mode, ilo, ihi, kf, fl, ce);
     const float thr_row = d2_threshold(eps, inclusive);
+#ifdef ACX_TIMING
+    asm volatile("" :: "v"(thr_row));
+#endif
+    ACX_T(8);
     float *X = thr + P.offX;
     if (lane == 0) {
         const int o = role ? P.pitchT + row : row;
@@ -1138,19 +1227,39 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     // wave still holds in registers and emit it as a bitmap -- word t = columns
     // [64 t - 7 + (row & 7), +64).  256 bytes per row instead of 8 KB of f32.
     if (role == 0 && bits) {
-        const float *tc = X + P.pitchT;                  // column thresholds (d2 domain)
+        // column thresholds (d2 domain).  All NV loads are issued back to back with no bounds
+        // check (columns -7 .. 64 ntiles + 63 of the threshold arena are always inside the pair's
+        // arena); only the tiles that stick out of the matrix (wave-uniform test) pay the fix-up.
+        const float *tc = X + P.pitchT + (wave + lane - (BAND - 1));
+        float tcv[NV];
+        static_for<0, NV>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            constexpr int tile = idx / NSTEP + 8 * (idx % NSTEP);
+            tcv[idx] = tc[64 * tile];
+        });
         unsigned mlo = 0u, mhi = 0u;
         static_for<0, NV>([&](auto ic) {
             constexpr int idx = decltype(ic)::value;
             constexpr int tile = idx / NSTEP + 8 * (idx % NSTEP);
-            const int j = 64 * tile - (BAND - 1) + wave + lane;
-            const float tcj = (j >= 0 && j < MB) ? tc[j] : -1.0f;
+            float tcj = tcv[idx];
+            if (tile == 0 || 64 * tile + 57 + wave > MB) {      // wave-uniform: some lanes are outside
+                const int j = 64 * tile - (BAND - 1) + wave + lane;
+                tcj = (j >= 0 && j < MB) ? tcj : -1.0f;
+            }
             const unsigned long long m = __ballot(xr[idx] <= fminf(thr_row, tcj));
             writelane_mask<tile>(mlo, mhi, m);
         });
         if (lane < P.nw)
             bits[P.offT + (size_t)row * P.nw + lane] = (lane < NV) ? (((unsigned long long)mhi << 32) | mlo) : 0ull;
     }
+    ACX_T(9);
+#ifdef ACX_TIMING
+    if (lane == 0 && (blockIdx.x & 31) == 5) {
+        for (int q = 0; q < 9; ++q) atomicAdd(&acx_tim[q], tstamp[q + 1] - tstamp[q]);
+        for (int q = 0; q < 3; ++q) atomicAdd(&acx_tim[16 + q], tsub[q]);
+        atomicAdd(&acx_tim[31], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
