@@ -199,12 +199,14 @@ void launch_band(acx_ctx *c, int B, int maxRows, int maxCols, const acx_serra09_
 {
     const dim3 grid((maxRows + acx::BAND - 1) / acx::BAND, B, 1);
     const int ndata = (maxCols + acx::BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
-#define ACX_BAND(V4_) hipLaunchKernelGGL((acx::band_kernel<M, V4_>), grid, dim3(acx::BAND_THREADS), 0, c->stream,     \
+#define ACX_BAND_R(V4_, R_) hipLaunchKernelGGL((acx::band_kernel<M, V4_, R_>), grid, dim3(acx::BAND_THREADS), 0, c->stream, \
                                          c->d_frames, c->d_toff, c->d_pd, c->d_scratch, c->d_thr, c->d_bits, p.kappa, \
-                                         p.pct_mode, p.inclusive, p.oti_target, role, write_d2)
+                                         p.pct_mode, p.inclusive, p.oti_target, write_d2)
+#define ACX_BAND(V4_) do { if (role) ACX_BAND_R(V4_, 1); else ACX_BAND_R(V4_, 0); } while (0)
     if (ndata <= 8) ACX_BAND(2);
     else if (ndata <= 16) ACX_BAND(4);
     else ACX_BAND(8);
+#undef ACX_BAND_R
 #undef ACX_BAND
 }
 

@@ -885,7 +885,7 @@ __device__ __forceinline__ float percentile_eps(const SelectResult &sr, int pct_
     return __fadd_rn(d0, d1);
 }
 
-template <int M, int V4>
+template <int M, int V4, int ROLE>
 __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__restrict__ pool,
                                                             const int64_t *__restrict__ toff,
                                                             const PairDesc *__restrict__ pd,
@@ -893,9 +893,10 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
                                                             float *__restrict__ thr,
                                                             unsigned long long *__restrict__ bits,
                                                             float kappa, int pct_mode, int inclusive, int oti_target,
-                                                            int role, int write_d2)
+                                                            int write_d2)
 {
     using G = BandGeom<M>;
+    constexpr int role = ROLE;           // 1: rows = reference frames (column thresholds); 0: rows = query frames
     constexpr int NV = 4 * V4;           // values per lane of a complete row
     constexpr int NSTEP = NV / 8;        // tiles per wave
     constexpr int ROWP = 64 * NV;        // exchange pitch (floats): row a = [wave w'][lane][step]
@@ -908,7 +909,11 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     constexpr int SWEEP_FLOATS = 8 * G::WAVE_FLOATS;            // (the row-frame stage As aliases the slabs)
     constexpr int HIST_OFF = BAND * ROWP;                       // fast histograms sit behind the exchange rows
     constexpr int TAIL_FLOATS = HIST_OFF + 8 * FBINS;
+#ifdef ACX_LDS_PAD      /* experiment: force one workgroup per CU */
+    constexpr int LDS_FLOATS = 24 * 1024;
+#else
     constexpr int LDS_FLOATS = SWEEP_FLOATS > TAIL_FLOATS ? SWEEP_FLOATS : TAIL_FLOATS;
+#endif
     static_assert(SelGeom<GBINS>::SLOTS + 64 + 4 <= ROWP, "generic selection must fit the wave's own exchange row");
     static_assert((HIST_OFF * 4) % (FBINS * 4) == 0, "fast histograms must be aligned to their size");
     __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
@@ -955,10 +960,12 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
         const float *nsrc = ncol + base + lane;
         float *ydst = Yw + ybuf * G::BW;
         if (base >= 0 && base + G::BW <= TB && base + G::BW <= MB) {      // wave-uniform: all frames exist
+#ifndef ACX_ABL_NODMA
 #pragma unroll
             for (int q = 0; q < G::NPIECE; ++q)
                 if (64 * q + 64 <= G::BW * 3 || lane + 64 * q < G::BW * 3)
                     __builtin_amdgcn_global_load_lds((glb_void *)(src + 256 * q), (lds_void *)(Bw + 256 * q), 16, 0, 0);
+#endif
             __builtin_amdgcn_global_load_lds((glb_void *)nsrc, (lds_void *)ydst, 4, 0, 0);
             if (G::BW > 64 && lane + 64 < G::BW)
                 __builtin_amdgcn_global_load_lds((glb_void *)(nsrc + 64), (lds_void *)(ydst + 64), 4, 0, 0);
@@ -1020,11 +1027,138 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) xv[a][st] = INF;
 
+    // ---- pieces of one tile step (shared by the two sweep schedules below)
+    typedef float BvT[G::NCT][3];
+    typedef f32x4 AccT[G::NRT][G::NCT];
+    auto load_operands = [&](BvT &bv) {          // column-frame MFMA operands out of the DMA slab
+#ifdef ACX_ABL_NODMA      /* ablation: synthetic operands, no DMA, no LDS operand reads */
 #pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {
+        for (int tb = 0; tb < G::NCT; ++tb)
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+                bv[tb][kb] = __uint_as_float(0x3f000000u + ((((unsigned)lane * 2654435761u) ^ ((unsigned)(tb * 977 + kb * 131 + 1) * 2246822519u) ^ ((unsigned)i0 * 3266489917u)) >> 10));
+#else
+#pragma unroll
+        for (int tb = 0; tb < G::NCT; ++tb)
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) bv[tb][kb] = Bw[browoff[kb] + 16 * NBIN * tb];
+#endif
+    };
+    // frame Gram on the matrix cores.  The COLUMN frames are the MFMA's row operand, so a lane ends
+    // up with four consecutive column frames of one row frame: one 16-byte LDS store per 16x16 tile
+    // (products commute, the k order is unchanged: same bits).  Chains interleaved k-step-major so
+    // that no MFMA waits on its predecessor.
+    auto gram = [&](const BvT &bv, AccT &acc) {
+#pragma unroll
+        for (int ta = 0; ta < G::NRT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < G::NCT; ++tb) acc[ta][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int ta = 0; ta < G::NRT; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < G::NCT; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[tb][kb], areg[ta][kb], acc[ta][tb], 0, 0, 0);
+    };
+    auto store_gram = [&](const AccT &acc) {
+#pragma unroll
+        for (int ta = 0; ta < G::NRT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < G::NCT; ++tb)
+                *reinterpret_cast<f32x4 *>(Sw + (16 * ta + lr) * G::SP + 16 * tb + 4 * lk) = acc[ta][tb];
+    };
+    // diagonal walk: lane c owns the 8 cells (a, c + a); m + 7 Gram values give all 8 window sums
+    auto walk = [&](const float (&sv)[M + BAND - 1], const float (&yv)[BAND], float (&dv)[BAND]) {
+#pragma unroll
+        for (int a = 0; a < BAND; ++a) {
+            const float xy = tree_sum<M>(sv + a);
+            // query-side norm first: (xx - 2xy) + yy.  2 * xy is exact, so the fused multiply-add
+            // rounds once exactly where the spec's subtraction does.
+            float t3 = ROLE ? (__builtin_fmaf(-2.0f, xy, yv[a]) + xrow[a]) : (__builtin_fmaf(-2.0f, xy, xrow[a]) + yv[a]);
+            if (!(t3 > 0.0f)) t3 = 0.0f;
+            dv[a] = t3;
+        }
+    };
+    auto keep = [&](auto st_tag, int tile, const float (&dv)[BAND]) {     // cells -> xv (+ debug D2)
+        constexpr int st = decltype(st_tag)::value;
+        const int base = 64 * tile - (BAND - 1);
+        const int j0 = base + lane;                       // column of the lane's first cell
+        const bool interior = base >= 0 && base + 64 + BAND - 1 <= MB && i0 + BAND <= MA;   // wave-uniform
+        if (interior) {
+#pragma unroll
+            for (int a = 0; a < BAND; ++a) xv[a][st] = dv[a];
+#ifndef ACX_ABL_NOSTORE
+            if (write_d2) {
+                float *Dl = D + j0;
+#pragma unroll
+                for (int a = 0; a < BAND; ++a) Dl[a * pitchD + a] = dv[a];
+            }
+#endif
+        } else {
+#pragma unroll
+            for (int a = 0; a < BAND; ++a) {
+                const int j = j0 + a;
+                const bool rowok = (i0 + a) < MA;
+                const bool ok = rowok && j >= 0 && j < MB;
+                const float v = ok ? dv[a] : INF;
+                xv[a][st] = v;
+                if (write_d2 && rowok && j >= 0 && j < pitchD) D[a * pitchD + j] = v;
+            }
+        }
+    };
+
+#ifndef ACX_NO_SWPIPE
+    if (wave + 8 * (NSTEP - 1) < ntiles) {
+        // ---- software-pipelined sweep (every step of this wave holds a tile): the MFMA chains of
+        // tile st+1 are issued between the VALU instructions of tile st's walk, so the wave keeps
+        // the matrix pipe and the VALU busy at the same time instead of alternating.
+        BvT bv;
+        AccT acc;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile 0 has landed
+        wave_lds_fence();
+        load_operands(bv);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // operands in registers: slab is free
+        if (NSTEP > 1) dma_tile(wave + 8, 1);
+        gram(bv, acc);
+        store_gram(acc);
+        static_for<0, NSTEP>([&](auto st_tag) {
+            constexpr int st = decltype(st_tag)::value;
+            const int tile = wave + 8 * st;
+            const float *Yt = Yw + (st & 1) * G::BW;
+            wave_lds_fence();
+            float sv[M + BAND - 1], yv[BAND], dv[BAND];
+#pragma unroll
+            for (int u = 0; u < M + BAND - 1; ++u) sv[u] = Sw[u * G::SP + lane + u];
+#pragma unroll
+            for (int a = 0; a < BAND; ++a) yv[a] = Yt[lane + a];
+            if constexpr (st + 1 < NSTEP) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile st+1 has landed
+                wave_lds_fence();
+                load_operands(bv);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // sv, yv, operands in registers
+                if (st + 2 < NSTEP) dma_tile(tile + 16, st & 1);     // Y buffer st&1 was consumed into yv
+                gram(bv, acc);
+                walk(sv, yv, dv);
+#pragma unroll
+                for (int q = 0; q < 3 * G::NRT * G::NCT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA ...
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // ... then five VALU
+                }
+                store_gram(acc);                                     // tile st's Gram values are all in sv
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                walk(sv, yv, dv);
+            }
+            keep(st_tag, tile, dv);
+        });
+        wave_lds_fence();
+    } else
+#endif
+    static_for<0, NSTEP>([&](auto st_tag) {
+        constexpr int st = decltype(st_tag)::value;
         const int tile = wave + 8 * st;
         if (tile < ntiles) {      // wave-uniform
-            const int base = 64 * tile - (BAND - 1);
             const float *Yt = Yw + (st & 1) * G::BW;
 #ifdef ACX_TIMING
             const unsigned long long ta0 = __builtin_readcyclecounter();
@@ -1034,35 +1168,13 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #ifdef ACX_TIMING
             const unsigned long long ta1 = __builtin_readcyclecounter();
 #endif
-            // ---- frame Gram on the matrix cores.  The COLUMN frames are the MFMA's row operand, so a
-            // lane ends up with four consecutive column frames of one row frame: one 16-byte LDS store
-            // per 16x16 tile (products commute, the k order is unchanged: same bits).
 #ifndef ACX_ABL_NOGRAM
             {
-                // all column tiles in flight at once: operand loads first, then the MFMA chains
-                // interleaved k-step-major so that no MFMA waits on its predecessor
-                float bv[G::NCT][3];
-#pragma unroll
-                for (int tb = 0; tb < G::NCT; ++tb)
-#pragma unroll
-                    for (int kb = 0; kb < 3; ++kb) bv[tb][kb] = Bw[browoff[kb] + 16 * NBIN * tb];
-                f32x4 acc[G::NRT][G::NCT];
-#pragma unroll
-                for (int ta = 0; ta < G::NRT; ++ta)
-#pragma unroll
-                    for (int tb = 0; tb < G::NCT; ++tb) acc[ta][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int kb = 0; kb < 3; ++kb)
-#pragma unroll
-                    for (int ta = 0; ta < G::NRT; ++ta)
-#pragma unroll
-                        for (int tb = 0; tb < G::NCT; ++tb)
-                            acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[tb][kb], areg[ta][kb], acc[ta][tb], 0, 0, 0);
-#pragma unroll
-                for (int ta = 0; ta < G::NRT; ++ta)
-#pragma unroll
-                    for (int tb = 0; tb < G::NCT; ++tb)
-                        *reinterpret_cast<f32x4 *>(Sw + (16 * ta + lr) * G::SP + 16 * tb + 4 * lk) = acc[ta][tb];
+                BvT bv;
+                AccT acc;
+                load_operands(bv);
+                gram(bv, acc);
+                store_gram(acc);
             }
 #endif
             wave_lds_fence();
@@ -1071,48 +1183,13 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
             const unsigned long long ta2 = __builtin_readcyclecounter();
 #endif
             if (st + 1 < NSTEP) dma_tile(tile + 8, (st + 1) & 1);
-            // ---- diagonal walk: 8 cells per lane
-            float sv[M + BAND - 1];
+            float sv[M + BAND - 1], yv[BAND], dv[BAND];
 #pragma unroll
             for (int u = 0; u < M + BAND - 1; ++u) sv[u] = Sw[u * G::SP + lane + u];
-            float dv[BAND];
-            auto dist = [&](auto role_tag) {
-                constexpr bool R1 = decltype(role_tag)::value;
 #pragma unroll
-                for (int a = 0; a < BAND; ++a) {
-                    const float xy = tree_sum<M>(sv + a);
-                    const float nc_ = Yt[lane + a];
-                    // query-side norm first: (xx - 2xy) + yy.  2 * xy is exact, so the fused
-                    // multiply-add rounds once exactly where the spec's subtraction does.
-                    float t3 = R1 ? (__builtin_fmaf(-2.0f, xy, nc_) + xrow[a]) : (__builtin_fmaf(-2.0f, xy, xrow[a]) + nc_);
-                    if (!(t3 > 0.0f)) t3 = 0.0f;
-                    dv[a] = t3;
-                }
-            };
-            if (role) dist(std::true_type()); else dist(std::false_type());   // block-uniform
-            const int j0 = base + lane;                       // column of the lane's first cell
-            const bool interior = base >= 0 && base + 64 + BAND - 1 <= MB && i0 + BAND <= MA;   // wave-uniform
-            if (interior) {
-#pragma unroll
-                for (int a = 0; a < BAND; ++a) xv[a][st] = dv[a];
-#ifndef ACX_ABL_NOSTORE
-                if (write_d2) {
-                    float *Dl = D + j0;
-#pragma unroll
-                    for (int a = 0; a < BAND; ++a) Dl[a * pitchD + a] = dv[a];
-                }
-#endif
-            } else {
-#pragma unroll
-                for (int a = 0; a < BAND; ++a) {
-                    const int j = j0 + a;
-                    const bool rowok = (i0 + a) < MA;
-                    const bool ok = rowok && j >= 0 && j < MB;
-                    const float v = ok ? dv[a] : INF;
-                    xv[a][st] = v;
-                    if (write_d2 && rowok && j >= 0 && j < pitchD) D[a * pitchD + j] = v;
-                }
-            }
+            for (int a = 0; a < BAND; ++a) yv[a] = Yt[lane + a];
+            walk(sv, yv, dv);
+            keep(st_tag, tile, dv);
             wave_lds_fence();
 #ifdef ACX_TIMING
             {
@@ -1122,7 +1199,7 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
             }
 #endif
         }
-    }
+    });
     ACX_T(2);
     // debug / v1 consumers: +inf into the pad columns [MB, pitchD) of the band's rows
     if (write_d2) {
@@ -1190,6 +1267,47 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     const bool interp = (pct_mode == 0 || pct_mode == 1);
     float *myrow = smem + wave * ROWP;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row has left LDS
+#if defined(ACX_EXTRA_VALU) || defined(ACX_EXTRA_LDS) || defined(ACX_EXTRA_MFMA) || defined(ACX_EXTRA_VALU4)
+    {   // sensitivity experiment (development): extra independent work of one kind per wave
+        float e0 = xr[0], e1 = xr[1], e2 = xr[2], e3 = xr[3];
+#ifdef ACX_EXTRA_VALU
+#pragma unroll
+        for (int q = 0; q < ACX_EXTRA_VALU / 4; ++q)
+            asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4"
+                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(xr[4]));
+#endif
+#ifdef ACX_EXTRA_VALU4
+#pragma unroll
+        for (int q = 0; q < ACX_EXTRA_VALU4 / 4; ++q)
+            asm volatile("v_max_f32 %0, %0, %4\n v_max_f32 %1, %1, %4\n v_max_f32 %2, %2, %4\n v_max_f32 %3, %3, %4"
+                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(xr[4]));
+#endif
+#ifdef ACX_EXTRA_LDS
+        {
+            const unsigned la = (unsigned)(uintptr_t)(lds_void *)(myrow) + 4u * lane;
+            unsigned t0, t1, t2, t3;
+#pragma unroll
+            for (int q = 0; q < ACX_EXTRA_LDS / 4; ++q) {
+                asm volatile("ds_read_b32 %0, %4\n ds_read_b32 %1, %4 offset:256\n ds_read_b32 %2, %4 offset:512\n ds_read_b32 %3, %4 offset:768\n s_waitcnt lgkmcnt(0)"
+                             : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3) : "v"(la) : "memory");
+                e0 += __uint_as_float(t0 ^ t1 ^ t2 ^ t3) * 0.0f;
+            }
+        }
+#endif
+#ifdef ACX_EXTRA_MFMA
+        {
+            f32x4 ac = {0.f, 0.f, 0.f, 0.f}, ad = ac;
+#pragma unroll
+            for (int q = 0; q < ACX_EXTRA_MFMA / 2; ++q) {
+                ac = __builtin_amdgcn_mfma_f32_16x16x4f32(e0, e1, ac, 0, 0, 0);
+                ad = __builtin_amdgcn_mfma_f32_16x16x4f32(e2, e3, ad, 0, 0, 0);
+            }
+            e0 += (ac[0] + ad[1]) * 0.0f;
+        }
+#endif
+        xr[0] += (e0 + e1 + e2 + e3) * 0.0f - (xr[0] + xr[1] + xr[2] + xr[3]) * 0.0f;
+    }
+#endif
     ACX_T(6);
     float slo, shi;
     const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + HIST_OFF + wave * FBINS);
@@ -1237,16 +1355,20 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
             constexpr int tile = idx / NSTEP + 8 * (idx % NSTEP);
             tcv[idx] = tc[64 * tile];
         });
+        // R = [d2 <= thr_row] & [d2 <= thr_col] as two compares whose lane masks are ANDed on the
+        // scalar unit, together with the mask of the lanes whose column exists (a contiguous lane
+        // range per tile): no per-lane bounds code, no min.
         unsigned mlo = 0u, mhi = 0u;
         static_for<0, NV>([&](auto ic) {
             constexpr int idx = decltype(ic)::value;
             constexpr int tile = idx / NSTEP + 8 * (idx % NSTEP);
-            float tcj = tcv[idx];
-            if (tile == 0 || 64 * tile + 57 + wave > MB) {      // wave-uniform: some lanes are outside
-                const int j = 64 * tile - (BAND - 1) + wave + lane;
-                tcj = (j >= 0 && j < MB) ? tcj : -1.0f;
-            }
-            const unsigned long long m = __ballot(xr[idx] <= fminf(thr_row, tcj));
+            const int jb = 64 * tile - (BAND - 1) + wave;              // column of lane 0
+            int lo = -jb, hi = MB - jb;                                 // lanes [lo, hi) are inside the matrix
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > 64 ? 64 : hi;
+            unsigned long long valid = 0ull;
+            if (hi > lo) valid = (hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+            const unsigned long long m = __ballot(xr[idx] <= thr_row) & __ballot(xr[idx] <= tcv[idx]) & valid;
             writelane_mask<tile>(mlo, mhi, m);
         });
         if (lane < P.nw)
