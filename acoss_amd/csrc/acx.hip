@@ -46,6 +46,7 @@ struct acx_ctx {
     std::string err;
     // pool
     float *d_frames = nullptr;
+    float *d_frot = nullptr;      // rotated frame pool (band kernel MFMA operands), 36 floats per frame
     int64_t *d_toff = nullptr;
     float *d_gch = nullptr;
     std::vector<int64_t> h_off;
@@ -200,7 +201,7 @@ void launch_band(acx_ctx *c, int B, int maxRows, int maxCols, const acx_serra09_
     const dim3 grid((maxRows + acx::BAND - 1) / acx::BAND, B, 1);
     const int ndata = (maxCols + acx::BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
 #define ACX_BAND_R(V4_, R_) hipLaunchKernelGGL((acx::band_kernel<M, V4_, R_>), grid, dim3(acx::BAND_THREADS), 0, c->stream, \
-                                         c->d_frames, c->d_toff, c->d_pd, c->d_scratch, c->d_thr, c->d_bits, p.kappa, \
+                                         c->d_frot, c->d_toff, c->d_pd, c->d_scratch, c->d_thr, c->d_bits, p.kappa, \
                                          p.pct_mode, p.inclusive, p.oti_target, write_d2)
 #define ACX_BAND(V4_) do { if (role) ACX_BAND_R(V4_, 1); else ACX_BAND_R(V4_, 0); } while (0)
     if (ndata <= 8) ACX_BAND(2);
@@ -593,6 +594,7 @@ void acx_destroy(acx_ctx *c)
     drain_profile(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->d_frames) (void)hipFree(c->d_frames);
+    if (c->d_frot) (void)hipFree(c->d_frot);
     if (c->d_toff) (void)hipFree(c->d_toff);
     if (c->d_gch) (void)hipFree(c->d_gch);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -632,6 +634,7 @@ int acx_upload_pool(acx_ctx *c, const float *frames, const int64_t *offsets, int
         if (offsets[i + 1] < offsets[i]) return fail(c, ACX_ERR_INVALID, "upload_pool: offsets must be non-decreasing");
     ACX_HIP(c, hipSetDevice(c->device));
     if (c->d_frames) { (void)hipFree(c->d_frames); c->d_frames = nullptr; }
+    if (c->d_frot) { (void)hipFree(c->d_frot); c->d_frot = nullptr; }
     if (c->d_toff) { (void)hipFree(c->d_toff); c->d_toff = nullptr; }
     if (c->d_gch) { (void)hipFree(c->d_gch); c->d_gch = nullptr; }
     const int64_t total = offsets[n_tracks];
@@ -643,6 +646,16 @@ int acx_upload_pool(acx_ctx *c, const float *frames, const int64_t *offsets, int
     ACX_HIP(c, hipMemcpy(c->d_frames, frames, sizeof(float) * total * dim, hipMemcpyHostToDevice));
     ACX_HIP(c, hipMemcpy(c->d_toff, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
     if (dim == acx::NBIN) {
+        // rotated copy of the pool: the band kernel loads its MFMA operands from it (12 bytes per
+        // lane per 16-frame tile, already in the rotated chain order) -- 144 B per frame
+        ACX_HIP(c, hipMalloc((void **)&c->d_frot, sizeof(float) * std::max<int64_t>(1, total) * acx::FROT));
+        if (total > 0) {
+            const int64_t nout = total * acx::FROT;
+            hipLaunchKernelGGL(acx::rotpool_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, c->stream,
+                               c->d_frames, c->d_frot, total);
+            ACX_HIP(c, hipGetLastError());
+            ACX_HIP(c, hipStreamSynchronize(c->stream));
+        }
         // global chroma profile per track: sequential f32 sum over frames, divided by its max
         // (arithmetic spec step 1; O(sum T) host work done once per pool)
         std::vector<float> g((size_t)n_tracks * acx::NBIN);

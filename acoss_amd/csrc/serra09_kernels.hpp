@@ -848,6 +848,19 @@ __global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ po
 // ------------------------------------------------------------------------------------
 constexpr int BAND = 8;
 constexpr int BAND_THREADS = 512;   // 8 waves
+constexpr int FROT = 3 * NBIN;      // floats per frame of the rotated frame pool
+
+// Rotated frame pool for the band kernel's MFMA operands (built once per upload): frame f ->
+// frot[f][r][cls][kb] = frame[f][cls + 4 ((r + kb) mod 3)], r = 0..2, cls = 0..3, kb = 0..2.
+__global__ void rotpool_kernel(const float *__restrict__ pool, float *__restrict__ frot, int64_t nframes)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one output float each
+    if (idx >= nframes * FROT) return;
+    const int64_t f = idx / FROT;
+    const int e = (int)(idx - f * FROT);
+    const int r = e / NBIN, rem = e - r * NBIN, cls = rem / 3, kb = rem - 3 * cls;
+    frot[idx] = pool[f * NBIN + cls + 4 * ((r + kb) % 3)];
+}
 
 // Development aid (-DACX_TIMING): per-phase shader-clock totals of band_kernel, summed over all
 // waves into acx_tim[] (slot 31 = number of waves).  Not compiled into the product library.
@@ -886,7 +899,7 @@ __device__ __forceinline__ float percentile_eps(const SelectResult &sr, int pct_
 }
 
 template <int M, int V4, int ROLE>
-__global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__restrict__ pool,
+__global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__restrict__ frot,
                                                             const int64_t *__restrict__ toff,
                                                             const PairDesc *__restrict__ pd,
                                                             float *__restrict__ scratch,
@@ -906,7 +919,7 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     constexpr int FBINS = NV >= 32 ? 512 : 256;                 // bins of the fast selection
 #endif
     constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
-    constexpr int SWEEP_FLOATS = 8 * G::WAVE_FLOATS;            // (the row-frame stage As aliases the slabs)
+    constexpr int SWEEP_FLOATS = 8 * G::AROWS * G::SP;          // one Gram tile per wave
     constexpr int HIST_OFF = BAND * ROWP;                       // fast histograms sit behind the exchange rows
     constexpr int TAIL_FLOATS = HIST_OFF + 8 * FBINS;
 #ifdef ACX_LDS_PAD      /* experiment: force one workgroup per CU */
@@ -925,8 +938,6 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     if (i0 >= MA) return;     // block-uniform
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: everything derived from it is scalar
-    const float *fa = pool + toff[role ? P.r : P.q] * NBIN;
-    const float *fb = pool + toff[role ? P.q : P.r] * NBIN;
     const bool rows_are_ref = role == 1;
     const int rota = (rows_are_ref == (oti_target == 0)) ? P.oti : 0;
     const int rotb = (rows_are_ref == (oti_target == 0)) ? 0 : P.oti;
@@ -941,108 +952,72 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #endif
     ACX_T(0);
 
-    float *Bw = smem + wave * G::WAVE_FLOATS;                  // this wave's slab: frames (frame-major)
-    float *Sw = Bw + G::BFLOATS;                               // Gram tile, [row frame][column frame], pitch SP
-    float *Yw = Sw + G::AROWS * G::SP;                         // column norms, double-buffered
-    float *As = smem + 7 * G::WAVE_FLOATS + G::BFLOATS;        // row-frame stage: aliases wave 7's Gram tile
-    static_assert(NBIN * G::AP <= G::AROWS * G::SP, "row-frame stage must fit a Gram tile");
-
-    const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= NV by dispatch
-    // Column frames + norms of a tile go HBM/L2 -> LDS by LDS-DMA (global_load_lds): the slab is
-    // a straight image of the frame memory (lane-linear 16-byte pieces), no VGPR round trip and
-    // no ds_write.  Pieces of frames outside the track are skipped (their cells are masked).
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
-    auto dma_tile = [&](int tile, int ybuf) {
-        if (tile >= ntiles) return;
-        const int base = 64 * tile - (BAND - 1);
-        const float *src = fb + (ptrdiff_t)base * NBIN + 4 * lane;
-        const float *nsrc = ncol + base + lane;
-        float *ydst = Yw + ybuf * G::BW;
-        if (base >= 0 && base + G::BW <= TB && base + G::BW <= MB) {      // wave-uniform: all frames exist
-#ifndef ACX_ABL_NODMA
-#pragma unroll
-            for (int q = 0; q < G::NPIECE; ++q)
-                if (64 * q + 64 <= G::BW * 3 || lane + 64 * q < G::BW * 3)
-                    __builtin_amdgcn_global_load_lds((glb_void *)(src + 256 * q), (lds_void *)(Bw + 256 * q), 16, 0, 0);
-#endif
-            __builtin_amdgcn_global_load_lds((glb_void *)nsrc, (lds_void *)ydst, 4, 0, 0);
-            if (G::BW > 64 && lane + 64 < G::BW)
-                __builtin_amdgcn_global_load_lds((glb_void *)(nsrc + 64), (lds_void *)(ydst + 64), 4, 0, 0);
-        } else {
-#pragma unroll
-            for (int q = 0; q < G::NPIECE; ++q) {
-                const int pidx = lane + 64 * q;
-                const int f = base + pidx / 3;
-                if (pidx < G::BW * 3 && f >= 0 && f < TB)
-                    __builtin_amdgcn_global_load_lds((glb_void *)(src + 256 * q), (lds_void *)(Bw + 256 * q), 16, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int idx = lane + 64 * q;
-                const int j = base + idx;
-                if (idx < G::BW && j >= 0 && j < MB)
-                    __builtin_amdgcn_global_load_lds((glb_void *)(nsrc + 64 * q), (lds_void *)(ydst + 64 * q), 4, 0, 0);
-            }
-        }
-    };
-    dma_tile(wave, 0);
-
-    // ---- stage the band's row frames once (bin-major, un-rotated)
-    for (int idx = tid; idx < G::AROWS * 3; idx += BAND_THREADS) {
-        const int a = idx / 3, part = idx - 3 * a;
-        const int f = i0 + a;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < TA) v = *reinterpret_cast<const float4 *>(fa + (size_t)f * NBIN + 4 * part);
-        As[(4 * part + 0) * G::AP + a] = v.x;
-        As[(4 * part + 1) * G::AP + a] = v.y;
-        As[(4 * part + 2) * G::AP + a] = v.z;
-        As[(4 * part + 3) * G::AP + a] = v.w;
-    }
-    __syncthreads();
-    // MFMA operands: position k of the chain holds rotated bin k = source bin (k - rot) mod 12
+    // ---- MFMA operands come straight from the rotated frame pool (frot, see rotpool_kernel):
+    // frame f holds, for each rotation r = 0..2 and residue class cls = 0..3, the three bins
+    // cls + 4 ((r + kb) mod 3), kb = 0..2, contiguously.  The lane that feeds k-position lk of
+    // the MFMA chain needs rotated bin 4 kb + lk = source bin (4 kb + lk - rot) mod 12, i.e. with
+    // c0 = (lk - rot) mod 12 exactly the triple (r = c0 / 4, cls = c0 % 4): ONE 12-byte load per
+    // 16-frame tile, already in chain order.  No LDS staging, no LDS-DMA, no barrier.
     const int lr = lane & 15, lk = lane >> 4;
+    int c0a = lk - rota; if (c0a < 0) c0a += NBIN;
+    int c0b = lk - rotb; if (c0b < 0) c0b += NBIN;
+    const int offA = (c0a >> 2) * NBIN + (c0a & 3) * 3;
+    const int offB = (c0b >> 2) * NBIN + (c0b & 3) * 3;
+    const float *fra = frot + toff[role ? P.r : P.q] * FROT + offA;
+    const float *frb = frot + toff[role ? P.q : P.r] * FROT + offB;
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    typedef f32x3 f32x3_u __attribute__((aligned(4)));
     float areg[G::NRT][3];
-    int browoff[3];
 #pragma unroll
-    for (int kb = 0; kb < 3; ++kb) {
-        int ka = 4 * kb + lk - rota; if (ka < 0) ka += NBIN;
-        int kbb = 4 * kb + lk - rotb; if (kbb < 0) kbb += NBIN;
-        browoff[kb] = kbb + lr * NBIN;       // frame-major slab: element (frame, bin) at frame*12 + bin
-#pragma unroll
-        for (int ta = 0; ta < G::NRT; ++ta) areg[ta][kb] = As[ka * G::AP + 16 * ta + lr];
+    for (int ta = 0; ta < G::NRT; ++ta) {
+        int f = i0 + 16 * ta + lr;
+        f = f > TA - 1 ? TA - 1 : f;           // rows beyond the matrix are masked below
+        const f32x3 v = *reinterpret_cast<const f32x3_u *>(fra + (size_t)f * FROT);
+        areg[ta][0] = v.x; areg[ta][1] = v.y; areg[ta][2] = v.z;
     }
     float xrow[BAND];
 #pragma unroll
     for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : 0.0f;
-    __syncthreads();     // As is dead (operands are in registers): wave 7 may write its Gram tile
-    ACX_T(1);
+    float *Sw = smem + wave * (G::AROWS * G::SP);               // this wave's Gram tile, [row frame][column frame]
 
-    const int pitchD = P.pitchD;
-    float *D = scratch + P.offD + (size_t)i0 * pitchD;
-
-    float xv[BAND][NSTEP];
-#pragma unroll
-    for (int a = 0; a < BAND; ++a)
-#pragma unroll
-        for (int st = 0; st < NSTEP; ++st) xv[a][st] = INF;
-
-    // ---- pieces of one tile step (shared by the two sweep schedules below)
+    const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= NV by dispatch
     typedef float BvT[G::NCT][3];
     typedef f32x4 AccT[G::NRT][G::NCT];
-    auto load_operands = [&](BvT &bv) {          // column-frame MFMA operands out of the DMA slab
-#ifdef ACX_ABL_NODMA      /* ablation: synthetic operands, no DMA, no LDS operand reads */
+    // column-frame operands of a tile (frames 64 tile - 7 ... + BW)
+    auto load_operands = [&](int tile, BvT &bv) {
+        const int base = 64 * tile - (BAND - 1);
+        if (base >= 0 && base + G::BW <= TB) {                  // wave-uniform: all frames exist
+            const float *p = frb + (ptrdiff_t)(base + lr) * FROT;
 #pragma unroll
-        for (int tb = 0; tb < G::NCT; ++tb)
+            for (int tb = 0; tb < G::NCT; ++tb) {
+                const f32x3 v = *reinterpret_cast<const f32x3_u *>(p + 16 * FROT * tb);
+                bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
+            }
+        } else {                                                // clamp: those cells are masked anyway
 #pragma unroll
-            for (int kb = 0; kb < 3; ++kb)
-                bv[tb][kb] = __uint_as_float(0x3f000000u + ((((unsigned)lane * 2654435761u) ^ ((unsigned)(tb * 977 + kb * 131 + 1) * 2246822519u) ^ ((unsigned)i0 * 3266489917u)) >> 10));
-#else
+            for (int tb = 0; tb < G::NCT; ++tb) {
+                int f = base + 16 * tb + lr;
+                f = f < 0 ? 0 : (f > TB - 1 ? TB - 1 : f);
+                const f32x3 v = *reinterpret_cast<const f32x3_u *>(frb + (ptrdiff_t)f * FROT);
+                bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
+            }
+        }
+    };
+    // embedded column norms of the lane's 8 cells
+    auto load_norms = [&](int tile, float (&yv)[BAND]) {
+        const int base = 64 * tile - (BAND - 1);
+        if (base >= 0 && base + 64 + BAND - 1 <= MB) {
+            const float *p = ncol + base + lane;
 #pragma unroll
-        for (int tb = 0; tb < G::NCT; ++tb)
+            for (int a = 0; a < BAND; ++a) yv[a] = p[a];
+        } else {
 #pragma unroll
-            for (int kb = 0; kb < 3; ++kb) bv[tb][kb] = Bw[browoff[kb] + 16 * NBIN * tb];
-#endif
+            for (int a = 0; a < BAND; ++a) {
+                int j = base + lane + a;
+                j = j < 0 ? 0 : (j > MB - 1 ? MB - 1 : j);
+                yv[a] = ncol[j];
+            }
+        }
     };
     // frame Gram on the matrix cores.  The COLUMN frames are the MFMA's row operand, so a lane ends
     // up with four consecutive column frames of one row frame: one 16-byte LDS store per 16x16 tile
@@ -1080,6 +1055,16 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
             dv[a] = t3;
         }
     };
+    ACX_T(1);
+
+    const int pitchD = P.pitchD;
+    float *D = scratch + P.offD + (size_t)i0 * pitchD;
+    float xv[BAND][NSTEP];
+#pragma unroll
+    for (int a = 0; a < BAND; ++a)
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) xv[a][st] = INF;
+
     auto keep = [&](auto st_tag, int tile, const float (&dv)[BAND]) {     // cells -> xv (+ debug D2)
         constexpr int st = decltype(st_tag)::value;
         const int base = 64 * tile - (BAND - 1);
@@ -1108,96 +1093,29 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
         }
     };
 
-#ifndef ACX_NO_SWPIPE
-    if (wave + 8 * (NSTEP - 1) < ntiles) {
-        // ---- software-pipelined sweep (every step of this wave holds a tile): the MFMA chains of
-        // tile st+1 are issued between the VALU instructions of tile st's walk, so the wave keeps
-        // the matrix pipe and the VALU busy at the same time instead of alternating.
-        BvT bv;
-        AccT acc;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile 0 has landed
-        wave_lds_fence();
-        load_operands(bv);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // operands in registers: slab is free
-        if (NSTEP > 1) dma_tile(wave + 8, 1);
-        gram(bv, acc);
-        store_gram(acc);
-        static_for<0, NSTEP>([&](auto st_tag) {
-            constexpr int st = decltype(st_tag)::value;
-            const int tile = wave + 8 * st;
-            const float *Yt = Yw + (st & 1) * G::BW;
-            wave_lds_fence();
-            float sv[M + BAND - 1], yv[BAND], dv[BAND];
-#pragma unroll
-            for (int u = 0; u < M + BAND - 1; ++u) sv[u] = Sw[u * G::SP + lane + u];
-#pragma unroll
-            for (int a = 0; a < BAND; ++a) yv[a] = Yt[lane + a];
-            if constexpr (st + 1 < NSTEP) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile st+1 has landed
-                wave_lds_fence();
-                load_operands(bv);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // sv, yv, operands in registers
-                if (st + 2 < NSTEP) dma_tile(tile + 16, st & 1);     // Y buffer st&1 was consumed into yv
-                gram(bv, acc);
-                walk(sv, yv, dv);
-#pragma unroll
-                for (int q = 0; q < 3 * G::NRT * G::NCT; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA ...
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // ... then five VALU
-                }
-                store_gram(acc);                                     // tile st's Gram values are all in sv
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                walk(sv, yv, dv);
-            }
-            keep(st_tag, tile, dv);
-        });
-        wave_lds_fence();
-    } else
-#endif
+    // ---- sweep: wave w takes tiles w, w + 8, ...; the operands of the next tile are in flight
+    // (plain global loads, L2 / L1 resident) while the current one is worked on.
+    BvT bvbuf[2];
+    if (wave < ntiles) load_operands(wave, bvbuf[0]);
     static_for<0, NSTEP>([&](auto st_tag) {
         constexpr int st = decltype(st_tag)::value;
         const int tile = wave + 8 * st;
         if (tile < ntiles) {      // wave-uniform
-            const float *Yt = Yw + (st & 1) * G::BW;
-#ifdef ACX_TIMING
-            const unsigned long long ta0 = __builtin_readcyclecounter();
-#endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's DMA has landed
-            wave_lds_fence();
-#ifdef ACX_TIMING
-            const unsigned long long ta1 = __builtin_readcyclecounter();
-#endif
-#ifndef ACX_ABL_NOGRAM
+            float yv[BAND];
+            load_norms(tile, yv);
+            if (st + 1 < NSTEP && tile + 8 < ntiles) load_operands(tile + 8, bvbuf[(st + 1) & 1]);
             {
-                BvT bv;
                 AccT acc;
-                load_operands(bv);
-                gram(bv, acc);
+                gram(bvbuf[st & 1], acc);
                 store_gram(acc);
             }
-#endif
             wave_lds_fence();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operand reads done: slab is free
-#ifdef ACX_TIMING
-            const unsigned long long ta2 = __builtin_readcyclecounter();
-#endif
-            if (st + 1 < NSTEP) dma_tile(tile + 8, (st + 1) & 1);
-            float sv[M + BAND - 1], yv[BAND], dv[BAND];
+            float sv[M + BAND - 1], dv[BAND];
 #pragma unroll
             for (int u = 0; u < M + BAND - 1; ++u) sv[u] = Sw[u * G::SP + lane + u];
-#pragma unroll
-            for (int a = 0; a < BAND; ++a) yv[a] = Yt[lane + a];
             walk(sv, yv, dv);
             keep(st_tag, tile, dv);
             wave_lds_fence();
-#ifdef ACX_TIMING
-            {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const unsigned long long ta3 = __builtin_readcyclecounter();
-                tsub[0] += ta1 - ta0; tsub[1] += ta2 - ta1; tsub[2] += ta3 - ta2;
-            }
-#endif
         }
     });
     ACX_T(2);
@@ -1310,6 +1228,7 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #endif
     ACX_T(6);
     float slo, shi;
+    typedef __attribute__((address_space(3))) void lds_void;
     const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + HIST_OFF + wave * FBINS);
     bool done = false;
 #ifndef ACX_NO_FASTSEL
