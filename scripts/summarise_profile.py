@@ -57,8 +57,15 @@ for k, st in sorted(stats.items(), key=lambda kv: -kv[1]["avg_ms"]):
         k, st["calls"], st["avg_ms"], st["pct"], c.get("_vgpr", [0])[0], c.get("_lds", [0])[0],
         fetch, write, hbm / 1e9, gbs))
     if "kernel" in k and hbm > 0:
-        traffic[k.split("<")[0]] = dict(hbm_bytes_per_launch=hbm, cells_per_launch=cells_per_launch,
-                                        fetch_kib_raw=fetch, write_kib_raw=write, avg_ms=st["avg_ms"])
+        # template instances of one kernel (band_kernel<.., role>) are averaged over their launches
+        base = k.split("<")[0]
+        t = traffic.setdefault(base, dict(hbm_bytes_per_launch=0.0, cells_per_launch=cells_per_launch,
+                                          fetch_kib_raw=0.0, write_kib_raw=0.0, avg_ms=0.0, _calls=0))
+        n0, n1 = t["_calls"], st["calls"]
+        for key, val in (("hbm_bytes_per_launch", hbm), ("fetch_kib_raw", fetch), ("write_kib_raw", write),
+                         ("avg_ms", st["avg_ms"])):
+            t[key] = (t[key] * n0 + val * n1) / (n0 + n1)
+        t["_calls"] = n0 + n1
 lines += ["", "## SQ counters (per launch, averaged)", ""]
 names = sorted({n for k in pmc for n in pmc[k] if not n.startswith("_") and n not in ("FETCH_SIZE", "WRITE_SIZE")})
 lines.append("| kernel | " + " | ".join(names) + " |")
@@ -73,5 +80,7 @@ for k in sorted(stats, key=lambda kk: -stats[kk]["avg_ms"]):
     lines.append("| %s | " % k + " | ".join(vals) + " |")
 os.makedirs("profiles", exist_ok=True)
 open(os.path.join("profiles", tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
+for t in traffic.values():
+    t.pop("_calls", None)
 json.dump(traffic, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
