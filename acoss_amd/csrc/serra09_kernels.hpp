@@ -557,15 +557,21 @@ struct OpMaxI { __device__ int operator()(int a, int b) const { return a > b ? a
 #else
 #define ACX_TS(k) do { } while (0)
 #endif
-template <int NV, int BINS>
+template <int NV, int BINS, int COPIES = 1>
 __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bool want_next, unsigned hist_addr,
                                                  float *cand, int lane, float &slo, float &shi,
                                                  unsigned long long *tsel = nullptr)
 {
     ACX_TS(0);
-    constexpr int BPL = BINS / 64;          // bins per lane in the scan
-    constexpr int NQ = BPL / 4;             // 16-byte pieces per lane
-    static_assert(BPL >= 4 && BPL <= 16 && (BPL & (BPL - 1)) == 0, "BINS must be 256, 512 or 1024");
+    // The histogram has NB = BINS / COPIES logical bins of COPIES counters each; a lane adds to
+    // copy (lane % COPIES), which spreads the lanes of one atomic over the banks (bank conflicts,
+    // not VALU work, dominate the histogram pass).  Bin b = dwords [b COPIES, +COPIES).
+    constexpr int DPL = BINS / 64;          // dwords per lane in the scan
+    constexpr int NQ = DPL / 4;             // 16-byte pieces per lane
+    constexpr int NB = BINS / COPIES;       // logical bins; the top one only ever holds +inf
+    constexpr int BPL = NB / 64;            // logical bins per lane
+    static_assert(DPL >= 4 && DPL <= 16 && (DPL & (DPL - 1)) == 0, "BINS must be 256, 512 or 1024");
+    static_assert(BPL >= 1 && (COPIES & (COPIES - 1)) == 0 && COPIES <= 8, "COPIES must be 1, 2, 4 or 8 with >= 64 bins");
     const float INF = __builtin_inff();
     // ---- value range over the finite cells
     unsigned mnu = 0xFFFFFFFFu;
@@ -588,19 +594,20 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
     // amount, at most 2^-24 * mn * scale4 -- kept below one quarter-bin unit by the guard (the top
     // half bin is spare), so no finite value can reach the top slot or wrap the address mask
     if (!(range >= 1e-30f) || !(range <= 1e30f) || !(mn <= 2048.0f * range)) return false;
-    const float scale4 = (4.0f * ((float)BINS - 1.5f)) * __builtin_amdgcn_rcpf(range);
+    const float scale4 = (4.0f * COPIES * ((float)NB - 1.5f)) * __builtin_amdgcn_rcpf(range);   // byte units
     const float off4 = -(mn * scale4);
     ACX_TS(1);
     // ---- histogram
     unsigned off[NV];
-    unsigned vmask = (unsigned)(4 * (BINS - 1));
-    asm volatile("" : "+v"(vmask));                 // keep the mask in a VGPR: v_and_or_b32 q, vmask, s_base
+    unsigned vmask = (unsigned)((NB - 1) * 4 * COPIES);
+    asm volatile("" : "+v"(vmask));                 // keep the mask in a VGPR: v_and_or_b32 q, vmask, base
+    const unsigned hb = hist_addr | (unsigned)((lane & (COPIES - 1)) << 2);   // this lane's copy
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         const float y = __builtin_fmaf(x[t], scale4, off4);
         unsigned q;
         asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(y));        // saturating: +inf -> 0xffffffff, y < 0 -> 0
-        off[t] = (q & vmask) | hist_addr;
+        off[t] = (q & vmask) | hb;
     }
 #pragma unroll
     for (int t = 0; t < NV; ++t)
@@ -614,7 +621,7 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int piece = (q + rot) & (NQ - 1);
-            const u32x4 h = *(const lds_u32x4 *)(hist_addr + (unsigned)(lane * BPL + 4 * piece) * 4u);
+            const u32x4 h = *(const lds_u32x4 *)(hist_addr + (unsigned)(lane * DPL + 4 * piece) * 4u);
             lsum += (int)(h.x + h.y) + (int)(h.z + h.w);
         }
     }
@@ -628,8 +635,20 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
     const int e = lane & 15;
     const bool lo16 = lane < 16;
     int c = 0;
-    if (lane < 32 && e < BPL)
-        c = (int)*(const lds_u32 *)(hist_addr + (unsigned)((lo16 ? L1 : L2) * BPL + e) * 4u);
+    if (lane < 32 && e < BPL) {
+        const unsigned ba = hist_addr + (unsigned)(((lo16 ? L1 : L2) * BPL + e) * COPIES) * 4u;
+        if constexpr (COPIES == 1) {
+            c = (int)*(const lds_u32 *)ba;
+        } else if constexpr (COPIES == 2) {
+            c = (int)(*(const lds_u32 *)ba + *(const lds_u32 *)(ba + 4u));
+        } else {
+#pragma unroll
+            for (int q = 0; q < COPIES / 4; ++q) {
+                const u32x4 h = *(const lds_u32x4 *)(ba + 16u * q);
+                c += (int)(h.x + h.y) + (int)(h.z + h.w);
+            }
+        }
+    }
     int P = c;                                        // inclusive prefix inside each row of 16 lanes
     P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, false);
     P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, false);
@@ -647,10 +666,10 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
         bin2 = L2 * BPL + (l2 - 16);
         if (bin2 != bin1) ncand += __builtin_amdgcn_readlane(c, l2);    // the bins between are empty
     }
-    if (ncand > 64 || bin2 >= BINS - 1) return false;
+    if (ncand > 64 || bin2 >= NB - 1) return false;
     ACX_TS(3);
     // ---- gather the members of [bin1, bin2]
-    const unsigned a1 = hist_addr + 4u * (unsigned)bin1, span = 4u * (unsigned)(bin2 - bin1);
+    const unsigned a1 = hb + 4u * COPIES * (unsigned)bin1, span = 4u * COPIES * (unsigned)(bin2 - bin1);
     int n = 0;
     auto put = [&](unsigned long long m, bool hit, float v) {
         if (m != 0ull) {
@@ -917,6 +936,11 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     constexpr int FBINS = ACX_FBINS;
 #else
     constexpr int FBINS = NV >= 32 ? 512 : 256;                 // bins of the fast selection
+#endif
+#ifdef ACX_FCOPIES
+    constexpr int FCOPIES = ACX_FCOPIES;
+#else
+    constexpr int FCOPIES = 1;                                  // counters per bin of the fast selection
 #endif
     constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
     constexpr int SWEEP_FLOATS = 8 * G::AROWS * G::SP;          // one Gram tile per wave
@@ -1234,10 +1258,10 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 #ifndef ACX_NO_FASTSEL
 #ifdef ACX_TIMING
     unsigned long long tsel[6] = {0, 0, 0, 0, 0, 0};
-    done = wave_select_fast<NV, FBINS>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, tsel);
+    done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, tsel);
     if (lane == 0 && done && tsel[5] && (blockIdx.x & 31) == 5) for (int q = 0; q < 5; ++q) atomicAdd(&acx_tim[20 + q], tsel[q + 1] - tsel[q]);
 #else
-    done = wave_select_fast<NV, FBINS>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi);
+    done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi);
 #endif
 #endif
     if (!done) {
