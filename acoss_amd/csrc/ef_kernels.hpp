@@ -69,10 +69,14 @@ __global__ void ef_oti_kernel(EfPair *pd, int B, const double *__restrict__ med)
 
 // ------------------------------------------------------------------------------------
 // E1: C[i][j] = epilogue( sum_k A[i][perm(k)] * B[j][k] ), 64 x 64 tile per workgroup,
-// 4 waves as 2 x 2, each wave 32 x 32 = 2 x 2 MFMA tiles, BK = 16.
+// 4 waves as 2 x 2, each wave 32 x 32 = 2 x 2 MFMA tiles.  K is walked in blocks of 48
+// (a multiple of the 12-bin chroma roll): the next block's 16-byte global loads are in flight
+// in registers while the current one is multiplied out of LDS (k-major, conflict-free operand
+// reads), two barriers per 48 k.  The blocked-OTI roll of the first song's chroma is applied as
+// a permutation of the LDS k-row on the way in.
 // feat: 0 mfcc (euclid), 1 ssm (euclid), 2 chroma (cosine, A rolled by oti).
 // ------------------------------------------------------------------------------------
-constexpr int EF_BK = 16;
+constexpr int EF_BK = 48;
 constexpr int EF_LP = 80;      // LDS pitch (k-major, 64 rows + pad; 80 % 32 == 16)
 
 __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ feat0, const float *__restrict__ feat1,
@@ -91,7 +95,6 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
     if (i0 >= P.M || j0 >= P.N) return;
     const int K = s == 0 ? K0 : (s == 1 ? K1 : K2);
     const float *F = s == 0 ? feat0 : (s == 1 ? feat1 : feat2);
-    const float *A = F + boff[P.q] * K, *Bm = F + boff[P.r] * K;
     const int rot = (s == 2) ? P.oti : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -103,25 +106,46 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging: thread -> (row = tid / 4, 4 consecutive k = 4 * (tid % 4))
-    const int srow = tid >> 2, sk = (tid & 3) * 4;
-    for (int k0 = 0; k0 < K; k0 += EF_BK) {
+    // staging: thread -> (row = tid / 4, 12 consecutive k = 12 * (tid % 4) ...) as three float4
+    const int srow = tid >> 2, sk = (tid & 3) * 12;
+    const bool rowa = i0 + srow < P.M, rowb = j0 + srow < P.N;
+    const float *Ap = F + (boff[P.q] + (rowa ? i0 + srow : 0)) * K + sk;
+    const float *Bp = F + (boff[P.r] + (rowb ? j0 + srow : 0)) * K + sk;
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    float ra[12], rb[12];
+    auto gload = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = k0 + sk + e;
-            float va = 0.f, vb = 0.f;
-            if (k < K) {
-                if (i0 + srow < P.M) {
-                    int ka = k;
-                    if (rot) { const int c = k % 12; int cs = c - rot; if (cs < 0) cs += 12; ka = k - c + cs; }
-                    va = A[(size_t)(i0 + srow) * K + ka];
+        for (int q = 0; q < 3; ++q) {
+            const int k = k0 + sk + 4 * q;
+            if (k + 3 < K) {                       // whole 16 bytes inside the row
+                const f32x4 va = *reinterpret_cast<const f32x4u *>(Ap + k0 + 4 * q);
+                const f32x4 vb = *reinterpret_cast<const f32x4u *>(Bp + k0 + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ra[4 * q + e] = rowa ? va[e] : 0.f; rb[4 * q + e] = rowb ? vb[e] : 0.f; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = k + e < K;
+                    ra[4 * q + e] = (ok && rowa) ? Ap[k0 + 4 * q + e] : 0.f;
+                    rb[4 * q + e] = (ok && rowb) ? Bp[k0 + 4 * q + e] : 0.f;
                 }
-                if (j0 + srow < P.N) vb = Bm[(size_t)(j0 + srow) * K + k];
             }
-            As[(sk + e) * EF_LP + srow] = va;
-            Bs[(sk + e) * EF_LP + srow] = vb;
         }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            // A[k] multiplies B[k'] with k' = k - c + (c + rot) mod 12, c = k mod 12 = e here
+            int ea = e + rot; ea = ea >= 12 ? ea - 12 : ea;
+            As[(sk + ea) * EF_LP + srow] = ra[e];
+            Bs[(sk + e) * EF_LP + srow] = rb[e];
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += EF_BK) {
+        lstore();
         __syncthreads();
+        if (k0 + EF_BK < K) gload(k0 + EF_BK);           // in flight during the MFMAs below
 #pragma unroll
         for (int kb = 0; kb < EF_BK / 4; ++kb) {
             float av[2], bv[2];
