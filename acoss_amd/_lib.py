@@ -25,6 +25,7 @@ EXPORTS = [
     "acx_serra09_embed_len", "acx_profile_enable", "acx_profile_reset", "acx_profile_count",
     "acx_profile_get", "acx_debug_sqrt", "acx_upload_pool_f64", "acx_simple_pairs",
     "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
+    "acx_chenfusion_pairs",
 ]
 
 
@@ -77,6 +78,7 @@ def load():
     L.acx_serra09_default_params.restype = None
     L.acx_serra09_default_params.argtypes = [pp]
     L.acx_serra09_pairs.argtypes = [vp, ip, ctypes.c_int64, pp, fp]
+    L.acx_chenfusion_pairs.argtypes = [vp, ip, ctypes.c_int64, pp, fp]
     L.acx_serra09_debug_pair.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, pp, fp, fp, fp, fp, fp, ip, fp, ip]
     L.acx_serra09_embed_len.restype = ctypes.c_int32
     L.acx_serra09_embed_len.argtypes = [ctypes.c_int32, pp]
@@ -230,6 +232,15 @@ class Context(object):
         out = np.empty(len(pairs), np.float32)
         self._check(self._L.acx_serra09_pairs(self._h, pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                               len(pairs), ctypes.byref(p), _fptr(out)))
+        return out
+
+    def chenfusion_pairs(self, pairs, params=None):
+        """(K, 2) float32: column 0 Qmax, column 1 Dmax of the same cross recurrence plot."""
+        p = params or serra09_params()
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        out = np.empty((len(pairs), 2), np.float32)
+        self._check(self._L.acx_chenfusion_pairs(self._h, pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                 len(pairs), ctypes.byref(p), _fptr(out)))
         return out
 
     def serra09_embed_len(self, T, params=None):

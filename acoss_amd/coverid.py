@@ -14,7 +14,7 @@ _LOG_FILE_PATH = "acoss.coverid.log"
 
 # names the reference advertises (coverid.py:19)
 algorithm_names = ["Serra09", "EarlyFusionTraile", "LateFusionChen", "FTM2D", "SiMPle"]
-_device_algorithms = ("Serra09", "SiMPle", "EarlyFusionTraile", "EarlyFusion")
+_device_algorithms = ("Serra09", "SiMPle", "EarlyFusionTraile", "EarlyFusion", "LateFusionChen")
 
 
 def benchmark(dataset_csv, feature_dir, feature_type="hpcp", algorithm="Serra09", shortname="covers80",
@@ -43,6 +43,14 @@ def benchmark(dataset_csv, feature_dir, feature_type="hpcp", algorithm="Serra09"
         logger.info("Computing pairwise similarity...")
         algo.all_pairwise(parallel, n_cores=n_workers, symmetric=True)
         algo.normalize_by_length()
+    elif algorithm == "LateFusionChen":
+        from .algorithms.latefusion_chen import ChenFusion
+        algo = ChenFusion(dataset_csv=dataset_csv, datapath=feature_dir, chroma_type=feature_type,
+                          shortname=shortname)
+        logger.info("Computing pairwise similarity...")
+        algo.all_pairwise(parallel, n_cores=n_workers, symmetric=True)
+        algo.normalize_by_length()
+        algo.do_late_fusion()
     elif algorithm == "SiMPle":
         from .algorithms.simple_silva import Simple
         algo = Simple(dataset_csv=dataset_csv, datapath=feature_dir, chroma_type=feature_type,

@@ -169,7 +169,8 @@ int check_params(acx_ctx *c, const acx_serra09_params &p)
     if (p.dp_start != 2 && p.dp_start != 3) return fail(c, ACX_ERR_INVALID, "serra09: dp_start must be 2 or 3");
     if (p.pct_mode < 0 || p.pct_mode > 3) return fail(c, ACX_ERR_INVALID, "serra09: pct_mode must be 0..3");
     if (p.oti_target != 0 && p.oti_target != 1) return fail(c, ACX_ERR_INVALID, "serra09: oti_target must be 0 or 1");
-    if (p.dmax != 0) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: Dmax (chen17) is not implemented on the device yet");
+    if (p.dmax != 0 && getenv("ACX_PIPELINE") && strcmp(getenv("ACX_PIPELINE"), "v1") == 0)
+        return fail(c, ACX_ERR_UNSUPPORTED, "serra09: Dmax (chen17) is not available on the v1 pipeline");
     if (!(p.gamma_o >= 0.0f) || !(p.gamma_e >= 0.0f)) return fail(c, ACX_ERR_INVALID, "serra09: gammas must be >= 0");
     return ACX_OK;
 }
@@ -249,8 +250,10 @@ struct DebugOut {
 
 // Runs the chain over `K` pairs in scratch-sized batches.
 int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params &p, float *out,
-                const DebugOut *dbg)
+                const DebugOut *dbg, bool both = false)
 {
+    if (both && getenv("ACX_PIPELINE") && strcmp(getenv("ACX_PIPELINE"), "v1") == 0)
+        return fail(c, ACX_ERR_UNSUPPORTED, "chenfusion: not available on the v1 pipeline");
     if (!c->d_frames) return fail(c, ACX_ERR_STATE, "serra09: feature pool not uploaded (acx_upload_pool)");
     if (c->dim != acx::NBIN) return fail(c, ACX_ERR_INVALID, "serra09: pool dim must be 12");
     int rc = check_params(c, p);
@@ -318,7 +321,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
         if ((rc = ensure(c, c->d_bits, c->bits_cap, (size_t)std::max<int64_t>(used_bits, 1))) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)used_thr)) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_pd, c->pd_cap, (size_t)B)) != ACX_OK) return rc;
-        if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)B)) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)2 * B)) != ACX_OK) return rc;
         ACX_HIP(c, hipMemcpyAsync(c->d_pd, pd.data(), sizeof(PairDesc) * B, hipMemcpyHostToDevice, c->stream));
 
         {   // K0
@@ -374,16 +377,23 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                 case 3: launch_qmax<3>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
                 default: launch_qmax<4>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
                 }
-            } else if (eqg) {
-                hipLaunchKernelGGL((acx::qmax_bits_kernel<true>), dim3(B), dim3(64), 0, c->stream,
-                                   c->d_pd, c->d_bits, c->d_out, p.gamma_o, p.gamma_e, p.dp_start);
             } else {
-                hipLaunchKernelGGL((acx::qmax_bits_kernel<false>), dim3(B), dim3(64), 0, c->stream,
-                                   c->d_pd, c->d_bits, c->d_out, p.gamma_o, p.gamma_e, p.dp_start);
+                // one sweep per requested alignment over the SAME recurrence bitmap:
+                // both == 0: Qmax or Dmax as p.dmax says; both == 1: out[2k] = Qmax, out[2k+1] = Dmax
+                const int stride = both ? 2 : 1;
+                auto sweep = [&](bool dmax, float *dst) {
+#define ACX_QB(E_, D_) hipLaunchKernelGGL((acx::qmax_bits_kernel<E_, D_>), dim3(B), dim3(64), 0, c->stream, \
+                                          c->d_pd, c->d_bits, dst, stride, p.gamma_o, p.gamma_e, p.dp_start)
+                    if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }
+                    else { if (dmax) ACX_QB(false, true); else ACX_QB(false, false); }
+#undef ACX_QB
+                };
+                if (both) { sweep(false, c->d_out); sweep(true, c->d_out + 1); }
+                else sweep(p.dmax != 0, c->d_out);
             }
         }
         ACX_HIP(c, hipGetLastError());
-        ACX_HIP(c, hipMemcpyAsync(out + k0, c->d_out, sizeof(float) * B, hipMemcpyDeviceToHost, c->stream));
+        ACX_HIP(c, hipMemcpyAsync(out + (both ? 2 : 1) * k0, c->d_out, sizeof(float) * B * (both ? 2 : 1), hipMemcpyDeviceToHost, c->stream));
         ACX_HIP(c, hipStreamSynchronize(c->stream));
         drain_profile(c);
 
@@ -695,6 +705,14 @@ int acx_serra09_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ser
     if (K < 0 || (K > 0 && (!pairs || !out)) || !params) return fail(c, ACX_ERR_INVALID, "serra09_pairs: bad argument");
     if (K == 0) return ACX_OK;
     return run_serra09(c, pairs, K, *params, out, nullptr);
+}
+
+int acx_chenfusion_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params *params, float *out)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (K < 0 || (K > 0 && (!pairs || !out)) || !params) return fail(c, ACX_ERR_INVALID, "chenfusion_pairs: bad argument");
+    if (K == 0) return ACX_OK;
+    return run_serra09(c, pairs, K, *params, out, nullptr, true);
 }
 
 int acx_serra09_debug_pair(acx_ctx *c, int32_t i, int32_t j, const acx_serra09_params *params,

@@ -1333,10 +1333,11 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
 // descending column order); the row's 32 recurrence bits of a lane are one funnel shift of two
 // dwords of the row bitmap (the bitmap of row i starts at column (i & 7) - 7).
 // ------------------------------------------------------------------------------------
-template <bool EQG>
+template <bool EQG, bool DMAX>
 __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restrict__ pd,
                                                        const unsigned long long *__restrict__ bits,
-                                                       float *__restrict__ out, float go, float ge, int dp_start)
+                                                       float *__restrict__ out, int out_stride,
+                                                       float go, float ge, int dp_start)
 {
     const int lane = threadIdx.x;
     const PairDesc P = pd[blockIdx.x];
@@ -1370,31 +1371,54 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
             if (has1) d1 = r[lane + 1];
         }
     };
+    auto row_bits = [&](int i, unsigned d0, unsigned d1) {      // recurrence bits of columns [32 lane, +32)
+        const int sh = (BAND - 1) - (i & (BAND - 1));           // bit position of column 0 in the row bitmap
+        return __builtin_amdgcn_alignbit(d1, d0, sh);
+    };
+    // Dmax (chen17, latefusion_chen.py:68): the (i-2, j-1) predecessor gains R[i-1][j], the
+    // (i-1, j-2) predecessor gains R[i][j-1]; wprev = raw bits of row i-1
+    unsigned wprev = 0u;
+    if constexpr (DMAX) {
+        unsigned p0, p1;
+        load_row(1, p0, p1);
+        wprev = row_bits(1, p0, p1);
+    }
     // One DP row: QA = row i-1, QB = row i-2 (overwritten with row i)
     auto dp_row = [&](int i, unsigned d0, unsigned d1, float (&QA)[32], float (&QB)[32],
                       float (&PA)[EQG ? 1 : 32], float (&PB)[EQG ? 1 : 32]) {
-        const int sh = (BAND - 1) - (i & (BAND - 1));           // bit position of column 0 in the row bitmap
-        const unsigned w = __builtin_amdgcn_alignbit(d1, d0, sh) & colmask;
+        const unsigned wraw = row_bits(i, d0, d1);
+        const unsigned w = wraw & colmask;
         float l1a = wave_shfl(QA[31], prev), l1b = wave_shfl(QA[30], prev), l2a = wave_shfl(QB[31], prev);
         float p1a = 0.f, p1b = 0.f, p2a = 0.f;
         if constexpr (!EQG) {
             p1a = wave_shfl(PA[31], prev); p1b = wave_shfl(PA[30], prev); p2a = wave_shfl(PB[31], prev);
         }
         if (lane == 0) { l1a = 0.f; l1b = 0.f; l2a = 0.f; p1a = 0.f; p1b = 0.f; p2a = 0.f; }
+        unsigned wleft = 0u;                                    // bit e = R[i][j-1]
+        if constexpr (DMAX) {
+            unsigned carry = (unsigned)__shfl((int)(wraw >> 31), prev, 64);
+            if (lane == 0) carry = 0u;
+            wleft = (wraw << 1) | carry;
+        }
 #pragma unroll
         for (int e = 31; e >= 0; --e) {
             const bool r = (w >> e) & 1u;
+            float x3 = 0.0f, x4 = 0.0f;
+            if constexpr (DMAX) {
+                x3 = ((wprev >> e) & 1u) ? 1.0f : 0.0f;
+                x4 = ((wleft >> e) & 1u) ? 1.0f : 0.0f;
+            }
             const float c2 = (e >= 1) ? QA[e - 1] : l1a;                          // (i-1, j-1)
-            const float c3 = (e >= 1) ? QB[e - 1] : l2a;                          // (i-2, j-1)
-            const float c4 = (e >= 2) ? QA[e - 2] : (e == 1 ? l1a : l1b);         // (i-1, j-2)
+            const float c3 = ((e >= 1) ? QB[e - 1] : l2a) + x3;                   // (i-2, j-1)
+            const float c4 = ((e >= 2) ? QA[e - 2] : (e == 1 ? l1a : l1b)) + x4;  // (i-1, j-2)
             const float mx = fmaxf(fmaxf(c2, c3), c4);
             float vgap;
             if constexpr (EQG) {
                 vgap = fmaxf(mx - go, 0.0f);
             } else {
                 const float a2 = (e >= 1) ? PA[e - 1] : p1a;
-                const float a3 = (e >= 1) ? PB[e - 1] : p2a;
-                const float a4 = (e >= 2) ? PA[e - 2] : (e == 1 ? p1a : p1b);
+                const float a3 = ((e >= 1) ? PB[e - 1] : p2a) + x3;
+                const float a4 = ((e >= 2) ? PA[e - 2] : (e == 1 ? p1a : p1b)) + x4;
                 vgap = fmaxf(fmaxf(fmaxf(a2, a3), a4), 0.0f);
             }
             float q = r ? (mx + 1.0f) : vgap;
@@ -1403,6 +1427,7 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
             if constexpr (!EQG) PB[e] = q - (r ? go : ge);
             best = fmaxf(best, q);
         }
+        if constexpr (DMAX) wprev = wraw;
     };
 
     unsigned a0, a1, b0, b1, c0, c1, d0, d1;
@@ -1416,7 +1441,7 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
         if (i + 3 < Me) { load_row(i + 7, n0, n1); dp_row(i + 3, d0, d1, Q2, Q1, P2, P1); d0 = n0; d1 = n1; }
     }
     best = wave_max(best);
-    if (lane == 0) out[blockIdx.x] = best;
+    if (lane == 0) out[(size_t)blockIdx.x * out_stride] = best;
 }
 
 // ------------------------------------------------------------------------------------

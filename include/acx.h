@@ -98,6 +98,15 @@ int acx_serra09_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K,
                       const acx_serra09_params *params, float *out);
 
 /*
+ * ChenFusion (latefusion_chen.py:58-72): for every pair ONE cross recurrence plot and two
+ * alignments of it -- out[2k] = Qmax ('serra09'), out[2k+1] = Dmax ('chen17') -- the two
+ * scalars ChenFusion.similarity() stores into Ds["qmax"][i][j] and Ds["dmax"][i][j].
+ * params->dmax is ignored.  out: 2*K floats, host memory.
+ */
+int acx_chenfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K,
+                         const acx_serra09_params *params, float *out);
+
+/*
  * One pair with intermediates, for parity tests (every pointer may be NULL):
  *   d2   (Mq*Mr) squared embedded distances (the ChromaCrossSimilarity distance
  *        matrix before sqrt, rqa_serra09.py:66)

@@ -123,7 +123,7 @@ def test_full_size_pair_2000(ctx):
     dict(pct_mode=1), dict(pct_mode=2), dict(pct_mode=3), dict(inclusive=0), dict(dp_start=3),
     dict(embed_full=1), dict(oti=False), dict(oti_target=1), dict(gamma_o=1.0, gamma_e=0.25),
     dict(gamma_o=0.25, gamma_e=1.5), dict(m=4), dict(m=12), dict(m=16), dict(m=1), dict(kappa=0.3),
-    dict(kappa=0.0), dict(kappa=1.0),
+    dict(kappa=0.0), dict(kappa=1.0), dict(dmax=1), dict(dmax=1, dp_start=3), dict(dmax=1, gamma_o=1.0, gamma_e=0.25),
 ])
 def test_parameter_switches_bit_exact(ctx, kw):
     from acoss_amd import synth, _lib
@@ -160,6 +160,29 @@ def test_all_pairs_scores_and_map(ctx):
         stats.append(oracle.eval_statistics(D, list(cl.values()), topsidx=(1, 10)))
     assert stats[0][:4] == stats[1][:4]
     assert abs(stats[0][3] - stats[2][3]) <= 1e-4 and stats[0][0] == stats[2][0]
+
+
+def test_chenfusion_pairs_qmax_and_dmax(ctx):
+    """acx_chenfusion_pairs: one recurrence plot, both alignments (latefusion_chen.py:58-72);
+    each column bit-exact vs the oracle run with dmax = 0 / 1, incl. a T = 2000 pair."""
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    d = synth.cover_set(n_works=3, versions=2, seed=12, t_range=(60, 260))
+    n = len(d["offsets"]) - 1
+    ctx.upload_pool(d["frames"], d["offsets"])
+    pairs = oracle.all_pairs(n, False).astype(np.int32)
+    got = ctx.chenfusion_pairs(pairs)
+    q = oracle.serra09_pairs(d["frames"], d["offsets"], pairs)
+    dm = oracle.serra09_pairs(d["frames"], d["offsets"], pairs, oracle.serra09_params(dmax=1))
+    assert np.array_equal(got[:, 0], q) and np.array_equal(got[:, 1], dm)
+    assert np.array_equal(ctx.serra09_pairs(pairs, _lib.serra09_params(dmax=1)), dm)
+    assert np.all(dm >= q)
+    big = synth.rand_set(2, T=2000, seed=5)
+    ctx.upload_pool(big["frames"], big["offsets"])
+    pr = np.array([[0, 1]], np.int32)
+    got = ctx.chenfusion_pairs(pr)
+    assert got[0, 0] == oracle.serra09_pairs(big["frames"], big["offsets"], pr)[0]
+    assert got[0, 1] == oracle.serra09_pairs(big["frames"], big["offsets"], pr, oracle.serra09_params(dmax=1))[0]
 
 
 def test_batching_is_invisible(ctx):
