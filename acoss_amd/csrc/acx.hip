@@ -47,6 +47,9 @@ struct acx_ctx {
     // pool
     float *d_frames = nullptr;
     float *d_frot = nullptr;      // rotated frame pool (band kernel MFMA operands), 36 floats per frame
+    float *d_normtab = nullptr;   // embedded norms per (track, rotation, frame) for normtab_m / normtab_span
+    int64_t *d_noff = nullptr;
+    int normtab_m = 0, normtab_span = -1;
     int64_t *d_toff = nullptr;
     float *d_gch = nullptr;
     std::vector<int64_t> h_off;
@@ -202,7 +205,7 @@ void launch_band(acx_ctx *c, int B, int maxRows, int maxCols, const acx_serra09_
     const dim3 grid((maxRows + acx::BAND - 1) / acx::BAND, B, 1);
     const int ndata = (maxCols + acx::BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
 #define ACX_BAND_R(V4_, R_) hipLaunchKernelGGL((acx::band_kernel<M, V4_, R_>), grid, dim3(acx::BAND_THREADS), 0, c->stream, \
-                                         c->d_frot, c->d_toff, c->d_pd, c->d_scratch, c->d_thr, c->d_bits, p.kappa, \
+                                         c->d_frot, c->d_toff, c->d_normtab, c->d_noff, c->d_pd, c->d_scratch, c->d_thr, c->d_bits, p.kappa, \
                                          p.pct_mode, p.inclusive, p.oti_target, write_d2)
 #define ACX_BAND(V4_) do { if (role) ACX_BAND_R(V4_, 1); else ACX_BAND_R(V4_, 0); } while (0)
     if (ndata <= 8) ACX_BAND(2);
@@ -213,10 +216,10 @@ void launch_band(acx_ctx *c, int B, int maxRows, int maxCols, const acx_serra09_
 }
 
 template <int M>
-void launch_norms(acx_ctx *c, int B, int maxRows, int oti_target)
+void launch_normtab(acx_ctx *c, int maxM, int span)
 {
-    hipLaunchKernelGGL((acx::norms_kernel<M>), dim3((maxRows + 255) / 256, B), dim3(256), 0, c->stream,
-                       c->d_frames, c->d_toff, c->d_pd, c->d_thr, oti_target);
+    hipLaunchKernelGGL((acx::normtab_kernel<M>), dim3((maxM + 255) / 256, c->n_tracks, acx::NBIN), dim3(256), 0, c->stream,
+                       c->d_frames, c->d_toff, c->d_noff, c->d_normtab, span);
 }
 
 #ifdef ACX_FAST_BUILD   /* development builds: only the default stack size */
@@ -230,6 +233,38 @@ void launch_norms(acx_ctx *c, int B, int maxRows, int oti_target)
         case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break; \
     }
 #endif
+
+// The table of embedded norms depends on the pool and on (m, embedded length): built on first use.
+int ensure_normtab(acx_ctx *c, const acx_serra09_params &p)
+{
+    const int span = p.embed_full ? (p.m - 1) * p.tau : p.m * p.tau;
+    if (c->d_normtab && c->normtab_m == p.m && c->normtab_span == span) return ACX_OK;
+    if (c->d_normtab) { ACX_HIP(c, hipFree(c->d_normtab)); c->d_normtab = nullptr; }
+    if (c->d_noff) { ACX_HIP(c, hipFree(c->d_noff)); c->d_noff = nullptr; }
+    std::vector<int64_t> noff((size_t)c->n_tracks + 1);
+    int64_t tot = 0;
+    int maxM = 1;
+    for (int t = 0; t < c->n_tracks; ++t) {
+        noff[t] = tot;
+        const int Me = std::max<int>(0, (int)(c->h_off[t + 1] - c->h_off[t]) - span);
+        maxM = std::max(maxM, Me);
+        tot += (int64_t)acx::NBIN * Me;
+    }
+    noff[c->n_tracks] = tot;
+    ACX_HIP(c, hipMalloc((void **)&c->d_normtab, sizeof(float) * std::max<int64_t>(1, tot)));
+    ACX_HIP(c, hipMalloc((void **)&c->d_noff, sizeof(int64_t) * noff.size()));
+    ACX_HIP(c, hipMemcpy(c->d_noff, noff.data(), sizeof(int64_t) * noff.size(), hipMemcpyHostToDevice));
+    {
+        ProfScope ps(c, KS_NORMS, 0);
+#define ACX_CALL(M_) launch_normtab<M_>(c, maxM, span)
+        ACX_M_SWITCH(p.m, ACX_CALL)
+#undef ACX_CALL
+    }
+    ACX_HIP(c, hipGetLastError());
+    c->normtab_m = p.m;
+    c->normtab_span = span;
+    return ACX_OK;
+}
 
 template <int NG>
 void launch_qmax(acx_ctx *c, int B, bool eqg, float go, float ge, int dp_start)
@@ -269,6 +304,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
     const int64_t limit_floats = limit / 4;
     const char *pipe = getenv("ACX_PIPELINE");
     const bool v1 = pipe && strcmp(pipe, "v1") == 0;     // A/B switch: materialised D2 + D2T pipeline
+    if (!v1 && (rc = ensure_normtab(c, p)) != ACX_OK) return rc;
 
     std::vector<PairDesc> pd;
     int64_t k0 = 0;
@@ -347,12 +383,6 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
 #undef ACX_SEL
             }
         } else {
-            {   // K0b: embedded norms
-                ProfScope ps(c, KS_NORMS, cells);
-#define ACX_CALL(M_) launch_norms<M_>(c, B, maxRows, p.oti_target)
-                ACX_M_SWITCH(p.m, ACX_CALL)
-#undef ACX_CALL
-            }
             {   // K1' role 1: rows = reference frames -> column thresholds
                 ProfScope ps(c, KS_BAND, cells);
 #define ACX_CALL(M_) launch_band<M_>(c, B, maxMr, maxMq, p, 1, 0)
@@ -605,6 +635,8 @@ void acx_destroy(acx_ctx *c)
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->d_frames) (void)hipFree(c->d_frames);
     if (c->d_frot) (void)hipFree(c->d_frot);
+    if (c->d_normtab) (void)hipFree(c->d_normtab);
+    if (c->d_noff) (void)hipFree(c->d_noff);
     if (c->d_toff) (void)hipFree(c->d_toff);
     if (c->d_gch) (void)hipFree(c->d_gch);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -645,6 +677,9 @@ int acx_upload_pool(acx_ctx *c, const float *frames, const int64_t *offsets, int
     ACX_HIP(c, hipSetDevice(c->device));
     if (c->d_frames) { (void)hipFree(c->d_frames); c->d_frames = nullptr; }
     if (c->d_frot) { (void)hipFree(c->d_frot); c->d_frot = nullptr; }
+    if (c->d_normtab) { (void)hipFree(c->d_normtab); c->d_normtab = nullptr; }
+    if (c->d_noff) { (void)hipFree(c->d_noff); c->d_noff = nullptr; }
+    c->normtab_m = 0; c->normtab_span = -1;
     if (c->d_toff) { (void)hipFree(c->d_toff); c->d_toff = nullptr; }
     if (c->d_gch) { (void)hipFree(c->d_gch); c->d_gch = nullptr; }
     const int64_t total = offsets[n_tracks];

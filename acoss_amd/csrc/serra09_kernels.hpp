@@ -806,30 +806,32 @@ __global__ __launch_bounds__(256) void rowsel_kernel(const PairDesc *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
-// K0b: embedded squared norms of every track of every pair (tiny): xx_i = tree over m frame
-// norms, each a 12-term fmaf chain over the (rotated) bins.  Written behind the thresholds
-// in the threshold arena: [.. 2 (pitchT + pitchD) ..][nq: pitchT][nr: pitchD].
+// K0b: table of embedded squared norms, built once per (pool, m): for every track, every
+// rotation rot = 0..11 and every embedded frame i: xx = tree over m frame norms, each a 12-term
+// fmaf chain over the bins in ROTATED order (rotated[c'] = src[(c' - rot) mod 12]) -- the chain
+// order is part of the arithmetic spec, so the norm depends on the rotation.  Layout:
+// tab[noff[track] + rot * Memb(track) + i].  A pair only picks two rows of it (query unrotated,
+// reference rotated by its OTI, or the other way round).
 // ------------------------------------------------------------------------------------
 template <int M>
-__global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ pool,
-                                                    const int64_t *__restrict__ toff,
-                                                    const PairDesc *__restrict__ pd,
-                                                    float *__restrict__ thr, int oti_target)
+__global__ __launch_bounds__(256) void normtab_kernel(const float *__restrict__ pool,
+                                                      const int64_t *__restrict__ toff,
+                                                      const int64_t *__restrict__ noff,
+                                                      float *__restrict__ tab, int span)
 {
-    const PairDesc P = pd[blockIdx.y];
-    const int e = blockIdx.x * 256 + threadIdx.x;     // 0 .. Mq + Mr
-    if (e >= P.Mq + P.Mr) return;
-    const bool isr = e >= P.Mq;
-    const int i = isr ? e - P.Mq : e;
-    const float *f = pool + toff[isr ? P.r : P.q] * NBIN + (size_t)i * NBIN;
-    const int rot = (isr == (oti_target == 0)) ? P.oti : 0;
+    const int track = blockIdx.y, rot = blockIdx.z;
+    const int64_t t0 = toff[track];
+    const int T = (int)(toff[track + 1] - t0);
+    const int Me = T - span;                                   // embedded frames (tau == 1)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Me) return;
+    const float *f = pool + (t0 + i) * NBIN;
     float s[M];
 #pragma unroll
     for (int k = 0; k < M; ++k) {
         float v[NBIN];
 #pragma unroll
         for (int c = 0; c < NBIN; ++c) v[c] = f[k * NBIN + c];
-        // chain over the ROTATED bin order: rotated[c'] = src[(c' - rot) mod 12]
         float acc = 0.0f;
         for (int cp = 0; cp < NBIN; ++cp) {
             int c = cp - rot; if (c < 0) c += NBIN;
@@ -840,8 +842,7 @@ __global__ __launch_bounds__(256) void norms_kernel(const float *__restrict__ po
         }
         s[k] = acc;
     }
-    float *N = thr + P.offX + 2 * (P.pitchT + P.pitchD);
-    N[isr ? P.pitchT + i : i] = tree_sum<M>(s);
+    tab[noff[track] + (int64_t)rot * Me + i] = tree_sum<M>(s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -920,6 +921,8 @@ __device__ __forceinline__ float percentile_eps(const SelectResult &sr, int pct_
 template <int M, int V4, int ROLE>
 __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__restrict__ frot,
                                                             const int64_t *__restrict__ toff,
+                                                            const float *__restrict__ normtab,
+                                                            const int64_t *__restrict__ noff,
                                                             const PairDesc *__restrict__ pd,
                                                             float *__restrict__ scratch,
                                                             float *__restrict__ thr,
@@ -965,9 +968,9 @@ __global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__re
     const bool rows_are_ref = role == 1;
     const int rota = (rows_are_ref == (oti_target == 0)) ? P.oti : 0;
     const int rotb = (rows_are_ref == (oti_target == 0)) ? 0 : P.oti;
-    const float *NRM = thr + P.offX + 2 * (P.pitchT + P.pitchD);
-    const float *nrow = role ? NRM + P.pitchT : NRM;   // embedded norms of the row track
-    const float *ncol = role ? NRM : NRM + P.pitchT;
+    // embedded norms of the row / column track in this pair's rotation (normtab_kernel)
+    const float *nrow = normtab + noff[role ? P.r : P.q] + (int64_t)rota * MA;
+    const float *ncol = normtab + noff[role ? P.q : P.r] + (int64_t)rotb * MB;
     const float INF = __builtin_inff();
 #ifdef ACX_TIMING
     unsigned long long tstamp[16];
