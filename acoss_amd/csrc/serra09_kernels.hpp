@@ -1412,24 +1412,32 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
                 x4 = ((wleft >> e) & 1u) ? 1.0f : 0.0f;
             }
             const float c2 = (e >= 1) ? QA[e - 1] : l1a;                          // (i-1, j-1)
-            const float c3 = ((e >= 1) ? QB[e - 1] : l2a) + x3;                   // (i-2, j-1)
-            const float c4 = ((e >= 2) ? QA[e - 2] : (e == 1 ? l1a : l1b)) + x4;  // (i-1, j-2)
+            float c3 = (e >= 1) ? QB[e - 1] : l2a;                                // (i-2, j-1)
+            float c4 = (e >= 2) ? QA[e - 2] : (e == 1 ? l1a : l1b);               // (i-1, j-2)
+            if constexpr (DMAX) { c3 += x3; c4 += x4; }
             const float mx = fmaxf(fmaxf(c2, c3), c4);
             float vgap;
             if constexpr (EQG) {
                 vgap = fmaxf(mx - go, 0.0f);
             } else {
                 const float a2 = (e >= 1) ? PA[e - 1] : p1a;
-                const float a3 = ((e >= 1) ? PB[e - 1] : p2a) + x3;
-                const float a4 = ((e >= 2) ? PA[e - 2] : (e == 1 ? p1a : p1b)) + x4;
+                float a3 = (e >= 1) ? PB[e - 1] : p2a;
+                float a4 = (e >= 2) ? PA[e - 2] : (e == 1 ? p1a : p1b);
+                if constexpr (DMAX) { a3 += x3; a4 += x4; }
                 vgap = fmaxf(fmaxf(fmaxf(a2, a3), a4), 0.0f);
             }
             float q = r ? (mx + 1.0f) : vgap;
-            if (!((colmask >> e) & 1u)) q = 0.0f;      // columns 0, 1 and columns right of the matrix
+            // Columns 0, 1 and the columns right of the matrix must not count.  For Qmax the masked
+            // recurrence bit does it alone: such a cell takes the gap branch, so it is <= a value an
+            // existing cell already reported (never a new maximum), it feeds only cells further
+            // right, and in columns 0 / 1 its predecessors are all 0.  Dmax adds raw recurrence bits
+            // to the predecessors, so there the cell is forced to 0.
+            if constexpr (DMAX) { if (!((colmask >> e) & 1u)) q = 0.0f; }
             QB[e] = q;
             if constexpr (!EQG) PB[e] = q - (r ? go : ge);
-            best = fmaxf(best, q);
         }
+#pragma unroll
+        for (int e = 0; e < 32; e += 2) best = fmaxf(best, fmaxf(QB[e], QB[e + 1]));
         if constexpr (DMAX) wprev = wraw;
     };
 
