@@ -5,10 +5,15 @@ Ds['mfccs'|'ssms'|'chromas'|'early'], do_late_fusion().  The per-pair chain (thr
 cross-similarity matrices, row-kappa binarisation, constrained Smith-Waterman x4, kernel
 fusion; earlyfusion_traile.py:157-198) runs in libacx's HIP kernels.
 
-Block-feature preparation (beat-synchronous MFCC / SSM / chroma blocks, :100-154, which needs
-skimage.transform.resize) is outside this engine's scope for now: the class
-reads ready block features -- keys mfccs (nb,650), ssms (nb,1225), chromas (nb,480),
-chroma_med (12,) -- from the per-track feature file or from its cache / set_block_features().
+Block-feature preparation (beat-synchronous MFCC / SSM / chroma blocks, :100-154) runs on the
+host (numpy + scipy.ndimage), once per track: `block_features()` / `resize_block()` below.  The
+reference resizes blocks with skimage.transform.resize(anti_aliasing=True, mode='constant'),
+a library that is neither pinned by the reference (not in its setup.py) nor installed here, so
+that step is a restatement of skimage's published algorithm (Gaussian pre-filter with
+sigma = (scale - 1) / 2, then order-1 scipy.ndimage.zoom on the pixel grid, then clipping to the
+input range) -- PARITY UNPINNED for it; everything around it follows the reference line by line.
+A track file that already holds block features (keys mfccs (nb,650), ssms (nb,1225), chromas
+(nb,480), chroma_med (12,)) is used as is.
 """
 import os
 
@@ -18,7 +23,74 @@ from .. import _lib
 from .algorithm_template import CoverAlgorithm
 from .similarity_fusion import doSimilarityFusion
 
-__all__ = ["EarlyFusion"]
+__all__ = ["EarlyFusion", "resize_block", "block_features"]
+
+
+def resize_block(X, i1, i2, frames_per_block):
+    """earlyfusion_traile.py:214-247 (median_aggregate=False): frames [i1, i2) of X resampled
+    to `frames_per_block` rows as skimage.transform.resize(x, (frames_per_block, d),
+    anti_aliasing=True, mode='constant') does (order 1, cval 0, clip to the input range),
+    restated with the scipy.ndimage primitives skimage itself calls; inf / nan -> 0."""
+    import scipy.ndimage as ndi
+    x = np.asarray(X)[i1:i2, :].astype(np.float64)
+    n = x.shape[0]
+    if n == 0:
+        return np.zeros((frames_per_block, x.shape[1]))
+    factor = n / float(frames_per_block)
+    sigma = max(0.0, (factor - 1.0) / 2.0)
+    filt = ndi.gaussian_filter(x, (sigma, 0.0), cval=0.0, mode="grid-constant") if sigma > 0 else x
+    out = ndi.zoom(filt, (frames_per_block / float(n), 1.0), order=1, mode="grid-constant", cval=0.0,
+                   grid_mode=True)
+    if out.shape[0] != frames_per_block:       # rounding of n * zoom
+        fixed = np.zeros((frames_per_block, x.shape[1]))
+        m = min(frames_per_block, out.shape[0])
+        fixed[:m] = out[:m]
+        out = fixed
+    lo, hi = min(float(x.min()), 0.0), max(float(x.max()), 0.0)
+    if np.isfinite(lo) and np.isfinite(hi):
+        out = np.clip(out, lo, hi)
+    out[~np.isfinite(out)] = 0
+    return out
+
+
+def _ssm(X):
+    """cross_recurrence.py:9-28 (get_ssm): Euclidean self-similarity matrix, zero diagonal."""
+    sq = np.sum(X ** 2, 1)
+    d2 = sq[:, None] + sq[None, :] - 2 * X.dot(X.T)
+    d2[d2 < 0] = 0
+    np.fill_diagonal(d2, 0)
+    return np.sqrt(d2)
+
+
+def block_features(feats, chroma_type="hpcp", blocksize=20, mfccs_per_block=50, chromas_per_block=40):
+    """earlyfusion_traile.py:100-140: beat-synchronous blocks of one track.
+    feats: the per-track dictionary of the feature store -- feats[chroma_type] (T, 12),
+    feats['mfcc_htk'] (n_coeffs, T'), feats['madmom_features']['onsets'] (frame indices of the
+    beats).  Returns mfccs (nb, mfccs_per_block * n_coeffs) f32 (z-normalised blocks), ssms
+    (nb, mfccs_per_block (mfccs_per_block - 1) / 2) f32, chromas (nb, chromas_per_block * 12)
+    f32, chroma_med (12,), nb = n_beats - blocksize."""
+    chroma = np.asarray(feats[chroma_type])
+    mfcc = np.array(feats["mfcc_htk"], dtype=np.float64).T
+    mfcc[np.isnan(mfcc)] = 0
+    onsets = np.asarray(feats["madmom_features"]["onsets"]).astype(np.int64)
+    n_blocks = max(0, len(onsets) - blocksize)
+    out = {"mfccs": np.zeros((n_blocks, mfccs_per_block * mfcc.shape[1]), dtype=np.float32)}
+    pix = np.arange(mfccs_per_block)
+    I, J = np.meshgrid(pix, pix)
+    out["ssms"] = np.zeros((n_blocks, mfccs_per_block * (mfccs_per_block - 1) // 2), dtype=np.float32)
+    for b in range(n_blocks):
+        x = resize_block(mfcc, onsets[b], onsets[b + blocksize - 1], mfccs_per_block)
+        x = x - np.mean(x, 0)[None, :]
+        nrm = np.sqrt(np.sum(x ** 2, 1))[:, None]
+        nrm[nrm == 0] = 1
+        xn = x / nrm
+        out["mfccs"][b, :] = xn.flatten()
+        out["ssms"][b, :] = _ssm(xn)[I < J]
+    out["chromas"] = np.zeros((n_blocks, chromas_per_block * chroma.shape[1]), dtype=np.float32)
+    out["chroma_med"] = np.median(chroma, axis=0)
+    for b in range(n_blocks):
+        out["chromas"][b, :] = resize_block(chroma, onsets[b], onsets[b + blocksize], chromas_per_block).flatten()
+    return out
 
 _KEYS = ("mfccs", "ssms", "chromas", "chroma_med")
 
@@ -53,13 +125,15 @@ class EarlyFusion(CoverAlgorithm):
         if i in self.all_block_feats:
             return self.all_block_feats[i]
         feats = CoverAlgorithm.load_features(self, i)
-        if not all(k in feats for k in _KEYS):
-            raise NotImplementedError(
-                "EarlyFusion.load_features: %s holds no block features (%s). Building them from raw "
-                "MFCC / chroma / beat onsets (earlyfusion_traile.py:100-154) is not part of the MI355X "
-                "engine yet; store the block features in the track file or call set_block_features()."
-                % (self.filepaths[i], ", ".join(_KEYS)))
-        self.all_block_feats[i] = {k: np.asarray(feats[k]) for k in _KEYS}
+        if all(k in feats for k in _KEYS):
+            self.all_block_feats[i] = {k: np.asarray(feats[k]) for k in _KEYS}
+        else:
+            import time
+            tic = time.time()
+            self.all_block_feats[i] = block_features(feats, self.chroma_type, self.blocksize,
+                                                     self.mfccs_per_block, self.chromas_per_block)
+            if self.log_times:
+                self.times['features'].append(time.time() - tic)
         return self.all_block_feats[i]
 
     def set_block_features(self, tracks, labels=None):

@@ -229,8 +229,8 @@ def test_earlyfusion_class_surface(tmp_path, monkeypatch):
                      ssm_res=50, chromas_per_block=40, kappa=0.1, K=10, niters=5, log_times=False)
     assert ef.name == "EarlyFusionTraile" and sorted(ef.Ds.keys()) == ["chromas", "early", "mfccs", "ssms"]
     assert ef.get_cacheprefix() == "cache/EarlyFusionTraile_toy_hpcp"
-    with pytest.raises(NotImplementedError):
-        ef.load_features(0)                       # the toy files hold no block features
+    with pytest.raises(KeyError):
+        ef.load_features(0)                       # the toy files hold neither block nor raw MFCC / beat features
     tracks = synth.earlyfusion_set(3, seed=0, nb_range=(8, 12))
     ef.set_block_features(tracks, ["a", "a", "b"])
     assert ef.load_features(1) is tracks[1] and ef.cliques == {"a": {0, 1}, "b": {2}}
@@ -247,3 +247,52 @@ def test_earlyfusion_class_surface(tmp_path, monkeypatch):
     big.do_late_fusion()
     assert big.Ds["late"].shape == (30, 30) and big.Ds["early+late"].shape == (30, 30)
     assert np.all(np.isfinite(big.Ds["late"]))
+
+
+def test_earlyfusion_block_feature_preparation(tmp_path, monkeypatch):
+    """earlyfusion_traile.py:100-154, 214-247 on the host.  skimage is neither pinned by the
+    reference nor installed, so resize_block is checked through the properties of the algorithm
+    it restates (identity at scale 1, constants and linear ramps preserved away from the zero
+    border, range clipping) and block_features through the reference's own definitions."""
+    from acoss_amd.algorithms.earlyfusion_traile import EarlyFusion, resize_block, block_features
+    rng = np.random.default_rng(11)
+    X = rng.random((400, 5))
+    np.testing.assert_allclose(resize_block(X, 30, 80, 50), X[30:80], atol=1e-12)          # scale 1: identity
+    r = resize_block(np.full((300, 2), 3.0), 0, 240, 40)
+    assert r.shape == (40, 2) and np.allclose(r[6:-6], 3.0) and r.max() <= 3.0 and r[0, 0] < 3.0   # zero border leaks in
+    ramp = np.arange(600, dtype=np.float64)[:, None] * np.ones((1, 2))
+    r = resize_block(ramp, 100, 500, 50)                                                   # 8 : 1
+    want = 100 + (np.arange(50) + 0.5) * 8 - 0.5                                           # pixel centres
+    np.testing.assert_allclose(r[8:-8, 0], want[8:-8], atol=1e-6)
+    up = resize_block(X, 10, 35, 50)                                                       # upsampling: no blur
+    assert up.shape == (50, 5) and up.min() >= min(X[10:35].min(), 0) and up.max() <= X[10:35].max()
+    bad = X.copy(); bad[50, 0] = np.nan
+    assert np.all(np.isfinite(resize_block(bad, 40, 90, 20)))
+
+    T = 2600
+    feats = {"hpcp": rng.random((T, 12)).astype(np.float32), "mfcc_htk": rng.standard_normal((13, T)),
+             "madmom_features": {"onsets": np.sort(rng.choice(T - 100, 48, replace=False))}}
+    feats["mfcc_htk"][3, 77] = np.nan
+    bf = block_features(feats)
+    nb = 48 - 20
+    assert bf["mfccs"].shape == (nb, 650) and bf["ssms"].shape == (nb, 1225) and bf["chromas"].shape == (nb, 480)
+    assert bf["mfccs"].dtype == np.float32 and bf["chroma_med"].shape == (12,)
+    np.testing.assert_array_equal(bf["chroma_med"], np.median(feats["hpcp"], axis=0))
+    blk = bf["mfccs"][5].reshape(50, 13).astype(np.float64)
+    np.testing.assert_allclose(np.linalg.norm(blk, axis=1), 1.0, atol=1e-6)               # z-normalised rows
+    pix = np.arange(50); I, J = np.meshgrid(pix, pix)
+    np.testing.assert_allclose(bf["ssms"][5], oracle.get_csm(blk.astype(np.float32), blk.astype(np.float32))[I < J], atol=2e-3)
+    on = feats["madmom_features"]["onsets"]
+    np.testing.assert_allclose(bf["chromas"][7], resize_block(feats["hpcp"], on[7], on[27], 40).flatten(), rtol=1e-6)
+
+    # class path: a track file with raw features only
+    labels = ["a", "a"]
+    csv, root = _toy_dataset(tmp_path, labels)
+    for k, l in enumerate(labels):
+        save_track(root + "%s/t%d.h5" % (l, k), {"label": l, "track_id": "t%d" % k, "hpcp": feats["hpcp"],
+                                                 "mfcc_htk": np.nan_to_num(feats["mfcc_htk"]),
+                                                 "madmom_features": {"onsets": on}})
+    monkeypatch.chdir(tmp_path)
+    ef = EarlyFusion(csv, root, chroma_type="hpcp", shortname="toy", log_times=True)
+    got = ef.load_features(1)
+    assert got["mfccs"].shape == (nb, 650) and ef.load_features(1) is got and len(ef.times["features"]) == 1
