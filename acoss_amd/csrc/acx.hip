@@ -200,12 +200,12 @@ void launch_csm_m(acx_ctx *c, int m, dim3 grid, int tiles_x, int oti_target)
 }
 
 template <int M>
-void launch_band(acx_ctx *c, int B, int maxRows, int maxCols, const acx_serra09_params &p, int role, int write_d2)
+void launch_band(acx_ctx *c, const PairDesc *dpd, int B, int maxRows, int maxCols, const acx_serra09_params &p, int role, int write_d2)
 {
     const dim3 grid((maxRows + acx::BAND - 1) / acx::BAND, B, 1);
     const int ndata = (maxCols + acx::BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
 #define ACX_BAND_R(V4_, R_) hipLaunchKernelGGL((acx::band_kernel<M, V4_, R_>), grid, dim3(acx::BAND_THREADS), 0, c->stream, \
-                                         c->d_frot, c->d_toff, c->d_normtab, c->d_noff, c->d_pd, c->d_scratch, c->d_thr, c->d_bits, p.kappa, \
+                                         c->d_frot, c->d_toff, c->d_normtab, c->d_noff, dpd, c->d_scratch, c->d_thr, c->d_bits, p.kappa, \
                                          p.pct_mode, p.inclusive, p.oti_target, write_d2)
 #define ACX_BAND(V4_) do { if (role) ACX_BAND_R(V4_, 1); else ACX_BAND_R(V4_, 0); } while (0)
     if (ndata <= 8) ACX_BAND(2);
@@ -353,6 +353,29 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             pd.push_back(d);
         }
         const int B = (int)pd.size();
+        // Band pipeline: pairs are processed in three size classes (row length <= 505 / 1017 / 2041
+        // cells -> 8 / 16 / 32 values per lane) so that a batch of mixed track lengths does not run
+        // its short pairs through the widest kernel.  `perm[k]` = original position of sorted pair k.
+        std::vector<int> perm(B);
+        int cls_begin[4] = {0, 0, 0, B};
+        {
+            auto cls_of = [](const PairDesc &d) {
+                const int nd = (std::max(d.Mq, d.Mr) + acx::BAND - 1 + 63) / 64;
+                return nd <= 8 ? 0 : (nd <= 16 ? 1 : 2);
+            };
+            int cnt[3] = {0, 0, 0};
+            if (!v1) for (const PairDesc &d : pd) cnt[cls_of(d)]++;
+            else cnt[2] = B;
+            cls_begin[1] = cnt[0]; cls_begin[2] = cnt[0] + cnt[1];
+            int fill[3] = {cls_begin[0], cls_begin[1], cls_begin[2]};
+            std::vector<PairDesc> sorted(B);
+            for (int k2 = 0; k2 < B; ++k2) {
+                const int cl = v1 ? 2 : cls_of(pd[k2]);
+                perm[fill[cl]] = k2;
+                sorted[fill[cl]++] = pd[k2];
+            }
+            pd.swap(sorted);
+        }
         if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)std::max<int64_t>(used, 1))) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_bits, c->bits_cap, (size_t)std::max<int64_t>(used_bits, 1))) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)used_thr)) != ACX_OK) return rc;
@@ -383,17 +406,29 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
 #undef ACX_SEL
             }
         } else {
-            {   // K1' role 1: rows = reference frames -> column thresholds
-                ProfScope ps(c, KS_BAND, cells);
-#define ACX_CALL(M_) launch_band<M_>(c, B, maxMr, maxMq, p, 1, 0)
-                ACX_M_SWITCH(p.m, ACX_CALL)
+            for (int cl = 0; cl < 3; ++cl) {
+                const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
+                if (Bc <= 0) continue;
+                int cMq = 0, cMr = 0;
+                int64_t ccells = 0;
+                for (int k2 = b0; k2 < b0 + Bc; ++k2) {
+                    cMq = std::max(cMq, pd[k2].Mq); cMr = std::max(cMr, pd[k2].Mr);
+                    ccells += (int64_t)pd[k2].Mq * pd[k2].Mr;
+                }
+                // both roles are dispatched on the class (the longer side of the pair)
+                const int cmax = std::max(cMq, cMr);
+                {   // K1' role 1: rows = reference frames -> column thresholds
+                    ProfScope ps(c, KS_BAND, ccells);
+#define ACX_CALL(M_) launch_band<M_>(c, c->d_pd + b0, Bc, cMr, cmax, p, 1, 0)
+                    ACX_M_SWITCH(p.m, ACX_CALL)
 #undef ACX_CALL
-            }
-            {   // K1' role 0: rows = query frames -> row thresholds + recurrence bitmap (needs role 1)
-                ProfScope ps(c, KS_BAND, cells);
-#define ACX_CALL(M_) launch_band<M_>(c, B, maxMq, maxMr, p, 0, dbg ? 1 : 0)
-                ACX_M_SWITCH(p.m, ACX_CALL)
+                }
+                {   // K1' role 0: rows = query frames -> row thresholds + recurrence bitmap (needs role 1)
+                    ProfScope ps(c, KS_BAND, ccells);
+#define ACX_CALL(M_) launch_band<M_>(c, c->d_pd + b0, Bc, cMq, cmax, p, 0, dbg ? 1 : 0)
+                    ACX_M_SWITCH(p.m, ACX_CALL)
 #undef ACX_CALL
+                }
             }
         }
         {   // K3
@@ -423,8 +458,14 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             }
         }
         ACX_HIP(c, hipGetLastError());
-        ACX_HIP(c, hipMemcpyAsync(out + (both ? 2 : 1) * k0, c->d_out, sizeof(float) * B * (both ? 2 : 1), hipMemcpyDeviceToHost, c->stream));
-        ACX_HIP(c, hipStreamSynchronize(c->stream));
+        {
+            const int w = both ? 2 : 1;
+            std::vector<float> tmp((size_t)B * w);
+            ACX_HIP(c, hipMemcpyAsync(tmp.data(), c->d_out, sizeof(float) * B * w, hipMemcpyDeviceToHost, c->stream));
+            ACX_HIP(c, hipStreamSynchronize(c->stream));
+            for (int k2 = 0; k2 < B; ++k2)
+                for (int e = 0; e < w; ++e) out[(size_t)w * (k0 + perm[k2]) + e] = tmp[(size_t)w * k2 + e];
+        }
         drain_profile(c);
 
         if (dbg && B >= 1) {
