@@ -39,6 +39,19 @@ __device__ __forceinline__ void work(int kind, int n, float &acc, float *lds, in
             }
         }
         x0 += a0[0] + a1[1];
+    } else if (kind == 5) {      // bf16 MFMA 16x16x32 (matrix pipe)
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        bf16x8 av, bw;
+        for (int q = 0; q < 8; ++q) { av[q] = (__bf16)(x0 + q); bw[q] = (__bf16)(x1 - q); }
+        f32x4 a0 = {0, 0, 0, 0}, a1 = a0;
+        for (int it = 0; it < n; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw, av, a1, 0, 0, 0);
+            }
+        }
+        x0 += a0[0] + a1[1];
     } else if (kind == 3) {
         const unsigned lw = (unsigned)(size_t)lds + 16u * lane;
         f32x4 v = {x0, x1, x2, x3};
@@ -90,9 +103,9 @@ int main()
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     const int ncu = p.multiProcessorCount;
     float *d; (void)hipMalloc(&d, sizeof(float) * 512 * ncu);
-    const char *names[5] = {"ds_read_b32", "v_add_f32", "mfma_f32", "ds_write_b128", "ds_add_u32(random)"};
+    const char *names[6] = {"ds_read_b32", "v_add_f32", "mfma_f32", "ds_write_b128", "ds_add_u32(random)", "mfma_bf16_16x16x32"};
     const int n = 3000;
-    const int pairs[][2] = {{0, 1}, {0, 2}, {3, 1}, {3, 2}, {4, 1}, {4, 2}, {0, 3}};
+    const int pairs[][2] = {{0, 1}, {0, 2}, {3, 1}, {3, 2}, {4, 1}, {4, 2}, {0, 3}, {5, 1}, {0, 5}, {4, 5}, {5, 2}};
     for (auto &pr : pairs) {
         const float ta = run(d, ncu, n, pr[0], pr[1], 1), tb = run(d, ncu, n, pr[0], pr[1], 2), tab = run(d, ncu, n, pr[0], pr[1], 0);
         printf("%-20s alone %.3f ms | %-12s alone %.3f ms | together %.3f ms  (max %.3f, sum %.3f)\n",
