@@ -185,6 +185,23 @@ def test_chenfusion_pairs_qmax_and_dmax(ctx):
     assert got[0, 1] == oracle.serra09_pairs(big["frames"], big["offsets"], pr, oracle.serra09_params(dmax=1))[0]
 
 
+def test_maximum_track_length(ctx):
+    """The device limit: 2041 embedded frames (T = 2050 with the default stack).  At the limit
+    the score equals the oracle's; one frame more is refused loudly (NotImplementedError)."""
+    from acoss_amd import synth
+    oracle = _oracle()
+    rng = np.random.default_rng(17)
+    tracks = [synth._frame_max_normalise(rng.random((T, 12))) for T in (2050, 2050, 2051, 1200)]
+    frames, offsets = synth.pack(tracks)
+    ctx.upload_pool(frames, offsets)
+    pairs = np.array([[0, 1], [1, 0], [3, 0], [0, 3]], np.int32)
+    got = ctx.serra09_pairs(pairs)
+    ref = oracle.serra09_pairs(frames, offsets, pairs)
+    assert np.array_equal(got, ref), (got, ref)
+    with pytest.raises(NotImplementedError):
+        ctx.serra09_pairs(np.array([[2, 0]], np.int32))
+
+
 def test_batching_is_invisible(ctx):
     """A tiny scratch limit forces many batches; results must not change."""
     from acoss_amd import synth
