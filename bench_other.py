@@ -30,13 +30,14 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=4)
     args = ap.parse_args()
     from acoss_amd import _lib, synth
-    import oracle
+    import oracle                      # only the cpu_baseline legs below use it (the checker, never the measured path)
     ctx = _lib.Context(0)
     rng = np.random.default_rng(0)
 
     # ---------------- SiMPle: 12 x 150-250 pooled frames, ordered pairs (simple_silva.py:120-126)
     n = 512
-    feats = [oracle.simple_smooth(rng.random((12, int(rng.integers(150, 251))))) for _ in range(n)]
+    from acoss_amd.algorithms.simple_silva import Simple
+    feats = [Simple.smooth(None, rng.random((12, int(rng.integers(150, 251))))) for _ in range(n)]   # product host code
     tm = [np.ascontiguousarray(f.T) for f in feats]                 # time-major for the pool
     offs = np.concatenate([[0], np.cumsum([len(f) for f in tm])]).astype(np.int64)
     ctx.upload_pool_f64(np.concatenate(tm), offs)
