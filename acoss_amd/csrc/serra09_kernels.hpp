@@ -3,19 +3,17 @@
 // Per-pair chain (reference call site acoss/algorithms/rqa_serra09.py:55-69, arithmetic
 // spec in DESIGN.md / oracle/acx_oracle.c):
 //
-//   K0 oti_kernel      12-bin optimal transposition index per pair
-//   K1 csm_tile_kernel 64x64 tiles of the embedded squared-distance matrix:
-//                      frame Gram on the matrix cores (v_mfma_f32_16x16x4_f32, K = 12 =
-//                      3 k-steps, exact f32 == fmaf chain), S tile staged in LDS, m-term
-//                      diagonal doubling-tree window sums, writes D2 (row-major) and its
-//                      transpose D2T (so column thresholds are row selections)
-//   K2 rowsel_kernel   one wave per row: exact order statistics by histogram radix
-//                      narrowing in LDS -> kappa-percentile threshold, moved to the d2
-//                      domain
-//   K3 qmax_kernel     one wave per pair, row sweep: binarise on the fly
-//                      (d2 <= min(thr_row, thr_col)) and run the Qmax recurrence with the
-//                      two previous rows in registers; neighbours j-1/j-2 across lanes by
-//                      wave rotate
+// Production pipeline (band pipeline):
+//   K0  oti_kernel        12-bin optimal transposition index per pair
+//   K0b normtab_kernel    embedded norms per (track, rotation, frame), once per (pool, m)
+//       rotpool_kernel    rotated frame pool (MFMA operands in chain order), once per upload
+//   K1' band_kernel       role 1 then role 0: frame Gram on the matrix cores
+//                         (v_mfma_f32_16x16x4_f32, K = 12 = 3 k-steps, exact f32 == fmaf chain),
+//                         diagonal doubling-tree window sums, exact kappa-percentile thresholds
+//                         per row (one histogram pass), recurrence bitmap; D2 never reaches HBM
+//   K3b qmax_bits_kernel  Qmax / Dmax row sweep over the recurrence bitmap, one wave per pair
+// A/B pipeline kept behind ACX_PIPELINE=v1 (materialised D2 + D2^T, 20 B/cell):
+//   K1 csm_tile_kernel, K2 rowsel_kernel, K3 qmax_kernel
 //
 // Everything is f32; the operation ORDER is part of the spec (bit-exact parity with the
 // oracle), so this file is compiled with -ffp-contract=off and uses explicit fmaf only
@@ -848,23 +846,25 @@ __global__ __launch_bounds__(256) void normtab_kernel(const float *__restrict__ 
 // ------------------------------------------------------------------------------------
 // K1': fused band kernel.  One workgroup (8 waves) owns a band of 8 rows of the embedded
 // distance matrix; the band is cut into tiles of 64 columns and WAVE w sweeps tiles
-// w, w+8, w+16, ... on its own -- there is no workgroup barrier inside the sweep:
-//   * the wave stages the tile's column frames into its private LDS slab (bin-major,
-//     un-rotated: the OTI rotation is applied by picking the operand ROW of the MFMA, so the
-//     k-order of the fmaf chain is still the rotated bin order of the arithmetic spec);
+// w, w+8, w+16, ... on its own -- no workgroup barrier and no LDS staging of inputs in the sweep:
+//   * MFMA operands are plain global loads from the rotated frame pool (rotpool_kernel): one
+//     12-byte load per lane per 16-frame tile, already in the rotated chain order of the
+//     arithmetic spec; the next tile's operands are in flight while the current one is worked on;
 //   * the (8+m-1) x (64+7+m-1) frame Gram is built on the matrix cores
 //     (v_mfma_f32_16x16x4_f32, K = 12 in 3 k-steps; row-frame operands stay in registers for
-//     the whole band) and parked in the wave's LDS slab;
+//     the whole band) and parked in the wave's private LDS slab (one 16-byte store per block);
 //   * lane c walks the 8 cells (a, c + a), a = 0..7, down one diagonal: m+7 LDS reads give
 //     all 8 window sums (doubling-tree subterms are shared between the cells); tile t
 //     therefore covers, for band row a, the 64 columns 64 t - 7 + a ...;
-//   * distances go (role 0) to the row-major D2 matrix in HBM, and into registers.
+//   * distances stay in registers (debug: also to the row-major D2 matrix in HBM).
 // After the sweep the 8 waves exchange their pieces through LDS so that wave w holds band
-// row w completely (32 values per lane) and runs the exact percentile selection on it.
-// role 0: rows = query frames  -> writes D2 + the row thresholds.
-// role 1: rows = reference frames, columns = query frames (the transposed problem, same
-//         bits) -> writes only the column thresholds.  D2 is never re-read for thresholds
-//         and its transpose is never materialised.
+// row w completely (32 values per lane) and runs the exact percentile selection on it
+// (wave_select_fast, one histogram pass; wave_select_regs as the generic fallback).
+// role 1 (launched first): rows = reference frames, columns = query frames (the transposed
+//         problem, same bits) -> the column thresholds.
+// role 0: rows = query frames -> the row thresholds and, with both thresholds known while the
+//         row is still in registers, the binarised row as a 256-byte bitmap.  D2 is never
+//         written for thresholds and its transpose is never materialised.
 // ------------------------------------------------------------------------------------
 constexpr int BAND = 8;
 constexpr int BAND_THREADS = 512;   // 8 waves
@@ -897,11 +897,7 @@ struct BandGeom {
     static constexpr int NCT = (64 + BAND - 1 + M - 1 + 15) / 16;   // 16-col MFMA tiles of column frames
     static constexpr int AROWS = 16 * NRT;
     static constexpr int BW = 16 * NCT;
-    static constexpr int AP = (AROWS % 32 == 16) ? AROWS : AROWS + 16;   // pitch % 32 == 16: the two
     static constexpr int SP = BW + 4;                              // S pitch: 16-byte aligned rows; 84 % 32 = 20 keeps the 16-byte tile stores conflict-free
-    static constexpr int NPIECE = (BW * 3 + 63) / 64;               // 16-byte LDS-DMA pieces per lane per tile
-    static constexpr int BFLOATS = 256 * NPIECE;                    // frame-major column-frame slab (DMA image)
-    static constexpr int WAVE_FLOATS = BFLOATS + AROWS * SP + 2 * BW;  // frames + S + column norms (x2)
 };
 
 // eps from the selected order statistics (oracle percentile_f32)
