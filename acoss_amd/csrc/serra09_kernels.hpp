@@ -915,7 +915,7 @@ __device__ __forceinline__ float percentile_eps(const SelectResult &sr, int pct_
 }
 
 template <int M, int V4, int ROLE>
-__global__ __launch_bounds__(BAND_THREADS, 4) void band_kernel(const float *__restrict__ frot,
+__global__ __launch_bounds__(BAND_THREADS, (V4 <= 4 ? 6 : 4)) void band_kernel(const float *__restrict__ frot,
                                                             const int64_t *__restrict__ toff,
                                                             const float *__restrict__ normtab,
                                                             const int64_t *__restrict__ noff,
