@@ -223,7 +223,10 @@ void launch_normtab(acx_ctx *c, int maxM, int span)
 }
 
 #ifdef ACX_FAST_BUILD   /* development builds: only the default stack size */
-#define ACX_M_SWITCH(m_, CALL) switch (m_) { case 9: CALL(9); break; }
+#ifndef ACX_FAST_BUILD_M
+#define ACX_FAST_BUILD_M 9
+#endif
+#define ACX_M_SWITCH(m_, CALL) switch (m_) { case ACX_FAST_BUILD_M: CALL(ACX_FAST_BUILD_M); break; }
 #else
 #define ACX_M_SWITCH(m_, CALL)                                                                      \
     switch (m_) {                                                                                   \

@@ -914,8 +914,14 @@ __device__ __forceinline__ float percentile_eps(const SelectResult &sr, int pct_
     return __fadd_rn(d0, d1);
 }
 
+// (short-row variants: 6 waves / SIMD = 3 workgroups per CU; ACX_OCC6_ALL is a development switch)
+#ifdef ACX_OCC6_ALL
+#define ACX_OCC6(M_, V4_) ((V4_) <= 4)
+#else
+#define ACX_OCC6(M_, V4_) ((V4_) <= 4 && (M_) <= 9)      /* (m >= 10 needs two MFMA row tiles: LDS-limited anyway) */
+#endif
 template <int M, int V4, int ROLE>
-__global__ __launch_bounds__(BAND_THREADS, (V4 <= 4 ? 6 : 4)) void band_kernel(const float *__restrict__ frot,
+__global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_kernel(const float *__restrict__ frot,
                                                             const int64_t *__restrict__ toff,
                                                             const float *__restrict__ normtab,
                                                             const int64_t *__restrict__ noff,
