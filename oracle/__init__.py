@@ -2,8 +2,8 @@
 CPU ORACLE -- test infrastructure, NOT product code.
 
 A restatement of the arithmetic on acoss's all-pairwise hot path, used only as
-the checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
-leg.  Nothing under acoss_amd/ imports this package.
+the checker by tests/, __graft_entry__.smoke() and the cpu_baseline legs of
+bench.py / bench_other.py.  Nothing under acoss_amd/ imports this package.
 
 Pinning (see DESIGN.md "Oracle"):
   * SiMPle, EarlyFusion per-pair kernels, the harness (pair grid, symmetrise,
