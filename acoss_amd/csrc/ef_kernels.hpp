@@ -220,10 +220,21 @@ __device__ __forceinline__ float mean_k_smallest(const float (&x)[8], int kw, fl
 __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
                                                          float *__restrict__ stat, int mode, int kw)
 {
-    __shared__ __attribute__((aligned(16))) unsigned hist[4][SEL_SLOTS];
-    __shared__ float cand[4][64];
+    __shared__ __attribute__((aligned(4096))) unsigned fhist[4][256];      // one-pass selection (wave_select_fast)
+    __shared__ __attribute__((aligned(16))) unsigned hist[4][SEL_SLOTS];   // generic fallback
+    __shared__ __attribute__((aligned(16))) float cand[4][64];
     __shared__ unsigned counter[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned fh_addr = (unsigned)(uintptr_t)(lds_void *)(&fhist[wave][0]);
+    // k-th smallest (0-based) of the row: one histogram pass, generic narrowing when that cannot decide
+    auto kth = [&](const float (&xx)[8], int k) -> float {
+        *reinterpret_cast<uint4 *>(&fhist[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_fence();
+        float lo, hi;
+        if (wave_select_fast<8, 256>(xx, k, false, fh_addr, cand[wave], lane, lo, hi)) return lo;
+        return wave_select_regs<8>(xx, k, hist[wave], cand[wave], &counter[wave], lane, false).value;
+    };
     const EfPair P = pd[blockIdx.y];
     const int s = blockIdx.z;                         // feature (mode 2: always 0)
     const int nrows = mode == 1 ? P.N : P.M;
@@ -251,12 +262,12 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         float t;
         if (kb <= 0) t = -INF;                         // no neighbours: empty rows
         else if (kb >= n) t = INF;
-        else t = wave_select_regs<8>(x, kb - 1, hist[wave], cand[wave], &counter[wave], lane, false).value;
+        else t = kth(x, kb - 1);
         if (lane == 0) S[row] = t;
     }
     if (mode != 2) {
         const int kk = kw < n ? kw : n;
-        const float vk = wave_select_regs<8>(x, kk - 1, hist[wave], cand[wave], &counter[wave], lane, false).value;
+        const float vk = kth(x, kk - 1);
         const float m = mean_k_smallest(x, kk, vk, lane);
         if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
     }
