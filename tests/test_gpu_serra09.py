@@ -185,6 +185,37 @@ def test_chenfusion_pairs_qmax_and_dmax(ctx):
     assert got[0, 1] == oracle.serra09_pairs(big["frames"], big["offsets"], pr, oracle.serra09_params(dmax=1))[0]
 
 
+def test_full_size_properties_without_the_oracle(ctx):
+    """Size-independent properties at the benchmark's track length (T = 2000), no oracle involved:
+    (1) OTI invariance -- rolling the chroma bins of either track by any number of semitones changes
+    the transposition index but not one bit of the score (the rotated chain order is the same);
+    (2) a pair scores the same alone, inside a large batch, and in any position of the pair list;
+    (3) Dmax >= Qmax on the same recurrence plot."""
+    from acoss_amd import synth, _lib
+    rng = np.random.default_rng(2024)
+    base = [synth._frame_max_normalise(rng.random((2000, 12))) for _ in range(3)]
+    tracks = list(base)
+    shifts = [1, 5, 7, 11]
+    for s in shifts:
+        tracks.append(np.ascontiguousarray(np.roll(base[1], s, axis=1)))      # 3 + k: base[1] transposed by s
+    frames, offsets = synth.pack(tracks)
+    ctx.upload_pool(frames, offsets)
+    ref = ctx.serra09_pairs(np.array([[0, 1], [1, 0], [2, 1]], np.int32))
+    for k, s in enumerate(shifts):
+        got = ctx.serra09_pairs(np.array([[0, 3 + k], [3 + k, 0], [2, 3 + k]], np.int32))
+        assert np.array_equal(got, ref), (s, got, ref)
+    n = len(tracks)
+    i, j = np.nonzero(~np.eye(n, dtype=bool))
+    pairs = np.stack([i, j], 1).astype(np.int32)
+    big = ctx.serra09_pairs(pairs)
+    perm = rng.permutation(len(pairs))
+    assert np.array_equal(ctx.serra09_pairs(pairs[perm]), big[perm])
+    for q in (0, 7, len(pairs) - 1):
+        assert ctx.serra09_pairs(pairs[q:q + 1])[0] == big[q]
+    qd = ctx.chenfusion_pairs(pairs[:6])
+    assert np.array_equal(qd[:, 0], big[:6]) and np.all(qd[:, 1] >= qd[:, 0])
+
+
 def test_maximum_track_length(ctx):
     """The device limit: 2041 embedded frames (T = 2050 with the default stack).  At the limit
     the score equals the oracle's; one frame more is refused loudly (NotImplementedError)."""
