@@ -1387,6 +1387,18 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
         unsigned p0, p1;
         load_row(1, p0, p1);
         wprev = row_bits(1, p0, p1);
+        // With distinct gap penalties the gap branch of row 2 / 3 reads Q - gamma of rows 0 / 1,
+        // where Q = 0 but gamma follows the recurrence bit; the Dmax increment can lift such a
+        // term above 0, so the two rows start at -gamma instead of 0.
+        if constexpr (!EQG) {
+            load_row(0, p0, p1);
+            const unsigned w0 = row_bits(0, p0, p1);
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                P1[e] = ((wprev >> e) & 1u) ? -go : -ge;
+                P2[e] = ((w0 >> e) & 1u) ? -go : -ge;
+            }
+        }
     }
     // One DP row: QA = row i-1, QB = row i-2 (overwritten with row i)
     auto dp_row = [&](int i, unsigned d0, unsigned d1, float (&QA)[32], float (&QB)[32],
@@ -1436,7 +1448,8 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
             // to the predecessors, so there the cell is forced to 0.
             if constexpr (DMAX) { if (!((colmask >> e) & 1u)) q = 0.0f; }
             QB[e] = q;
-            if constexpr (!EQG) PB[e] = q - (r ? go : ge);
+            // (Dmax: the penalty of a forced-0 cell in columns 0 / 1 follows its raw recurrence bit)
+            if constexpr (!EQG) PB[e] = q - ((DMAX ? (((wraw >> e) & 1u) != 0u) : r) ? go : ge);
         }
 #pragma unroll
         for (int e = 0; e < 32; e += 2) best = fmaxf(best, fmaxf(QB[e], QB[e + 1]));

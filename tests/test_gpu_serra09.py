@@ -124,6 +124,8 @@ def test_full_size_pair_2000(ctx):
     dict(embed_full=1), dict(oti=False), dict(oti_target=1), dict(gamma_o=1.0, gamma_e=0.25),
     dict(gamma_o=0.25, gamma_e=1.5), dict(m=4), dict(m=12), dict(m=16), dict(m=1), dict(kappa=0.3),
     dict(kappa=0.0), dict(kappa=1.0), dict(dmax=1), dict(dmax=1, dp_start=3), dict(dmax=1, gamma_o=1.0, gamma_e=0.25),
+    dict(dmax=1, gamma_o=1.0, gamma_e=0.5, m=1, kappa=0.3, pct_mode=2, inclusive=0, dp_start=3, oti=False),
+    dict(dmax=1, gamma_o=0.25, gamma_e=2.0, kappa=0.7),
 ])
 def test_parameter_switches_bit_exact(ctx, kw):
     from acoss_amd import synth, _lib
