@@ -25,7 +25,7 @@ EXPORTS = [
     "acx_serra09_embed_len", "acx_profile_enable", "acx_profile_reset", "acx_profile_count",
     "acx_profile_get", "acx_debug_sqrt", "acx_upload_pool_f64", "acx_simple_pairs",
     "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
-    "acx_chenfusion_pairs",
+    "acx_chenfusion_pairs", "acx_csm_binary_sw",
 ]
 
 
@@ -96,6 +96,7 @@ def load():
     L.acx_earlyfusion_pairs.argtypes = [vp, ip, ctypes.c_int64, ep, fp]
     L.acx_ef_debug_pair.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ep, fp, fp, fp, ip]
     L.acx_sw_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, fp]
+    L.acx_csm_binary_sw.argtypes = [vp, fp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, fp]
     _lib = L
     return L
 
@@ -224,6 +225,14 @@ class Context(object):
         if rc == ACX_ERR_INVALID and b"Non-binary" in (self._L.acx_last_error(self._h) or b""):
             raise IOError("Non-binary elements found in input")       # alignment_tools.py:23
         self._check(rc)
+        return float(sc.value)
+
+    def csm_binary_sw(self, D, kappa=0.1):
+        """smith_waterman_constrained(csm_to_binary(D, kappa)) of one f32 matrix (tests)."""
+        D = np.ascontiguousarray(D, dtype=np.float32)
+        sc = ctypes.c_float(0)
+        self._check(self._L.acx_csm_binary_sw(self._h, _fptr(D), D.shape[0], D.shape[1], ctypes.c_double(kappa),
+                                              ctypes.byref(sc)))
         return float(sc.value)
 
     def serra09_pairs(self, pairs, params=None):

@@ -549,7 +549,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             d.offC = used;
             d.offS = used_s;
             used += need;
-            used_s += 4 * (2 * (int64_t)d.pitchT + d.pitchC);
+            used_s += 4 * acx::ef_s_stride(d);
             maxM = std::max(maxM, d.M);
             maxN = std::max(maxN, d.N);
             cells += (int64_t)d.M * d.N;
@@ -956,6 +956,19 @@ int acx_ef_debug_pair(acx_ctx *c, int32_t i, int32_t j, const acx_ef_params *par
     return rc;
 }
 
+int acx_csm_binary_sw(acx_ctx *c, const float *D, int32_t M, int32_t N, double kappa, float *score)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!D || !score || M < 1 || N < 1) return fail(c, ACX_ERR_INVALID, "csm_binary_sw: bad argument");
+    if (M > acx::EF_MAXNB || N > acx::EF_MAXNB)
+        return fail(c, ACX_ERR_UNSUPPORTED, "csm_binary_sw: matrices larger than 512 are not supported on the device yet");
+    acx_ef_params p{kappa, 1};
+    float sc[4] = {0, 0, 0, 0};
+    const int rc = run_ef(c, nullptr, 1, p, sc, nullptr, D, M, N);
+    if (rc == ACX_OK) *score = sc[0];
+    return rc;
+}
+
 int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *score)
 {
     if (!c) return ACX_ERR_INVALID;
@@ -976,13 +989,14 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
     int rc;
     ACX_HIP(c, hipSetDevice(c->device));
     if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)M * d.pitchC)) != ACX_OK) return rc;
-    if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)4 * (2 * d.pitchT + d.pitchC))) != ACX_OK) return rc;
+    if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)4 * acx::ef_s_stride(d))) != ACX_OK) return rc;
     if ((rc = ensure(c, c->d_efpd, c->efpd_cap, (size_t)1)) != ACX_OK) return rc;
     if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)4)) != ACX_OK) return rc;
     ACX_HIP(c, hipMemcpyAsync(c->d_efpd, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
     ACX_HIP(c, hipMemcpy2DAsync(c->d_scratch, sizeof(float) * d.pitchC, Cm.data(), sizeof(float) * N, sizeof(float) * N, M,
                                 hipMemcpyHostToDevice, c->stream));
     ACX_HIP(c, hipMemsetAsync(c->d_thr, 0, sizeof(float) * M, c->stream));
+    ACX_HIP(c, hipMemsetAsync(c->d_thr + acx::ef_jcut_off(d, 0), 0x7f, sizeof(int) * M, c->stream));   // every tie counts
     hipLaunchKernelGGL(acx::sw_kernel, dim3(1, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
     ACX_HIP(c, hipGetLastError());
     ACX_HIP(c, hipMemcpyAsync(sc, c->d_out, sizeof(float) * 4, hipMemcpyDeviceToHost, c->stream));

@@ -36,7 +36,7 @@ struct EfPair {
     int32_t kbin;          // neighbours per row of csm_to_binary (host: int(round(kappa * N)), half-to-even)
     int64_t offC;          // float offset of the pair's matrices: [C x3][C^T x3][F]
     int64_t offS;          // float offset of the pair's vectors:
-                           //   per feature s<3: [t rows][r rows][c cols]; then [t rows of F]
+                           //   per feature s<3: [t rows][r rows][c cols][jcut rows]; then [t rows][jcut rows] of F
 };
 
 __device__ __forceinline__ int64_t ef_c_off(const EfPair &P, int s) { return P.offC + (int64_t)s * P.M * P.pitchC; }
@@ -48,8 +48,15 @@ __device__ __forceinline__ int64_t ef_f_off(const EfPair &P)
 {
     return P.offC + (int64_t)3 * P.M * P.pitchC + (int64_t)3 * P.N * P.pitchT;
 }
-// vectors: feature s: t at +0, r at +pitchT, c at +2 pitchT (size pitchC); stride per feature
-__device__ __forceinline__ int64_t ef_s_stride(const EfPair &P) { return 2 * (int64_t)P.pitchT + P.pitchC; }
+// vectors: feature s: t at +0, r at +pitchT, c at +2 pitchT (size pitchC), jcut (int) behind c; stride
+// per feature.  The fused matrix (4th slot) keeps t at +0 and jcut at +pitchT.
+// Binarisation rule (csm_to_binary keeps exactly k cells per row): B_ij = C_ij < t_i, or C_ij == t_i
+// and j <= jcut_i -- ties at the k-th value are taken in column order until k cells are set.
+__host__ __device__ __forceinline__ int64_t ef_s_stride(const EfPair &P) { return 3 * (int64_t)P.pitchT + P.pitchC; }
+__host__ __device__ __forceinline__ int64_t ef_jcut_off(const EfPair &P, int src)
+{
+    return src < 3 ? 2 * (int64_t)P.pitchT + P.pitchC : (int64_t)P.pitchT;
+}
 
 // ---- OTI of the pair (cross_recurrence.py:75-103): argmax_s sum(roll(C1, s) * C2), f64, first max
 __global__ void ef_oti_kernel(EfPair *pd, int B, const double *__restrict__ med)
@@ -260,10 +267,51 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
     if (mode != 1) {
         const int kb = P.kbin;
         float t;
+        int jcut = 0x7fffffff;
         if (kb <= 0) t = -INF;                         // no neighbours: empty rows
         else if (kb >= n) t = INF;
-        else t = kth(x, kb - 1);
-        if (lane == 0) S[row] = t;
+        else {
+            t = kth(x, kb - 1);
+            // cells equal to t: if there are more than the row may still take, find the column of
+            // the last one taken (column of x[4 q + e] = 256 q + 4 lane + e)
+            int lt = 0, eq[2] = {0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                lt += x[e] < t ? 1 : 0;
+                eq[e >> 2] += x[e] == t ? 1 : 0;
+            }
+            const int budget = kb - wave_sum_i(lt);
+            const int tot0 = wave_sum_i(eq[0]), tot1 = wave_sum_i(eq[1]);
+            if (tot0 + tot1 > budget) {
+                int cand_j = -1;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    int incl = eq[q];
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int up = __shfl_up(incl, o, 64);
+                        if (lane >= o) incl += up;
+                    }
+                    int rank = incl - eq[q] + (q ? tot0 : 0);      // ties before this lane's group
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (x[4 * q + e] == t) {
+                            ++rank;
+                            if (rank == budget) cand_j = 256 * q + 4 * lane + e;
+                        }
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const int other = __shfl_xor(cand_j, o, 64);
+                    cand_j = cand_j > other ? cand_j : other;
+                }
+                jcut = cand_j;
+            }
+        }
+        if (lane == 0) {
+            S[row] = t;
+            reinterpret_cast<int *>(S)[ef_jcut_off(P, mode == 2 ? 3 : s) + row] = jcut;
+        }
     }
     if (mode != 2) {
         const int kk = kw < n ? kw : n;
@@ -314,7 +362,7 @@ __global__ __launch_bounds__(256) void ef_fuse_kernel(const EfPair *__restrict__
 // reference and U = T + delta(B) (delta = 0 if B else -7):
 //   T[i][j] = max(0, mv(B[i][j]) + max(U[i-1][j-1], U[i-2][j-1], U[i-1][j-2])),  i, j >= 2,
 //   i <= M-2, j <= N-2;  T = 0 (and U = delta(B)) in rows / columns 0, 1;  score = max T / 10.
-// One wave per matrix; lane owns 8 contiguous columns (N <= 512).  B_ij = C_ij <= t_i.
+// One wave per matrix; lane owns 8 contiguous columns (N <= 512).  B_ij from (t_i, jcut_i), see ef_s_stride.
 // src: 0..2 = feature CSM, 3 = fused matrix.  out[pair * 4 + src].
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
@@ -326,6 +374,7 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
     const int M = P.M, N = P.N, pitch = P.pitchC;
     const float *C = scratch + (src < 3 ? ef_c_off(P, src) : ef_f_off(P));
     const float *thr = stat + P.offS + src * ef_s_stride(P);
+    const int *jcut = reinterpret_cast<const int *>(thr) + ef_jcut_off(P, src);
     float result = 0.0f;
     if (M >= 4 && N >= 4) {
         int U1[8], U2[8];          // U of rows i-1, i-2
@@ -334,6 +383,7 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
         // rows 0 and 1: T = 0, U = delta(B)
         auto load_b = [&](int row, bool (&b)[8]) {
             const float t = thr[row];
+            const int jc = jcut[row];
             float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
             if (j0 < pitch) {
                 const float4 *p = reinterpret_cast<const float4 *>(C + (size_t)row * pitch + j0);
@@ -342,7 +392,7 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
             }
             const float d[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) b[e] = (j0 + e < N) && (d[e] <= t);
+            for (int e = 0; e < 8; ++e) b[e] = (j0 + e < N) && (d[e] < t || (d[e] == t && j0 + e <= jc));
         };
         bool b[8];
         load_b(0, b);

@@ -174,6 +174,12 @@ int acx_earlyfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const a
 int acx_ef_debug_pair(acx_ctx *ctx, int32_t i, int32_t j, const acx_ef_params *params,
                       float *csm, float *fused, float *scores, int32_t *oti);
 
+/* csm_to_binary(D, kappa) (cross_recurrence.py:136-161: exactly k = round(kappa N) cells per row;
+ * ties at the k-th value are taken in column order) followed by smith_waterman_constrained, for
+ * one (M, N) f32 matrix -- the tail of every feature's chain in earlyfusion_traile.py:165-197
+ * (tests). */
+int acx_csm_binary_sw(acx_ctx *ctx, const float *D, int32_t M, int32_t N, double kappa, float *score);
+
 /* smith_waterman_constrained (alignment_tools.py:26-46) of one binary (M, N) uint8 matrix on
  * the device DP (tests against the reference goldens).  Non-{0,1} input -> ACX_ERR_INVALID
  * (the reference raises IOError). */

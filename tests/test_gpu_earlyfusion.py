@@ -51,6 +51,27 @@ def test_smith_waterman_random_shapes_vs_oracle(ctx):
     assert ctx.sw_binary(np.eye(300, dtype=np.uint8)) == oracle.sw_constrained(np.eye(300, dtype=np.uint8))
 
 
+def test_binarise_with_ties_keeps_k_cells_in_column_order(ctx):
+    """csm_to_binary keeps exactly k cells per row; the oracle (and the device) take ties at the
+    k-th value in column order.  Heavily tied matrices: few distinct values, constant rows, the
+    saturated fused matrix (most cells exactly 1.0f)."""
+    import oracle
+    rng = np.random.default_rng(21)
+    cases = []
+    for (m, n) in [(40, 50), (64, 257), (130, 512), (75, 68), (9, 300)]:
+        cases.append(rng.integers(0, 4, (m, n)).astype(np.float32))                       # 4 distinct values
+        cases.append(np.ones((m, n), np.float32))                                         # one value
+        D = np.ones((m, n), np.float32)
+        hits = rng.random((m, n)) < 0.03
+        D[hits] = rng.random(int(hits.sum())).astype(np.float32)                          # saturated + a few neighbours
+        cases.append(D)
+        cases.append(np.round(rng.random((m, n)) * 20).astype(np.float32) / 20)
+    for D in cases:
+        for kappa in (0.05, 0.1, 0.5, 0.0, 3):
+            ref = oracle.sw_constrained(oracle.csm_to_binary(D, kappa))
+            assert ctx.csm_binary_sw(D, kappa) == pytest.approx(ref, abs=1e-5), (D.shape, kappa)
+
+
 def _golden_feats(g, pk):
     f1 = {s: g["p%d_f1_%s" % (pk, s)] for s in ("mfccs", "ssms", "chromas", "chroma_med")}
     f2 = {s: g["p%d_f2_%s" % (pk, s)] for s in ("mfccs", "ssms", "chromas", "chroma_med")}
