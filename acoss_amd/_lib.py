@@ -25,7 +25,8 @@ EXPORTS = [
     "acx_serra09_embed_len", "acx_profile_enable", "acx_profile_reset", "acx_profile_count",
     "acx_profile_get", "acx_debug_sqrt", "acx_upload_pool_f64", "acx_simple_pairs",
     "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
-    "acx_chenfusion_pairs", "acx_csm_binary_sw",
+    "acx_chenfusion_pairs", "acx_csm_binary_sw", "acx_upload_raw_pool", "acx_download_pool",
+    "acx_simple_upload_raw_pool", "acx_download_pool_f64",
 ]
 
 
@@ -75,6 +76,8 @@ def load():
     L.acx_last_error.argtypes = [vp]
     L.acx_set_scratch_limit.argtypes = [vp, ctypes.c_int64]
     L.acx_upload_pool.argtypes = [vp, fp, lp, ctypes.c_int32, ctypes.c_int32]
+    L.acx_upload_raw_pool.argtypes = [vp, fp, lp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, lp]
+    L.acx_download_pool.argtypes = [vp, fp, ctypes.c_int64]
     L.acx_serra09_default_params.restype = None
     L.acx_serra09_default_params.argtypes = [pp]
     L.acx_serra09_pairs.argtypes = [vp, ip, ctypes.c_int64, pp, fp]
@@ -90,6 +93,9 @@ def load():
     L.acx_debug_sqrt.argtypes = [vp, fp, ctypes.c_int64, fp]
     dp = ctypes.POINTER(ctypes.c_double)
     L.acx_upload_pool_f64.argtypes = [vp, dp, lp, ctypes.c_int32, ctypes.c_int32]
+    L.acx_simple_upload_raw_pool.argtypes = [vp, fp, lp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_int32, lp]
+    L.acx_download_pool_f64.argtypes = [vp, dp, ctypes.c_int64]
     L.acx_simple_pairs.argtypes = [vp, ip, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, dp]
     ep = ctypes.POINTER(EfParams)
     L.acx_ef_upload_pool.argtypes = [vp, fp, fp, fp, dp, lp, ctypes.c_int32, ip]
@@ -164,6 +170,38 @@ class Context(object):
                                             len(offsets) - 1, frames.shape[1]))
         self.n_tracks = len(offsets) - 1
         self.lengths = np.diff(offsets)
+
+    def upload_raw_pool(self, raw, raw_offsets, fac=40):
+        """Raw (sum T0, 12) f32 chroma -> block-median pooled pool on the device; returns the pooled offsets."""
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        raw_offsets = np.ascontiguousarray(raw_offsets, dtype=np.int64)
+        poff = np.zeros(len(raw_offsets), np.int64)
+        self._check(self._L.acx_upload_raw_pool(self._h, _fptr(raw), raw_offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                len(raw_offsets) - 1, raw.shape[1] if raw.ndim == 2 else 12, int(fac),
+                                                poff.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        self.pool_offsets = poff
+        return poff
+
+    def download_pool(self, total_frames):
+        out = np.empty((int(total_frames), 12), np.float32)
+        self._check(self._L.acx_download_pool(self._h, _fptr(out), out.size))
+        return out
+
+    def simple_upload_raw_pool(self, raw, raw_offsets, win=200, skip=100, win_len_smooth=4):
+        """Raw (sum T0, 12) f32 chroma -> SiMPle features (mean pooling, Hann smoothing, L2) on the device."""
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        raw_offsets = np.ascontiguousarray(raw_offsets, dtype=np.int64)
+        poff = np.zeros(len(raw_offsets), np.int64)
+        self._check(self._L.acx_simple_upload_raw_pool(self._h, _fptr(raw), raw_offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                       len(raw_offsets) - 1, raw.shape[1] if raw.ndim == 2 else 12, int(win),
+                                                       int(skip), int(win_len_smooth),
+                                                       poff.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        return poff
+
+    def download_pool_f64(self, total_frames):
+        out = np.empty((int(total_frames), 12), np.float64)
+        self._check(self._L.acx_download_pool_f64(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), out.size))
+        return out
 
     def upload_pool_f64(self, frames, offsets):
         """SiMPle features: (sum n_i, 12) f64 time-major + offsets."""

@@ -44,7 +44,7 @@ class ChenFusion(Serra09):
     def normalize_by_length(self):
         """D[i, j] = sqrt(T_j) / D[i, j] (latefusion_chen.py:75-85): a DISTANCE, smaller =
         closer; unfilled cells (the diagonal) become +inf exactly as in the reference."""
-        norm = np.sqrt(np.array([self.load_features(j).shape[0] for j in range(self.N)], dtype=np.float64))
+        norm = np.sqrt(self._pooled_lengths().astype(np.float64))
         for key in self.Ds.keys():
             D = self.Ds[key]
             with np.errstate(divide="ignore"):

@@ -49,6 +49,7 @@ class Serra09(CoverAlgorithm):
         self._engine = dict(engine or {})
         self._ctx = None
         self._pool_ready = False
+        self._pooled_len = None
         CoverAlgorithm.__init__(self, dataset_csv=dataset_csv, name="Serra09", datapath=datapath,
                                 shortname=shortname)
 
@@ -81,12 +82,26 @@ class Serra09(CoverAlgorithm):
                 dev = int(os.environ.get("LOCAL_RANK", "0"))
             self._ctx = _lib.Context(dev)
         if not self._pool_ready:
-            tracks = [np.ascontiguousarray(self.load_features(i), dtype=np.float32) for i in range(self.N)]
-            lens = np.array([t.shape[0] for t in tracks], dtype=np.int64)
-            offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-            self._ctx.upload_pool(np.concatenate(tracks, axis=0), offsets)
+            if len(self.all_feats) == self.N or self.downsample_fac > 64:
+                # pooled features injected (set_pooled_features) or already prepared by load_features
+                tracks = [np.ascontiguousarray(self.load_features(i), dtype=np.float32) for i in range(self.N)]
+                lens = np.array([t.shape[0] for t in tracks], dtype=np.int64)
+                offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                self._ctx.upload_pool(np.concatenate(tracks, axis=0), offsets)
+            else:
+                # raw chroma of every track -> block medians on the device (acx_upload_raw_pool)
+                raw = [np.ascontiguousarray(CoverAlgorithm.load_features(self, i)[self.chroma_type], dtype=np.float32)
+                       for i in range(self.N)]
+                offsets = np.concatenate([[0], np.cumsum([t.shape[0] for t in raw])]).astype(np.int64)
+                lens = np.diff(self._ctx.upload_raw_pool(np.concatenate(raw, axis=0), offsets, self.downsample_fac))
+            self._pooled_len = np.asarray(lens, dtype=np.int64)
             self._pool_ready = True
         return self._ctx
+
+    def _pooled_lengths(self):
+        if self._pool_ready:
+            return self._pooled_len
+        return np.array([self.load_features(j).shape[0] for j in range(self.N)], dtype=np.int64)
 
     def similarity(self, idxs):
         idxs = np.asarray(idxs).reshape(-1, 2)
@@ -99,7 +114,7 @@ class Serra09(CoverAlgorithm):
     def normalize_by_length(self):
         """Non-symmetric normalisation: D[i, j] /= sqrt(T_j), T_j the pooled length
         (rqa_serra09.py:71-83; the reciprocal of the paper's distance, so larger = closer)."""
-        norm = np.sqrt(np.array([self.load_features(j).shape[0] for j in range(self.N)], dtype=np.float64))
+        norm = np.sqrt(self._pooled_lengths().astype(np.float64))
         for key in self.Ds.keys():
             D = self.Ds[key]
             for j0 in range(0, self.N, 2048):

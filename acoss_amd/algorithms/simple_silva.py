@@ -1,9 +1,11 @@
 """
 SiMPle: similarity matrix profile (Silva, Yeh, Batista & Keogh, ISMIR 2016).  Drop-in for
 acoss/algorithms/simple_silva.py: same constructor and methods.  Feature preparation (mean
-pooling, Hann smoothing, L2 column normalisation, simple_silva.py:34-43,56-66) runs on the
-host ONCE per track (the reference redoes it for every pair); OTI + matrix profile + median
-of every ordered pair run in libacx's HIP kernel, in f64 like the reference.
+pooling, Hann smoothing, L2 column normalisation, simple_silva.py:34-43,56-66) runs ONCE
+per track (the reference redoes it for every pair) -- on the device for the whole collection
+(acx_simple_upload_raw_pool) when the tracks come from feature files, on the host in
+load_features(i) for single-track access; OTI + matrix profile + median of every ordered pair
+run in libacx's HIP kernel, in f64 like the reference.
 """
 import numpy as np
 
@@ -89,9 +91,17 @@ class Simple(CoverAlgorithm):
             dev = self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0"))
             self._ctx = _lib.Context(dev)
         if not self._pool_ready:
-            tracks = [np.ascontiguousarray(self.load_features(i).T, dtype=np.float64) for i in range(self.N)]
-            offs = np.concatenate([[0], np.cumsum([t.shape[0] for t in tracks])]).astype(np.int64)
-            self._ctx.upload_pool_f64(np.concatenate(tracks, axis=0), offs)
+            if len(self.all_feats) == self.N:
+                # features injected (set_features) or already prepared by load_features
+                tracks = [np.ascontiguousarray(self.load_features(i).T, dtype=np.float64) for i in range(self.N)]
+                offs = np.concatenate([[0], np.cumsum([t.shape[0] for t in tracks])]).astype(np.int64)
+                self._ctx.upload_pool_f64(np.concatenate(tracks, axis=0), offs)
+            else:
+                # raw chroma of every track -> pooling, smoothing and normalisation on the device
+                raw = [np.ascontiguousarray(CoverAlgorithm.load_features(self, i)[self.chroma_type], dtype=np.float32)
+                       for i in range(self.N)]
+                offs = np.concatenate([[0], np.cumsum([t.shape[0] for t in raw])]).astype(np.int64)
+                self._ctx.simple_upload_raw_pool(np.concatenate(raw, axis=0), offs, self.WIN, self.SKIP, 4)
             self._pool_ready = True
         return self._ctx
 

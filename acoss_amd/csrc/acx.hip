@@ -15,6 +15,7 @@
 
 #include "../../include/acx.h"
 #include "serra09_kernels.hpp"
+#include "prep_kernels.hpp"
 #include "simple_kernels.hpp"
 #include "ef_kernels.hpp"
 
@@ -765,6 +766,93 @@ int acx_upload_pool(acx_ctx *c, const float *frames, const int64_t *offsets, int
     return ACX_OK;
 }
 
+// Raw pools are prepared in slices of whole tracks so that the staging buffer stays bounded
+// whatever the collection size (a 15 k-track collection is ~60 GB of raw chroma).
+static const int64_t RAW_SLICE_FLOATS = (int64_t)1 << 28;       // 1 GiB of f32
+
+static int check_raw_args(acx_ctx *c, const char *who, const float *raw, const int64_t *roff, int32_t n_tracks, int32_t dim)
+{
+    if (!raw || !roff || n_tracks <= 0 || dim != 12) return fail(c, ACX_ERR_INVALID, std::string(who) + ": bad argument (dim must be 12)");
+    if (roff[0] != 0) return fail(c, ACX_ERR_INVALID, std::string(who) + ": offsets[0] must be 0");
+    for (int i = 0; i < n_tracks; ++i)
+        if (roff[i + 1] < roff[i]) return fail(c, ACX_ERR_INVALID, std::string(who) + ": offsets must be non-decreasing");
+    return ACX_OK;
+}
+
+int acx_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_offsets, int32_t n_tracks, int32_t dim,
+                        int32_t fac, int64_t *pooled_offsets_out)
+{
+    if (!c) return ACX_ERR_INVALID;
+    int rc;
+    if ((rc = check_raw_args(c, "upload_raw_pool", raw, raw_offsets, n_tracks, dim)) != ACX_OK) return rc;
+    if (fac < 1) return fail(c, ACX_ERR_INVALID, "upload_raw_pool: downsample factor must be >= 1");
+    if (fac > acx::POOL_MAXFAC) return fail(c, ACX_ERR_UNSUPPORTED, "upload_raw_pool: downsample factors above 64 are not supported on the device");
+    ACX_HIP(c, hipSetDevice(c->device));
+    std::vector<int64_t> poff((size_t)n_tracks + 1, 0);
+    for (int t = 0; t < n_tracks; ++t) {
+        const int64_t T0 = raw_offsets[t + 1] - raw_offsets[t];
+        poff[t + 1] = poff[t] + (T0 + fac - 1) / fac;            // boundaries unique({0, fac, 2 fac, ..., T0})
+    }
+    const int64_t ptotal = poff[n_tracks];
+    std::vector<float> pooled((size_t)std::max<int64_t>(1, ptotal) * 12);
+    int64_t *d_roff = nullptr, *d_poff = nullptr;
+    float *d_raw = nullptr, *d_pooled = nullptr;
+    auto cleanup = [&]() {
+        if (d_roff) (void)hipFree(d_roff);
+        if (d_poff) (void)hipFree(d_poff);
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_pooled) (void)hipFree(d_pooled);
+    };
+#define ACX_HIPC(expr_) do { const hipError_t ec_ = (expr_); if (ec_ != hipSuccess) { cleanup(); ACX_HIP(c, ec_); } } while (0)
+    ACX_HIPC(hipMalloc((void **)&d_roff, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIPC(hipMalloc((void **)&d_poff, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIPC(hipMemcpy(d_roff, raw_offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    ACX_HIPC(hipMemcpy(d_poff, poff.data(), sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    int64_t cap_raw = 0, cap_pooled = 0;
+    for (int t0 = 0; t0 < n_tracks;) {
+        int t1 = t0 + 1;
+        while (t1 < n_tracks && (raw_offsets[t1 + 1] - raw_offsets[t0]) * 12 <= RAW_SLICE_FLOATS) ++t1;
+        const int64_t nraw = raw_offsets[t1] - raw_offsets[t0], npool = poff[t1] - poff[t0];
+        if (npool > 0) {
+            if (nraw * 12 > cap_raw) {
+                if (d_raw) (void)hipFree(d_raw);
+                d_raw = nullptr;
+                cap_raw = nraw * 12;
+                ACX_HIPC(hipMalloc((void **)&d_raw, sizeof(float) * cap_raw));
+            }
+            if (npool * 12 > cap_pooled) {
+                if (d_pooled) (void)hipFree(d_pooled);
+                d_pooled = nullptr;
+                cap_pooled = npool * 12;
+                ACX_HIPC(hipMalloc((void **)&d_pooled, sizeof(float) * cap_pooled));
+            }
+            ACX_HIPC(hipMemcpyAsync(d_raw, raw + raw_offsets[t0] * 12, sizeof(float) * nraw * 12, hipMemcpyHostToDevice, c->stream));
+            const int64_t blocks = (npool + acx::POOL_FPB - 1) / acx::POOL_FPB;
+            hipLaunchKernelGGL(acx::pool_median_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                               d_raw, raw_offsets[t0], d_roff, d_poff, n_tracks, poff[t0], poff[t1], fac, d_pooled);
+            ACX_HIPC(hipGetLastError());
+            ACX_HIPC(hipMemcpyAsync(pooled.data() + poff[t0] * 12, d_pooled, sizeof(float) * npool * 12, hipMemcpyDeviceToHost, c->stream));
+            ACX_HIPC(hipStreamSynchronize(c->stream));
+        }
+        t0 = t1;
+    }
+#undef ACX_HIPC
+    cleanup();
+    if (pooled_offsets_out) memcpy(pooled_offsets_out, poff.data(), sizeof(int64_t) * (n_tracks + 1));
+    return acx_upload_pool(c, pooled.data(), poff.data(), n_tracks, dim);
+}
+
+int acx_download_pool(acx_ctx *c, float *frames, int64_t capacity)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!c->d_frames) return fail(c, ACX_ERR_STATE, "download_pool: feature pool not uploaded");
+    const int64_t need = c->h_off[c->n_tracks] * c->dim;
+    if (!frames || capacity < need) return fail(c, ACX_ERR_INVALID, "download_pool: buffer too small");
+    ACX_HIP(c, hipSetDevice(c->device));
+    ACX_HIP(c, hipMemcpy(frames, c->d_frames, sizeof(float) * need, hipMemcpyDeviceToHost));
+    return ACX_OK;
+}
+
 void acx_serra09_default_params(acx_serra09_params *p)
 {
     if (!p) return;
@@ -833,6 +921,92 @@ int acx_upload_pool_f64(acx_ctx *c, const double *frames, const int64_t *offsets
     ACX_HIP(c, hipMemcpy(c->d_frames64, frames, sizeof(double) * total * 12, hipMemcpyHostToDevice));
     ACX_HIP(c, hipMemcpy(c->d_toff64, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
     ACX_HIP(c, hipMemcpy(c->d_prof64, prof.data(), sizeof(double) * prof.size(), hipMemcpyHostToDevice));
+    return ACX_OK;
+}
+
+int acx_simple_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_offsets, int32_t n_tracks, int32_t dim,
+                               int32_t win, int32_t skip, int32_t win_len_smooth, int64_t *pooled_offsets_out)
+{
+    if (!c) return ACX_ERR_INVALID;
+    int rc;
+    if ((rc = check_raw_args(c, "simple_upload_raw_pool", raw, raw_offsets, n_tracks, dim)) != ACX_OK) return rc;
+    if (win < 1 || skip < 1 || win_len_smooth < 0) return fail(c, ACX_ERR_INVALID, "simple_upload_raw_pool: WIN, SKIP must be >= 1 and the smoothing length >= 0");
+    if (win_len_smooth + 2 > acx::SIMPLE_PREP_MAXW) return fail(c, ACX_ERR_UNSUPPORTED, "simple_upload_raw_pool: smoothing windows above 14 are not supported on the device");
+    ACX_HIP(c, hipSetDevice(c->device));
+    std::vector<int64_t> poff((size_t)n_tracks + 1, 0);
+    for (int t = 0; t < n_tracks; ++t) {
+        const int64_t n = (raw_offsets[t + 1] - raw_offsets[t]) / skip;          // int(T0 / SKIP), simple_silva.py:37
+        if (n > acx::SIMPLE_PREP_MAXN) return fail(c, ACX_ERR_UNSUPPORTED, "simple_upload_raw_pool: tracks with more than 512 pooled frames are not supported on the device yet");
+        poff[t + 1] = poff[t] + n;
+    }
+    // scipy.signal.get_window('hann', n, fftbins=False) / sum  (simple_silva.py:58-60)
+    acx::SmoothWin sw;
+    sw.nw = win_len_smooth + 2;
+    {
+        double sum = 0.0;
+        for (int k = 0; k < sw.nw; ++k) {
+            sw.w[k] = sw.nw > 1 ? 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)k / (double)(sw.nw - 1)) : 1.0;
+            sum += sw.w[k];
+        }
+        for (int k = 0; k < sw.nw; ++k) sw.w[k] /= sum;
+    }
+    const int64_t ptotal = poff[n_tracks];
+    std::vector<double> feats((size_t)std::max<int64_t>(1, ptotal) * 12);
+    int64_t *d_roff = nullptr, *d_poff = nullptr;
+    float *d_raw = nullptr;
+    double *d_feats = nullptr;
+    auto cleanup = [&]() {
+        if (d_roff) (void)hipFree(d_roff);
+        if (d_poff) (void)hipFree(d_poff);
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_feats) (void)hipFree(d_feats);
+    };
+#define ACX_HIPC(expr_) do { const hipError_t ec_ = (expr_); if (ec_ != hipSuccess) { cleanup(); ACX_HIP(c, ec_); } } while (0)
+    ACX_HIPC(hipMalloc((void **)&d_roff, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIPC(hipMalloc((void **)&d_poff, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIPC(hipMemcpy(d_roff, raw_offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    ACX_HIPC(hipMemcpy(d_poff, poff.data(), sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    int64_t cap_raw = 0, cap_feats = 0;
+    for (int t0 = 0; t0 < n_tracks;) {
+        int t1 = t0 + 1;
+        while (t1 < n_tracks && t1 - t0 < 65535 && (raw_offsets[t1 + 1] - raw_offsets[t0]) * 12 <= RAW_SLICE_FLOATS) ++t1;
+        const int64_t nraw = raw_offsets[t1] - raw_offsets[t0], npool = poff[t1] - poff[t0];
+        if (npool > 0) {
+            if (nraw * 12 > cap_raw) {
+                if (d_raw) (void)hipFree(d_raw);
+                d_raw = nullptr;
+                cap_raw = nraw * 12;
+                ACX_HIPC(hipMalloc((void **)&d_raw, sizeof(float) * cap_raw));
+            }
+            if (npool * 12 > cap_feats) {
+                if (d_feats) (void)hipFree(d_feats);
+                d_feats = nullptr;
+                cap_feats = npool * 12;
+                ACX_HIPC(hipMalloc((void **)&d_feats, sizeof(double) * cap_feats));
+            }
+            ACX_HIPC(hipMemcpyAsync(d_raw, raw + raw_offsets[t0] * 12, sizeof(float) * nraw * 12, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(acx::simple_prep_kernel, dim3((unsigned)(t1 - t0)), dim3(256), 0, c->stream,
+                               d_raw, raw_offsets[t0], d_roff, d_poff, t0, win, skip, sw, d_feats, poff[t0]);
+            ACX_HIPC(hipGetLastError());
+            ACX_HIPC(hipMemcpyAsync(feats.data() + poff[t0] * 12, d_feats, sizeof(double) * npool * 12, hipMemcpyDeviceToHost, c->stream));
+            ACX_HIPC(hipStreamSynchronize(c->stream));
+        }
+        t0 = t1;
+    }
+#undef ACX_HIPC
+    cleanup();
+    if (pooled_offsets_out) memcpy(pooled_offsets_out, poff.data(), sizeof(int64_t) * (n_tracks + 1));
+    return acx_upload_pool_f64(c, feats.data(), poff.data(), n_tracks, 12);
+}
+
+int acx_download_pool_f64(acx_ctx *c, double *frames, int64_t capacity)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!c->d_frames64) return fail(c, ACX_ERR_STATE, "download_pool_f64: f64 feature pool not uploaded");
+    const int64_t need = c->h_off64[c->n_tracks64] * 12;
+    if (!frames || capacity < need) return fail(c, ACX_ERR_INVALID, "download_pool_f64: buffer too small");
+    ACX_HIP(c, hipSetDevice(c->device));
+    ACX_HIP(c, hipMemcpy(frames, c->d_frames64, sizeof(double) * need, hipMemcpyDeviceToHost));
     return ACX_OK;
 }
 

@@ -65,6 +65,21 @@ int acx_set_scratch_limit(acx_ctx *ctx, int64_t bytes);
 int acx_upload_pool(acx_ctx *ctx, const float *frames, const int64_t *offsets,
                     int32_t n_tracks, int32_t dim);
 
+/*
+ * The same pool from RAW chroma: `raw` is row-major (sum_i T0_i, 12) f32, track i occupies rows
+ * raw_offsets[i] .. raw_offsets[i+1]; the device takes the median over consecutive blocks of
+ * `fac` frames (the last block of a track may be shorter) -- what Serra09.load_features does per
+ * track with librosa.util.sync(chroma.T, arange(0, T0, fac), aggregate=np.median).T
+ * (rqa_serra09.py:49-52; downsample_fac = 40 by default, <= 64 here).  Bit-identical to np.median
+ * on f32 input.  pooled_offsets_out (n_tracks + 1 entries, may be NULL) receives the offsets of
+ * the pooled tracks: ceil(T0_i / fac) frames each.
+ */
+int acx_upload_raw_pool(acx_ctx *ctx, const float *raw, const int64_t *raw_offsets, int32_t n_tracks,
+                        int32_t dim, int32_t fac, int64_t *pooled_offsets_out);
+
+/* Copy the f32 pool back (tests): `frames` has room for `capacity` floats. */
+int acx_download_pool(acx_ctx *ctx, float *frames, int64_t capacity);
+
 /* ---- Serra09 (OTI + delay embedding + CSM + mutual-kappa + Qmax) --------- */
 
 /* Mirrors the constructor arguments of Serra09 (rqa_serra09.py:31-32) that reach
@@ -134,6 +149,22 @@ int32_t acx_serra09_embed_len(int32_t T, const acx_serra09_params *params);
  */
 int acx_upload_pool_f64(acx_ctx *ctx, const double *frames, const int64_t *offsets,
                         int32_t n_tracks, int32_t dim);
+
+/*
+ * The same pool from RAW chroma (row-major (sum_i T0_i, 12) f32, C-contiguous per track as
+ * deepdish loads it): Simple.load_features on the device for every track at once --
+ * n_i = int(T0_i / skip) frames, frame k = mean of raw frames [k skip, k skip + win) clipped to
+ * the track (f32, summed in time order like numpy reduces this axis; simple_silva.py:36-41), then
+ * smooth(): hann(win_len_smooth + 2, sym) / sum, 'same' convolution along time, L2 norm per
+ * frame (simple_silva.py:56-66), in f64.  Defaults of the reference: win 200, skip 100,
+ * win_len_smooth 4.  pooled_offsets_out as in acx_upload_raw_pool.
+ */
+int acx_simple_upload_raw_pool(acx_ctx *ctx, const float *raw, const int64_t *raw_offsets, int32_t n_tracks,
+                               int32_t dim, int32_t win, int32_t skip, int32_t win_len_smooth,
+                               int64_t *pooled_offsets_out);
+
+/* Copy the f64 pool back (tests): `frames` has room for `capacity` doubles. */
+int acx_download_pool_f64(acx_ctx *ctx, double *frames, int64_t capacity);
 
 /*
  * out[k] = -median(matrix profile) of the ORDERED pair (pairs[2k], pairs[2k+1]): OTI of the
