@@ -18,18 +18,23 @@ rounds = pairs_done = fails = 0
 while time.time() < t_end:
     rounds += 1
     m = int(rng.choice([1, 2, 4, 7, 9, 9, 9, 12, 16]))
-    kw = dict(m=m, kappa=float(rng.choice([0.02, 0.095, 0.095, 0.3, 0.7])), pct_mode=int(rng.integers(0, 4)),
+    kw = dict(m=m, kappa=float(rng.choice([0.0, 0.004, 0.02, 0.095, 0.095, 0.3, 0.7, 1.0])), pct_mode=int(rng.integers(0, 4)),
               inclusive=int(rng.integers(0, 2)), dp_start=int(rng.choice([2, 3])), embed_full=int(rng.integers(0, 2)),
               oti=bool(rng.integers(0, 2)), oti_target=int(rng.integers(0, 2)), dmax=int(rng.integers(0, 2)))
     if rng.random() < 0.3:
         kw.update(gamma_o=float(rng.choice([0.25, 1.0, 1.5])), gamma_e=float(rng.choice([0.25, 0.5, 2.0])))
     ntr = int(rng.integers(3, 7))
-    tmax = int(rng.choice([60, 150, 400, 700, 1100]))
+    tmax = int(rng.choice([60, 150, 400, 700, 1100, 2040 - m]))
+    if tmax > 1500:
+        ntr = 3
     tracks = []
     for _ in range(ntr):
         T = int(rng.integers(m + 2, tmax + m + 2))
         kind = rng.random()
-        if kind < 0.6:
+        if kind < 0.1:
+            T = min(T, 2050 - 2 * m) if tmax > 1500 else T
+            x = np.tile(rng.random((1, 12)), (T, 1))       # a constant track: every distance equal
+        elif kind < 0.6:
             x = rng.random((T, 12))
         elif kind < 0.85:                      # piecewise constant: heavy ties
             protos = rng.random((int(rng.integers(1, 5)), 12))
