@@ -940,12 +940,15 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
 #ifdef ACX_FBINS
     constexpr int FBINS = ACX_FBINS;
 #else
-    constexpr int FBINS = NV >= 32 ? 512 : 256;                 // bins of the fast selection
+    constexpr int FBINS = 512;                                  // counters of the fast selection
 #endif
 #ifdef ACX_FCOPIES
     constexpr int FCOPIES = ACX_FCOPIES;
 #else
-    constexpr int FCOPIES = 1;                                  // counters per bin of the fast selection
+    // counters per bin: neighbouring columns of real chroma give neighbouring lanes the same bin, and
+    // same-address LDS atomics serialise; two copies (lane parity) cost nothing on i.i.d. data and
+    // take 24 % off the band kernel on the covers80-shaped set.  The longest rows keep 512 bins.
+    constexpr int FCOPIES = NV >= 32 ? 1 : 2;
 #endif
     constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
     constexpr int SWEEP_FLOATS = 8 * G::AROWS * G::SP;          // one Gram tile per wave
@@ -960,10 +963,11 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     static_assert((HIST_OFF * 4) % (FBINS * 4) == 0, "fast histograms must be aligned to their size");
     __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
 
-    const PairDesc P = pd[blockIdx.y];
+    const int bid_x = blockIdx.x, bid_y = blockIdx.y;
+    const PairDesc P = pd[bid_y];
     const int MA = role ? P.Mr : P.Mq, MB = role ? P.Mq : P.Mr;
     const int TA = role ? P.Tr : P.Tq, TB = role ? P.Tq : P.Tr;
-    const int i0 = blockIdx.x * BAND;
+    const int i0 = bid_x * BAND;
     if (i0 >= MA) return;     // block-uniform
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: everything derived from it is scalar
@@ -1265,6 +1269,7 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     unsigned long long tsel[6] = {0, 0, 0, 0, 0, 0};
     done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, tsel);
     if (lane == 0 && done && tsel[5] && (blockIdx.x & 31) == 5) for (int q = 0; q < 5; ++q) atomicAdd(&acx_tim[20 + q], tsel[q + 1] - tsel[q]);
+    if (lane == 0 && (blockIdx.x & 31) == 5) atomicAdd(&acx_tim[done ? 26 : 25], 1ull);      // fast-path hits / fallbacks
 #else
     done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi);
 #endif
@@ -1276,6 +1281,10 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
         slo = sr.value;
         shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
     }
+#if defined(ACX_ABL_STAGE) && ACX_ABL_STAGE == 1
+    if (lane == 0) thr[P.offX + (role ? P.pitchT + row : row)] = slo + shi;
+    return;
+#endif
     ACX_T(7);
     const float eps = percentile_eps2(slo, shi, pct_mode, ilo, ihi, kf, fl, ce);
     const float thr_row = d2_threshold(eps, inclusive);
@@ -1289,6 +1298,9 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
         X[o] = thr_row;
         X[P.pitchT + P.pitchD + o] = eps;
     }
+#if defined(ACX_ABL_STAGE) && ACX_ABL_STAGE == 2
+    return;
+#endif
     // ---- role 0 (the column thresholds of the pair are already there): binarise the row the
     // wave still holds in registers and emit it as a bitmap -- word t = columns
     // [64 t - 7 + (row & 7), +64).  256 bytes per row instead of 8 KB of f32.

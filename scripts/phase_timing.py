@@ -10,7 +10,11 @@ from acoss_amd import _lib, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-d = synth.rand_set(n, T=T, seed=1234)
+if len(sys.argv) > 3 and sys.argv[3] == "covers":      # structured (cover-song-like) tracks of about T frames
+    d = synth.cover_set(n_works=max(1, n // 2), versions=2, seed=4321, t_range=(int(0.7 * T), int(1.3 * T)))
+    n = len(d["offsets"]) - 1
+else:
+    d = synth.rand_set(n, T=T, seed=1234)
 ctx = _lib.Context(0)
 ctx.upload_pool(d["frames"], d["offsets"])
 i, j = np.triu_indices(n, 1)
@@ -24,7 +28,7 @@ ctx.serra09_pairs(pairs)
 L.acx_debug_timing(ctx._h, buf, 1)
 t = np.array(list(buf), dtype=np.float64)
 w = t[31]
-names = ["stage row frames", "sweep", "wait B1", "exchange write + hist clear", "wait B2", "row read",
+names = ["row operands + norms", "sweep", "wait B1", "exchange write + hist clear", "wait B2", "row read",
          "selection", "eps + d2 threshold", "bitmap (role 0 only)"]
 tot = t[:9].sum()
 print("waves %d, mean cycles per wave %.0f" % (w, tot / w))
@@ -32,3 +36,4 @@ for k, nm in enumerate(names):
     print("  %-28s %8.0f  %5.1f %%" % (nm, t[k] / w, 100 * t[k] / tot))
 print("  sweep split: dma wait %.0f  gram %.0f  walk %.0f" % (t[16] / w, t[17] / w, t[18] / w))
 print("  fast selection split: range %.0f  bin+atomics %.0f  scan+find %.0f  gather %.0f  rank %.0f" % tuple(t[20:25] / w))
+print("  fast selection: %d rows decided, %d rows fell back to the generic selection" % (t[26], t[25]))

@@ -8,7 +8,11 @@ sys.path.insert(0, ".")
 from acoss_amd import _lib, synth  # noqa: E402
 
 sizes = [2] * 77 + [3, 3, 4]
-d = synth.cover_set(clique_sizes=sizes, seed=4321, t_range=(300, 600))
+t_range = (300, 600)
+if len(sys.argv) > 2:                      # quick_bench_covers.py n_works t_lo t_hi
+    sizes = [2] * int(sys.argv[1])
+    t_range = (int(sys.argv[2]), int(sys.argv[3]))
+d = synth.cover_set(clique_sizes=sizes, seed=4321, t_range=t_range)
 n = len(d["offsets"]) - 1
 ctx = _lib.Context(0)
 ctx.upload_pool(d["frames"], d["offsets"])
