@@ -1162,15 +1162,22 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     }
     __syncthreads();     // all slabs dead -> reuse LDS as the exchange rows + the fast histograms
     ACX_T(3);
-    // ---- exchange: wave w hands its NSTEP cells of band row a to X[a][w][lane][0..NSTEP) -- one
-    // 16-byte store per row; the order of a row's cells is irrelevant to the selection, only the
-    // bitmap below needs to know that element w' * NSTEP + st sits in tile w' + 8 st.
+    // ---- exchange: row a of the band becomes a row of LDS in POSITION order (position p = 64 tile +
+    // lane <-> column p - 7 + a), so that the owner of the row can pick up NV CONSECUTIVE positions
+    // per lane.  With that layout one instruction of the selection handles 64 columns that are NV
+    // apart: neighbouring columns of real chroma are similar, and 64 neighbours in one LDS atomic
+    // would pile onto a few histogram counters (same-address atomics serialise).  The 16-byte chunk
+    // index is XORed with the tile's low bits -- for the writer a constant XOR of the lane number --
+    // which makes both the 4-byte writes and the owner's 16-byte reads bank-conflict free.
+    constexpr int CH = NV / 4;           // 16-byte chunks per lane of a complete row
+    constexpr int LPT = 64 / NV == 0 ? 1 : 64 / NV;     // lanes of the owner per 64-position tile
+    static_assert(NV == 8 || NV == 16 || NV == 32, "row owners hold 8, 16 or 32 consecutive positions");
+    {
+        const int wl = lane ^ (4 * (wave & (CH - 1)));
 #pragma unroll
-    for (int a = 0; a < BAND; ++a) {
-        float *dst = smem + a * ROWP + (wave * 64 + lane) * NSTEP;
-        if constexpr (NSTEP == 4) *reinterpret_cast<float4 *>(dst) = make_float4(xv[a][0], xv[a][1], xv[a][2], xv[a][3]);
-        else if constexpr (NSTEP == 2) *reinterpret_cast<float2 *>(dst) = make_float2(xv[a][0], xv[a][1]);
-        else dst[0] = xv[a][0];
+        for (int a = 0; a < BAND; ++a)
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) smem[a * ROWP + 64 * (wave + 8 * st) + wl] = xv[a][st];
     }
     {   // zero this wave's fast histogram
         float *h = smem + HIST_OFF + wave * FBINS;
@@ -1180,18 +1187,13 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     ACX_T(4);
     __syncthreads();
     ACX_T(5);
-    float xr[NV];      // xr[w' * NSTEP + st] = cell of column 64 (w' + 8 st) - 7 + wave + lane of band row `wave`
+    float xr[NV];      // xr[t] = cell at position NV lane + t of band row `wave` (column = position - 7 + wave)
+    {
+        const int rsw = (lane / LPT) & (CH - 1);
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const float *src = smem + wave * ROWP + (w * 64 + lane) * NSTEP;
-        if constexpr (NSTEP == 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(src);
-            xr[4 * w + 0] = v.x; xr[4 * w + 1] = v.y; xr[4 * w + 2] = v.z; xr[4 * w + 3] = v.w;
-        } else if constexpr (NSTEP == 2) {
-            const float2 v = *reinterpret_cast<const float2 *>(src);
-            xr[2 * w + 0] = v.x; xr[2 * w + 1] = v.y;
-        } else {
-            xr[w] = src[0];
+        for (int j = 0; j < CH; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(smem + wave * ROWP + lane * NV + 4 * (j ^ rsw));
+            xr[4 * j + 0] = v.x; xr[4 * j + 1] = v.y; xr[4 * j + 2] = v.z; xr[4 * j + 3] = v.w;
         }
     }
     // From here on the waves are independent: wave w owns exchange row w (its cells are in
@@ -1302,37 +1304,47 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     return;
 #endif
     // ---- role 0 (the column thresholds of the pair are already there): binarise the row the
-    // wave still holds in registers and emit it as a bitmap -- word t = columns
-    // [64 t - 7 + (row & 7), +64).  256 bytes per row instead of 8 KB of f32.
+    // wave still holds in registers and emit it as a bitmap -- bit p of the row = position p =
+    // column p - 7 + (row & 7).  256 bytes per row instead of 8 KB of f32.  A lane owns NV
+    // consecutive positions, i.e. NV consecutive bits: R = [d2 <= min(thr_row, thr_col)] is shifted
+    // into the lane's own word bit by bit (compare -> carry -> add-with-carry), no cross-lane traffic.
     if (role == 0 && bits) {
-        // column thresholds (d2 domain).  All NV loads are issued back to back with no bounds
-        // check (columns -7 .. 64 ntiles + 63 of the threshold arena are always inside the pair's
-        // arena); only the tiles that stick out of the matrix (wave-uniform test) pay the fix-up.
-        const float *tc = X + P.pitchT + (wave + lane - (BAND - 1));
+        // column thresholds (d2 domain): NV consecutive floats per lane, no bounds check (columns
+        // -7 .. 64 ntiles + 63 of the threshold arena are always inside the pair's arena)
+        const float *tc = X + P.pitchT + (lane * NV + wave - (BAND - 1));
+        typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
         float tcv[NV];
-        static_for<0, NV>([&](auto ic) {
-            constexpr int idx = decltype(ic)::value;
-            constexpr int tile = idx / NSTEP + 8 * (idx % NSTEP);
-            tcv[idx] = tc[64 * tile];
-        });
-        // R = [d2 <= thr_row] & [d2 <= thr_col] as two compares whose lane masks are ANDed on the
-        // scalar unit, together with the mask of the lanes whose column exists (a contiguous lane
-        // range per tile): no per-lane bounds code, no min.
-        unsigned mlo = 0u, mhi = 0u;
-        static_for<0, NV>([&](auto ic) {
-            constexpr int idx = decltype(ic)::value;
-            constexpr int tile = idx / NSTEP + 8 * (idx % NSTEP);
-            const int jb = 64 * tile - (BAND - 1) + wave;              // column of lane 0
-            int lo = -jb, hi = MB - jb;                                 // lanes [lo, hi) are inside the matrix
-            lo = lo < 0 ? 0 : lo;
-            hi = hi > 64 ? 64 : hi;
-            unsigned long long valid = 0ull;
-            if (hi > lo) valid = (hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
-            const unsigned long long m = __ballot(xr[idx] <= thr_row) & __ballot(xr[idx] <= tcv[idx]) & valid;
-            writelane_mask<tile>(mlo, mhi, m);
-        });
-        if (lane < P.nw)
-            bits[P.offT + (size_t)row * P.nw + lane] = (lane < NV) ? (((unsigned long long)mhi << 32) | mlo) : 0ull;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const f32x4_u v = *reinterpret_cast<const f32x4_u *>(tc + 4 * j);
+            tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
+        }
+        // positions of this lane whose column exists: t in [lo, hi)
+        int lo = (BAND - 1) - wave - lane * NV, hi = MB + (BAND - 1) - wave - lane * NV;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > NV ? NV : hi;
+        unsigned valid = 0u;
+        if (hi > lo) valid = (hi - lo >= 32 ? ~0u : ((1u << (hi - lo)) - 1u)) << lo;
+        unsigned acc = 0u;
+#pragma unroll
+        for (int t = NV - 1; t >= 0; --t) {
+            float mthr;
+            asm("v_min_f32 %0, %1, %2" : "=v"(mthr) : "v"(tcv[t]), "v"(thr_row));
+            asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(xr[t]), "v"(mthr) : "vcc");
+        }
+        acc &= valid;
+        // NV < 32: neighbouring lanes complete a dword
+        if constexpr (NV == 16) {
+            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 16;
+        } else if constexpr (NV == 8) {
+            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 8;
+            acc |= (unsigned)__shfl_down((int)acc, 2, 64) << 16;
+        }
+        constexpr int LPD = 32 / NV;                                    // lanes per dword
+        unsigned *rowbits = reinterpret_cast<unsigned *>(bits + P.offT + (size_t)row * P.nw);
+        const int ndw = 2 * P.nw, d = lane / LPD;
+        if ((lane & (LPD - 1)) == 0 && d < ndw) rowbits[d] = acc;
+        for (int z = 2 * NV + lane; z < ndw; z += 64) rowbits[z] = 0u;  // words beyond this size class
     }
     ACX_T(9);
 #ifdef ACX_TIMING
