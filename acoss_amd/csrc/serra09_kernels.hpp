@@ -558,7 +558,7 @@ struct OpMaxI { __device__ int operator()(int a, int b) const { return a > b ? a
 template <int NV, int BINS, int COPIES = 1>
 __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bool want_next, unsigned hist_addr,
                                                  float *cand, int lane, float &slo, float &shi,
-                                                 unsigned long long *tsel = nullptr)
+                                                 unsigned long long *tsel = nullptr, bool lane_has_data = true)
 {
     ACX_TS(0);
     // The histogram has NB = BINS / COPIES logical bins of COPIES counters each; a lane adds to
@@ -607,9 +607,13 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
         asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(y));        // saturating: +inf -> 0xffffffff, y < 0 -> 0
         off[t] = (q & vmask) | hb;
     }
+    // lanes that hold nothing but +inf pads stay out: their counts would all land on the top
+    // counter (a same-address pile-up in every atomic), which no rank below ever reads
+    if (lane_has_data) {
 #pragma unroll
-    for (int t = 0; t < NV; ++t)
-        __hip_atomic_fetch_add((lds_u32 *)off[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int t = 0; t < NV; ++t)
+            __hip_atomic_fetch_add((lds_u32 *)off[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     wave_lds_fence();
     ACX_TS(2);
     // ---- scan: lane owns bins [BPL lane, +BPL); pieces read in a staggered order (conflict-free)
@@ -1266,14 +1270,15 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     typedef __attribute__((address_space(3))) void lds_void;
     const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + HIST_OFF + wave * FBINS);
     bool done = false;
+    const bool lane_has_data = lane * NV < MB + (BAND - 1) - wave;      // first position of the lane is a cell or a low pad
 #ifndef ACX_NO_FASTSEL
 #ifdef ACX_TIMING
     unsigned long long tsel[6] = {0, 0, 0, 0, 0, 0};
-    done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, tsel);
+    done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, tsel, lane_has_data);
     if (lane == 0 && done && tsel[5] && (blockIdx.x & 31) == 5) for (int q = 0; q < 5; ++q) atomicAdd(&acx_tim[20 + q], tsel[q + 1] - tsel[q]);
     if (lane == 0 && (blockIdx.x & 31) == 5) atomicAdd(&acx_tim[done ? 26 : 25], 1ull);      // fast-path hits / fallbacks
 #else
-    done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi);
+    done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, nullptr, lane_has_data);
 #endif
 #endif
     if (!done) {
