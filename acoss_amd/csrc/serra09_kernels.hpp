@@ -941,30 +941,35 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     constexpr int NV = 4 * V4;           // values per lane of a complete row
     constexpr int NSTEP = NV / 8;        // tiles per wave
     constexpr int ROWP = 64 * NV;        // exchange pitch (floats): row a = [wave w'][lane][step]
+    // Fast selection: FBINS counters = FBINS / FCOPIES bins x FCOPIES copies.  (Copies spread
+    // same-address atomics -- they paid while one instruction handled 64 NEIGHBOURING columns; with
+    // the position-order rows below one copy and twice the bins measure best on every workload.)
+    // For rows of >= 1024 positions the histogram lives in the upper part of the wave's OWN
+    // exchange row, free once the row sits in registers; the shortest rows (2 KB) keep a separate
+    // area behind the exchange rows.
 #ifdef ACX_FBINS
     constexpr int FBINS = ACX_FBINS;
 #else
-    constexpr int FBINS = 512;                                  // counters of the fast selection
+    constexpr int FBINS = NV >= 32 ? 1024 : 512;
 #endif
 #ifdef ACX_FCOPIES
     constexpr int FCOPIES = ACX_FCOPIES;
 #else
-    // counters per bin: neighbouring columns of real chroma give neighbouring lanes the same bin, and
-    // same-address LDS atomics serialise; two copies (lane parity) cost nothing on i.i.d. data and
-    // take 24 % off the band kernel on the covers80-shaped set.  The longest rows keep 512 bins.
-    constexpr int FCOPIES = NV >= 32 ? 1 : 2;
+    constexpr int FCOPIES = 1;
 #endif
+    constexpr bool HIST_IN_ROW = ROWP >= 2 * FBINS;
     constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
     constexpr int SWEEP_FLOATS = 8 * G::AROWS * G::SP;          // one Gram tile per wave
-    constexpr int HIST_OFF = BAND * ROWP;                       // fast histograms sit behind the exchange rows
-    constexpr int TAIL_FLOATS = HIST_OFF + 8 * FBINS;
+    constexpr int HIST_OFF = HIST_IN_ROW ? ROWP - FBINS : BAND * ROWP;     // float offset of wave 0's histogram
+    constexpr int HIST_STRIDE = HIST_IN_ROW ? ROWP : FBINS;                // ... and from wave to wave
+    constexpr int TAIL_FLOATS = BAND * ROWP + (HIST_IN_ROW ? 0 : 8 * FBINS);
 #ifdef ACX_LDS_PAD      /* experiment: force one workgroup per CU */
     constexpr int LDS_FLOATS = 24 * 1024;
 #else
     constexpr int LDS_FLOATS = SWEEP_FLOATS > TAIL_FLOATS ? SWEEP_FLOATS : TAIL_FLOATS;
 #endif
     static_assert(SelGeom<GBINS>::SLOTS + 64 + 4 <= ROWP, "generic selection must fit the wave's own exchange row");
-    static_assert((HIST_OFF * 4) % (FBINS * 4) == 0, "fast histograms must be aligned to their size");
+    static_assert(HIST_OFF % FBINS == 0 && HIST_STRIDE % FBINS == 0, "fast histograms must be aligned to their size");
     __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
 
     const int bid_x = blockIdx.x, bid_y = blockIdx.y;
@@ -1183,8 +1188,8 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) smem[a * ROWP + 64 * (wave + 8 * st) + wl] = xv[a][st];
     }
-    {   // zero this wave's fast histogram
-        float *h = smem + HIST_OFF + wave * FBINS;
+    if constexpr (!HIST_IN_ROW) {   // zero this wave's fast histogram
+        float *h = smem + HIST_OFF + wave * HIST_STRIDE;
 #pragma unroll
         for (int q = 0; q < FBINS / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -1268,7 +1273,13 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     ACX_T(6);
     float slo, shi;
     typedef __attribute__((address_space(3))) void lds_void;
-    const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + HIST_OFF + wave * FBINS);
+    const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + HIST_OFF + wave * HIST_STRIDE);
+    if constexpr (HIST_IN_ROW) {    // the row has left LDS: its upper part becomes the zeroed histogram
+        float *h = smem + HIST_OFF + wave * HIST_STRIDE;
+#pragma unroll
+        for (int q = 0; q < FBINS / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+        wave_lds_fence();
+    }
     bool done = false;
     const bool lane_has_data = lane * NV < MB + (BAND - 1) - wave;      // first position of the lane is a cell or a low pad
 #ifndef ACX_NO_FASTSEL
