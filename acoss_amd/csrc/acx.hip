@@ -535,7 +535,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             }
             if (d.M < 1 || d.N < 1) return fail(c, ACX_ERR_SHORT, "earlyfusion: track without blocks (pair " + std::to_string(k) + ")");
             if (d.M > acx::EF_MAXNB || d.N > acx::EF_MAXNB)
-                return fail(c, ACX_ERR_UNSUPPORTED, "earlyfusion: tracks with more than 512 blocks are not supported on the device yet");
+                return fail(c, ACX_ERR_UNSUPPORTED, "earlyfusion: tracks with more than 1024 blocks are not supported on the device yet");
             d.oti = 0;
             d.pitchC = round_up(d.N, 64);
             d.pitchT = round_up(d.M, 64);
@@ -578,17 +578,20 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             }
         }
         const int nfeat = ext_matrix ? 1 : 3;
+        // rows of more than 512 cells take the wide variants (16 values / columns per lane)
+        const bool wide_rows = std::max(maxM, maxN) > 512, wide_cols = maxN > 512;
+#define ACX_ROWSTAT(grid_, mode_) do { if (wide_rows) hipLaunchKernelGGL((acx::ef_rowstat_kernel<4>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); \
+                                       else hipLaunchKernelGGL((acx::ef_rowstat_kernel<2>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); } while (0)
+#define ACX_SW(grid_, src_) do { if (wide_cols) hipLaunchKernelGGL((acx::sw_kernel<16>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); \
+                                 else hipLaunchKernelGGL((acx::sw_kernel<8>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); } while (0)
         {
             ProfScope ps(c, KS_EFSTAT, cells);
-            hipLaunchKernelGGL(acx::ef_rowstat_kernel, dim3(rows_g, B, nfeat), dim3(256), 0, c->stream,
-                               c->d_efpd, c->d_scratch, c->d_thr, 0, p.K);
-            if (!ext_matrix)
-                hipLaunchKernelGGL(acx::ef_rowstat_kernel, dim3(rows_g, B, 3), dim3(256), 0, c->stream,
-                                   c->d_efpd, c->d_scratch, c->d_thr, 1, p.K);
+            ACX_ROWSTAT(dim3(rows_g, B, nfeat), 0);
+            if (!ext_matrix) ACX_ROWSTAT(dim3(rows_g, B, 3), 1);
         }
         {
             ProfScope ps(c, KS_EFSW, cells);
-            hipLaunchKernelGGL(acx::sw_kernel, dim3(B, nfeat), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
+            ACX_SW(dim3(B, nfeat), 0);
         }
         if (!ext_matrix) {
             {
@@ -597,12 +600,11 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             }
             {
                 ProfScope ps(c, KS_EFSTAT, 0);
-                hipLaunchKernelGGL(acx::ef_rowstat_kernel, dim3(rows_g, B, 1), dim3(256), 0, c->stream,
-                                   c->d_efpd, c->d_scratch, c->d_thr, 2, p.K);
+                ACX_ROWSTAT(dim3(rows_g, B, 1), 2);
             }
             {
                 ProfScope ps(c, KS_EFSW, 0);
-                hipLaunchKernelGGL(acx::sw_kernel, dim3(B, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 3);
+                ACX_SW(dim3(B, 1), 3);
             }
         }
         ACX_HIP(c, hipGetLastError());
@@ -625,6 +627,8 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
         k0 = k;
         if (ext_matrix) break;
     }
+#undef ACX_ROWSTAT
+#undef ACX_SW
     return ACX_OK;
 }
 
@@ -1135,7 +1139,7 @@ int acx_csm_binary_sw(acx_ctx *c, const float *D, int32_t M, int32_t N, double k
     if (!c) return ACX_ERR_INVALID;
     if (!D || !score || M < 1 || N < 1) return fail(c, ACX_ERR_INVALID, "csm_binary_sw: bad argument");
     if (M > acx::EF_MAXNB || N > acx::EF_MAXNB)
-        return fail(c, ACX_ERR_UNSUPPORTED, "csm_binary_sw: matrices larger than 512 are not supported on the device yet");
+        return fail(c, ACX_ERR_UNSUPPORTED, "csm_binary_sw: matrices larger than 1024 are not supported on the device yet");
     acx_ef_params p{kappa, 1};
     float sc[4] = {0, 0, 0, 0};
     const int rc = run_ef(c, nullptr, 1, p, sc, nullptr, D, M, N);
@@ -1147,7 +1151,7 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
 {
     if (!c) return ACX_ERR_INVALID;
     if (!B || !score || M < 1 || N < 1) return fail(c, ACX_ERR_INVALID, "sw_binary: bad argument");
-    if (M > acx::EF_MAXNB || N > acx::EF_MAXNB) return fail(c, ACX_ERR_UNSUPPORTED, "sw_binary: matrices larger than 512 are not supported on the device yet");
+    if (M > acx::EF_MAXNB || N > acx::EF_MAXNB) return fail(c, ACX_ERR_UNSUPPORTED, "sw_binary: matrices larger than 1024 are not supported on the device yet");
     std::vector<float> Cm((size_t)M * N);
     for (size_t k = 0; k < Cm.size(); ++k) {
         if (B[k] > 1) return fail(c, ACX_ERR_INVALID, "Non-binary elements found in input");
@@ -1171,7 +1175,8 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
                                 hipMemcpyHostToDevice, c->stream));
     ACX_HIP(c, hipMemsetAsync(c->d_thr, 0, sizeof(float) * M, c->stream));
     ACX_HIP(c, hipMemsetAsync(c->d_thr + acx::ef_jcut_off(d, 0), 0x7f, sizeof(int) * M, c->stream));   // every tie counts
-    hipLaunchKernelGGL(acx::sw_kernel, dim3(1, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
+    if (N > 512) hipLaunchKernelGGL((acx::sw_kernel<16>), dim3(1, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
+    else hipLaunchKernelGGL((acx::sw_kernel<8>), dim3(1, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
     ACX_HIP(c, hipGetLastError());
     ACX_HIP(c, hipMemcpyAsync(sc, c->d_out, sizeof(float) * 4, hipMemcpyDeviceToHost, c->stream));
     ACX_HIP(c, hipStreamSynchronize(c->stream));

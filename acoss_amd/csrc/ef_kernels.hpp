@@ -25,7 +25,7 @@
 
 namespace acx {
 
-constexpr int EF_MAXNB = 512;     // blocks per track supported on the device
+constexpr int EF_MAXNB = 1024;    // blocks per track supported on the device (rows of <= 512 take the narrow kernels)
 
 struct EfPair {
     int32_t q, r;          // track indices
@@ -198,19 +198,20 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
-// E2: per-row statistics of a matrix with rows <= 512 long.  mode 0 (C rows): threshold
+// E2: per-row statistics of a matrix with rows <= 256 NQ long (NQ = 2: 512, NQ = 4: 1024).  mode 0 (C rows): threshold
 // t_i = the kb-th smallest (k = round(kappa n), kappa < 1; kappa >= 1: k = kappa; k = 0 or
 // kappa == 0 handled by the host) and r_i = mean of the kw smallest; mode 1 (C^T rows):
 // only the mean (= column statistic c_j); mode 2 (F rows): only the threshold.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ float mean_k_smallest(const float (&x)[8], int kw, float vk, int lane)
+template <int NX>
+__device__ __forceinline__ float mean_k_smallest(const float (&x)[NX], int kw, float vk, int lane)
 {
     // vk = kw-th smallest (rank kw-1).  sum of elements < vk, plus (kw - count) * vk: exact
     // whatever the ties.
     float acc = 0.0f;
     int cnt = 0;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < NX; ++t) {
         const bool lt = x[t] < vk;
         acc += lt ? x[t] : 0.0f;
         cnt += lt ? 1 : 0;
@@ -224,9 +225,11 @@ __device__ __forceinline__ float mean_k_smallest(const float (&x)[8], int kw, fl
     return (s + (float)(kw - tot) * vk) / (float)kw;
 }
 
+template <int NQ>
 __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
                                                          float *__restrict__ stat, int mode, int kw)
 {
+    constexpr int NX = 4 * NQ;                        // values per lane
     __shared__ __attribute__((aligned(4096))) unsigned fhist[4][256];      // one-pass selection (wave_select_fast)
     __shared__ __attribute__((aligned(16))) unsigned hist[4][SEL_SLOTS];   // generic fallback
     __shared__ __attribute__((aligned(16))) float cand[4][64];
@@ -235,12 +238,12 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
     typedef __attribute__((address_space(3))) void lds_void;
     const unsigned fh_addr = (unsigned)(uintptr_t)(lds_void *)(&fhist[wave][0]);
     // k-th smallest (0-based) of the row: one histogram pass, generic narrowing when that cannot decide
-    auto kth = [&](const float (&xx)[8], int k) -> float {
+    auto kth = [&](const float (&xx)[NX], int k) -> float {
         *reinterpret_cast<uint4 *>(&fhist[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_fence();
         float lo, hi;
-        if (wave_select_fast<8, 256>(xx, k, false, fh_addr, cand[wave], lane, lo, hi)) return lo;
-        return wave_select_regs<8>(xx, k, hist[wave], cand[wave], &counter[wave], lane, false).value;
+        if (wave_select_fast<NX, 256>(xx, k, false, fh_addr, cand[wave], lane, lo, hi)) return lo;
+        return wave_select_regs<NX>(xx, k, hist[wave], cand[wave], &counter[wave], lane, false).value;
     };
     const EfPair P = pd[blockIdx.y];
     const int s = blockIdx.z;                         // feature (mode 2: always 0)
@@ -251,10 +254,10 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
     if (row >= nrows) return;
     const int64_t base = mode == 0 ? ef_c_off(P, s) : (mode == 1 ? ef_ct_off(P, s) : ef_f_off(P));
     const float *v = scratch + base + (size_t)row * pitch;
-    float x[8];
+    float x[NX];
     const float INF = __builtin_inff();
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int j = 256 * q + 4 * lane;
         float4 t = make_float4(INF, INF, INF, INF);
         if (j < pitch) t = *reinterpret_cast<const float4 *>(v + j);
@@ -274,25 +277,30 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
             t = kth(x, kb - 1);
             // cells equal to t: if there are more than the row may still take, find the column of
             // the last one taken (column of x[4 q + e] = 256 q + 4 lane + e)
-            int lt = 0, eq[2] = {0, 0};
+            int lt = 0, eq[NQ];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int q = 0; q < NQ; ++q) eq[q] = 0;
+#pragma unroll
+            for (int e = 0; e < NX; ++e) {
                 lt += x[e] < t ? 1 : 0;
                 eq[e >> 2] += x[e] == t ? 1 : 0;
             }
             const int budget = kb - wave_sum_i(lt);
-            const int tot0 = wave_sum_i(eq[0]), tot1 = wave_sum_i(eq[1]);
-            if (tot0 + tot1 > budget) {
+            int before[NQ + 1];                                     // ties in the groups before group q
+            before[0] = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) before[q + 1] = before[q] + wave_sum_i(eq[q]);
+            if (before[NQ] > budget) {
                 int cand_j = -1;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     int incl = eq[q];
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) {
                         const int up = __shfl_up(incl, o, 64);
                         if (lane >= o) incl += up;
                     }
-                    int rank = incl - eq[q] + (q ? tot0 : 0);      // ties before this lane's group
+                    int rank = incl - eq[q] + before[q];           // ties before this lane's group
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (x[4 * q + e] == t) {
@@ -362,9 +370,10 @@ __global__ __launch_bounds__(256) void ef_fuse_kernel(const EfPair *__restrict__
 // reference and U = T + delta(B) (delta = 0 if B else -7):
 //   T[i][j] = max(0, mv(B[i][j]) + max(U[i-1][j-1], U[i-2][j-1], U[i-1][j-2])),  i, j >= 2,
 //   i <= M-2, j <= N-2;  T = 0 (and U = delta(B)) in rows / columns 0, 1;  score = max T / 10.
-// One wave per matrix; lane owns 8 contiguous columns (N <= 512).  B_ij from (t_i, jcut_i), see ef_s_stride.
+// One wave per matrix; lane owns CPL contiguous columns (CPL = 8: N <= 512, CPL = 16: N <= 1024).  B_ij from (t_i, jcut_i), see ef_s_stride.
 // src: 0..2 = feature CSM, 3 = fused matrix.  out[pair * 4 + src].
 // ------------------------------------------------------------------------------------
+template <int CPL>
 __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
                                                 const float *__restrict__ stat, float *__restrict__ out, int src_base)
 {
@@ -377,37 +386,37 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
     const int *jcut = reinterpret_cast<const int *>(thr) + ef_jcut_off(P, src);
     float result = 0.0f;
     if (M >= 4 && N >= 4) {
-        int U1[8], U2[8];          // U of rows i-1, i-2
+        int U1[CPL], U2[CPL];      // U of rows i-1, i-2
         const int prev = (lane + 63) & 63;
-        const int j0 = 8 * lane;
+        const int j0 = CPL * lane;
         // rows 0 and 1: T = 0, U = delta(B)
-        auto load_b = [&](int row, bool (&b)[8]) {
+        auto load_b = [&](int row, bool (&b)[CPL]) {
             const float t = thr[row];
             const int jc = jcut[row];
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            if (j0 < pitch) {
-                const float4 *p = reinterpret_cast<const float4 *>(C + (size_t)row * pitch + j0);
-                v0 = p[0];
-                v1 = p[1];
-            }
-            const float d[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            float d[CPL];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) b[e] = (j0 + e < N) && (d[e] < t || (d[e] == t && j0 + e <= jc));
+            for (int q = 0; q < CPL / 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j0 + 4 * q < pitch) v = *reinterpret_cast<const float4 *>(C + (size_t)row * pitch + j0 + 4 * q);
+                d[4 * q + 0] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) b[e] = (j0 + e < N) && (d[e] < t || (d[e] == t && j0 + e <= jc));
         };
-        bool b[8];
+        bool b[CPL];
         load_b(0, b);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) U2[e] = b[e] ? 0 : -7;
+        for (int e = 0; e < CPL; ++e) U2[e] = b[e] ? 0 : -7;
         load_b(1, b);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) U1[e] = b[e] ? 0 : -7;
+        for (int e = 0; e < CPL; ++e) U1[e] = b[e] ? 0 : -7;
         int best = 0;
         for (int i = 2; i <= M - 2; ++i) {
             load_b(i, b);
-            const int l1a = __shfl(U1[7], prev, 64), l1b = __shfl(U1[6], prev, 64), l2a = __shfl(U2[7], prev, 64);
-            int Tn[8];
+            const int l1a = __shfl(U1[CPL - 1], prev, 64), l1b = __shfl(U1[CPL - 2], prev, 64), l2a = __shfl(U2[CPL - 1], prev, 64);
+            int Tn[CPL];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < CPL; ++e) {
                 const int c2 = (e >= 1) ? U1[e - 1] : l1a;                        // U[i-1][j-1]
                 const int c3 = (e >= 1) ? U2[e - 1] : l2a;                        // U[i-2][j-1]
                 const int c4 = (e >= 2) ? U1[e - 2] : (e == 1 ? l1a : l1b);       // U[i-1][j-2]
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
                 if (j <= N - 2) best = best > t ? best : t;
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < CPL; ++e) {
                 U2[e] = U1[e];
                 U1[e] = Tn[e] + (b[e] ? 0 : -7);
             }

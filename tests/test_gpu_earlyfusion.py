@@ -43,7 +43,8 @@ def test_smith_waterman_goldens_bit_exact(ctx, golden):
 def test_smith_waterman_random_shapes_vs_oracle(ctx):
     import oracle
     rng = np.random.default_rng(9)
-    for (m, n) in [(4, 4), (5, 64), (64, 5), (65, 65), (300, 511), (512, 512), (129, 8), (8, 500)]:
+    for (m, n) in [(4, 4), (5, 64), (64, 5), (65, 65), (300, 511), (512, 512), (129, 8), (8, 500),
+                   (513, 513), (700, 40), (40, 700), (1024, 1024), (600, 1023)]:       # > 512 columns: wide kernel
         for dens in (0.05, 0.3, 0.8):
             B = (rng.random((m, n)) < dens).astype(np.uint8)
             assert round(ctx.sw_binary(B) * 10) == oracle.sw_constrained_i32(B), (m, n, dens)
@@ -58,7 +59,7 @@ def test_binarise_with_ties_keeps_k_cells_in_column_order(ctx):
     import oracle
     rng = np.random.default_rng(21)
     cases = []
-    for (m, n) in [(40, 50), (64, 257), (130, 512), (75, 68), (9, 300)]:
+    for (m, n) in [(40, 50), (64, 257), (130, 512), (75, 68), (9, 300), (33, 777), (600, 1024)]:
         cases.append(rng.integers(0, 4, (m, n)).astype(np.float32))                       # 4 distinct values
         cases.append(np.ones((m, n), np.float32))                                         # one value
         D = np.ones((m, n), np.float32)
@@ -69,7 +70,7 @@ def test_binarise_with_ties_keeps_k_cells_in_column_order(ctx):
     for D in cases:
         for kappa in (0.05, 0.1, 0.5, 0.0, 3):
             ref = oracle.sw_constrained(oracle.csm_to_binary(D, kappa))
-            assert ctx.csm_binary_sw(D, kappa) == pytest.approx(ref, abs=1e-5), (D.shape, kappa)
+            assert round(ctx.csm_binary_sw(D, kappa) * 10) == round(ref * 10), (D.shape, kappa)   # scores are tenths (f32 out)
 
 
 def _golden_feats(g, pk):
@@ -95,13 +96,13 @@ def _check_pair(ctx, i, j, f1, f2, ref_csms=None, ref_fused=None, ref_scores=Non
             true2 = np.maximum(0, np.sum(x64 ** 2, 1)[:, None] + np.sum(y64 ** 2, 1)[None, :] - 2 * x64.dot(y64.T))
             assert np.max(np.abs(d["csm"][k].astype(np.float64) ** 2 - true2)) <= 4e-6 * scale
         # exact downstream: oracle binarise + SW on the DEVICE matrix == device score
-        assert oracle.sw_constrained(oracle.csm_to_binary(d["csm"][k], 0.1)) == pytest.approx(float(d["scores"][k]), abs=1e-5)
+        assert round(oracle.sw_constrained(oracle.csm_to_binary(d["csm"][k], 0.1)) * 10) == round(float(d["scores"][k]) * 10)
     # fused matrix from the device CSMs with the oracle's getWCSM
     ws = np.zeros_like(d["csm"][0])
     for k in range(3):
         ws += oracle.get_wcsm(d["csm"][k], 10, 10)
     np.testing.assert_allclose(d["fused"], np.exp(-ws), rtol=2e-3, atol=1e-6)
-    assert oracle.sw_constrained(oracle.csm_to_binary(d["fused"], 0.1)) == pytest.approx(float(d["scores"][3]), abs=1e-5)
+    assert round(oracle.sw_constrained(oracle.csm_to_binary(d["fused"], 0.1)) * 10) == round(float(d["scores"][3]) * 10)
     want = ref_scores if ref_scores is not None else np.array([oscores[s] for s in ("mfccs", "ssms", "chromas", "early")])
     assert np.all(np.abs(d["scores"] - want) <= 2.0), (d["scores"], want)
     return d
@@ -136,6 +137,29 @@ def test_chain_synthetic_ragged(ctx):
     b = ctx.earlyfusion_pairs(pairs)
     ctx.set_scratch_limit(0)
     assert np.array_equal(a, b) and a.shape == (6, 4)
+
+
+def test_chain_long_tracks_wide_kernels(ctx):
+    """Tracks of 513..1024 blocks (songs beyond ~4.5 min at 120 bpm) run through the 16-values-per-lane
+    row statistics and Smith-Waterman variants; mixed with a short track in the same batch."""
+    from acoss_amd import synth
+    rng = np.random.default_rng(6)
+    tracks = synth.earlyfusion_set(2, seed=8, nb_range=(560, 700)) + synth.earlyfusion_set(1, seed=9, nb_range=(1024, 1024)) \
+        + synth.earlyfusion_set(1, seed=10, nb_range=(60, 80))
+    for key in ("mfccs", "ssms", "chromas"):
+        n = 200
+        tracks[1][key][300:300 + n] = tracks[0][key][250:250 + n] + 0.02 * rng.standard_normal((n, tracks[0][key].shape[1])).astype(np.float32)
+    ctx.ef_upload_pool(tracks)
+    d = _check_pair(ctx, 0, 1, tracks[0], tracks[1])
+    assert d["scores"].max() > 50.0
+    for (i, j) in [(1, 2), (2, 0), (3, 2), (2, 3)]:
+        _check_pair(ctx, i, j, tracks[i], tracks[j])
+    pairs = np.array([[0, 1], [1, 2], [2, 0], [3, 2], [2, 3], [3, 0]], np.int32)
+    a = ctx.earlyfusion_pairs(pairs)
+    assert np.array_equal(a[0], d["scores"])
+    with pytest.raises(NotImplementedError):
+        ctx.ef_upload_pool(tracks[:1] + synth.earlyfusion_set(1, seed=11, nb_range=(1025, 1025)))
+        ctx.earlyfusion_pairs(np.array([[0, 1]], np.int32))
 
 
 def test_errors(ctx):
