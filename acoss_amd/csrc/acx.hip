@@ -450,12 +450,19 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                 // one sweep per requested alignment over the SAME recurrence bitmap:
                 // both == 0: Qmax or Dmax as p.dmax says; both == 1: out[2k] = Qmax, out[2k+1] = Dmax
                 const int stride = both ? 2 : 1;
+                // one launch per size class: a lane owns 8 / 16 / 32 columns of rows up to 505 / 1017 / 2041 cells
                 auto sweep = [&](bool dmax, float *dst) {
-#define ACX_QB(E_, D_) hipLaunchKernelGGL((acx::qmax_bits_kernel<E_, D_>), dim3(B), dim3(64), 0, c->stream, \
-                                          c->d_pd, c->d_bits, dst, stride, p.gamma_o, p.gamma_e, p.dp_start)
-                    if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }
-                    else { if (dmax) ACX_QB(false, true); else ACX_QB(false, false); }
+                    for (int cl = 0; cl < 3; ++cl) {
+                        const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
+                        if (Bc <= 0) continue;
+#define ACX_QB3(E_, D_, C_) hipLaunchKernelGGL((acx::qmax_bits_kernel<E_, D_, C_>), dim3(Bc), dim3(64), 0, c->stream, \
+                                               c->d_pd + b0, c->d_bits, dst + (size_t)b0 * stride, stride, p.gamma_o, p.gamma_e, p.dp_start)
+#define ACX_QB(E_, D_) do { if (cl == 0) ACX_QB3(E_, D_, 8); else if (cl == 1) ACX_QB3(E_, D_, 16); else ACX_QB3(E_, D_, 32); } while (0)
+                        if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }
+                        else { if (dmax) ACX_QB(false, true); else ACX_QB(false, false); }
 #undef ACX_QB
+#undef ACX_QB3
+                    }
                 };
                 if (both) { sweep(false, c->d_out); sweep(true, c->d_out + 1); }
                 else sweep(p.dmax != 0, c->d_out);

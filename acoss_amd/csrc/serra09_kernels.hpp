@@ -1373,12 +1373,14 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
 }
 
 // ------------------------------------------------------------------------------------
-// K3b: Qmax on the recurrence bitmap (band pipeline).  One wave per pair; lane owns the 32
-// contiguous columns [32 lane, +32); Q rows i-1 / i-2 live in registers (updated in place,
-// descending column order); the row's 32 recurrence bits of a lane are one funnel shift of two
-// dwords of the row bitmap (the bitmap of row i starts at column (i & 7) - 7).
+// K3b: Qmax on the recurrence bitmap (band pipeline).  One wave per pair; lane owns the CPL
+// contiguous columns [CPL lane, +CPL) -- CPL = 32 / 16 / 8 for the three size classes (rows of up
+// to 2041 / 1017 / 505 cells), so that short pairs still use all 64 lanes; Q rows i-1 / i-2 live
+// in registers (updated in place, descending column order); the row's CPL recurrence bits of a
+// lane are one funnel shift of two dwords of the row bitmap (the bitmap of row i starts at column
+// (i & 7) - 7).
 // ------------------------------------------------------------------------------------
-template <bool EQG, bool DMAX>
+template <bool EQG, bool DMAX, int CPL>
 __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restrict__ pd,
                                                        const unsigned long long *__restrict__ bits,
                                                        float *__restrict__ out, int out_stride,
@@ -1393,32 +1395,33 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
     // columns of this lane that exist (and are >= 2: the first two columns of Q stay 0)
     unsigned colmask = 0u;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
-        const int j = 32 * lane + e;
+    for (int e = 0; e < CPL; ++e) {
+        const int j = CPL * lane + e;
         if (j >= 2 && j < Ne) colmask |= (1u << e);
     }
-    float Q1[32], Q2[32];
-    float P1[EQG ? 1 : 32], P2[EQG ? 1 : 32];
+    float Q1[CPL], Q2[CPL];
+    float P1[EQG ? 1 : CPL], P2[EQG ? 1 : CPL];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
+    for (int e = 0; e < CPL; ++e) {
         Q1[e] = 0.0f; Q2[e] = 0.0f;
         if constexpr (!EQG) { P1[e] = 0.0f; P2[e] = 0.0f; }
     }
     float best = 0.0f;
     const int prev = (lane + 63) & 63;
-    const bool has0 = lane < ndw, has1 = lane + 1 < ndw;
+    const int dw0 = (CPL * lane) >> 5, bit0 = (CPL * lane) & 31;      // first dword / bit of the lane's columns
+    const bool has0 = dw0 < ndw, has1 = dw0 + 1 < ndw;
 
     auto load_row = [&](int i, unsigned &d0, unsigned &d1) {
         d0 = 0u; d1 = 0u;
         if (i < Me) {
             const unsigned *r = rows + (size_t)i * ndw;
-            if (has0) d0 = r[lane];
-            if (has1) d1 = r[lane + 1];
+            if (has0) d0 = r[dw0];
+            if (has1) d1 = r[dw0 + 1];
         }
     };
-    auto row_bits = [&](int i, unsigned d0, unsigned d1) {      // recurrence bits of columns [32 lane, +32)
+    auto row_bits = [&](int i, unsigned d0, unsigned d1) {      // recurrence bits of columns [CPL lane, +CPL)
         const int sh = (BAND - 1) - (i & (BAND - 1));           // bit position of column 0 in the row bitmap
-        return __builtin_amdgcn_alignbit(d1, d0, sh);
+        return __builtin_amdgcn_alignbit(d1, d0, bit0 + sh);    // bit0 + sh <= 31; bits >= CPL are never read
     };
     // Dmax (chen17, latefusion_chen.py:68): the (i-2, j-1) predecessor gains R[i-1][j], the
     // (i-1, j-2) predecessor gains R[i][j-1]; wprev = raw bits of row i-1
@@ -1434,31 +1437,31 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
             load_row(0, p0, p1);
             const unsigned w0 = row_bits(0, p0, p1);
 #pragma unroll
-            for (int e = 0; e < 32; ++e) {
+            for (int e = 0; e < CPL; ++e) {
                 P1[e] = ((wprev >> e) & 1u) ? -go : -ge;
                 P2[e] = ((w0 >> e) & 1u) ? -go : -ge;
             }
         }
     }
     // One DP row: QA = row i-1, QB = row i-2 (overwritten with row i)
-    auto dp_row = [&](int i, unsigned d0, unsigned d1, float (&QA)[32], float (&QB)[32],
-                      float (&PA)[EQG ? 1 : 32], float (&PB)[EQG ? 1 : 32]) {
+    auto dp_row = [&](int i, unsigned d0, unsigned d1, float (&QA)[CPL], float (&QB)[CPL],
+                      float (&PA)[EQG ? 1 : CPL], float (&PB)[EQG ? 1 : CPL]) {
         const unsigned wraw = row_bits(i, d0, d1);
         const unsigned w = wraw & colmask;
-        float l1a = wave_shfl(QA[31], prev), l1b = wave_shfl(QA[30], prev), l2a = wave_shfl(QB[31], prev);
+        float l1a = wave_shfl(QA[CPL - 1], prev), l1b = wave_shfl(QA[CPL - 2], prev), l2a = wave_shfl(QB[CPL - 1], prev);
         float p1a = 0.f, p1b = 0.f, p2a = 0.f;
         if constexpr (!EQG) {
-            p1a = wave_shfl(PA[31], prev); p1b = wave_shfl(PA[30], prev); p2a = wave_shfl(PB[31], prev);
+            p1a = wave_shfl(PA[CPL - 1], prev); p1b = wave_shfl(PA[CPL - 2], prev); p2a = wave_shfl(PB[CPL - 1], prev);
         }
         if (lane == 0) { l1a = 0.f; l1b = 0.f; l2a = 0.f; p1a = 0.f; p1b = 0.f; p2a = 0.f; }
         unsigned wleft = 0u;                                    // bit e = R[i][j-1]
         if constexpr (DMAX) {
-            unsigned carry = (unsigned)__shfl((int)(wraw >> 31), prev, 64);
+            unsigned carry = (unsigned)__shfl((int)((wraw >> (CPL - 1)) & 1u), prev, 64);
             if (lane == 0) carry = 0u;
             wleft = (wraw << 1) | carry;
         }
 #pragma unroll
-        for (int e = 31; e >= 0; --e) {
+        for (int e = CPL - 1; e >= 0; --e) {
             const bool r = (w >> e) & 1u;
             float x3 = 0.0f, x4 = 0.0f;
             if constexpr (DMAX) {
@@ -1492,7 +1495,7 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
             if constexpr (!EQG) PB[e] = q - ((DMAX ? (((wraw >> e) & 1u) != 0u) : r) ? go : ge);
         }
 #pragma unroll
-        for (int e = 0; e < 32; e += 2) best = fmaxf(best, fmaxf(QB[e], QB[e + 1]));
+        for (int e = 0; e < CPL; e += 2) best = fmaxf(best, fmaxf(QB[e], QB[e + 1]));
         if constexpr (DMAX) wprev = wraw;
     };
 
