@@ -69,14 +69,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ACX_BENCH_BACKEND=gloo (development): functional run of the N > 1 path on a box with fewer
+    # GPUs than ranks -- ranks share the devices and the score gather goes through host memory
+    backend = os.environ.get("ACX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     # ---- synthetic pool (SURVEY 8d "rand" set), resident in HBM before timing
     data = synth.rand_set(N_TRACKS, T=T_FRAMES, seed=1234)
