@@ -26,7 +26,7 @@ EXPORTS = [
     "acx_profile_get", "acx_debug_sqrt", "acx_upload_pool_f64", "acx_simple_pairs",
     "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
     "acx_chenfusion_pairs", "acx_csm_binary_sw", "acx_upload_raw_pool", "acx_download_pool",
-    "acx_simple_upload_raw_pool", "acx_download_pool_f64",
+    "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse",
 ]
 
 
@@ -102,6 +102,9 @@ def load():
     L.acx_earlyfusion_pairs.argtypes = [vp, ip, ctypes.c_int64, ep, fp]
     L.acx_ef_debug_pair.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ep, fp, fp, fp, ip]
     L.acx_sw_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, fp]
+    L.acx_snf_fuse.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                               ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                               ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
     L.acx_csm_binary_sw.argtypes = [vp, fp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, fp]
     _lib = L
     return L
@@ -272,6 +275,20 @@ class Context(object):
         self._check(self._L.acx_csm_binary_sw(self._h, _fptr(D), D.shape[0], D.shape[1], ctypes.c_double(kappa),
                                               ctypes.byref(sc)))
         return float(sc.value)
+
+    def snf_fuse(self, Ws, Js, Vs, niters=20, reg_diag=1.0):
+        """Cross-diffusion loop of similarity network fusion on the device: Ws affinity matrices (n, n) f64,
+        (Js, Vs) their K-nearest-neighbour kernels as (n, K) index / weight arrays; returns the fused (n, n)."""
+        m = len(Ws)
+        Ws = [np.ascontiguousarray(W, dtype=np.float64) for W in Ws]
+        Js = [np.ascontiguousarray(J, dtype=np.int32) for J in Js]
+        Vs = [np.ascontiguousarray(V, dtype=np.float64) for V in Vs]
+        n, K = Js[0].shape
+        out = np.empty((n, n), np.float64)
+        arr = lambda xs: (ctypes.c_void_p * m)(*[x.ctypes.data for x in xs])
+        self._check(self._L.acx_snf_fuse(self._h, arr(Ws), arr(Js), arr(Vs), m, n, K, int(niters), float(reg_diag),
+                                         out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return out
 
     def serra09_pairs(self, pairs, params=None):
         p = params or serra09_params()

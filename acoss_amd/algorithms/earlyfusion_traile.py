@@ -165,7 +165,8 @@ class EarlyFusion(CoverAlgorithm):
         """SNF of 1/(1+D) over the three / four score matrices (earlyfusion_traile.py:200-206)."""
         def inv(s):
             return 1.0 / (1.0 + np.array(self.Ds[s], dtype=np.float64))
+        ctx = getattr(self, "_ctx", None)      # the pair grid's GPU context (None before similarity() ran: host loop)
         self.Ds["late"] = doSimilarityFusion([inv(s) for s in ("chromas", "ssms", "mfccs")],
-                                             K=20, niters=20, reg_diag=1)[1]
+                                             K=20, niters=20, reg_diag=1, ctx=ctx)[1]
         self.Ds["early+late"] = doSimilarityFusion([inv(s) for s in ("chromas", "ssms", "mfccs", "early")],
-                                                   K=20, niters=20, reg_diag=1)[1]
+                                                   K=20, niters=20, reg_diag=1, ctx=ctx)[1]

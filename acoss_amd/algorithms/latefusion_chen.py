@@ -55,7 +55,7 @@ class ChenFusion(Serra09):
     def do_late_fusion(self):
         """SNF of the two distance matrices (latefusion_chen.py:87-91): Ds["Late"] = fused
         similarity; the two inputs are negated so that larger = closer everywhere."""
-        DLate = doSimilarityFusion([self.Ds[s] for s in self.Ds], K=20, niters=20, reg_diag=1)[1]
+        DLate = doSimilarityFusion([self.Ds[s] for s in self.Ds], K=20, niters=20, reg_diag=1, ctx=getattr(self, "_ctx", None))[1]
         for key in self.Ds:
             self.Ds[key] *= -1
         self.Ds["Late"] = DLate

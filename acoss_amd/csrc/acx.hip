@@ -16,6 +16,7 @@
 #include "../../include/acx.h"
 #include "serra09_kernels.hpp"
 #include "prep_kernels.hpp"
+#include "snf_kernels.hpp"
 #include "simple_kernels.hpp"
 #include "ef_kernels.hpp"
 
@@ -1189,6 +1190,86 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
     ACX_HIP(c, hipStreamSynchronize(c->stream));
     (void)p;
     *score = sc[0];
+    return ACX_OK;
+}
+
+int acx_snf_fuse(acx_ctx *c, const double *const *Ws, const int32_t *const *Js, const double *const *Vs, int32_t m,
+                 int32_t n, int32_t K, int32_t niters, double reg_diag, double *out)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!Ws || !Js || !Vs || !out || m < 2 || m > 8 || n < 1 || K < 1 || K > n || niters < 1)
+        return fail(c, ACX_ERR_INVALID, "snf_fuse: bad argument (2 <= m <= 8, 1 <= K <= n, niters >= 1)");
+    for (int i = 0; i < m; ++i)
+        if (!Ws[i] || !Js[i] || !Vs[i]) return fail(c, ACX_ERR_INVALID, "snf_fuse: null matrix");
+    for (int i = 0; i < m; ++i)
+        for (int64_t e = 0; e < (int64_t)n * K; ++e)
+            if (Js[i][e] < 0 || Js[i][e] >= n) return fail(c, ACX_ERR_INVALID, "snf_fuse: neighbour index out of range");
+    ACX_HIP(c, hipSetDevice(c->device));
+    const size_t nn = (size_t)n * n;
+    const size_t need = ((size_t)2 * m + 2) * nn * sizeof(double) + (size_t)m * n * K * (sizeof(double) + sizeof(int32_t));
+    if (need > (size_t)(0.8 * (double)c->total_mem)) return fail(c, ACX_ERR_NOMEM, "snf_fuse: matrices do not fit the device");
+    std::vector<double *> cur(m, nullptr), nxt(m, nullptr), dV(m, nullptr);
+    std::vector<int32_t *> dJ(m, nullptr);
+    double *acc = nullptr, *ut = nullptr;
+    auto cleanup = [&]() {
+        for (int i = 0; i < m; ++i) {
+            if (cur[i]) (void)hipFree(cur[i]);
+            if (nxt[i]) (void)hipFree(nxt[i]);
+            if (dV[i]) (void)hipFree(dV[i]);
+            if (dJ[i]) (void)hipFree(dJ[i]);
+        }
+        if (acc) (void)hipFree(acc);
+        if (ut) (void)hipFree(ut);
+    };
+#define ACX_HIPC(expr_) do { const hipError_t ec_ = (expr_); if (ec_ != hipSuccess) { cleanup(); ACX_HIP(c, ec_); } } while (0)
+    ACX_HIPC(hipMalloc((void **)&acc, nn * sizeof(double)));
+    ACX_HIPC(hipMalloc((void **)&ut, nn * sizeof(double)));
+    for (int i = 0; i < m; ++i) {
+        ACX_HIPC(hipMalloc((void **)&cur[i], nn * sizeof(double)));
+        ACX_HIPC(hipMalloc((void **)&nxt[i], nn * sizeof(double)));
+        ACX_HIPC(hipMalloc((void **)&dV[i], (size_t)n * K * sizeof(double)));
+        ACX_HIPC(hipMalloc((void **)&dJ[i], (size_t)n * K * sizeof(int32_t)));
+        ACX_HIPC(hipMemcpyAsync(dV[i], Vs[i], (size_t)n * K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        ACX_HIPC(hipMemcpyAsync(dJ[i], Js[i], (size_t)n * K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        // P_i = row-normalised W_i (getP, similarity_fusion.py:101-122); `acc` is the staging buffer
+        ACX_HIPC(hipMemcpyAsync(acc, Ws[i], nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(acx::snf_rownorm_kernel, dim3(n), dim3(256), 0, c->stream, acc, cur[i], n);
+    }
+    const bool ldsrow = (size_t)n * sizeof(double) <= 160 * 1024 - 1024;
+    if (ldsrow)
+        ACX_HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(acx::snf_ast_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)n * sizeof(double))));
+    for (int it = 0; it < niters; ++it) {
+        // from the second sweep on the reference's two work lists alias: a matrix updated earlier in
+        // the sweep is already seen by the later ones (similarity_fusion.py:179)
+        std::vector<double *> &src = it == 0 ? cur : nxt;
+        for (int i = 0; i < m; ++i) {
+            acx::SnfSrc sp;
+            sp.count = 0;
+            for (int k = 0; k < m; ++k)
+                if (k != i) sp.p[sp.count++] = src[k];
+            hipLaunchKernelGGL(acx::snf_mean_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream,
+                               sp, 1.0 / (double)(m - 1), acc, (int64_t)nn);
+            if (ldsrow)
+                hipLaunchKernelGGL((acx::snf_ast_kernel<true>), dim3(n), dim3(256), (size_t)n * sizeof(double), c->stream,
+                                   acc, dJ[i], dV[i], ut, n, K);
+            else
+                hipLaunchKernelGGL((acx::snf_ast_kernel<false>), dim3(n), dim3(256), 0, c->stream, acc, dJ[i], dV[i], ut, n, K);
+            hipLaunchKernelGGL(acx::snf_sut_kernel, dim3(n), dim3(256), 0, c->stream, ut, dJ[i], dV[i], nxt[i], n, K, reg_diag);
+        }
+    }
+    {
+        acx::SnfSrc sp;
+        sp.count = m;
+        for (int k = 0; k < m; ++k) sp.p[k] = nxt[k];
+        hipLaunchKernelGGL(acx::snf_mean_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream,
+                           sp, 1.0 / (double)m, acc, (int64_t)nn);
+    }
+    ACX_HIPC(hipGetLastError());
+    ACX_HIPC(hipMemcpyAsync(out, acc, nn * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ACX_HIPC(hipStreamSynchronize(c->stream));
+#undef ACX_HIPC
+    cleanup();
     return ACX_OK;
 }
 

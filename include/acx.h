@@ -216,6 +216,24 @@ int acx_csm_binary_sw(acx_ctx *ctx, const float *D, int32_t M, int32_t N, double
  * (the reference raises IOError). */
 int acx_sw_binary(acx_ctx *ctx, const uint8_t *B, int32_t M, int32_t N, float *score);
 
+/* ---- late fusion (N x N post-step) ---------------------------------------- */
+
+/*
+ * Similarity network fusion of m affinity matrices: the cross-diffusion loop of
+ * doSimilarityFusionWs (similarity_fusion.py:146-186; EarlyFusion.do_late_fusion,
+ * earlyfusion_traile.py:200-206; LateFusionChen.do_late_fusion) in f64 on the device.
+ *   Ws[i]  (n, n) f64 row-major affinity matrix W_i (getW, :15-36 -- prepared by the host)
+ *   Js[i]  (n, K) int32, Vs[i] (n, K) f64: the row-normalised K-nearest-neighbour kernel S_i of
+ *          W_i (getS, :124-144) as K (column, weight) pairs per row
+ *   out    (n, n) f64: the fused matrix, mean of the P_i after `niters` sweeps
+ * P_i starts as the row-normalised W_i (getP, :101-122); per sweep and matrix
+ * P_i <- S_i mean_{k != i}(P_k) S_i^T + reg_diag I, where from the second sweep on a matrix updated
+ * earlier in the sweep is already seen by the later ones, as in the reference (:179).
+ * 2 <= m <= 8.  Device memory: (2 m + 2) n^2 doubles.
+ */
+int acx_snf_fuse(acx_ctx *ctx, const double *const *Ws, const int32_t *const *Js, const double *const *Vs,
+                 int32_t m, int32_t n, int32_t K, int32_t niters, double reg_diag, double *out);
+
 /* ---- measurement -------------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on the library's own stream around
