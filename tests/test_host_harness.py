@@ -296,3 +296,23 @@ def test_earlyfusion_block_feature_preparation(tmp_path, monkeypatch):
     ef = EarlyFusion(csv, root, chroma_type="hpcp", shortname="toy", log_times=True)
     got = ef.load_features(1)
     assert got["mfccs"].shape == (nb, 650) and ef.load_features(1) is got and len(ef.times["features"]) == 1
+
+
+def test_snf_neighbour_lists_equal_the_stable_sort():
+    """_knn_lists (argpartition + repair of rows tied across the cut) == the first K of a stable
+    descending argsort, also with heavy ties; and the dense kernel built from it row-sums to 1."""
+    from acoss_amd.algorithms import similarity_fusion as sf
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        n = int(rng.integers(5, 70))
+        K = int(rng.integers(1, n + 1))
+        W = rng.random((n, n))
+        if trial % 3 == 0:
+            W = np.round(W * 4) / 4
+        if trial % 7 == 0:
+            W[:] = 0.5
+        J, V = sf._knn_lists(W, K)
+        assert J.dtype == np.int32 and np.array_equal(J, np.argsort(-W, 1, kind="stable")[:, :K])
+        assert np.allclose(V.sum(1), 1.0)
+        S = sf._knn_kernel(W, K)
+        assert np.all((S > 0).sum(1) <= K) and np.allclose(S.sum(1), 1.0)
