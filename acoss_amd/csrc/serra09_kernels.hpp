@@ -1101,11 +1101,7 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
 
     const int pitchD = P.pitchD;
     float *D = scratch + P.offD + (size_t)i0 * pitchD;
-    float xv[BAND][NSTEP];
-#pragma unroll
-    for (int a = 0; a < BAND; ++a)
-#pragma unroll
-        for (int st = 0; st < NSTEP; ++st) xv[a][st] = INF;
+    float xv[BAND][NSTEP];      // (every element is written below: cells of a tile, or +inf for a tile past the row)
 
     auto keep = [&](auto st_tag, int tile, const float (&dv)[BAND]) {     // cells -> xv (+ debug D2)
         constexpr int st = decltype(st_tag)::value;
@@ -1158,6 +1154,9 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
             walk(sv, yv, dv);
             keep(st_tag, tile, dv);
             wave_lds_fence();
+        } else {
+#pragma unroll
+            for (int a = 0; a < BAND; ++a) xv[a][st] = INF;
         }
     });
     ACX_T(2);
