@@ -139,13 +139,18 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
             }
         }
     };
+    // k-row k of the LDS tiles keeps its 64 rows XORed with 16 (k / 12 mod 4): the four threads that
+    // stage one row (k = 12 q + e, q = 0..3) then land in four different bank groups -- without it all
+    // four hit the same bank (12 * 80 = 0 mod 64) and half the LDS cycles were conflicts -- while the
+    // operand reads (one k / 12 group per MFMA step) stay conflict free
+    const int swrow = srow ^ (16 * (tid & 3));
     auto lstore = [&]() {
 #pragma unroll
         for (int e = 0; e < 12; ++e) {
             // A[k] multiplies B[k'] with k' = k - c + (c + rot) mod 12, c = k mod 12 = e here
             int ea = e + rot; ea = ea >= 12 ? ea - 12 : ea;
-            As[(sk + ea) * EF_LP + srow] = ra[e];
-            Bs[(sk + e) * EF_LP + srow] = rb[e];
+            As[(sk + ea) * EF_LP + swrow] = ra[e];
+            Bs[(sk + e) * EF_LP + swrow] = rb[e];
         }
     };
     gload(0);
@@ -157,9 +162,9 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
         for (int kb = 0; kb < EF_BK / 4; ++kb) {
             float av[2], bv[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) av[a] = As[(4 * kb + lk) * EF_LP + 32 * wr + 16 * a + lr];
+            for (int a = 0; a < 2; ++a) av[a] = As[(4 * kb + lk) * EF_LP + ((32 * wr + 16 * a + lr) ^ (16 * ((kb / 3) & 3)))];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bv[b] = Bs[(4 * kb + lk) * EF_LP + 32 * wc + 16 * b + lr];
+            for (int b = 0; b < 2; ++b) bv[b] = Bs[(4 * kb + lk) * EF_LP + ((32 * wc + 16 * b + lr) ^ (16 * ((kb / 3) & 3)))];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
