@@ -120,37 +120,51 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
     const float *Bp = F + (boff[P.r] + (rowb ? j0 + srow : 0)) * K + sk;
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     float ra[12], rb[12];
-    auto gload = [&](int k0) {
+    // Every instruction here competes with the MFMAs for the SIMD (an f32 MFMA blocks VALU and LDS
+    // issue), so the staging is kept to the bare loads / stores: full 48-k blocks take the unchecked
+    // path (three dwordx4 per operand off a running pointer), only the last partial block checks k.
+    const float *ap = Ap, *bp = Bp;                   // start of the block being loaded
+    auto gload_full = [&]() {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const int k = k0 + sk + 4 * q;
-            if (k + 3 < K) {                       // whole 16 bytes inside the row
-                const f32x4 va = *reinterpret_cast<const f32x4u *>(Ap + k0 + 4 * q);
-                const f32x4 vb = *reinterpret_cast<const f32x4u *>(Bp + k0 + 4 * q);
+            const f32x4 va = *reinterpret_cast<const f32x4u *>(ap + 4 * q);
+            const f32x4 vb = *reinterpret_cast<const f32x4u *>(bp + 4 * q);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ra[4 * q + e] = rowa ? va[e] : 0.f; rb[4 * q + e] = rowb ? vb[e] : 0.f; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = k + e < K;
-                    ra[4 * q + e] = (ok && rowa) ? Ap[k0 + 4 * q + e] : 0.f;
-                    rb[4 * q + e] = (ok && rowb) ? Bp[k0 + 4 * q + e] : 0.f;
-                }
-            }
+            for (int e = 0; e < 4; ++e) { ra[4 * q + e] = va[e]; rb[4 * q + e] = vb[e]; }   // (rows past the matrix read row 0; never stored)
         }
+        ap += EF_BK;
+        bp += EF_BK;
+    };
+    auto gload_tail = [&](int k0) {                   // the block that crosses K: element-wise, zeros beyond K
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const bool ok = k0 + sk + e < K;
+            ra[e] = ok ? ap[e] : 0.f;
+            rb[e] = ok ? bp[e] : 0.f;
+        }
+    };
+    auto gload = [&](int k0) {
+        if (k0 + EF_BK <= K) gload_full();            // workgroup-uniform
+        else gload_tail(k0);
     };
     // k-row k of the LDS tiles keeps its 64 rows XORed with 16 (k / 12 mod 4): the four threads that
     // stage one row (k = 12 q + e, q = 0..3) then land in four different bank groups -- without it all
     // four hit the same bank (12 * 80 = 0 mod 64) and half the LDS cycles were conflicts -- while the
     // operand reads (one k / 12 group per MFMA step) stay conflict free
     const int swrow = srow ^ (16 * (tid & 3));
+    float *as0 = As + sk * EF_LP + swrow, *bs0 = Bs + sk * EF_LP + swrow;
     auto lstore = [&]() {
+        if (rot == 0) {                                // workgroup-uniform: all offsets are immediates
 #pragma unroll
-        for (int e = 0; e < 12; ++e) {
-            // A[k] multiplies B[k'] with k' = k - c + (c + rot) mod 12, c = k mod 12 = e here
-            int ea = e + rot; ea = ea >= 12 ? ea - 12 : ea;
-            As[(sk + ea) * EF_LP + swrow] = ra[e];
-            Bs[(sk + e) * EF_LP + swrow] = rb[e];
+            for (int e = 0; e < 12; ++e) { as0[e * EF_LP] = ra[e]; bs0[e * EF_LP] = rb[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                // A[k] multiplies B[k'] with k' = k - c + (c + rot) mod 12, c = k mod 12 = e here
+                int ea = e + rot; ea = ea >= 12 ? ea - 12 : ea;
+                as0[ea * EF_LP] = ra[e];
+                bs0[e * EF_LP] = rb[e];
+            }
         }
     };
     gload(0);
