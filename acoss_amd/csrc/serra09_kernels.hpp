@@ -555,7 +555,10 @@ struct OpMaxI { __device__ int operator()(int a, int b) const { return a > b ? a
 #else
 #define ACX_TS(k) do { } while (0)
 #endif
-template <int NV, int BINS, int COPIES = 1>
+// NEGPAD: pads are negative instead of +inf.  They are skipped by the range pass without the bias
+// add, fall into bin 0 (the conversion saturates at 0) and rank below every cell, so the caller
+// passes k already raised by the number of pads that take part in the histogram.
+template <int NV, int BINS, int COPIES = 1, bool NEGPAD = false>
 __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bool want_next, unsigned hist_addr,
                                                  float *cand, int lane, float &slo, float &shi,
                                                  unsigned long long *tsel = nullptr, bool lane_has_data = true)
@@ -578,14 +581,15 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
     for (int t = 0; t < NV; ++t) {
         const unsigned b = __float_as_uint(x[t]);
         mnu = b < mnu ? b : mnu;
-        const int bb = (int)(b + 0x00800000u);
+        const int bb = NEGPAD ? (int)b : (int)(b + 0x00800000u);
         mxb = bb > mxb ? bb : mxb;
     }
     mnu = (unsigned)__builtin_amdgcn_readlane(wave_scan_bits((int)mnu, -1, OpMinU()), 63);
     mxb = __builtin_amdgcn_readlane(wave_scan_bits(mxb, (int)0x80000000, OpMaxI()), 63);
     const float mn = __uint_as_float(mnu);
-    const float mx = __uint_as_float((unsigned)mxb - 0x00800000u);
+    const float mx = __uint_as_float(NEGPAD ? (unsigned)mxb : (unsigned)mxb - 0x00800000u);
     if (mxb < 0) return false;                       // no finite cell at all
+    if (NEGPAD && (int)mnu < 0) return false;        // (only pads: cannot happen for a row of the matrix)
     if (!(mn < mx)) { slo = mn; shi = mn; return true; }   // every finite cell equal
     const float range = mx - mn;
     // y = fma(x, scale4, off4) is monotone in x; the rounding of off4 shifts every y by the same
@@ -671,7 +675,11 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
     if (ncand > 64 || bin2 >= NB - 1) return false;
     ACX_TS(3);
     // ---- gather the members of [bin1, bin2]
-    const unsigned a1 = hb + 4u * COPIES * (unsigned)bin1, span = 4u * COPIES * (unsigned)(bin2 - bin1);
+    unsigned a1 = hb + 4u * COPIES * (unsigned)bin1;
+    const unsigned span = 4u * COPIES * (unsigned)(bin2 - bin1);
+    // (NEGPAD: the pads of the lanes that stayed out of the histogram share bin 0's address; give those
+    // lanes a target no address matches)
+    if (NEGPAD && !lane_has_data) a1 = 0x7fffffffu;
     int n = 0;
     auto put = [&](unsigned long long m, bool hit, float v) {
         if (m != 0ull) {
@@ -987,6 +995,10 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     const float *nrow = normtab + noff[role ? P.r : P.q] + (int64_t)rota * MA;
     const float *ncol = normtab + noff[role ? P.q : P.r] + (int64_t)rotb * MB;
     const float INF = __builtin_inff();
+    // Cells outside the matrix travel through the exchange as -1: distances are >= +0, so a negative
+    // pad is the largest UNSIGNED and the smallest SIGNED bit pattern -- the selection's integer min /
+    // max skip it for free (a +inf pad needed a bias add per value for the max)
+    const float PADV = -1.0f;
 #ifdef ACX_TIMING
     unsigned long long tstamp[16];
     unsigned long long tsub[4] = {0, 0, 0, 0};
@@ -1125,7 +1137,7 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
                 const bool rowok = (i0 + a) < MA;
                 const bool ok = rowok && j >= 0 && j < MB;
                 const float v = ok ? dv[a] : INF;
-                xv[a][st] = v;
+                xv[a][st] = ok ? dv[a] : PADV;
                 if (write_d2 && rowok && j >= 0 && j < pitchD) D[a * pitchD + j] = v;
             }
         }
@@ -1156,7 +1168,7 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
             wave_lds_fence();
         } else {
 #pragma unroll
-            for (int a = 0; a < BAND; ++a) xv[a][st] = INF;
+            for (int a = 0; a < BAND; ++a) xv[a][st] = PADV;
         }
     });
     ACX_T(2);
@@ -1280,21 +1292,28 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
         wave_lds_fence();
     }
     bool done = false;
-    const bool lane_has_data = lane * NV < MB + (BAND - 1) - wave;      // first position of the lane is a cell or a low pad
+    const int end_valid = MB + (BAND - 1) - wave;                       // positions [7 - wave, end_valid) are cells
+    const bool lane_has_data = lane * NV < end_valid;                   // first position of the lane is a cell or a low pad
+    // pads inside the lanes that take part in the histogram: the low ones of lane 0 and the tail of the
+    // last lane with cells; they sit in bin 0 and rank below every cell
+    const int npadc = ((BAND - 1) - wave) + (((end_valid + NV - 1) / NV) * NV - end_valid);
 #ifndef ACX_NO_FASTSEL
 #ifdef ACX_TIMING
     unsigned long long tsel[6] = {0, 0, 0, 0, 0, 0};
-    done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, tsel, lane_has_data);
+    done = wave_select_fast<NV, FBINS, FCOPIES, true>(xr, k + npadc, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, tsel, lane_has_data);
     if (lane == 0 && done && tsel[5] && (blockIdx.x & 31) == 5) for (int q = 0; q < 5; ++q) atomicAdd(&acx_tim[20 + q], tsel[q + 1] - tsel[q]);
     if (lane == 0 && (blockIdx.x & 31) == 5) atomicAdd(&acx_tim[done ? 26 : 25], 1ull);      // fast-path hits / fallbacks
 #else
-    done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, nullptr, lane_has_data);
+    done = wave_select_fast<NV, FBINS, FCOPIES, true>(xr, k + npadc, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, nullptr, lane_has_data);
 #endif
 #endif
     if (!done) {
         unsigned *ghist = reinterpret_cast<unsigned *>(myrow) + 64;
         unsigned *counter = reinterpret_cast<unsigned *>(myrow) + 64 + SelGeom<GBINS>::SLOTS;
-        const SelectResult sr = wave_select_regs<NV, GBINS>(xr, k, ghist, myrow, counter, lane, interp);
+        float xi[NV];                                   // the generic selection wants its pads at +inf
+#pragma unroll
+        for (int t = 0; t < NV; ++t) xi[t] = xr[t] < 0.0f ? INF : xr[t];
+        const SelectResult sr = wave_select_regs<NV, GBINS>(xi, k, ghist, myrow, counter, lane, interp);
         slo = sr.value;
         shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
     }
