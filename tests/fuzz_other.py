@@ -1,5 +1,5 @@
-"""Development aid: randomised GPU-vs-oracle comparison of the SiMPle, Smith-Waterman, EarlyFusion and
-ChenFusion entry points.   usage: python scripts/fuzz_other.py [seconds] [seed]"""
+"""Test aid (not collected by pytest; needs a GPU): randomised GPU-vs-oracle comparison of the SiMPle, Smith-Waterman, EarlyFusion and
+ChenFusion entry points.   usage: python tests/fuzz_other.py [seconds] [seed]"""
 import sys
 import time
 

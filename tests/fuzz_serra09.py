@@ -1,5 +1,5 @@
-"""Development aid: randomised GPU-vs-oracle comparison of Serra09 scores (sizes, parameters, ties).
-usage: python scripts/fuzz_serra09.py [seconds] [seed]"""
+"""Test aid (not collected by pytest; needs a GPU): randomised GPU-vs-oracle comparison of Serra09 scores (sizes, parameters, ties).
+usage: python tests/fuzz_serra09.py [seconds] [seed]"""
 import sys
 import time
 
