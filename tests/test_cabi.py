@@ -42,3 +42,18 @@ def test_no_silent_cpu_fallback():
         pytest.skip("GPU present")
     with pytest.raises(_lib.AcxError):
         _lib.Context(0)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under acoss_amd/ (nor the C sources) may import,
+    load or link it."""
+    pkg = os.path.join(ROOT, "acoss_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for name in files:
+            if name.endswith((".py", ".hip", ".hpp", ".h")) or name == "Makefile":
+                txt = open(os.path.join(dirpath, name), errors="ignore").read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), (dirpath, name)
+                assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", txt), (dirpath, name)
+                assert not re.search(r"(CDLL|LoadLibrary|-l\s*acx_oracle|libacx_oracle)", txt) or name == "_lib.py", (dirpath, name)
+                if name == "_lib.py":
+                    assert "oracle" not in txt
