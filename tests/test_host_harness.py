@@ -173,7 +173,7 @@ def test_chenfusion_class_surface(tmp_path, monkeypatch):
     np.testing.assert_allclose(got[off], want[off].astype(np.float32), rtol=1e-6)
     assert np.all(np.isinf(np.diag(got)))
     dq, dd = np.array(c.Ds["qmax"]), np.array(c.Ds["dmax"])
-    c.do_late_fusion()
+    c.do_late_fusion(host=True)          # (the device loop is covered by tests/test_gpu_snf.py)
     assert list(c.Ds.keys()) == ["qmax", "dmax", "Late"]
     np.testing.assert_array_equal(np.array(c.Ds["qmax"]), -dq)
     np.testing.assert_allclose(c.Ds["Late"], oracle.snf_fuse([dq, dd], K=20, niters=20, reg_diag=1)[1], rtol=1e-9, atol=1e-12)
@@ -244,7 +244,7 @@ def test_earlyfusion_class_surface(tmp_path, monkeypatch):
     for s in ("mfccs", "ssms", "chromas", "early"):
         D = rng.random((30, 30)) * 5
         big.Ds[s] = D + D.T
-    big.do_late_fusion()
+    big.do_late_fusion(host=True)
     assert big.Ds["late"].shape == (30, 30) and big.Ds["early+late"].shape == (30, 30)
     assert np.all(np.isfinite(big.Ds["late"]))
 
