@@ -1038,18 +1038,21 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     typedef float BvT[G::NCT][3];
     typedef f32x4 AccT[G::NRT][G::NCT];
     // column-frame operands of a tile (frames 64 tile - 7 ... + BW)
-    auto load_operands = [&](int tile, BvT &bv) {
+    // (tb0: first 16-frame block wanted -- a wave's second and later tiles inherit their first HB
+    // blocks from the tile before, see the sweep)
+    auto load_operands = [&](int tile, BvT &bv, auto tb0_tag) {
+        constexpr int tb0 = decltype(tb0_tag)::value;
         const int base = 64 * tile - (BAND - 1);
         if (base >= 0 && base + G::BW <= TB) {                  // wave-uniform: all frames exist
             const float *p = frb + (ptrdiff_t)(base + lr) * FROT;
 #pragma unroll
-            for (int tb = 0; tb < G::NCT; ++tb) {
+            for (int tb = tb0; tb < G::NCT; ++tb) {
                 const f32x3 v = *reinterpret_cast<const f32x3_u *>(p + 16 * FROT * tb);
                 bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
             }
         } else {                                                // clamp: those cells are masked anyway
 #pragma unroll
-            for (int tb = 0; tb < G::NCT; ++tb) {
+            for (int tb = tb0; tb < G::NCT; ++tb) {
                 int f = base + 16 * tb + lr;
                 f = f < 0 ? 0 : (f > TB - 1 ? TB - 1 : f);
                 const f32x3 v = *reinterpret_cast<const f32x3_u *>(frb + (ptrdiff_t)f * FROT);
@@ -1077,24 +1080,26 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     // up with four consecutive column frames of one row frame: one 16-byte LDS store per 16x16 tile
     // (products commute, the k order is unchanged: same bits).  Chains interleaved k-step-major so
     // that no MFMA waits on its predecessor.
-    auto gram = [&](const BvT &bv, AccT &acc) {
+    auto gram = [&](const BvT &bv, AccT &acc, auto tb0_tag) {
+        constexpr int tb0 = decltype(tb0_tag)::value;
 #pragma unroll
         for (int ta = 0; ta < G::NRT; ++ta)
 #pragma unroll
-            for (int tb = 0; tb < G::NCT; ++tb) acc[ta][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int tb = tb0; tb < G::NCT; ++tb) acc[ta][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
             for (int ta = 0; ta < G::NRT; ++ta)
 #pragma unroll
-                for (int tb = 0; tb < G::NCT; ++tb)
+                for (int tb = tb0; tb < G::NCT; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[tb][kb], areg[ta][kb], acc[ta][tb], 0, 0, 0);
     };
-    auto store_gram = [&](const AccT &acc) {
+    auto store_gram = [&](const AccT &acc, auto tb0_tag) {
+        constexpr int tb0 = decltype(tb0_tag)::value;
 #pragma unroll
         for (int ta = 0; ta < G::NRT; ++ta)
 #pragma unroll
-            for (int tb = 0; tb < G::NCT; ++tb)
+            for (int tb = tb0; tb < G::NCT; ++tb)
                 *reinterpret_cast<f32x4 *>(Sw + (16 * ta + lr) * G::SP + 16 * tb + 4 * lk) = acc[ta][tb];
     };
     // diagonal walk: lane c owns the 8 cells (a, c + a); m + 7 Gram values give all 8 window sums
@@ -1143,21 +1148,44 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
         }
     };
 
-    // ---- sweep: wave w takes tiles w, w + 8, ...; the operands of the next tile are in flight
-    // (plain global loads, L2 / L1 resident) while the current one is worked on.
+    // ---- sweep: wave w takes CONSECUTIVE tiles w cpw .. w cpw + cpw - 1 (cpw = ceil(ntiles / 8)); the
+    // operands of the next tile are in flight (plain global loads, L2 / L1 resident) while the current
+    // one is worked on.  Consecutive tiles overlap by the halo: the last HB 16-frame blocks of one
+    // tile's Gram ARE the first HB of the next, so from its second tile on a wave stores them again from
+    // registers at their new place and multiplies only the four new blocks -- 12 instead of 15 MFMAs
+    // per tile at m = 9 (an f32 MFMA blocks the SIMD for 32 cycles), and four operand loads instead of five.
+    constexpr int HB = G::NCT - 4;                       // halo blocks shared with the neighbouring tile
+    const int cpw = (ntiles + 7) >> 3;                   // tiles per wave (<= NSTEP)
+    // tile of step st: a computed one, or (st >= cpw) one of the tiles past all data that this wave pads
+    auto tile_of = [&](int st) { return st < cpw ? wave * cpw + st : 8 * cpw + wave * (NSTEP - cpw) + (st - cpw); };
     BvT bvbuf[2];
-    if (wave < ntiles) load_operands(wave, bvbuf[0]);
+    f32x4 halo[G::NRT][HB];
+    if (wave * cpw < ntiles) load_operands(wave * cpw, bvbuf[0], std::integral_constant<int, 0>());
     static_for<0, NSTEP>([&](auto st_tag) {
         constexpr int st = decltype(st_tag)::value;
-        const int tile = wave + 8 * st;
-        if (tile < ntiles) {      // wave-uniform
+        constexpr int tb0 = st == 0 ? 0 : HB;            // first block this step computes
+        const int tile = tile_of(st);
+        if (st < cpw && tile < ntiles) {      // wave-uniform
             float yv[BAND];
             load_norms(tile, yv);
-            if (st + 1 < NSTEP && tile + 8 < ntiles) load_operands(tile + 8, bvbuf[(st + 1) & 1]);
+            if (st + 1 < NSTEP && st + 1 < cpw && tile + 1 < ntiles)
+                load_operands(tile + 1, bvbuf[(st + 1) & 1], std::integral_constant<int, HB>());
+            if constexpr (st > 0) {
+                // inherit the halo: block 4 + h of the previous tile is block h of this one (still in registers)
+#pragma unroll
+                for (int ta = 0; ta < G::NRT; ++ta)
+#pragma unroll
+                    for (int h = 0; h < HB; ++h)
+                        *reinterpret_cast<f32x4 *>(Sw + (16 * ta + lr) * G::SP + 16 * h + 4 * lk) = halo[ta][h];
+            }
             {
                 AccT acc;
-                gram(bvbuf[st & 1], acc);
-                store_gram(acc);
+                gram(bvbuf[st & 1], acc, std::integral_constant<int, tb0>());
+                store_gram(acc, std::integral_constant<int, tb0>());
+#pragma unroll
+                for (int ta = 0; ta < G::NRT; ++ta)
+#pragma unroll
+                    for (int h = 0; h < HB; ++h) halo[ta][h] = acc[ta][4 + h];
             }
             wave_lds_fence();
             float sv[M + BAND - 1], dv[BAND];
@@ -1193,11 +1221,13 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     constexpr int LPT = 64 / NV == 0 ? 1 : 64 / NV;     // lanes of the owner per 64-position tile
     static_assert(NV == 8 || NV == 16 || NV == 32, "row owners hold 8, 16 or 32 consecutive positions");
     {
-        const int wl = lane ^ (4 * (wave & (CH - 1)));
 #pragma unroll
-        for (int a = 0; a < BAND; ++a)
+        for (int st = 0; st < NSTEP; ++st) {
+            const int T = tile_of(st);
+            float *dst = smem + 64 * T + (lane ^ (4 * (T & (CH - 1))));
 #pragma unroll
-            for (int st = 0; st < NSTEP; ++st) smem[a * ROWP + 64 * (wave + 8 * st) + wl] = xv[a][st];
+            for (int a = 0; a < BAND; ++a) dst[a * ROWP] = xv[a][st];
+        }
     }
     if constexpr (!HIST_IN_ROW) {   // zero this wave's fast histogram
         float *h = smem + HIST_OFF + wave * HIST_STRIDE;
