@@ -201,20 +201,12 @@ void launch_csm_m(acx_ctx *c, int m, dim3 grid, int tiles_x, int oti_target)
     }
 }
 
-template <int M>
-void launch_band(acx_ctx *c, const PairDesc *dpd, int B, int maxRows, int maxCols, const acx_serra09_params &p, int role, int write_d2)
+// band_kernel is launched from its own translation unit (acx_band.hip)
+bool launch_band(acx_ctx *c, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, const acx_serra09_params &p, int role, int write_d2)
 {
-    const dim3 grid((maxRows + acx::BAND - 1) / acx::BAND, B, 1);
-    const int ndata = (maxCols + acx::BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
-#define ACX_BAND_R(V4_, R_) hipLaunchKernelGGL((acx::band_kernel<M, V4_, R_>), grid, dim3(acx::BAND_THREADS), 0, c->stream, \
-                                         c->d_frot, c->d_toff, c->d_normtab, c->d_noff, dpd, c->d_scratch, c->d_thr, c->d_bits, p.kappa, \
-                                         p.pct_mode, p.inclusive, p.oti_target, write_d2)
-#define ACX_BAND(V4_) do { if (role) ACX_BAND_R(V4_, 1); else ACX_BAND_R(V4_, 0); } while (0)
-    if (ndata <= 8) ACX_BAND(2);
-    else if (ndata <= 16) ACX_BAND(4);
-    else ACX_BAND(8);
-#undef ACX_BAND_R
-#undef ACX_BAND
+    acx::BandLaunch L{c->stream, c->d_frot, c->d_toff, c->d_normtab, c->d_noff, c->d_scratch, c->d_thr, c->d_bits,
+                      p.kappa, p.pct_mode, p.inclusive, p.oti_target};
+    return acx::launch_band_kernel(L, m, dpd, B, maxRows, maxCols, role, write_d2);
 }
 
 template <int M>
@@ -424,15 +416,11 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                 const int cmax = std::max(cMq, cMr);
                 {   // K1' role 1: rows = reference frames -> column thresholds
                     ProfScope ps(c, KS_BAND, ccells);
-#define ACX_CALL(M_) launch_band<M_>(c, c->d_pd + b0, Bc, cMr, cmax, p, 1, 0)
-                    ACX_M_SWITCH(p.m, ACX_CALL)
-#undef ACX_CALL
+                    launch_band(c, p.m, c->d_pd + b0, Bc, cMr, cmax, p, 1, 0);
                 }
                 {   // K1' role 0: rows = query frames -> row thresholds + recurrence bitmap (needs role 1)
                     ProfScope ps(c, KS_BAND, ccells);
-#define ACX_CALL(M_) launch_band<M_>(c, c->d_pd + b0, Bc, cMq, cmax, p, 0, dbg ? 1 : 0)
-                    ACX_M_SWITCH(p.m, ACX_CALL)
-#undef ACX_CALL
+                    launch_band(c, p.m, c->d_pd + b0, Bc, cMq, cmax, p, 0, dbg ? 1 : 0);
                 }
             }
         }
@@ -1300,11 +1288,7 @@ int acx_profile_get(acx_ctx *c, int idx, char *name, int name_len, double *ms, i
 /* development builds only: read (and optionally clear) band_kernel's per-phase clock totals */
 int acx_debug_timing(acx_ctx *c, unsigned long long *out32, int reset)
 {
-    ACX_HIP(c, hipMemcpyFromSymbol(out32, HIP_SYMBOL(acx::acx_tim), sizeof(unsigned long long) * 32));
-    if (reset) {
-        unsigned long long z[32] = {0};
-        ACX_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(acx::acx_tim), z, sizeof(z)));
-    }
+    ACX_HIP(c, acx::band_timing(out32, reset));       // the counters live with the kernel, in acx_band.hip
     return ACX_OK;
 }
 #endif

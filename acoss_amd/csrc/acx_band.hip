@@ -1,0 +1,60 @@
+// libacx: launcher of the Serra09 band kernel (serra09_kernels.hpp, K1').  A translation unit of its
+// own: the Makefile compiles it with -mllvm -amdgpu-sched-strategy=max-ilp, which gives this kernel
+// +1 % and would cost simple_kernel 26 % and ef_rowstat_kernel 20 %.
+#include <hip/hip_runtime.h>
+
+#include "serra09_kernels.hpp"
+
+namespace acx {
+
+namespace {
+
+template <int M>
+void launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2)
+{
+    const dim3 grid((maxRows + BAND - 1) / BAND, B, 1);
+    const int ndata = (maxCols + BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
+#define ACX_BAND_R(V4_, R_) hipLaunchKernelGGL((band_kernel<M, V4_, R_>), grid, dim3(BAND_THREADS), 0, L.stream, \
+                                               L.frot, L.toff, L.normtab, L.noff, dpd, L.scratch, L.thr, L.bits, L.kappa, \
+                                               L.pct_mode, L.inclusive, L.oti_target, write_d2)
+#define ACX_BAND(V4_) do { if (role) ACX_BAND_R(V4_, 1); else ACX_BAND_R(V4_, 0); } while (0)
+    if (ndata <= 8) ACX_BAND(2);
+    else if (ndata <= 16) ACX_BAND(4);
+    else ACX_BAND(8);
+#undef ACX_BAND_R
+#undef ACX_BAND
+}
+
+}  // namespace
+
+bool launch_band_kernel(const BandLaunch &L, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2)
+{
+    switch (m) {
+#define ACX_CASE(M_) case M_: launch_band_m<M_>(L, dpd, B, maxRows, maxCols, role, write_d2); return true;
+#ifdef ACX_FAST_BUILD   /* development builds: only the default stack size */
+#ifndef ACX_FAST_BUILD_M
+#define ACX_FAST_BUILD_M 9
+#endif
+        ACX_CASE(ACX_FAST_BUILD_M)
+#else
+        ACX_CASE(1) ACX_CASE(2) ACX_CASE(3) ACX_CASE(4) ACX_CASE(5) ACX_CASE(6) ACX_CASE(7) ACX_CASE(8)
+        ACX_CASE(9) ACX_CASE(10) ACX_CASE(11) ACX_CASE(12) ACX_CASE(13) ACX_CASE(14) ACX_CASE(15) ACX_CASE(16)
+#endif
+#undef ACX_CASE
+    }
+    return false;
+}
+
+#ifdef ACX_TIMING
+hipError_t band_timing(unsigned long long *out32, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(acx_tim), sizeof(unsigned long long) * 32);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[32] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(acx_tim), z, sizeof(z));
+    }
+    return e;
+}
+#endif
+
+}  // namespace acx

@@ -98,7 +98,7 @@ __device__ __forceinline__ float tree_sum(const float *s)
 // ------------------------------------------------------------------------------------
 // K0: OTI.  argmax_s <ga, roll(gb, s)>, s = 0..12, first max wins; separate mul / add.
 // ------------------------------------------------------------------------------------
-__global__ void oti_kernel(PairDesc *pd, int B, const float *__restrict__ gch, int oti_on, int oti_target)
+static __global__ void oti_kernel(PairDesc *pd, int B, const float *__restrict__ gch, int oti_on, int oti_target)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
@@ -884,7 +884,7 @@ constexpr int FROT = 3 * NBIN;      // floats per frame of the rotated frame poo
 
 // Rotated frame pool for the band kernel's MFMA operands (built once per upload): frame f ->
 // frot[f][r][cls][kb] = frame[f][cls + 4 ((r + kb) mod 3)], r = 0..2, cls = 0..3, kb = 0..2.
-__global__ void rotpool_kernel(const float *__restrict__ pool, float *__restrict__ frot, int64_t nframes)
+static __global__ void rotpool_kernel(const float *__restrict__ pool, float *__restrict__ frot, int64_t nframes)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one output float each
     if (idx >= nframes * FROT) return;
@@ -897,10 +897,30 @@ __global__ void rotpool_kernel(const float *__restrict__ pool, float *__restrict
 // Development aid (-DACX_TIMING): per-phase shader-clock totals of band_kernel, summed over all
 // waves into acx_tim[] (slot 31 = number of waves).  Not compiled into the product library.
 #ifdef ACX_TIMING
-__device__ unsigned long long acx_tim[32];
+static __device__ unsigned long long acx_tim[32];
 #define ACX_T(k) do { tstamp[k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define ACX_T(k) do { } while (0)
+#endif
+
+// Host-side launcher of band_kernel: its own translation unit (acx_band.hip), so that the kernel
+// can be compiled with the scheduling strategy that suits it without touching the others.
+struct BandLaunch {
+    hipStream_t stream;
+    const float *frot;
+    const int64_t *toff;
+    const float *normtab;
+    const int64_t *noff;
+    float *scratch, *thr;
+    unsigned long long *bits;
+    float kappa;
+    int pct_mode, inclusive, oti_target;
+};
+// role 1 / 0 over B pairs of one size class; false when the stack size m has no instantiation
+bool launch_band_kernel(const BandLaunch &L, int m, const struct PairDesc *dpd, int B, int maxRows, int maxCols, int role,
+                        int write_d2);
+#ifdef ACX_TIMING
+hipError_t band_timing(unsigned long long *out32, int reset);      // development builds: per-phase clock totals
 #endif
 
 template <int M>
@@ -1719,7 +1739,7 @@ __global__ __launch_bounds__(64) void qmax_kernel(const PairDesc *__restrict__ p
     if (lane == 0) out[blockIdx.x] = best;
 }
 
-__global__ void sqrt_probe_kernel(const float *in, float *out, int64_t n)
+static __global__ void sqrt_probe_kernel(const float *in, float *out, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = __builtin_sqrtf(in[i]);
