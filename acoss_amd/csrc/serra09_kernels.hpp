@@ -968,7 +968,8 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     constexpr int role = ROLE;           // 1: rows = reference frames (column thresholds); 0: rows = query frames
     constexpr int NV = 4 * V4;           // values per lane of a complete row
     constexpr int NSTEP = NV / 8;        // tiles per wave
-    constexpr int ROWP = 64 * NV;        // exchange pitch (floats): row a = [wave w'][lane][step]
+    constexpr int LNP = NV + 4;          // floats per owner lane in an exchange row: its NV positions + 16 bytes of pad
+    constexpr int ROWP = 64 * LNP;       // exchange pitch (floats)
     // Fast selection: FBINS counters = FBINS / FCOPIES bins x FCOPIES copies.  (Copies spread
     // same-address atomics -- they paid while one instruction handled 64 NEIGHBOURING columns; with
     // the position-order rows below one copy and twice the bins measure best on every workload.)
@@ -985,11 +986,9 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
 #else
     constexpr int FCOPIES = 1;
 #endif
-    constexpr bool HIST_IN_ROW = ROWP >= 2 * FBINS;
+    constexpr bool HIST_IN_ROW = ROWP >= 64 + 2 * FBINS;        // room for an FBINS-aligned block behind the 64 candidate slots
     constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
     constexpr int SWEEP_FLOATS = 8 * G::AROWS * G::SP;          // one Gram tile per wave
-    constexpr int HIST_OFF = HIST_IN_ROW ? ROWP - FBINS : BAND * ROWP;     // float offset of wave 0's histogram
-    constexpr int HIST_STRIDE = HIST_IN_ROW ? ROWP : FBINS;                // ... and from wave to wave
     constexpr int TAIL_FLOATS = BAND * ROWP + (HIST_IN_ROW ? 0 : 8 * FBINS);
 #ifdef ACX_LDS_PAD      /* experiment: force one workgroup per CU */
     constexpr int LDS_FLOATS = 24 * 1024;
@@ -997,7 +996,7 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     constexpr int LDS_FLOATS = SWEEP_FLOATS > TAIL_FLOATS ? SWEEP_FLOATS : TAIL_FLOATS;
 #endif
     static_assert(SelGeom<GBINS>::SLOTS + 64 + 4 <= ROWP, "generic selection must fit the wave's own exchange row");
-    static_assert(HIST_OFF % FBINS == 0 && HIST_STRIDE % FBINS == 0, "fast histograms must be aligned to their size");
+    static_assert(HIST_IN_ROW || (BAND * ROWP) % FBINS == 0, "fast histograms must be aligned to their size");
     __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
 
     const int bid_x = blockIdx.x, bid_y = blockIdx.y;
@@ -1234,23 +1233,27 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     // lane <-> column p - 7 + a), so that the owner of the row can pick up NV CONSECUTIVE positions
     // per lane.  With that layout one instruction of the selection handles 64 columns that are NV
     // apart: neighbouring columns of real chroma are similar, and 64 neighbours in one LDS atomic
-    // would pile onto a few histogram counters (same-address atomics serialise).  The 16-byte chunk
-    // index is XORed with the tile's low bits -- for the writer a constant XOR of the lane number --
-    // which makes both the 4-byte writes and the owner's 16-byte reads bank-conflict free.
+    // would pile onto a few histogram counters (same-address atomics serialise).  Every owner lane's
+    // NV positions are followed by 16 bytes of pad: with a lane pitch of NV + 4 floats the owner's
+    // 16-byte reads are bank-conflict free at plain immediate offsets (no address arithmetic at all),
+    // and the writers' 4-byte stores stay contiguous up to that pad.
     constexpr int CH = NV / 4;           // 16-byte chunks per lane of a complete row
     constexpr int LPT = 64 / NV == 0 ? 1 : 64 / NV;     // lanes of the owner per 64-position tile
     static_assert(NV == 8 || NV == 16 || NV == 32, "row owners hold 8, 16 or 32 consecutive positions");
     {
+        const int wl = lane + 4 * (lane / NV);           // position 64 T + lane -> float T * (LPT * LNP) + wl
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
-            const int T = tile_of(st);
-            float *dst = smem + 64 * T + (lane ^ (4 * (T & (CH - 1))));
+            float *dst = smem + tile_of(st) * (LPT * LNP) + wl;
 #pragma unroll
             for (int a = 0; a < BAND; ++a) dst[a * ROWP] = xv[a][st];
         }
     }
-    if constexpr (!HIST_IN_ROW) {   // zero this wave's fast histogram
-        float *h = smem + HIST_OFF + wave * HIST_STRIDE;
+    // this wave's fast histogram: inside its own exchange row (the first FBINS-aligned block behind
+    // the 64 candidate slots), or in the separate area behind the rows
+    const int hist_off = HIST_IN_ROW ? ((wave * ROWP + 64 + FBINS - 1) & ~(FBINS - 1)) : BAND * ROWP + wave * FBINS;
+    if constexpr (!HIST_IN_ROW) {   // zero it before the barrier: nobody else touches that area
+        float *h = smem + hist_off;
 #pragma unroll
         for (int q = 0; q < FBINS / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -1259,10 +1262,10 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     ACX_T(5);
     float xr[NV];      // xr[t] = cell at position NV lane + t of band row `wave` (column = position - 7 + wave)
     {
-        const int rsw = (lane / LPT) & (CH - 1);
+        const float *mine = smem + wave * ROWP + lane * LNP;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const float4 v = *reinterpret_cast<const float4 *>(smem + wave * ROWP + lane * NV + 4 * (j ^ rsw));
+            const float4 v = *reinterpret_cast<const float4 *>(mine + 4 * j);
             xr[4 * j + 0] = v.x; xr[4 * j + 1] = v.y; xr[4 * j + 2] = v.z; xr[4 * j + 3] = v.w;
         }
     }
@@ -1334,9 +1337,9 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     ACX_T(6);
     float slo, shi;
     typedef __attribute__((address_space(3))) void lds_void;
-    const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + HIST_OFF + wave * HIST_STRIDE);
-    if constexpr (HIST_IN_ROW) {    // the row has left LDS: its upper part becomes the zeroed histogram
-        float *h = smem + HIST_OFF + wave * HIST_STRIDE;
+    const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + hist_off);
+    if constexpr (HIST_IN_ROW) {    // the row has left LDS: part of it becomes the zeroed histogram
+        float *h = smem + hist_off;
 #pragma unroll
         for (int q = 0; q < FBINS / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
         wave_lds_fence();
