@@ -1083,9 +1083,13 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     auto load_norms = [&](int tile, float (&yv)[BAND]) {
         const int base = 64 * tile - (BAND - 1);
         if (base >= 0 && base + 64 + BAND - 1 <= MB) {
-            const float *p = ncol + base + lane;
-#pragma unroll
-            for (int a = 0; a < BAND; ++a) yv[a] = p[a];
+            // the lane's 8 consecutive norms as two (4-byte aligned) 16-byte loads
+            typedef float f32x4n __attribute__((ext_vector_type(4), aligned(4)));
+            const f32x4n *p = reinterpret_cast<const f32x4n *>(ncol + base + lane);
+            const f32x4n v0 = p[0], v1 = p[1];
+            yv[0] = v0.x; yv[1] = v0.y; yv[2] = v0.z; yv[3] = v0.w;
+            yv[4] = v1.x; yv[5] = v1.y; yv[6] = v1.z; yv[7] = v1.w;
+            static_assert(BAND == 8, "two 16-byte loads cover the band's 8 norms");
         } else {
 #pragma unroll
             for (int a = 0; a < BAND; ++a) {
