@@ -26,7 +26,7 @@ EXPORTS = [
     "acx_profile_get", "acx_debug_sqrt", "acx_upload_pool_f64", "acx_simple_pairs",
     "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
     "acx_chenfusion_pairs", "acx_csm_binary_sw", "acx_upload_raw_pool", "acx_download_pool",
-    "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse",
+    "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse", "acx_qmax_binary",
 ]
 
 
@@ -106,6 +106,7 @@ def load():
                                ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
     L.acx_csm_binary_sw.argtypes = [vp, fp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, fp]
+    L.acx_qmax_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, pp, fp]
     _lib = L
     return L
 
@@ -328,6 +329,15 @@ class Context(object):
                                                    ctypes.byref(oti), ctypes.byref(score), dims))
         assert (dims[0], dims[1]) == (Mq, Mr)
         return dict(d2=d2, eps_q=eq, eps_r=er, thr_q=tq, thr_r=tr, oti=int(oti.value), score=float(score.value))
+
+    def qmax_binary(self, R, params=None):
+        """Qmax / Dmax of a binary (M, N) cross recurrence plot (acx_qmax_binary)."""
+        p = params or serra09_params()
+        R = np.ascontiguousarray(R, dtype=np.uint8)
+        score = ctypes.c_float(0)
+        self._check(self._L.acx_qmax_binary(self._h, R.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                            R.shape[0], R.shape[1], ctypes.byref(p), ctypes.byref(score)))
+        return float(score.value)
 
     def profile_enable(self, on=True):
         self._check(self._L.acx_profile_enable(self._h, int(bool(on))))

@@ -15,6 +15,7 @@
 
 #include "../../include/acx.h"
 #include "serra09_kernels.hpp"
+#include "serra09_long_kernels.hpp"
 #include "prep_kernels.hpp"
 #include "snf_kernels.hpp"
 #include "simple_kernels.hpp"
@@ -40,13 +41,31 @@ struct PendingEvent {
     int64_t cells;
 };
 
+// One batch of Serra09 pairs in flight: descriptors, device results and their pinned staging copy.
+struct Serra09Slot {
+    std::vector<PairDesc> pd, sorted;
+    std::vector<int> perm;
+    PairDesc *d_pd = nullptr; size_t pd_cap = 0;
+    float *d_out = nullptr;   size_t out_cap = 0;
+    float *h_out = nullptr;   size_t h_cap = 0;      // pinned
+    hipEvent_t done = nullptr;
+    bool busy = false;
+    int B = 0, w = 1;
+    int64_t k0 = 0;
+};
+
 }  // namespace
 
 struct acx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    // pool
+    // pool as uploaded (d_frames0 / d_toff0 / h_off0) and the ACTIVE pool: the upload decimated by the
+    // stack stride tau of the last Serra09 call (tau == 1: the same buffers)
+    float *d_frames0 = nullptr;
+    int64_t *d_toff0 = nullptr;
+    std::vector<int64_t> h_off0;
+    int pool_tau = 0;
     float *d_frames = nullptr;
     float *d_frot = nullptr;      // rotated frame pool (band kernel MFMA operands), 36 floats per frame
     float *d_normtab = nullptr;   // embedded norms per (track, rotation, frame) for normtab_m / normtab_span
@@ -76,7 +95,7 @@ struct acx_ctx {
     // scratch (grow-only)
     float *d_scratch = nullptr; size_t scratch_cap = 0;   // floats
     float *d_thr = nullptr;     size_t thr_cap = 0;
-    PairDesc *d_pd = nullptr;   size_t pd_cap = 0;
+    Serra09Slot slot[2];
     float *d_out = nullptr;     size_t out_cap = 0;
     unsigned long long *d_bits = nullptr; size_t bits_cap = 0;   // recurrence bitmaps (u64 words)
     int64_t scratch_limit = 0;                            // bytes
@@ -84,7 +103,7 @@ struct acx_ctx {
     // profiling
     bool prof = false;
     KStat stats[KS_COUNT] = {{"oti_kernel", 0, 0, 0}, {"norms_kernel", 0, 0, 0}, {"band_kernel", 0, 0, 0},
-                             {"csm_tile_kernel", 0, 0, 0}, {"rowsel_kernel", 0, 0, 0}, {"qmax_kernel", 0, 0, 0},
+                             {"csm_long_kernel", 0, 0, 0}, {"rowsel_long_kernel", 0, 0, 0}, {"qmax_bits_kernel", 0, 0, 0},
                              {"simple_kernel", 0, 0, 0}, {"ef_gemm_kernel", 0, 0, 0}, {"ef_rowstat_kernel", 0, 0, 0},
                              {"ef_fuse_kernel", 0, 0, 0}, {"sw_kernel", 0, 0, 0}};
     std::vector<PendingEvent> pending;
@@ -158,6 +177,8 @@ void drain_profile(acx_ctx *c)
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Number of embedded frames of a track of T pooled frames (oracle embed_len): the stack at base
+// frame i = 0, tau, 2 tau, ... holds frames i, i + tau, ..., i + (m - 1) tau.
 int embed_len(int T, const acx_serra09_params &p)
 {
     int span = p.embed_full ? (p.m - 1) * p.tau : p.m * p.tau;
@@ -168,37 +189,14 @@ int embed_len(int T, const acx_serra09_params &p)
 
 int check_params(acx_ctx *c, const acx_serra09_params &p)
 {
-    if (p.m < 1 || p.m > acx::MAX_M) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: m must be in 1..16 on the device");
-    if (p.tau != 1) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: tau != 1 is not implemented on the device");
+    if (p.m < 1 || p.m > acx::MAX_M_LONG) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: m must be in 1..33 on the device");
+    if (p.tau < 1) return fail(c, ACX_ERR_INVALID, "serra09: tau must be >= 1");
     if (!(p.kappa >= 0.0f && p.kappa <= 1.0f)) return fail(c, ACX_ERR_INVALID, "serra09: kappa must be in [0, 1]");
     if (p.dp_start != 2 && p.dp_start != 3) return fail(c, ACX_ERR_INVALID, "serra09: dp_start must be 2 or 3");
     if (p.pct_mode < 0 || p.pct_mode > 3) return fail(c, ACX_ERR_INVALID, "serra09: pct_mode must be 0..3");
     if (p.oti_target != 0 && p.oti_target != 1) return fail(c, ACX_ERR_INVALID, "serra09: oti_target must be 0 or 1");
-    if (p.dmax != 0 && getenv("ACX_PIPELINE") && strcmp(getenv("ACX_PIPELINE"), "v1") == 0)
-        return fail(c, ACX_ERR_UNSUPPORTED, "serra09: Dmax (chen17) is not available on the v1 pipeline");
     if (!(p.gamma_o >= 0.0f) || !(p.gamma_e >= 0.0f)) return fail(c, ACX_ERR_INVALID, "serra09: gammas must be >= 0");
     return ACX_OK;
-}
-
-template <int M>
-void launch_csm(acx_ctx *c, dim3 grid, int tiles_x, int oti_target)
-{
-    hipLaunchKernelGGL((acx::csm_tile_kernel<M>), grid, dim3(256), 0, c->stream,
-                       c->d_frames, c->d_toff, c->d_pd, c->d_scratch, tiles_x, oti_target);
-}
-
-void launch_csm_m(acx_ctx *c, int m, dim3 grid, int tiles_x, int oti_target)
-{
-    switch (m) {
-#define ACX_CASE(M_) case M_: launch_csm<M_>(c, grid, tiles_x, oti_target); break;
-#ifdef ACX_FAST_BUILD
-        ACX_CASE(9)
-#else
-        ACX_CASE(1) ACX_CASE(2) ACX_CASE(3) ACX_CASE(4) ACX_CASE(5) ACX_CASE(6) ACX_CASE(7) ACX_CASE(8)
-        ACX_CASE(9) ACX_CASE(10) ACX_CASE(11) ACX_CASE(12) ACX_CASE(13) ACX_CASE(14) ACX_CASE(15) ACX_CASE(16)
-#endif
-#undef ACX_CASE
-    }
 }
 
 // band_kernel is launched from its own translation unit (acx_band.hip)
@@ -220,7 +218,7 @@ void launch_normtab(acx_ctx *c, int maxM, int span)
 #ifndef ACX_FAST_BUILD_M
 #define ACX_FAST_BUILD_M 9
 #endif
-#define ACX_M_SWITCH(m_, CALL) switch (m_) { case ACX_FAST_BUILD_M: CALL(ACX_FAST_BUILD_M); break; }
+#define ACX_M_SWITCH(m_, CALL) switch (m_) { case ACX_FAST_BUILD_M: CALL(ACX_FAST_BUILD_M); break; default: handled = false; }
 #else
 #define ACX_M_SWITCH(m_, CALL)                                                                      \
     switch (m_) {                                                                                   \
@@ -228,14 +226,68 @@ void launch_normtab(acx_ctx *c, int maxM, int span)
         case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;     \
         case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
         case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break; \
+        default: handled = false;                                                                   \
     }
 #endif
+
+// The active pool is the uploaded one decimated by the stack stride: the stack at base frame e tau
+// holds frames (e + k) tau, so with X'[t] = X[t tau] it is the tau = 1 stack of X' (same frames,
+// same order, same count: ceil(T / tau) - m = ceil((T - m tau) / tau)).  The OTI's global chroma
+// stays the one of the complete track.  Rebuilt when tau changes; tau = 1 aliases the upload.
+int ensure_tau(acx_ctx *c, int tau)
+{
+    if (c->pool_tau == tau) return ACX_OK;
+    if (c->d_frames && c->d_frames != c->d_frames0) { ACX_HIP(c, hipFree(c->d_frames)); }
+    if (c->d_toff && c->d_toff != c->d_toff0) { ACX_HIP(c, hipFree(c->d_toff)); }
+    c->d_frames = nullptr; c->d_toff = nullptr;
+    if (c->d_frot) { ACX_HIP(c, hipFree(c->d_frot)); c->d_frot = nullptr; }
+    if (c->d_normtab) { ACX_HIP(c, hipFree(c->d_normtab)); c->d_normtab = nullptr; }
+    if (c->d_noff) { ACX_HIP(c, hipFree(c->d_noff)); c->d_noff = nullptr; }
+    c->normtab_m = 0; c->normtab_span = -1;
+    c->pool_tau = 0;
+    const int n = c->n_tracks;
+    if (tau == 1) {
+        c->d_frames = c->d_frames0; c->d_toff = c->d_toff0; c->h_off = c->h_off0;
+    } else {
+        c->h_off.assign((size_t)n + 1, 0);
+        int maxT = 1;
+        for (int t = 0; t < n; ++t) {
+            const int64_t T = c->h_off0[t + 1] - c->h_off0[t];
+            const int64_t Td = (T + tau - 1) / tau;
+            c->h_off[t + 1] = c->h_off[t] + Td;
+            maxT = std::max<int>(maxT, (int)Td);
+        }
+        const int64_t total = c->h_off[n];
+        ACX_HIP(c, hipMalloc((void **)&c->d_frames, sizeof(float) * std::max<int64_t>(1, total) * acx::NBIN));
+        ACX_HIP(c, hipMalloc((void **)&c->d_toff, sizeof(int64_t) * (n + 1)));
+        ACX_HIP(c, hipMemcpy(c->d_toff, c->h_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+        if (total > 0) {
+            hipLaunchKernelGGL(acx::decimate_kernel, dim3(n, (maxT * acx::NBIN + 255) / 256), dim3(256), 0, c->stream,
+                               c->d_frames0, c->d_toff0, c->d_toff, c->d_frames, tau);
+            ACX_HIP(c, hipGetLastError());
+        }
+    }
+    const int64_t total = c->h_off[n];
+    // rotated copy of the active pool: the band kernel loads its MFMA operands from it (12 bytes per
+    // lane per 16-frame tile, already in the rotated chain order) -- 144 B per frame
+    ACX_HIP(c, hipMalloc((void **)&c->d_frot, sizeof(float) * std::max<int64_t>(1, total) * acx::FROT));
+    if (total > 0) {
+        const int64_t nout = total * acx::FROT;
+        hipLaunchKernelGGL(acx::rotpool_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_frames, c->d_frot, total);
+        ACX_HIP(c, hipGetLastError());
+    }
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    c->pool_tau = tau;
+    return ACX_OK;
+}
 
 // The table of embedded norms depends on the pool and on (m, embedded length): built on first use.
 int ensure_normtab(acx_ctx *c, const acx_serra09_params &p)
 {
-    const int span = p.embed_full ? (p.m - 1) * p.tau : p.m * p.tau;
+    const int span = p.embed_full ? (p.m - 1) : p.m;           // (active pool: tau == 1)
     if (c->d_normtab && c->normtab_m == p.m && c->normtab_span == span) return ACX_OK;
+    if (c->n_tracks > 65535) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: pools of more than 65535 tracks are not supported");
     if (c->d_normtab) { ACX_HIP(c, hipFree(c->d_normtab)); c->d_normtab = nullptr; }
     if (c->d_noff) { ACX_HIP(c, hipFree(c->d_noff)); c->d_noff = nullptr; }
     std::vector<int64_t> noff((size_t)c->n_tracks + 1);
@@ -251,27 +303,18 @@ int ensure_normtab(acx_ctx *c, const acx_serra09_params &p)
     ACX_HIP(c, hipMalloc((void **)&c->d_normtab, sizeof(float) * std::max<int64_t>(1, tot)));
     ACX_HIP(c, hipMalloc((void **)&c->d_noff, sizeof(int64_t) * noff.size()));
     ACX_HIP(c, hipMemcpy(c->d_noff, noff.data(), sizeof(int64_t) * noff.size(), hipMemcpyHostToDevice));
+    bool handled = true;
     {
         ProfScope ps(c, KS_NORMS, 0);
 #define ACX_CALL(M_) launch_normtab<M_>(c, maxM, span)
         ACX_M_SWITCH(p.m, ACX_CALL)
 #undef ACX_CALL
     }
+    if (!handled) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: this build of libacx has no band kernel for the requested m");
     ACX_HIP(c, hipGetLastError());
     c->normtab_m = p.m;
     c->normtab_span = span;
     return ACX_OK;
-}
-
-template <int NG>
-void launch_qmax(acx_ctx *c, int B, bool eqg, float go, float ge, int dp_start)
-{
-    if (eqg)
-        hipLaunchKernelGGL((acx::qmax_kernel<NG, true>), dim3(B), dim3(64), 0, c->stream,
-                           c->d_pd, c->d_scratch, c->d_thr, c->d_out, go, ge, dp_start);
-    else
-        hipLaunchKernelGGL((acx::qmax_kernel<NG, false>), dim3(B), dim3(64), 0, c->stream,
-                           c->d_pd, c->d_scratch, c->d_thr, c->d_out, go, ge, dp_start);
 }
 
 struct DebugOut {
@@ -280,36 +323,54 @@ struct DebugOut {
     int32_t *dims;
 };
 
+int64_t scratch_limit_bytes(const acx_ctx *c)
+{
+    if (c->scratch_limit > 0) return c->scratch_limit;
+    const char *env = getenv("ACX_SCRATCH_GB");
+    if (env && atof(env) > 0) return (int64_t)(atof(env) * (double)(1ull << 30));
+    return (int64_t)(0.40 * (double)c->total_mem);
+}
+
+// Results of one batch come back through a pinned staging slot; two slots, so that the host packs
+// batch b + 1 (descriptors, size classes) while the device works on batch b.
+int collect_slot(acx_ctx *c, Serra09Slot &s, float *out)
+{
+    if (!s.busy) return ACX_OK;
+    ACX_HIP(c, hipEventSynchronize(s.done));
+    for (int k2 = 0; k2 < s.B; ++k2)
+        for (int e = 0; e < s.w; ++e) out[(size_t)s.w * (s.k0 + s.perm[k2]) + e] = s.h_out[(size_t)s.w * k2 + e];
+    s.busy = false;
+    drain_profile(c);
+    return ACX_OK;
+}
+
 // Runs the chain over `K` pairs in scratch-sized batches.
-int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params &p, float *out,
+int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params &p_in, float *out,
                 const DebugOut *dbg, bool both = false)
 {
-    if (both && getenv("ACX_PIPELINE") && strcmp(getenv("ACX_PIPELINE"), "v1") == 0)
-        return fail(c, ACX_ERR_UNSUPPORTED, "chenfusion: not available on the v1 pipeline");
-    if (!c->d_frames) return fail(c, ACX_ERR_STATE, "serra09: feature pool not uploaded (acx_upload_pool)");
+    if (!c->d_frames0) return fail(c, ACX_ERR_STATE, "serra09: feature pool not uploaded (acx_upload_pool)");
     if (c->dim != acx::NBIN) return fail(c, ACX_ERR_INVALID, "serra09: pool dim must be 12");
-    int rc = check_params(c, p);
+    int rc = check_params(c, p_in);
     if (rc != ACX_OK) return rc;
     ACX_HIP(c, hipSetDevice(c->device));
-
-    int64_t limit = c->scratch_limit;
-    if (limit <= 0) {
-        const char *env = getenv("ACX_SCRATCH_GB");
-        if (env && atof(env) > 0) limit = (int64_t)(atof(env) * (double)(1ull << 30));
-        else limit = (int64_t)(0.40 * (double)c->total_mem);
+    if ((rc = ensure_tau(c, p_in.tau)) != ACX_OK) return rc;
+    acx_serra09_params p = p_in;
+    p.tau = 1;                                   // from here on: the decimated pool
+    const int64_t limit_floats = scratch_limit_bytes(c) / 4;
+    const bool band_ok = p.m <= acx::MAX_M;      // larger stacks: every pair takes the long-track kernels
+    const int w = both ? 2 : 1;
+    for (int s = 0; s < 2; ++s) {
+        if (!c->slot[s].done) ACX_HIP(c, hipEventCreateWithFlags(&c->slot[s].done, hipEventDisableTiming));
+        c->slot[s].busy = false;
     }
-    const int64_t limit_floats = limit / 4;
-    const char *pipe = getenv("ACX_PIPELINE");
-    const bool v1 = pipe && strcmp(pipe, "v1") == 0;     // A/B switch: materialised D2 + D2T pipeline
-    if (!v1 && (rc = ensure_normtab(c, p)) != ACX_OK) return rc;
 
-    std::vector<PairDesc> pd;
     int64_t k0 = 0;
-    while (k0 < K) {
+    for (int batch = 0; k0 < K; ++batch) {
+        Serra09Slot &S = c->slot[batch & 1];
+        if ((rc = collect_slot(c, S, out)) != ACX_OK) return rc;
+        std::vector<PairDesc> &pd = S.pd;
         pd.clear();
         int64_t used = 0, used_thr = 0, used_bits = 0;
-        int maxMq = 0, maxMr = 0, maxRows = 0, maxNe = 0;
-        int64_t cells = 0;
         int64_t k = k0;
         for (; k < K && pd.size() < 65535; ++k) {
             const int qi = pairs[2 * k], ri = pairs[2 * k + 1];
@@ -323,154 +384,150 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             d.Mr = embed_len(d.Tr, p);
             if (d.Mq <= 0 || d.Mr <= 0)
                 return fail(c, ACX_ERR_SHORT, "serra09: track shorter than the delay-embedding stack (pair " + std::to_string(k) + ")");
-            const int Ne = d.Mr - (p.dp_start == 3 ? 1 : 0);
-            if (Ne > 2041 || d.Mq > 2041 || d.Mr > 2041)
-                return fail(c, ACX_ERR_UNSUPPORTED, "serra09: tracks with more than 2041 embedded frames are not supported on the device yet");
             d.oti = 0;
             d.pitchD = round_up(d.Mr, 64);
             d.pitchT = round_up(d.Mq, 64);
             d.nw = (d.Mr + acx::BAND - 1 + 63) / 64;
-            const bool want_d2 = v1 || dbg != nullptr;      // the band pipeline keeps D2 out of HBM
-            const int64_t need = (want_d2 ? (int64_t)d.Mq * d.pitchD : 0) + (v1 ? (int64_t)d.Mr * d.pitchT : 0);
-            const int64_t need_bits = v1 ? 0 : (int64_t)d.Mq * d.nw;
-            if (need > limit_floats)
-                return fail(c, ACX_ERR_NOMEM, "serra09: one pair does not fit the scratch limit");
-            if (used + need + 2 * (used_bits + need_bits) > limit_floats) break;
+            const bool is_long = !band_ok || (std::max(d.Mq, d.Mr) + acx::BAND - 1 + 63) / 64 > 32;
+            const int64_t needD = (dbg != nullptr || is_long) ? (int64_t)d.Mq * d.pitchD : 0;     // the band pipeline keeps D2 out of HBM
+            const int64_t needL = is_long ? (int64_t)d.Mr * d.pitchT + 8 * (int64_t)d.Mq : 0;      // D2^T + the DP's strip records
+            const int64_t need_bits = (int64_t)d.Mq * d.nw;
+            if (needD + needL + 2 * need_bits > limit_floats)
+                return fail(c, ACX_ERR_NOMEM, "serra09: pair " + std::to_string(k) + " does not fit the scratch limit");
+            if (used + needD + needL + 2 * (used_bits + need_bits) > limit_floats) break;
             d.offD = used;
-            d.offT = v1 ? used + (int64_t)d.Mq * d.pitchD : used_bits;
-            used_bits += need_bits;
+            d.offL = used + needD;
+            d.offT = used_bits;
             d.offX = used_thr;
-            used += need;
+            used += needD + needL;
+            used_bits += need_bits;
             used_thr += 3 * ((int64_t)d.pitchD + d.pitchT);
-            maxMq = std::max(maxMq, d.Mq);
-            maxMr = std::max(maxMr, d.Mr);
-            maxRows = std::max(maxRows, d.Mq + d.Mr);
-            maxNe = std::max(maxNe, Ne);
-            cells += (int64_t)d.Mq * d.Mr;
             pd.push_back(d);
         }
         const int B = (int)pd.size();
-        // Band pipeline: pairs are processed in three size classes (row length <= 505 / 1017 / 2041
-        // cells -> 8 / 16 / 32 values per lane) so that a batch of mixed track lengths does not run
-        // its short pairs through the widest kernel.  `perm[k]` = original position of sorted pair k.
-        std::vector<int> perm(B);
-        int cls_begin[4] = {0, 0, 0, B};
+        // Pairs are processed in size classes: rows of <= 505 / 1017 / 2041 cells -> the band kernel with
+        // 8 / 16 / 32 values per lane (a batch of mixed track lengths does not run its short pairs
+        // through the widest kernel); longer rows -> class 3, the streaming kernels.
+        // `perm[k]` = position in the batch of sorted pair k.
+        std::vector<int> &perm = S.perm;
+        perm.resize(B);
+        int cls_begin[5] = {0, 0, 0, 0, B};
         {
-            auto cls_of = [](const PairDesc &d) {
+            auto cls_of = [&](const PairDesc &d) {
                 const int nd = (std::max(d.Mq, d.Mr) + acx::BAND - 1 + 63) / 64;
+                if (!band_ok || nd > 32) return 3;
                 return nd <= 8 ? 0 : (nd <= 16 ? 1 : 2);
             };
-            int cnt[3] = {0, 0, 0};
-            if (!v1) for (const PairDesc &d : pd) cnt[cls_of(d)]++;
-            else cnt[2] = B;
-            cls_begin[1] = cnt[0]; cls_begin[2] = cnt[0] + cnt[1];
-            int fill[3] = {cls_begin[0], cls_begin[1], cls_begin[2]};
-            std::vector<PairDesc> sorted(B);
+            int cnt[4] = {0, 0, 0, 0};
+            for (const PairDesc &d : pd) cnt[cls_of(d)]++;
+            for (int cl = 1; cl < 4; ++cl) cls_begin[cl] = cls_begin[cl - 1] + cnt[cl - 1];
+            int fill[4] = {cls_begin[0], cls_begin[1], cls_begin[2], cls_begin[3]};
+            std::vector<PairDesc> &sorted = S.sorted;
+            sorted.resize(B);
             for (int k2 = 0; k2 < B; ++k2) {
-                const int cl = v1 ? 2 : cls_of(pd[k2]);
+                const int cl = cls_of(pd[k2]);
                 perm[fill[cl]] = k2;
                 sorted[fill[cl]++] = pd[k2];
             }
             pd.swap(sorted);
         }
+        if (cls_begin[3] > 0 && (rc = ensure_normtab(c, p)) != ACX_OK) return rc;
+        // (the band kernel reads its column thresholds 16 bytes at a time without a bounds check, up to
+        // 64 x 32 floats behind a pair's column-threshold row: the arena carries that much slack)
         if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)std::max<int64_t>(used, 1))) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_bits, c->bits_cap, (size_t)std::max<int64_t>(used_bits, 1))) != ACX_OK) return rc;
-        if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)used_thr)) != ACX_OK) return rc;
-        if ((rc = ensure(c, c->d_pd, c->pd_cap, (size_t)B)) != ACX_OK) return rc;
-        if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)2 * B)) != ACX_OK) return rc;
-        ACX_HIP(c, hipMemcpyAsync(c->d_pd, pd.data(), sizeof(PairDesc) * B, hipMemcpyHostToDevice, c->stream));
+        if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)used_thr + 64 * 32 + 16)) != ACX_OK) return rc;
+        if ((rc = ensure(c, S.d_pd, S.pd_cap, (size_t)B)) != ACX_OK) return rc;
+        if ((rc = ensure(c, S.d_out, S.out_cap, (size_t)2 * B)) != ACX_OK) return rc;
+        if ((size_t)2 * B > S.h_cap) {
+            if (S.h_out) ACX_HIP(c, hipHostFree(S.h_out));
+            S.h_out = nullptr; S.h_cap = 0;
+            ACX_HIP(c, hipHostMalloc((void **)&S.h_out, sizeof(float) * 2 * (size_t)B, hipHostMallocDefault));
+            S.h_cap = (size_t)2 * B;
+        }
+        ACX_HIP(c, hipMemcpyAsync(S.d_pd, pd.data(), sizeof(PairDesc) * B, hipMemcpyHostToDevice, c->stream));
 
+        int64_t cells = 0;
+        for (const PairDesc &d : pd) cells += (int64_t)d.Mq * d.Mr;
         {   // K0
             ProfScope ps(c, KS_OTI, cells);
             hipLaunchKernelGGL(acx::oti_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream,
-                               c->d_pd, B, c->d_gch, p.oti, p.oti_target);
+                               S.d_pd, B, c->d_gch, p.oti, p.oti_target);
         }
-        if (v1) {
-            {   // K1 (v1): tiles -> D2 and D2T
-                const int tiles_x = (maxMr + 63) / 64, tiles_y = (maxMq + 63) / 64;
-                ProfScope ps(c, KS_CSM, cells);
-                launch_csm_m(c, p.m, dim3(tiles_x * tiles_y, B), tiles_x, p.oti_target);
+        for (int cl = 0; cl < 4; ++cl) {
+            const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
+            if (Bc <= 0) continue;
+            int cMq = 0, cMr = 0;
+            int64_t ccells = 0;
+            for (int k2 = b0; k2 < b0 + Bc; ++k2) {
+                cMq = std::max(cMq, pd[k2].Mq); cMr = std::max(cMr, pd[k2].Mr);
+                ccells += (int64_t)pd[k2].Mq * pd[k2].Mr;
             }
-            {   // K2 (v1): row selection on D2 and D2T
-                ProfScope ps(c, KS_SEL, cells);
-                const int maxN = std::max(maxMq, maxMr);
-                const dim3 g((maxRows + 3) / 4, B);
-#define ACX_SEL(V4_) hipLaunchKernelGGL((acx::rowsel_kernel<V4_>), g, dim3(256), 0, c->stream, \
-                                        c->d_pd, c->d_scratch, c->d_thr, p.kappa, p.pct_mode, p.inclusive)
-                if (maxN <= 512) ACX_SEL(2);
-                else if (maxN <= 1024) ACX_SEL(4);
-                else ACX_SEL(8);
-#undef ACX_SEL
-            }
-        } else {
-            for (int cl = 0; cl < 3; ++cl) {
-                const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
-                if (Bc <= 0) continue;
-                int cMq = 0, cMr = 0;
-                int64_t ccells = 0;
-                for (int k2 = b0; k2 < b0 + Bc; ++k2) {
-                    cMq = std::max(cMq, pd[k2].Mq); cMr = std::max(cMr, pd[k2].Mr);
-                    ccells += (int64_t)pd[k2].Mq * pd[k2].Mr;
-                }
+            if (cl < 3) {
                 // both roles are dispatched on the class (the longer side of the pair)
                 const int cmax = std::max(cMq, cMr);
+                bool ok;
                 {   // K1' role 1: rows = reference frames -> column thresholds
                     ProfScope ps(c, KS_BAND, ccells);
-                    launch_band(c, p.m, c->d_pd + b0, Bc, cMr, cmax, p, 1, 0);
+                    ok = launch_band(c, p.m, S.d_pd + b0, Bc, cMr, cmax, p, 1, 0);
                 }
                 {   // K1' role 0: rows = query frames -> row thresholds + recurrence bitmap (needs role 1)
                     ProfScope ps(c, KS_BAND, ccells);
-                    launch_band(c, p.m, c->d_pd + b0, Bc, cMq, cmax, p, 0, dbg ? 1 : 0);
+                    ok = ok && launch_band(c, p.m, S.d_pd + b0, Bc, cMq, cmax, p, 0, dbg ? 1 : 0);
+                }
+                if (!ok) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: this build of libacx has no band kernel for the requested m");
+            } else {
+                {   // L1: D2 and D2^T
+                    const int tiles_x = (cMr + acx::LT - 1) / acx::LT, tiles_y = (cMq + acx::LT - 1) / acx::LT;
+                    ProfScope ps(c, KS_CSM, ccells);
+                    hipLaunchKernelGGL(acx::csm_long_kernel, dim3(tiles_x * tiles_y, Bc), dim3(256), 0, c->stream,
+                                       c->d_frames, c->d_toff, S.d_pd + b0, c->d_scratch, tiles_x, p.oti_target, p.m);
+                }
+                {   // L2: thresholds of every row and column;  L3: recurrence bitmap
+                    int maxRows = 0;
+                    for (int k2 = b0; k2 < b0 + Bc; ++k2) maxRows = std::max(maxRows, pd[k2].Mq + pd[k2].Mr);
+                    ProfScope ps(c, KS_SEL, ccells);
+                    hipLaunchKernelGGL(acx::rowsel_long_kernel, dim3((maxRows + 3) / 4, Bc), dim3(256), 0, c->stream,
+                                       S.d_pd + b0, c->d_scratch, c->d_thr, p.kappa, p.pct_mode, p.inclusive);
+                    hipLaunchKernelGGL(acx::binarise_long_kernel, dim3((cMq + 3) / 4, Bc), dim3(256), 0, c->stream,
+                                       S.d_pd + b0, c->d_scratch, c->d_thr, c->d_bits);
                 }
             }
         }
-        {   // K3
+        {   // K3: one sweep per requested alignment over the SAME recurrence bitmap:
+            // both == 0: Qmax or Dmax as p.dmax says; both == 1: out[2k] = Qmax, out[2k+1] = Dmax
             const bool eqg = p.gamma_o == p.gamma_e;
             ProfScope ps(c, KS_QMAX, cells);
-            if (v1) {
-                const int NG = (maxNe + 511) / 512;
-                switch (NG) {
-                case 0: case 1: launch_qmax<1>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
-                case 2: launch_qmax<2>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
-                case 3: launch_qmax<3>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
-                default: launch_qmax<4>(c, B, eqg, p.gamma_o, p.gamma_e, p.dp_start); break;
-                }
-            } else {
-                // one sweep per requested alignment over the SAME recurrence bitmap:
-                // both == 0: Qmax or Dmax as p.dmax says; both == 1: out[2k] = Qmax, out[2k+1] = Dmax
-                const int stride = both ? 2 : 1;
-                // one launch per size class: a lane owns 8 / 16 / 32 columns of rows up to 505 / 1017 / 2041 cells
-                auto sweep = [&](bool dmax, float *dst) {
-                    for (int cl = 0; cl < 3; ++cl) {
-                        const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
-                        if (Bc <= 0) continue;
+            // one launch per size class: a lane owns 8 / 16 / 32 columns of rows up to 505 / 1017 / 2041 cells
+            auto sweep = [&](bool dmax, float *dst) {
+                for (int cl = 0; cl < 4; ++cl) {
+                    const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
+                    if (Bc <= 0) continue;
 #define ACX_QB3(E_, D_, C_) hipLaunchKernelGGL((acx::qmax_bits_kernel<E_, D_, C_>), dim3(Bc), dim3(64), 0, c->stream, \
-                                               c->d_pd + b0, c->d_bits, dst + (size_t)b0 * stride, stride, p.gamma_o, p.gamma_e, p.dp_start)
-#define ACX_QB(E_, D_) do { if (cl == 0) ACX_QB3(E_, D_, 8); else if (cl == 1) ACX_QB3(E_, D_, 16); else ACX_QB3(E_, D_, 32); } while (0)
-                        if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }
-                        else { if (dmax) ACX_QB(false, true); else ACX_QB(false, false); }
+                                               S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.gamma_o, p.gamma_e, p.dp_start)
+#define ACX_QBL(E_, D_) hipLaunchKernelGGL((acx::qmax_bits_long_kernel<E_, D_>), dim3(Bc), dim3(64), 0, c->stream, \
+                                           S.d_pd + b0, c->d_bits, c->d_scratch, dst + (size_t)b0 * w, w, p.gamma_o, p.gamma_e, p.dp_start)
+#define ACX_QB(E_, D_) do { if (cl == 0) ACX_QB3(E_, D_, 8); else if (cl == 1) ACX_QB3(E_, D_, 16); else if (cl == 2) ACX_QB3(E_, D_, 32); \
+                            else ACX_QBL(E_, D_); } while (0)
+                    if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }
+                    else { if (dmax) ACX_QB(false, true); else ACX_QB(false, false); }
 #undef ACX_QB
+#undef ACX_QBL
 #undef ACX_QB3
-                    }
-                };
-                if (both) { sweep(false, c->d_out); sweep(true, c->d_out + 1); }
-                else sweep(p.dmax != 0, c->d_out);
-            }
+                }
+            };
+            if (both) { sweep(false, S.d_out); sweep(true, S.d_out + 1); }
+            else sweep(p.dmax != 0, S.d_out);
         }
         ACX_HIP(c, hipGetLastError());
-        {
-            const int w = both ? 2 : 1;
-            std::vector<float> tmp((size_t)B * w);
-            ACX_HIP(c, hipMemcpyAsync(tmp.data(), c->d_out, sizeof(float) * B * w, hipMemcpyDeviceToHost, c->stream));
-            ACX_HIP(c, hipStreamSynchronize(c->stream));
-            for (int k2 = 0; k2 < B; ++k2)
-                for (int e = 0; e < w; ++e) out[(size_t)w * (k0 + perm[k2]) + e] = tmp[(size_t)w * k2 + e];
-        }
-        drain_profile(c);
+        ACX_HIP(c, hipMemcpyAsync(S.h_out, S.d_out, sizeof(float) * B * w, hipMemcpyDeviceToHost, c->stream));
+        ACX_HIP(c, hipEventRecord(S.done, c->stream));
+        S.busy = true; S.B = B; S.w = w; S.k0 = k0;
 
         if (dbg && B >= 1) {
+            if ((rc = collect_slot(c, S, out)) != ACX_OK) return rc;
             PairDesc d;
-            ACX_HIP(c, hipMemcpy(&d, c->d_pd, sizeof(PairDesc), hipMemcpyDeviceToHost));
+            ACX_HIP(c, hipMemcpy(&d, S.d_pd, sizeof(PairDesc), hipMemcpyDeviceToHost));
             if (dbg->oti) *dbg->oti = d.oti;
             if (dbg->dims) { dbg->dims[0] = d.Mq; dbg->dims[1] = d.Mr; }
             if (dbg->d2)
@@ -484,6 +541,8 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
         }
         k0 = k;
     }
+    for (int s = 0; s < 2; ++s)
+        if ((rc = collect_slot(c, c->slot[s], out)) != ACX_OK) return rc;
     return ACX_OK;
 }
 
@@ -628,6 +687,24 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
     return ACX_OK;
 }
 
+static void free_pool(acx_ctx *c)
+{
+    if (c->d_frames && c->d_frames != c->d_frames0) (void)hipFree(c->d_frames);
+    if (c->d_toff && c->d_toff != c->d_toff0) (void)hipFree(c->d_toff);
+    if (c->d_frames0) (void)hipFree(c->d_frames0);
+    if (c->d_toff0) (void)hipFree(c->d_toff0);
+    if (c->d_frot) (void)hipFree(c->d_frot);
+    if (c->d_normtab) (void)hipFree(c->d_normtab);
+    if (c->d_noff) (void)hipFree(c->d_noff);
+    if (c->d_gch) (void)hipFree(c->d_gch);
+    c->d_frames = c->d_frames0 = nullptr;
+    c->d_toff = c->d_toff0 = nullptr;
+    c->d_frot = c->d_normtab = c->d_gch = nullptr;
+    c->d_noff = nullptr;
+    c->normtab_m = 0; c->normtab_span = -1;
+    c->pool_tau = 0;
+}
+
 template <int L>
 int launch_simple(acx_ctx *c, int n, size_t smem, int oti)
 {
@@ -678,15 +755,15 @@ void acx_destroy(acx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     drain_profile(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
-    if (c->d_frames) (void)hipFree(c->d_frames);
-    if (c->d_frot) (void)hipFree(c->d_frot);
-    if (c->d_normtab) (void)hipFree(c->d_normtab);
-    if (c->d_noff) (void)hipFree(c->d_noff);
-    if (c->d_toff) (void)hipFree(c->d_toff);
-    if (c->d_gch) (void)hipFree(c->d_gch);
+    free_pool(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_thr) (void)hipFree(c->d_thr);
-    if (c->d_pd) (void)hipFree(c->d_pd);
+    for (Serra09Slot &sl : c->slot) {
+        if (sl.d_pd) (void)hipFree(sl.d_pd);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_bits) (void)hipFree(c->d_bits);
     if (c->d_frames64) (void)hipFree(c->d_frames64);
@@ -720,32 +797,19 @@ int acx_upload_pool(acx_ctx *c, const float *frames, const int64_t *offsets, int
     for (int i = 0; i < n_tracks; ++i)
         if (offsets[i + 1] < offsets[i]) return fail(c, ACX_ERR_INVALID, "upload_pool: offsets must be non-decreasing");
     ACX_HIP(c, hipSetDevice(c->device));
-    if (c->d_frames) { (void)hipFree(c->d_frames); c->d_frames = nullptr; }
-    if (c->d_frot) { (void)hipFree(c->d_frot); c->d_frot = nullptr; }
-    if (c->d_normtab) { (void)hipFree(c->d_normtab); c->d_normtab = nullptr; }
-    if (c->d_noff) { (void)hipFree(c->d_noff); c->d_noff = nullptr; }
-    c->normtab_m = 0; c->normtab_span = -1;
-    if (c->d_toff) { (void)hipFree(c->d_toff); c->d_toff = nullptr; }
-    if (c->d_gch) { (void)hipFree(c->d_gch); c->d_gch = nullptr; }
+    free_pool(c);
     const int64_t total = offsets[n_tracks];
-    c->h_off.assign(offsets, offsets + n_tracks + 1);
+    c->h_off0.assign(offsets, offsets + n_tracks + 1);
     c->n_tracks = n_tracks;
     c->dim = dim;
-    ACX_HIP(c, hipMalloc((void **)&c->d_frames, sizeof(float) * std::max<int64_t>(1, total) * dim));
-    ACX_HIP(c, hipMalloc((void **)&c->d_toff, sizeof(int64_t) * (n_tracks + 1)));
-    ACX_HIP(c, hipMemcpy(c->d_frames, frames, sizeof(float) * total * dim, hipMemcpyHostToDevice));
-    ACX_HIP(c, hipMemcpy(c->d_toff, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    ACX_HIP(c, hipMalloc((void **)&c->d_frames0, sizeof(float) * std::max<int64_t>(1, total) * dim));
+    ACX_HIP(c, hipMalloc((void **)&c->d_toff0, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIP(c, hipMemcpy(c->d_frames0, frames, sizeof(float) * total * dim, hipMemcpyHostToDevice));
+    ACX_HIP(c, hipMemcpy(c->d_toff0, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
     if (dim == acx::NBIN) {
-        // rotated copy of the pool: the band kernel loads its MFMA operands from it (12 bytes per
-        // lane per 16-frame tile, already in the rotated chain order) -- 144 B per frame
-        ACX_HIP(c, hipMalloc((void **)&c->d_frot, sizeof(float) * std::max<int64_t>(1, total) * acx::FROT));
-        if (total > 0) {
-            const int64_t nout = total * acx::FROT;
-            hipLaunchKernelGGL(acx::rotpool_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, c->stream,
-                               c->d_frames, c->d_frot, total);
-            ACX_HIP(c, hipGetLastError());
-            ACX_HIP(c, hipStreamSynchronize(c->stream));
-        }
+        // the active pool (rotated copy included) for the default stack stride
+        const int rc = ensure_tau(c, 1);
+        if (rc != ACX_OK) return rc;
         // global chroma profile per track: sequential f32 sum over frames, divided by its max
         // (arithmetic spec step 1; O(sum T) host work done once per pool)
         std::vector<float> g((size_t)n_tracks * acx::NBIN);
@@ -845,11 +909,11 @@ int acx_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_offsets
 int acx_download_pool(acx_ctx *c, float *frames, int64_t capacity)
 {
     if (!c) return ACX_ERR_INVALID;
-    if (!c->d_frames) return fail(c, ACX_ERR_STATE, "download_pool: feature pool not uploaded");
-    const int64_t need = c->h_off[c->n_tracks] * c->dim;
+    if (!c->d_frames0) return fail(c, ACX_ERR_STATE, "download_pool: feature pool not uploaded");
+    const int64_t need = c->h_off0[c->n_tracks] * c->dim;
     if (!frames || capacity < need) return fail(c, ACX_ERR_INVALID, "download_pool: buffer too small");
     ACX_HIP(c, hipSetDevice(c->device));
-    ACX_HIP(c, hipMemcpy(frames, c->d_frames, sizeof(float) * need, hipMemcpyDeviceToHost));
+    ACX_HIP(c, hipMemcpy(frames, c->d_frames0, sizeof(float) * need, hipMemcpyDeviceToHost));
     return ACX_OK;
 }
 
@@ -894,6 +958,56 @@ int acx_serra09_debug_pair(acx_ctx *c, int32_t i, int32_t j, const acx_serra09_p
     int rc = run_serra09(c, pr, 1, *params, &s, &dbg);
     if (rc == ACX_OK && score) *score = s;
     return rc;
+}
+
+int acx_qmax_binary(acx_ctx *c, const uint8_t *R, int32_t M, int32_t N, const acx_serra09_params *params, float *score)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!R || !params || !score || M < 1 || N < 1) return fail(c, ACX_ERR_INVALID, "qmax_binary: bad argument");
+    if (params->dp_start != 2 && params->dp_start != 3) return fail(c, ACX_ERR_INVALID, "qmax_binary: dp_start must be 2 or 3");
+    if (!(params->gamma_o >= 0.0f) || !(params->gamma_e >= 0.0f)) return fail(c, ACX_ERR_INVALID, "qmax_binary: gammas must be >= 0");
+    ACX_HIP(c, hipSetDevice(c->device));
+    // the recurrence plot in the pipeline's bitmap layout: word t of row i = columns [64 t - 7 + (i & 7), +64)
+    PairDesc d;
+    memset(&d, 0, sizeof(d));
+    d.Mq = M; d.Mr = N; d.Tq = M; d.Tr = N;
+    d.pitchD = round_up(N, 64); d.pitchT = 0;
+    d.nw = (N + acx::BAND - 1 + 63) / 64;
+    std::vector<unsigned long long> words((size_t)M * d.nw, 0ull);
+    for (int i = 0; i < M; ++i) {
+        const int c0 = (i & (acx::BAND - 1)) - (acx::BAND - 1);
+        for (int j = 0; j < N; ++j) {
+            const uint8_t v = R[(size_t)i * N + j];
+            if (v > 1) return fail(c, ACX_ERR_INVALID, "qmax_binary: non-binary elements found in input");
+            if (v) { const int pos = j - c0; words[(size_t)i * d.nw + (pos >> 6)] |= 1ull << (pos & 63); }
+        }
+    }
+    int rc;
+    Serra09Slot &S = c->slot[0];
+    if ((rc = ensure(c, c->d_bits, c->bits_cap, words.size())) != ACX_OK) return rc;
+    if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)8 * M + 16)) != ACX_OK) return rc;     // strip records of the long DP
+    if ((rc = ensure(c, S.d_pd, S.pd_cap, (size_t)1)) != ACX_OK) return rc;
+    if ((rc = ensure(c, S.d_out, S.out_cap, (size_t)2)) != ACX_OK) return rc;
+    ACX_HIP(c, hipMemcpyAsync(c->d_bits, words.data(), sizeof(unsigned long long) * words.size(), hipMemcpyHostToDevice, c->stream));
+    ACX_HIP(c, hipMemcpyAsync(S.d_pd, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+    const int nd = (std::max(M, N) + acx::BAND - 1 + 63) / 64;
+    const int cl = nd <= 8 ? 0 : (nd <= 16 ? 1 : (nd <= 32 ? 2 : 3));
+    const bool eqg = params->gamma_o == params->gamma_e, dmax = params->dmax != 0;
+#define ACX_QB3(E_, D_, C_) hipLaunchKernelGGL((acx::qmax_bits_kernel<E_, D_, C_>), dim3(1), dim3(64), 0, c->stream, \
+                                           S.d_pd, c->d_bits, S.d_out, 1, params->gamma_o, params->gamma_e, params->dp_start)
+#define ACX_QBL(E_, D_) hipLaunchKernelGGL((acx::qmax_bits_long_kernel<E_, D_>), dim3(1), dim3(64), 0, c->stream, \
+                                       S.d_pd, c->d_bits, c->d_scratch, S.d_out, 1, params->gamma_o, params->gamma_e, params->dp_start)
+#define ACX_QB(E_, D_) do { if (cl == 0) ACX_QB3(E_, D_, 8); else if (cl == 1) ACX_QB3(E_, D_, 16); else if (cl == 2) ACX_QB3(E_, D_, 32); \
+                        else ACX_QBL(E_, D_); } while (0)
+    if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }
+    else { if (dmax) ACX_QB(false, true); else ACX_QB(false, false); }
+#undef ACX_QB
+#undef ACX_QBL
+#undef ACX_QB3
+    ACX_HIP(c, hipGetLastError());
+    ACX_HIP(c, hipMemcpyAsync(score, S.d_out, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    return ACX_OK;
 }
 
 int acx_upload_pool_f64(acx_ctx *c, const double *frames, const int64_t *offsets, int32_t n_tracks, int32_t dim)
@@ -1284,14 +1398,6 @@ int acx_profile_get(acx_ctx *c, int idx, char *name, int name_len, double *ms, i
     return ACX_OK;
 }
 
-#ifdef ACX_TIMING
-/* development builds only: read (and optionally clear) band_kernel's per-phase clock totals */
-int acx_debug_timing(acx_ctx *c, unsigned long long *out32, int reset)
-{
-    ACX_HIP(c, acx::band_timing(out32, reset));       // the counters live with the kernel, in acx_band.hip
-    return ACX_OK;
-}
-#endif
 
 int acx_debug_sqrt(acx_ctx *c, const float *in, int64_t n, float *out)
 {

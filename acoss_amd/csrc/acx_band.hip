@@ -45,16 +45,5 @@ bool launch_band_kernel(const BandLaunch &L, int m, const PairDesc *dpd, int B, 
     return false;
 }
 
-#ifdef ACX_TIMING
-hipError_t band_timing(unsigned long long *out32, int reset)
-{
-    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(acx_tim), sizeof(unsigned long long) * 32);
-    if (e == hipSuccess && reset) {
-        unsigned long long z[32] = {0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(acx_tim), z, sizeof(z));
-    }
-    return e;
-}
-#endif
 
 }  // namespace acx

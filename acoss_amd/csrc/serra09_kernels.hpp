@@ -12,8 +12,9 @@
 //                         diagonal doubling-tree window sums, exact kappa-percentile thresholds
 //                         per row (one histogram pass), recurrence bitmap; D2 never reaches HBM
 //   K3b qmax_bits_kernel  Qmax / Dmax row sweep over the recurrence bitmap, one wave per pair
-// A/B pipeline kept behind ACX_PIPELINE=v1 (materialised D2 + D2^T, 20 B/cell):
-//   K1 csm_tile_kernel, K2 rowsel_kernel, K3 qmax_kernel
+// Tracks whose embedded matrix has rows of more than 2041 cells (or a stack size m > 16) take the
+// streaming kernels of serra09_long_kernels.hpp (materialised D2 + D2^T) and rejoin this pipeline at
+// the recurrence bitmap.
 //
 // Everything is f32; the operation ORDER is part of the spec (bit-exact parity with the
 // oracle), so this file is compiled with -ffp-contract=off and uses explicit fmaf only
@@ -26,14 +27,8 @@
 namespace acx {
 
 constexpr int NBIN = 12;       // chroma bins
-constexpr int TILE = 64;       // output tile edge of K1
-constexpr int STILE = 80;      // S tile edge (TILE + 16 halo): supports m <= 17
-constexpr int SPITCH = 81;
-#ifndef ACX_SEL_BINS
-#define ACX_SEL_BINS 2048
-#endif
-constexpr int SEL_BINS = ACX_SEL_BINS; // histogram bins of the percentile selection
-constexpr int MAX_M = 16;
+constexpr int SEL_BINS = 2048; // histogram bins of the generic percentile selection
+constexpr int MAX_M = 16;      // largest stack size of the band kernel (larger m: long-track kernels)
 
 struct PairDesc {
     int32_t q, r;          // track indices (query, reference)
@@ -42,12 +37,13 @@ struct PairDesc {
     int32_t oti;           // filled by K0
     int32_t pitchD;        // row pitch of D2  (floats, multiple of 64, >= Mr)
     int32_t pitchT;        // row pitch of D2T (floats, multiple of 64, >= Mq)
-    int32_t nw;            // 64-bit words per row of the recurrence bitmap (band pipeline)
-    int64_t offD, offT;    // offD: float offset of D2 in the scratch arena (v1 / debug);
-                           // offT: v1: float offset of D2^T; band pipeline: u64-word offset of the
-                           // pair's recurrence bitmap (Mq rows x nw words) in the bit arena
+    int32_t nw;            // 64-bit words per row of the recurrence bitmap
+    int64_t offD;          // float offset of D2 in the scratch arena (debug entry point and long tracks only)
+    int64_t offT;          // u64-word offset of the pair's recurrence bitmap (Mq rows x nw words) in the bit arena
     int64_t offX;          // float offset into the threshold arena:
                            //   [thr rows: pitchT][thr cols: pitchD][eps rows: pitchT][eps cols: pitchD]
+    int64_t offL;          // long tracks: float offset of D2^T (Mr rows x pitchT) in the scratch arena,
+                           // followed by the DP's strip-boundary records (2 x 4 floats per row)
 };
 
 __device__ __forceinline__ float wave_shfl(float v, int src)
@@ -122,144 +118,9 @@ static __global__ void oti_kernel(PairDesc *pd, int B, const float *__restrict__
     pd[p].oti = best;
 }
 
-// ------------------------------------------------------------------------------------
-// K1: squared embedded distances, 64x64 tile per workgroup (256 threads = 4 waves).
-// ------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int M>
-__global__ __launch_bounds__(256) void csm_tile_kernel(const float *__restrict__ pool,
-                                                       const int64_t *__restrict__ toff,
-                                                       const PairDesc *__restrict__ pd,
-                                                       float *__restrict__ scratch,
-                                                       int tiles_x, int oti_target)
-{
-    __shared__ float Qs[NBIN][STILE];   // chroma tiles, bin-major (conflict-free MFMA operand reads)
-    __shared__ float Rs[NBIN][STILE];
-    __shared__ float NQ[STILE], NR[STILE];
-    __shared__ float XX[TILE], YY[TILE];
-    __shared__ float S[STILE * SPITCH];  // frame Gram tile; reused as the transpose stage
-
-    const PairDesc P = pd[blockIdx.y];
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int i0 = ty * TILE, j0 = tx * TILE;
-    if (i0 >= P.Mq || j0 >= P.Mr) return;   // block-uniform
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *qf = pool + toff[P.q] * NBIN;
-    const float *rf = pool + toff[P.r] * NBIN;
-    const int rotq = (oti_target == 1) ? P.oti : 0;
-    const int rotr = (oti_target == 0) ? P.oti : 0;
-
-    // ---- stage chroma (rotation = roll right: dst bin (c + s) % 12 <- src bin c)
-    for (int idx = tid; idx < STILE * NBIN; idx += 256) {
-        int a = idx / NBIN, c = idx - a * NBIN;
-        int fq = i0 + a, fr = j0 + a;
-        float vq = (fq < P.Tq) ? qf[(size_t)fq * NBIN + c] : 0.0f;
-        float vr = (fr < P.Tr) ? rf[(size_t)fr * NBIN + c] : 0.0f;
-        int cq = c + rotq; if (cq >= NBIN) cq -= NBIN;
-        int cr = c + rotr; if (cr >= NBIN) cr -= NBIN;
-        Qs[cq][a] = vq;
-        Rs[cr][a] = vr;
-    }
-    __syncthreads();
-
-    // ---- frame norms (fmaf chain over the bins, rotated order)
-    if (tid < 2 * STILE) {
-        const bool isq = tid < STILE;
-        const int a = isq ? tid : tid - STILE;
-        float acc = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NBIN; ++c) {
-            float v = isq ? Qs[c][a] : Rs[c][a];
-            acc = fmaf(v, v, acc);
-        }
-        if (isq) NQ[a] = acc; else NR[a] = acc;
-    }
-
-    // ---- frame Gram on the matrix cores: 5x5 tiles of 16x16, K = 12 in 3 k-steps
-    {
-        const int lr = lane & 15, lk = lane >> 4;
-        for (int t = wave; t < 25; t += 4) {
-            const int ta = t / 5, tb = t - ta * 5;
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int kb = 0; kb < 3; ++kb) {
-                float av = Qs[4 * kb + lk][16 * ta + lr];
-                float bv = Rs[4 * kb + lk][16 * tb + lr];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                S[(16 * ta + 4 * lk + reg) * SPITCH + 16 * tb + lr] = acc[reg];
-        }
-    }
-    __syncthreads();
-
-    // ---- embedded norms of the tile's rows / columns
-    if (tid < 2 * TILE) {
-        const bool isq = tid < TILE;
-        const int a = isq ? tid : tid - TILE;
-        float s[M];
-#pragma unroll
-        for (int k = 0; k < M; ++k) s[k] = isq ? NQ[a + k] : NR[a + k];
-        float v = tree_sum<M>(s);
-        if (isq) XX[a] = v; else YY[a] = v;
-    }
-    __syncthreads();
-
-    // ---- window sums along the diagonal + distance, 16 rows per thread
-    const int c = lane;          // tile column
-    const int rq = wave;         // 16-row quarter
-    float o[16];
-    {
-        const float yy = YY[c];
-        const bool colok = (j0 + c) < P.Mr;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int a = 16 * rq + t;
-            float s[M];
-#pragma unroll
-            for (int k = 0; k < M; ++k) s[k] = S[(a + k) * SPITCH + c + k];
-            const float xy = tree_sum<M>(s);
-            const float t1 = 2.0f * xy;
-            const float t2 = XX[a] - t1;
-            float t3 = t2 + yy;
-            if (!(t3 > 0.0f)) t3 = 0.0f;
-            o[t] = colok ? t3 : __builtin_inff();
-        }
-    }
-    // row-major store (256 B contiguous per wave-instruction)
-    {
-        float *D = scratch + P.offD;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int i = i0 + 16 * rq + t;
-            if (i < P.Mq) D[(size_t)i * P.pitchD + j0 + c] = o[t];
-        }
-    }
-    __syncthreads();   // all S reads done -> reuse as transpose stage O[64][65]
-#pragma unroll
-    for (int t = 0; t < 16; ++t) S[(16 * rq + t) * 65 + c] = o[t];
-    __syncthreads();
-    {
-        float *DT = scratch + P.offT;
-        const bool iok = (i0 + c) < P.Mq;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int b = 16 * rq + t;      // tile column -> row of D2T
-            const int j = j0 + b;
-            float v = S[c * 65 + b];
-            if (j < P.Mr) DT[(size_t)j * P.pitchT + i0 + c] = iok ? v : __builtin_inff();
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// K2: per-row kappa-percentile threshold.  One wave per row; 4 waves per workgroup,
-// each with a private LDS histogram.  No __syncthreads (waves are independent); LDS
-// operations of one wave execute in order.
-// ------------------------------------------------------------------------------------
+// LDS operations of one wave execute in order; this keeps the compiler from reordering them
 __device__ __forceinline__ void wave_lds_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -337,9 +198,6 @@ __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], i
     mx = wave_max(mx);
     int below = 0;           // elements strictly below the active range [mn, mx]
     float result = mn;
-#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 1
-    return SelectResult{mn + mx, 0, INF};
-#endif
     for (int iter = 0; iter < 64; ++iter) {
         if (!(mn < mx)) { result = mn; break; }
         const float scale = (float)SB / (mx - mn);
@@ -362,9 +220,6 @@ __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], i
         for (int t = 0; t < NV; ++t)
             __hip_atomic_fetch_add(&hist[SG::slot(bins[t])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         wave_lds_fence();
-#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 2
-        return SelectResult{(float)hist[lane] + (float)bins[3], 0, INF};
-#endif
         // scan: lane owns bins [BPL*lane, BPL*lane+BPL)
         int hv[BPL];
         int lsum = 0;
@@ -391,14 +246,10 @@ __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], i
         const int binsel = __builtin_amdgcn_readlane(binsel_v, L);
         const int cum = __builtin_amdgcn_readlane(cum_v, L);
         const int cnt = __builtin_amdgcn_readlane(cnt_v, L);
-#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 3
-        return SelectResult{(float)(binsel + cum + cnt) + (float)bins[3], 0, INF};
-#endif
         if (cnt <= 64) {
             // append the bin's elements (<= 64) to cand[] (order irrelevant), rank, pick.  Only
             // a handful of the NV register slots hold a hit in any lane: a wave-uniform ballot
             // skips the others.
-#if !(defined(ACX_SEL_STOP) && ACX_SEL_STOP == 41)
 #pragma unroll
             for (int t = 0; t < NV; ++t) {
                 const bool hit = bins[t] == binsel;
@@ -409,15 +260,11 @@ __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], i
                     }
                 }
             }
-#endif
             wave_lds_fence();
             const float mine = (lane < cnt) ? cand[lane] : INF;
             int rank = 0;
 #pragma unroll 1
             for (int t = 0; t < cnt; ++t) {      // cnt is an SGPR: scalar loop, no LDS traffic
-#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 42
-                break;
-#endif
                 const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), t));
                 rank += (o < mine || (o == mine && t < lane)) ? 1 : 0;
             }
@@ -441,9 +288,6 @@ __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], i
         wave_lds_fence();
     }
     SelectResult res{result, 0, INF};
-#if defined(ACX_SEL_STOP) && ACX_SEL_STOP == 4
-    return res;
-#endif
     if (want_next) {
         int cle = 0;
         float nx = INF;
@@ -456,28 +300,6 @@ __device__ __forceinline__ SelectResult wave_select_regs(const float (&x)[NV], i
         res.next = wave_min(nx);
     }
     return res;
-}
-
-// row in HBM -> registers (V4 back-to-back 16-byte loads per lane), then select
-template <int V4>
-__device__ __forceinline__ SelectResult wave_select(const float *__restrict__ v, int n, int pitch, int k,
-                                                    unsigned *hist, float *cand, unsigned *counter,
-                                                    int lane, bool want_next)
-{
-    constexpr int NV = 4 * V4;
-    float x[NV];
-    const float INF = __builtin_inff();
-#pragma unroll
-    for (int q = 0; q < V4; ++q) {
-        const int j = 256 * q + 4 * lane;
-        float4 t = make_float4(INF, INF, INF, INF);
-        if (j < pitch) t = *reinterpret_cast<const float4 *>(v + j);
-        x[4 * q + 0] = (j + 0 < n) ? t.x : INF;
-        x[4 * q + 1] = (j + 1 < n) ? t.y : INF;
-        x[4 * q + 2] = (j + 2 < n) ? t.z : INF;
-        x[4 * q + 3] = (j + 3 < n) ? t.w : INF;
-    }
-    return wave_select_regs<NV>(x, k, hist, cand, counter, lane, want_next);
 }
 
 // largest f32 x with sqrtf(x) <= eps (inclusive) or sqrtf(x) < eps (exclusive); -1 if none.
@@ -550,20 +372,14 @@ __device__ __forceinline__ void writelane_mask(unsigned &lo, unsigned &hi, unsig
 struct OpMinU { __device__ int operator()(int a, int b) const { return (unsigned)a < (unsigned)b ? a : b; } };
 struct OpMaxI { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
 
-#ifdef ACX_TIMING
-#define ACX_TS(k) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (tsel) tsel[k] = __builtin_readcyclecounter(); } while (0)
-#else
-#define ACX_TS(k) do { } while (0)
-#endif
 // NEGPAD: pads are negative instead of +inf.  They are skipped by the range pass without the bias
 // add, fall into bin 0 (the conversion saturates at 0) and rank below every cell, so the caller
 // passes k already raised by the number of pads that take part in the histogram.
 template <int NV, int BINS, int COPIES = 1, bool NEGPAD = false>
 __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bool want_next, unsigned hist_addr,
                                                  float *cand, int lane, float &slo, float &shi,
-                                                 unsigned long long *tsel = nullptr, bool lane_has_data = true)
+                                                 bool lane_has_data = true)
 {
-    ACX_TS(0);
     // The histogram has NB = BINS / COPIES logical bins of COPIES counters each; a lane adds to
     // copy (lane % COPIES), which spreads the lanes of one atomic over the banks (bank conflicts,
     // not VALU work, dominate the histogram pass).  Bin b = dwords [b COPIES, +COPIES).
@@ -598,7 +414,6 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
     if (!(range >= 1e-30f) || !(range <= 1e30f) || !(mn <= 2048.0f * range)) return false;
     const float scale4 = (4.0f * COPIES * ((float)NB - 1.5f)) * __builtin_amdgcn_rcpf(range);   // byte units
     const float off4 = -(mn * scale4);
-    ACX_TS(1);
     // ---- histogram
     unsigned off[NV];
     unsigned vmask = (unsigned)((NB - 1) * 4 * COPIES);
@@ -619,7 +434,6 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
             __hip_atomic_fetch_add((lds_u32 *)off[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     wave_lds_fence();
-    ACX_TS(2);
     // ---- scan: lane owns bins [BPL lane, +BPL); pieces read in a staggered order (conflict-free)
     int lsum = 0;
     {
@@ -673,7 +487,6 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
         if (bin2 != bin1) ncand += __builtin_amdgcn_readlane(c, l2);    // the bins between are empty
     }
     if (ncand > 64 || bin2 >= NB - 1) return false;
-    ACX_TS(3);
     // ---- gather the members of [bin1, bin2]
     unsigned a1 = hb + 4u * COPIES * (unsigned)bin1;
     const unsigned span = 4u * COPIES * (unsigned)(bin2 - bin1);
@@ -712,7 +525,6 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
         }
     }
     wave_lds_fence();
-    ACX_TS(4);
     // ---- rank them
     // every lane reads the candidates as LDS broadcasts, four per 16-byte read; slots beyond
     // ncand are padded with +inf first so that no tail test is needed
@@ -739,7 +551,6 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
         shi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), s2));
     }
     wave_lds_fence();
-    ACX_TS(5);
     return true;
 }
 
@@ -753,66 +564,6 @@ __device__ __forceinline__ float percentile_eps2(float slo, float shi, int pct_m
     const float d0 = __fmul_rn(dlo, __fsub_rn(ce, kf));
     const float d1 = __fmul_rn(dhi, __fsub_rn(kf, fl));
     return __fadd_rn(d0, d1);
-}
-
-template <int V4>
-__global__ __launch_bounds__(256) void rowsel_kernel(const PairDesc *__restrict__ pd,
-                                                     const float *__restrict__ scratch,
-                                                     float *__restrict__ thr,
-                                                     float kappa, int pct_mode, int inclusive)
-{
-    __shared__ __attribute__((aligned(16))) unsigned hist[4][SEL_SLOTS];
-    __shared__ float cand[4][64];
-    __shared__ unsigned counter[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const PairDesc P = pd[blockIdx.y];
-    const int r = blockIdx.x * 4 + wave;
-    if (r >= P.Mq + P.Mr) return;   // wave-uniform; no workgroup barriers below
-    const bool side = r >= P.Mq;    // false: row of D2 (query frame), true: row of D2T (reference frame)
-    const int row = side ? r - P.Mq : r;
-    const int n = side ? P.Mq : P.Mr;
-    const int pitch = side ? P.pitchT : P.pitchD;
-    const float *v = side ? scratch + P.offT + (size_t)row * P.pitchT
-                          : scratch + P.offD + (size_t)row * P.pitchD;
-
-    // percentile position, f32 like the oracle (percentile_f32)
-    const float kf = (n > 1) ? __fmul_rn((float)(n - 1), kappa) : __fmul_rn((float)n, kappa);
-    const float fl = floorf(kf), ce = ceilf(kf);
-    int ilo = (int)fl, ihi = (int)ce;
-    ilo = ilo < 0 ? 0 : (ilo > n - 1 ? n - 1 : ilo);
-    ihi = ihi < 0 ? 0 : (ihi > n - 1 ? n - 1 : ihi);
-
-    // one selection: rank k, plus (interpolating modes) the next order statistic
-    int k = ilo;
-    if (pct_mode == 3) {
-        k = (int)floorf(__fadd_rn(kf, 0.5f));
-        k = k > n - 1 ? n - 1 : k;
-    }
-    const bool interp = (pct_mode == 0 || pct_mode == 1);
-    const SelectResult sr = wave_select<V4>(v, n, pitch, k, hist[wave], cand[wave], &counter[wave], lane, interp);
-    const float slo = sr.value, nx = sr.next;
-    const int cle = sr.cnt_le;
-    float eps;
-    if (!interp) {
-        eps = __builtin_sqrtf(slo);
-    } else {
-        float shi = slo;
-        if (ihi != ilo && cle <= ihi) shi = nx;     // rank ihi is the next distinct value
-        const float dlo = __builtin_sqrtf(slo), dhi = __builtin_sqrtf(shi);
-        if (pct_mode == 0 && ihi == ilo) {
-            eps = dlo;
-        } else {
-            const float d0 = __fmul_rn(dlo, __fsub_rn(ce, kf));
-            const float d1 = __fmul_rn(dhi, __fsub_rn(kf, fl));
-            eps = __fadd_rn(d0, d1);
-        }
-    }
-    if (lane == 0) {
-        float *X = thr + P.offX;
-        const int o = side ? P.pitchT + row : row;
-        X[o] = d2_threshold(eps, inclusive);
-        X[P.pitchT + P.pitchD + o] = eps;
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -894,14 +645,19 @@ static __global__ void rotpool_kernel(const float *__restrict__ pool, float *__r
     frot[idx] = pool[f * NBIN + cls + 4 * ((r + kb) % 3)];
 }
 
-// Development aid (-DACX_TIMING): per-phase shader-clock totals of band_kernel, summed over all
-// waves into acx_tim[] (slot 31 = number of waves).  Not compiled into the product library.
-#ifdef ACX_TIMING
-static __device__ unsigned long long acx_tim[32];
-#define ACX_T(k) do { tstamp[k] = __builtin_readcyclecounter(); } while (0)
-#else
-#define ACX_T(k) do { } while (0)
-#endif
+// Pool decimated by the stack stride tau: frame t of the output track = frame t tau of the input
+// track (grid: x = track, y = chunks of 256 floats).
+static __global__ void decimate_kernel(const float *__restrict__ in, const int64_t *__restrict__ toff_in,
+                                       const int64_t *__restrict__ toff_out, float *__restrict__ out, int tau)
+{
+    const int track = blockIdx.x;
+    const int64_t o0 = toff_out[track];
+    const int n = (int)(toff_out[track + 1] - o0) * NBIN;
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int t = e / NBIN, b = e - t * NBIN;
+    out[o0 * NBIN + e] = in[(toff_in[track] + (int64_t)t * tau) * NBIN + b];
+}
 
 // Host-side launcher of band_kernel: its own translation unit (acx_band.hip), so that the kernel
 // can be compiled with the scheduling strategy that suits it without touching the others.
@@ -919,9 +675,6 @@ struct BandLaunch {
 // role 1 / 0 over B pairs of one size class; false when the stack size m has no instantiation
 bool launch_band_kernel(const BandLaunch &L, int m, const struct PairDesc *dpd, int B, int maxRows, int maxCols, int role,
                         int write_d2);
-#ifdef ACX_TIMING
-hipError_t band_timing(unsigned long long *out32, int reset);      // development builds: per-phase clock totals
-#endif
 
 template <int M>
 struct BandGeom {
@@ -946,14 +699,10 @@ __device__ __forceinline__ float percentile_eps(const SelectResult &sr, int pct_
     return __fadd_rn(d0, d1);
 }
 
-// (short-row variants: 6 waves / SIMD = 3 workgroups per CU; ACX_OCC6_ALL is a development switch)
-#ifdef ACX_OCC6_ALL
-#define ACX_OCC6(M_, V4_) ((V4_) <= 4)
-#else
-#define ACX_OCC6(M_, V4_) ((V4_) <= 4 && (M_) <= 9)      /* (m >= 10 needs two MFMA row tiles: LDS-limited anyway) */
-#endif
+// (short-row variants: 6 waves / SIMD = 3 workgroups per CU; m >= 10 needs two MFMA row tiles and is LDS-limited anyway)
+constexpr int band_waves_per_simd(int m, int v4) { return (v4 <= 4 && m <= 9) ? 6 : 4; }
 template <int M, int V4, int ROLE>
-__global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_kernel(const float *__restrict__ frot,
+__global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band_kernel(const float *__restrict__ frot,
                                                             const int64_t *__restrict__ toff,
                                                             const float *__restrict__ normtab,
                                                             const int64_t *__restrict__ noff,
@@ -976,25 +725,13 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     // For rows of >= 1024 positions the histogram lives in the upper part of the wave's OWN
     // exchange row, free once the row sits in registers; the shortest rows (2 KB) keep a separate
     // area behind the exchange rows.
-#ifdef ACX_FBINS
-    constexpr int FBINS = ACX_FBINS;
-#else
     constexpr int FBINS = NV >= 32 ? 1024 : 512;
-#endif
-#ifdef ACX_FCOPIES
-    constexpr int FCOPIES = ACX_FCOPIES;
-#else
     constexpr int FCOPIES = 1;
-#endif
     constexpr bool HIST_IN_ROW = ROWP >= 64 + 2 * FBINS;        // room for an FBINS-aligned block behind the 64 candidate slots
     constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
     constexpr int SWEEP_FLOATS = 8 * G::AROWS * G::SP;          // one Gram tile per wave
     constexpr int TAIL_FLOATS = BAND * ROWP + (HIST_IN_ROW ? 0 : 8 * FBINS);
-#ifdef ACX_LDS_PAD      /* experiment: force one workgroup per CU */
-    constexpr int LDS_FLOATS = 24 * 1024;
-#else
     constexpr int LDS_FLOATS = SWEEP_FLOATS > TAIL_FLOATS ? SWEEP_FLOATS : TAIL_FLOATS;
-#endif
     static_assert(SelGeom<GBINS>::SLOTS + 64 + 4 <= ROWP, "generic selection must fit the wave's own exchange row");
     static_assert(HIST_IN_ROW || (BAND * ROWP) % FBINS == 0, "fast histograms must be aligned to their size");
     __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
@@ -1018,12 +755,6 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     // pad is the largest UNSIGNED and the smallest SIGNED bit pattern -- the selection's integer min /
     // max skip it for free (a +inf pad needed a bias add per value for the max)
     const float PADV = -1.0f;
-#ifdef ACX_TIMING
-    unsigned long long tstamp[16];
-    unsigned long long tsub[4] = {0, 0, 0, 0};
-    for (int q = 0; q < 16; ++q) tstamp[q] = 0;
-#endif
-    ACX_T(0);
 
     // ---- MFMA operands come straight from the rotated frame pool (frot, see rotpool_kernel):
     // frame f holds, for each rotation r = 0..2 and residue class cls = 0..3, the three bins
@@ -1137,7 +868,6 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
             dv[a] = t3;
         }
     };
-    ACX_T(1);
 
     const int pitchD = P.pitchD;
     float *D = scratch + P.offD + (size_t)i0 * pitchD;
@@ -1151,13 +881,11 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
         if (interior) {
 #pragma unroll
             for (int a = 0; a < BAND; ++a) xv[a][st] = dv[a];
-#ifndef ACX_ABL_NOSTORE
             if (write_d2) {
                 float *Dl = D + j0;
 #pragma unroll
                 for (int a = 0; a < BAND; ++a) Dl[a * pitchD + a] = dv[a];
             }
-#endif
         } else {
 #pragma unroll
             for (int a = 0; a < BAND; ++a) {
@@ -1222,7 +950,6 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
             for (int a = 0; a < BAND; ++a) xv[a][st] = PADV;
         }
     });
-    ACX_T(2);
     // debug / v1 consumers: +inf into the pad columns [MB, pitchD) of the band's rows
     if (write_d2) {
         const int npad = pitchD - MB;
@@ -1232,7 +959,6 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
         }
     }
     __syncthreads();     // all slabs dead -> reuse LDS as the exchange rows + the fast histograms
-    ACX_T(3);
     // ---- exchange: row a of the band becomes a row of LDS in POSITION order (position p = 64 tile +
     // lane <-> column p - 7 + a), so that the owner of the row can pick up NV CONSECUTIVE positions
     // per lane.  With that layout one instruction of the selection handles 64 columns that are NV
@@ -1261,9 +987,7 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
 #pragma unroll
         for (int q = 0; q < FBINS / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    ACX_T(4);
     __syncthreads();
-    ACX_T(5);
     float xr[NV];      // xr[t] = cell at position NV lane + t of band row `wave` (column = position - 7 + wave)
     {
         const float *mine = smem + wave * ROWP + lane * LNP;
@@ -1279,10 +1003,6 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     // ---- exact percentile selection: wave w owns band row w
     const int row = i0 + wave;
     if (row >= MA) return;
-#ifdef ACX_ABL_NOSELECT
-    if (lane == 0) { float acc_ = 0; for (int e = 0; e < NV; ++e) acc_ += xr[e]; thr[P.offX + (role ? P.pitchT + row : row)] = acc_; }
-    return;
-#endif
     const int n = MB;
     const float kf = (n > 1) ? __fmul_rn((float)(n - 1), kappa) : __fmul_rn((float)n, kappa);
     const float fl = floorf(kf), ce = ceilf(kf);
@@ -1297,48 +1017,6 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     const bool interp = (pct_mode == 0 || pct_mode == 1);
     float *myrow = smem + wave * ROWP;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row has left LDS
-#if defined(ACX_EXTRA_VALU) || defined(ACX_EXTRA_LDS) || defined(ACX_EXTRA_MFMA) || defined(ACX_EXTRA_VALU4)
-    {   // sensitivity experiment (development): extra independent work of one kind per wave
-        float e0 = xr[0], e1 = xr[1], e2 = xr[2], e3 = xr[3];
-#ifdef ACX_EXTRA_VALU
-#pragma unroll
-        for (int q = 0; q < ACX_EXTRA_VALU / 4; ++q)
-            asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4"
-                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(xr[4]));
-#endif
-#ifdef ACX_EXTRA_VALU4
-#pragma unroll
-        for (int q = 0; q < ACX_EXTRA_VALU4 / 4; ++q)
-            asm volatile("v_max_f32 %0, %0, %4\n v_max_f32 %1, %1, %4\n v_max_f32 %2, %2, %4\n v_max_f32 %3, %3, %4"
-                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(xr[4]));
-#endif
-#ifdef ACX_EXTRA_LDS
-        {
-            const unsigned la = (unsigned)(uintptr_t)(lds_void *)(myrow) + 4u * lane;
-            unsigned t0, t1, t2, t3;
-#pragma unroll
-            for (int q = 0; q < ACX_EXTRA_LDS / 4; ++q) {
-                asm volatile("ds_read_b32 %0, %4\n ds_read_b32 %1, %4 offset:256\n ds_read_b32 %2, %4 offset:512\n ds_read_b32 %3, %4 offset:768\n s_waitcnt lgkmcnt(0)"
-                             : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3) : "v"(la) : "memory");
-                e0 += __uint_as_float(t0 ^ t1 ^ t2 ^ t3) * 0.0f;
-            }
-        }
-#endif
-#ifdef ACX_EXTRA_MFMA
-        {
-            f32x4 ac = {0.f, 0.f, 0.f, 0.f}, ad = ac;
-#pragma unroll
-            for (int q = 0; q < ACX_EXTRA_MFMA / 2; ++q) {
-                ac = __builtin_amdgcn_mfma_f32_16x16x4f32(e0, e1, ac, 0, 0, 0);
-                ad = __builtin_amdgcn_mfma_f32_16x16x4f32(e2, e3, ad, 0, 0, 0);
-            }
-            e0 += (ac[0] + ad[1]) * 0.0f;
-        }
-#endif
-        xr[0] += (e0 + e1 + e2 + e3) * 0.0f - (xr[0] + xr[1] + xr[2] + xr[3]) * 0.0f;
-    }
-#endif
-    ACX_T(6);
     float slo, shi;
     typedef __attribute__((address_space(3))) void lds_void;
     const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + hist_off);
@@ -1354,16 +1032,7 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
     // pads inside the lanes that take part in the histogram: the low ones of lane 0 and the tail of the
     // last lane with cells; they sit in bin 0 and rank below every cell
     const int npadc = ((BAND - 1) - wave) + (((end_valid + NV - 1) / NV) * NV - end_valid);
-#ifndef ACX_NO_FASTSEL
-#ifdef ACX_TIMING
-    unsigned long long tsel[6] = {0, 0, 0, 0, 0, 0};
-    done = wave_select_fast<NV, FBINS, FCOPIES, true>(xr, k + npadc, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, tsel, lane_has_data);
-    if (lane == 0 && done && tsel[5] && (blockIdx.x & 31) == 5) for (int q = 0; q < 5; ++q) atomicAdd(&acx_tim[20 + q], tsel[q + 1] - tsel[q]);
-    if (lane == 0 && (blockIdx.x & 31) == 5) atomicAdd(&acx_tim[done ? 26 : 25], 1ull);      // fast-path hits / fallbacks
-#else
-    done = wave_select_fast<NV, FBINS, FCOPIES, true>(xr, k + npadc, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, nullptr, lane_has_data);
-#endif
-#endif
+    done = wave_select_fast<NV, FBINS, FCOPIES, true>(xr, k + npadc, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, lane_has_data);
     if (!done) {
         unsigned *ghist = reinterpret_cast<unsigned *>(myrow) + 64;
         unsigned *counter = reinterpret_cast<unsigned *>(myrow) + 64 + SelGeom<GBINS>::SLOTS;
@@ -1374,26 +1043,14 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
         slo = sr.value;
         shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
     }
-#if defined(ACX_ABL_STAGE) && ACX_ABL_STAGE == 1
-    if (lane == 0) thr[P.offX + (role ? P.pitchT + row : row)] = slo + shi;
-    return;
-#endif
-    ACX_T(7);
     const float eps = percentile_eps2(slo, shi, pct_mode, ilo, ihi, kf, fl, ce);
     const float thr_row = d2_threshold(eps, inclusive);
-#ifdef ACX_TIMING
-    asm volatile("" :: "v"(thr_row));
-#endif
-    ACX_T(8);
     float *X = thr + P.offX;
     if (lane == 0) {
         const int o = role ? P.pitchT + row : row;
         X[o] = thr_row;
         X[P.pitchT + P.pitchD + o] = eps;
     }
-#if defined(ACX_ABL_STAGE) && ACX_ABL_STAGE == 2
-    return;
-#endif
     // ---- role 0 (the column thresholds of the pair are already there): binarise the row the
     // wave still holds in registers and emit it as a bitmap -- bit p of the row = position p =
     // column p - 7 + (row & 7).  256 bytes per row instead of 8 KB of f32.  A lane owns NV
@@ -1437,14 +1094,56 @@ __global__ __launch_bounds__(BAND_THREADS, (ACX_OCC6(M, V4) ? 6 : 4)) void band_
         if ((lane & (LPD - 1)) == 0 && d < ndw) rowbits[d] = acc;
         for (int z = 2 * NV + lane; z < ndw; z += 64) rowbits[z] = 0u;  // words beyond this size class
     }
-    ACX_T(9);
-#ifdef ACX_TIMING
-    if (lane == 0 && (blockIdx.x & 31) == 5) {
-        for (int q = 0; q < 9; ++q) atomicAdd(&acx_tim[q], tstamp[q + 1] - tstamp[q]);
-        for (int q = 0; q < 3; ++q) atomicAdd(&acx_tim[16 + q], tsub[q]);
-        atomicAdd(&acx_tim[31], 1ull);
+}
+
+// One DP row for the CPL columns of a lane (descending column order, in place): QA = row i-1,
+// QB = row i-2 (overwritten with row i); l1a / l1b / l2a (p1a / p1b / p2a: their penalised
+// versions) = the left neighbour lane's Q[i-1][j0-1], Q[i-1][j0-2], Q[i-2][j0-1]; wraw = raw
+// recurrence bits of row i, wprev = of row i-1, wleft bit e = R[i][j-1] (Dmax only).
+template <bool EQG, bool DMAX, int CPL>
+__device__ __forceinline__ void qmax_cells(unsigned wraw, unsigned colmask, unsigned wprev, unsigned wleft,
+                                           float l1a, float l1b, float l2a, float p1a, float p1b, float p2a,
+                                           const float (&QA)[CPL], float (&QB)[CPL],
+                                           const float (&PA)[EQG ? 1 : CPL], float (&PB)[EQG ? 1 : CPL],
+                                           float go, float ge, float &best)
+{
+    const unsigned w = wraw & colmask;
+#pragma unroll
+    for (int e = CPL - 1; e >= 0; --e) {
+        const bool r = (w >> e) & 1u;
+        float x3 = 0.0f, x4 = 0.0f;
+        if constexpr (DMAX) {
+            x3 = ((wprev >> e) & 1u) ? 1.0f : 0.0f;
+            x4 = ((wleft >> e) & 1u) ? 1.0f : 0.0f;
+        }
+        const float c2 = (e >= 1) ? QA[e - 1] : l1a;                          // (i-1, j-1)
+        float c3 = (e >= 1) ? QB[e - 1] : l2a;                                // (i-2, j-1)
+        float c4 = (e >= 2) ? QA[e - 2] : (e == 1 ? l1a : l1b);               // (i-1, j-2)
+        if constexpr (DMAX) { c3 += x3; c4 += x4; }
+        const float mx = fmaxf(fmaxf(c2, c3), c4);
+        float vgap;
+        if constexpr (EQG) {
+            vgap = fmaxf(mx - go, 0.0f);
+        } else {
+            const float a2 = (e >= 1) ? PA[e - 1] : p1a;
+            float a3 = (e >= 1) ? PB[e - 1] : p2a;
+            float a4 = (e >= 2) ? PA[e - 2] : (e == 1 ? p1a : p1b);
+            if constexpr (DMAX) { a3 += x3; a4 += x4; }
+            vgap = fmaxf(fmaxf(fmaxf(a2, a3), a4), 0.0f);
+        }
+        float q = r ? (mx + 1.0f) : vgap;
+        // Columns 0, 1 and the columns right of the matrix must not count.  For Qmax the masked
+        // recurrence bit does it alone: such a cell takes the gap branch, so it is <= a value an
+        // existing cell already reported (never a new maximum), it feeds only cells further
+        // right, and in columns 0 / 1 its predecessors are all 0.  Dmax adds raw recurrence bits
+        // to the predecessors, so there the cell is forced to 0.
+        if constexpr (DMAX) { if (!((colmask >> e) & 1u)) q = 0.0f; }
+        QB[e] = q;
+        // (Dmax: the penalty of a forced-0 cell in columns 0 / 1 follows its raw recurrence bit)
+        if constexpr (!EQG) PB[e] = q - ((DMAX ? (((wraw >> e) & 1u) != 0u) : r) ? go : ge);
     }
-#endif
+#pragma unroll
+    for (int e = 0; e < CPL; e += 2) best = fmaxf(best, fmaxf(QB[e], QB[e + 1]));
 }
 
 // ------------------------------------------------------------------------------------
@@ -1522,7 +1221,6 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
     auto dp_row = [&](int i, unsigned d0, unsigned d1, float (&QA)[CPL], float (&QB)[CPL],
                       float (&PA)[EQG ? 1 : CPL], float (&PB)[EQG ? 1 : CPL]) {
         const unsigned wraw = row_bits(i, d0, d1);
-        const unsigned w = wraw & colmask;
         float l1a = wave_shfl(QA[CPL - 1], prev), l1b = wave_shfl(QA[CPL - 2], prev), l2a = wave_shfl(QB[CPL - 1], prev);
         float p1a = 0.f, p1b = 0.f, p2a = 0.f;
         if constexpr (!EQG) {
@@ -1535,42 +1233,7 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
             if (lane == 0) carry = 0u;
             wleft = (wraw << 1) | carry;
         }
-#pragma unroll
-        for (int e = CPL - 1; e >= 0; --e) {
-            const bool r = (w >> e) & 1u;
-            float x3 = 0.0f, x4 = 0.0f;
-            if constexpr (DMAX) {
-                x3 = ((wprev >> e) & 1u) ? 1.0f : 0.0f;
-                x4 = ((wleft >> e) & 1u) ? 1.0f : 0.0f;
-            }
-            const float c2 = (e >= 1) ? QA[e - 1] : l1a;                          // (i-1, j-1)
-            float c3 = (e >= 1) ? QB[e - 1] : l2a;                                // (i-2, j-1)
-            float c4 = (e >= 2) ? QA[e - 2] : (e == 1 ? l1a : l1b);               // (i-1, j-2)
-            if constexpr (DMAX) { c3 += x3; c4 += x4; }
-            const float mx = fmaxf(fmaxf(c2, c3), c4);
-            float vgap;
-            if constexpr (EQG) {
-                vgap = fmaxf(mx - go, 0.0f);
-            } else {
-                const float a2 = (e >= 1) ? PA[e - 1] : p1a;
-                float a3 = (e >= 1) ? PB[e - 1] : p2a;
-                float a4 = (e >= 2) ? PA[e - 2] : (e == 1 ? p1a : p1b);
-                if constexpr (DMAX) { a3 += x3; a4 += x4; }
-                vgap = fmaxf(fmaxf(fmaxf(a2, a3), a4), 0.0f);
-            }
-            float q = r ? (mx + 1.0f) : vgap;
-            // Columns 0, 1 and the columns right of the matrix must not count.  For Qmax the masked
-            // recurrence bit does it alone: such a cell takes the gap branch, so it is <= a value an
-            // existing cell already reported (never a new maximum), it feeds only cells further
-            // right, and in columns 0 / 1 its predecessors are all 0.  Dmax adds raw recurrence bits
-            // to the predecessors, so there the cell is forced to 0.
-            if constexpr (DMAX) { if (!((colmask >> e) & 1u)) q = 0.0f; }
-            QB[e] = q;
-            // (Dmax: the penalty of a forced-0 cell in columns 0 / 1 follows its raw recurrence bit)
-            if constexpr (!EQG) PB[e] = q - ((DMAX ? (((wraw >> e) & 1u) != 0u) : r) ? go : ge);
-        }
-#pragma unroll
-        for (int e = 0; e < CPL; e += 2) best = fmaxf(best, fmaxf(QB[e], QB[e + 1]));
+        qmax_cells<EQG, DMAX, CPL>(wraw, colmask, wprev, wleft, l1a, l1b, l2a, p1a, p1b, p2a, QA, QB, PA, PB, go, ge, best);
         if constexpr (DMAX) wprev = wraw;
     };
 
@@ -1586,164 +1249,6 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
     }
     best = wave_max(best);
     if (lane == 0) out[(size_t)blockIdx.x * out_stride] = best;
-}
-
-// ------------------------------------------------------------------------------------
-// K3: Qmax / Dmax row sweep, one wave per pair.  Lane owns NG groups of 8 contiguous
-// columns: group g = columns [512 g + 8 lane, +8).  Q rows i-1 / i-2 live in registers;
-// the row in flight is updated in place (descending column order).
-// EQG: gamma_o == gamma_e (the default) -> max(a-g, b-g, c-g) == max(a,b,c)-g exactly.
-// ------------------------------------------------------------------------------------
-template <int NG>
-__device__ __forceinline__ void qmax_load_row(float (&buf)[NG][8], const float *__restrict__ D,
-                                              int pitch, int row, int nrows, int lane)
-{
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int col = 512 * g + 8 * lane;
-        float4 t0 = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());
-        float4 t1 = t0;
-        if (row < nrows && col < pitch) {
-            const float4 *p = reinterpret_cast<const float4 *>(D + (size_t)row * pitch + col);
-            t0 = p[0];
-            t1 = p[1];
-        }
-        buf[g][0] = t0.x; buf[g][1] = t0.y; buf[g][2] = t0.z; buf[g][3] = t0.w;
-        buf[g][4] = t1.x; buf[g][5] = t1.y; buf[g][6] = t1.z; buf[g][7] = t1.w;
-    }
-}
-
-// One DP row.  P1/P2: Q rows i-1 / i-2 (P2 is overwritten with row i).
-template <int NG, bool EQG>
-__device__ __forceinline__ void qmax_row(const float (&buf)[NG][8],
-                                         float (&Q1)[NG][8], float (&Q2)[NG][8],
-                                         float (&Pn1)[EQG ? 1 : NG][8], float (&Pn2)[EQG ? 1 : NG][8],
-                                         const float (&xc)[NG][8], float xrow,
-                                         float go, float ge, int lane, float &best)
-{
-    const int prev = (lane + 63) & 63;
-    // values of the left neighbour columns (previous lane, or lane 63 of the previous group)
-    float l1a[NG], l1b[NG], l2a[NG];     // Q1[j0-1], Q1[j0-2], Q2[j0-1]
-    float p1a[NG], p1b[NG], p2a[NG];     // penalised versions (gammas differ)
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        float a = wave_shfl(Q1[g][7], prev), b = wave_shfl(Q1[g][6], prev), c = wave_shfl(Q2[g][7], prev);
-        l1a[g] = a; l1b[g] = b; l2a[g] = c;
-        if constexpr (!EQG) {
-            p1a[g] = wave_shfl(Pn1[g][7], prev);
-            p1b[g] = wave_shfl(Pn1[g][6], prev);
-            p2a[g] = wave_shfl(Pn2[g][7], prev);
-        }
-    }
-    // lane 0 takes the wrapped values from the previous group (or zeros at the matrix edge)
-#pragma unroll
-    for (int g = NG - 1; g >= 0; --g) {
-        if (lane == 0) {
-            l1a[g] = g > 0 ? l1a[g - 1] : 0.0f;
-            l1b[g] = g > 0 ? l1b[g - 1] : 0.0f;
-            l2a[g] = g > 0 ? l2a[g - 1] : 0.0f;
-            if constexpr (!EQG) {
-                p1a[g] = g > 0 ? p1a[g - 1] : 0.0f;
-                p1b[g] = g > 0 ? p1b[g - 1] : 0.0f;
-                p2a[g] = g > 0 ? p2a[g - 1] : 0.0f;
-            }
-        }
-    }
-    // NOTE on the lane-0 fix-up above: for lane 0 the shuffled value is lane 63's register of
-    // the SAME group; the wanted one is lane 63's register of group g-1, which is what
-    // l1a[g-1] holds for lane 0 BEFORE its own fix-up -- hence the descending g order.
-
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const float (&d)[8] = buf[g];
-        float qn[8], pn[8];
-        bool rr[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rr[e] = d[e] <= fminf(xrow, xc[g][e]);
-#pragma unroll
-        for (int e = 7; e >= 0; --e) {
-            const float c2 = (e >= 1) ? Q1[g][e - 1] : l1a[g];                       // (i-1, j-1)
-            const float c3 = (e >= 1) ? Q2[g][e - 1] : l2a[g];                             // (i-2, j-1)
-            const float c4 = (e >= 2) ? Q1[g][e - 2] : (e == 1 ? l1a[g] : l1b[g]);         // (i-1, j-2)
-            float mx = fmaxf(fmaxf(c2, c3), c4);
-            float vmatch = mx + 1.0f;
-            float vgap;
-            if constexpr (EQG) {
-                vgap = fmaxf(mx - go, 0.0f);
-            } else {
-                const float a2 = (e >= 1) ? Pn1[g][e - 1] : p1a[g];
-                float a3 = (e >= 1) ? Pn2[g][e - 1] : p2a[g];
-                float a4 = (e >= 2) ? Pn1[g][e - 2] : (e == 1 ? p1a[g] : p1b[g]);
-                vgap = fmaxf(fmaxf(fmaxf(a2, a3), a4), 0.0f);
-            }
-            qn[e] = rr[e] ? vmatch : vgap;
-            pn[e] = qn[e] - (rr[e] ? go : ge);
-        }
-        if (g == 0 && lane == 0) { qn[0] = 0.0f; qn[1] = 0.0f; pn[0] = 0.0f; pn[1] = 0.0f; }   // first two columns stay 0
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            Q2[g][e] = qn[e];
-            if constexpr (!EQG) Pn2[g][e] = pn[e];
-            best = fmaxf(best, qn[e]);
-        }
-    }
-}
-
-template <int NG, bool EQG>
-__global__ __launch_bounds__(64) void qmax_kernel(const PairDesc *__restrict__ pd,
-                                                  const float *__restrict__ scratch,
-                                                  const float *__restrict__ thr,
-                                                  float *__restrict__ out,
-                                                  float go, float ge, int dp_start)
-{
-    const int lane = threadIdx.x;
-    const PairDesc P = pd[blockIdx.x];
-    int Me = P.Mq, Ne = P.Mr;
-    if (dp_start == 3) { Me -= 1; Ne -= 1; }
-    const float *D = scratch + P.offD;
-    const int pitch = P.pitchD;
-    const float *xr = thr + P.offX;
-    const float *xcp = xr + P.pitchT;
-
-    float xc[NG][8];
-    float QA[NG][8], QB[NG][8];
-    float PA[EQG ? 1 : NG][8], PB[EQG ? 1 : NG][8];
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int j = 512 * g + 8 * lane + e;
-            xc[g][e] = (j < Ne) ? xcp[j] : -1.0f;    // -1: never recurrent (d2 >= 0)
-            QA[g][e] = 0.0f;
-            QB[g][e] = 0.0f;
-            if constexpr (!EQG) { PA[g][e] = 0.0f; PB[g][e] = 0.0f; }
-        }
-    float best = 0.0f;
-
-    float b0[NG][8], b1[NG][8], b2[NG][8];
-    qmax_load_row<NG>(b0, D, pitch, 2, Me, lane);
-    qmax_load_row<NG>(b1, D, pitch, 3, Me, lane);
-    float xrv = 0.0f;
-    for (int i = 2; i < Me; i += 6) {
-        // thresholds of rows i .. i+5 (lane t holds row i + t)
-        xrv = (i + lane < Me && lane < 6) ? xr[i + lane] : -1.0f;
-#define ACX_QSTEP(S, BUF, NEXT, Q1, Q2, P1, P2)                                                     \
-        if (i + S < Me) {                                                                           \
-            qmax_load_row<NG>(NEXT, D, pitch, i + S + 2, Me, lane);                                 \
-            const float xrow = __shfl(xrv, S, 64);                                                  \
-            qmax_row<NG, EQG>(BUF, Q1, Q2, P1, P2, xc, xrow, go, ge, lane, best);              \
-        }
-        // row i+S reads Q1 = row i+S-1, Q2 = row i+S-2 and overwrites Q2
-        ACX_QSTEP(0, b0, b2, QA, QB, PA, PB)   // QA = row i-1, QB = row i-2 -> QB = row i
-        ACX_QSTEP(1, b1, b0, QB, QA, PB, PA)
-        ACX_QSTEP(2, b2, b1, QA, QB, PA, PB)
-        ACX_QSTEP(3, b0, b2, QB, QA, PB, PA)
-        ACX_QSTEP(4, b1, b0, QA, QB, PA, PB)
-        ACX_QSTEP(5, b2, b1, QB, QA, PB, PA)
-#undef ACX_QSTEP
-    }
-    best = wave_max(best);
-    if (lane == 0) out[blockIdx.x] = best;
 }
 
 static __global__ void sqrt_probe_kernel(const float *in, float *out, int64_t n)

@@ -44,7 +44,7 @@ M_STACK = 9
 # recurrence bitmap); each launch carries one 4 B/cell pass over the distance matrix of the
 # model (write / read-back), together the 8 B/cell of v1's csm_tile_kernel + rowsel_kernel;
 # qmax_kernel = the DP over the recurrence plot.
-ALGO_BYTES_PER_CELL = {"band_kernel": 4.0, "csm_tile_kernel": 4.0, "rowsel_kernel": 4.0, "qmax_kernel": 2.0,
+ALGO_BYTES_PER_CELL = {"band_kernel": 4.0, "csm_long_kernel": 4.0, "rowsel_long_kernel": 4.0, "qmax_bits_kernel": 2.0,
                        "oti_kernel": 0.0, "norms_kernel": 0.0}
 
 
@@ -134,7 +134,7 @@ def main():
         cells_per_launch = kst["cells"] / launches
         avg_ms = kst["ms"] / launches
         algo_bytes = ALGO_BYTES_PER_CELL[kname] * cells_per_launch
-        if kname in ("csm_tile_kernel", "band_kernel"):
+        if kname in ("csm_long_kernel", "band_kernel"):
             algo_bytes += 48.0 * 2 * T_FRAMES * (cells_per_launch / float((T_FRAMES - M_STACK) ** 2))
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None

@@ -86,8 +86,8 @@ int acx_download_pool(acx_ctx *ctx, float *frames, int64_t capacity);
  * essentia (rqa_serra09.py:60-64), plus the switchable recalled-essentia details
  * documented in oracle/acx_oracle.c. */
 typedef struct {
-    int32_t m;           /* frameStackSize,   default 9      */
-    int32_t tau;         /* frameStackStride, default 1 (device: 1 only) */
+    int32_t m;           /* frameStackSize,   default 9 (device: 1..33) */
+    int32_t tau;         /* frameStackStride, default 1 */
     float kappa;         /* binarizePercentile, default 0.095 */
     int32_t oti;         /* default 1 */
     float gamma_o;       /* disOnset, default 0.5 */
@@ -135,6 +135,15 @@ int acx_serra09_debug_pair(acx_ctx *ctx, int32_t i, int32_t j,
                            float *d2, float *epsq, float *epsr,
                            float *thrq, float *thrr,
                            int32_t *oti, float *score, int32_t *dims);
+
+/*
+ * The alignment alone (tests): Qmax ('serra09', params->dmax = 0) or Dmax ('chen17', dmax = 1) of a
+ * given binary (M, N) uint8 cross recurrence plot -- the scalar CoverSongSimilarity returns for the
+ * matrix ChromaCrossSimilarity produced (rqa_serra09.py:64,67; latefusion_chen.py:68-71).  Uses
+ * params->gamma_o, gamma_e, dp_start, dmax; any M, N.  Non-{0,1} input -> ACX_ERR_INVALID.
+ */
+int acx_qmax_binary(acx_ctx *ctx, const uint8_t *R, int32_t M, int32_t N, const acx_serra09_params *params,
+                    float *score);
 
 /* Number of embedded frames for a pooled length T (0 if too short). */
 int32_t acx_serra09_embed_len(int32_t T, const acx_serra09_params *params);

@@ -166,6 +166,20 @@ def serra09_pairs(frames, offsets, pairs, params=None):
     return out
 
 
+def serra09_pairs_mt(frames, offsets, pairs, params=None, workers=None, chunk=8):
+    """serra09_pairs over a thread pool (ctypes releases the GIL; the C routine keeps no global
+    state): same results, in the order of `pairs`."""
+    from concurrent.futures import ThreadPoolExecutor
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    workers = workers or max(1, min(64, os.cpu_count() or 1))
+    lib()
+    frames = _f32(frames)
+    chunks = [pairs[a:a + chunk] for a in range(0, len(pairs), chunk)]
+    with ThreadPoolExecutor(workers) as ex:
+        parts = list(ex.map(lambda ch: serra09_pairs(frames, offsets, ch, params), chunks))
+    return np.concatenate(parts) if parts else np.empty(0, np.float32)
+
+
 def qmax_binary(R, gamma_o=0.5, gamma_e=0.5, dmax=False):
     R = np.ascontiguousarray(R, dtype=np.uint8)
     return float(lib().acx_o_qmax_binary(R.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),

@@ -1,0 +1,166 @@
+"""
+GPU parity tests at the sizes BASELINE.json's configs state (run with -m gpu on a real MI355X):
+
+  configs[1]  covers80 Serra09 Qmax on one MI355X: 164 tracks / 80 works with the clique sizes of
+              acoss/data/covers80_annotations.csv, 300-600 pooled frames, ALL 13 366 unordered pairs
+              -- HIP scores bit-identical to the oracle's, identical MR / MRR / MDR / MAP / Top-k, and
+              |dMAP| <= 1e-4 against the oracle's essentia-like "seq108" arithmetic;
+  metric      T = 2000: the HIP scores against seq108 on 64 pairs (stated tolerance +-2.0);
+  configs[2], north_star target
+              a DA-TACOS-size pool (15 000 tracks x 2000 frames: 1.44 GB of chroma, a 4.3 GB rotated
+              pool, offsets beyond 2^31 bytes): 20 000 random pairs through oracle-free properties,
+              64 sampled pairs bit-exact vs the oracle.
+
+The measured |dscore| histogram and flipped-cell fraction between the two arithmetics are written
+to gpurun_out/parity_serra09.json (copied to profiles/ by hand).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from acoss_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _record(key, value):
+    path = os.path.join(ROOT, "gpurun_out", "parity_serra09.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = value
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _stats(oracle, d, pairs, scores, topsidx=(1, 10, 100)):
+    n = len(d["offsets"]) - 1
+    D = np.zeros((n, n), np.float32)
+    D[pairs[:, 0], pairs[:, 1]] = scores
+    D += D.T
+    D = oracle.serra09_normalize_by_length(D, np.diff(d["offsets"]))
+    cl = {}
+    for i, l in enumerate(d["labels"]):
+        cl.setdefault(l, []).append(i)
+    return oracle.eval_statistics(D, list(cl.values()), topsidx=topsidx)
+
+
+def _hist(delta):
+    edges = [0, 0.5, 1.0, 1.5, 2.0, 3.0, 5.0, 1e9]
+    a = np.abs(np.asarray(delta, np.float64))
+    return {"n": int(a.size), "equal": int(np.sum(a == 0)),
+            "bins_le": {str(e): int(np.sum(a <= e)) for e in edges[:-1]}, "max": float(a.max()) if a.size else 0.0}
+
+
+def test_covers80_shaped_all_pairs(ctx):
+    import oracle
+    from acoss_amd import synth
+    d = synth.covers80_shaped(seed=4321, t_range=(300, 600))
+    n = len(d["offsets"]) - 1
+    assert n == 164 and len(set(d["labels"])) == 80
+    ctx.upload_pool(d["frames"], d["offsets"])
+    pairs = oracle.all_pairs(n, True).astype(np.int32)
+    assert len(pairs) == 13366
+    got = ctx.serra09_pairs(pairs)
+    ref = oracle.serra09_pairs_mt(d["frames"], d["offsets"], pairs)
+    assert np.array_equal(got, ref), "scores differ for %d / %d pairs" % (int(np.sum(got != ref)), len(ref))
+    sg, sr = _stats(oracle, d, pairs, got), _stats(oracle, d, pairs, ref)
+    assert sg[:4] == sr[:4] and np.array_equal(sg[4], sr[4])
+    # essentia-like arithmetic: sequential 108-dim inner products
+    ref108 = oracle.serra09_pairs_mt(d["frames"], d["offsets"], pairs, oracle.serra09_params(arith="seq108"))
+    s108 = _stats(oracle, d, pairs, ref108)
+    assert abs(sg[3] - s108[3]) <= 1e-4, (sg[3], s108[3])
+    assert np.max(np.abs(got - ref108)) <= 2.0
+    # flipped recurrence cells between the two arithmetics on a sample of pairs
+    rng = np.random.default_rng(0)
+    flipped = cells = 0
+    for k in rng.choice(len(pairs), 24, replace=False):
+        i, j = pairs[k]
+        qi = d["frames"][d["offsets"][i]:d["offsets"][i + 1]]
+        rj = d["frames"][d["offsets"][j]:d["offsets"][j + 1]]
+        _, a = oracle.serra09_pair(qi, rj, oracle.serra09_params(), want_intermediates=True)
+        _, b = oracle.serra09_pair(qi, rj, oracle.serra09_params(arith="seq108"), want_intermediates=True)
+        flipped += int(np.sum(a["R"] != b["R"]))
+        cells += a["R"].size
+    _record("covers80_shaped", {"tracks": n, "pairs": int(len(pairs)), "hip_vs_tree_oracle": "bit-identical",
+                                "MR_MRR_MDR_MAP_hip": [float(x) for x in sg[:4]], "MAP_seq108": float(s108[3]),
+                                "MR_seq108": float(s108[0]), "tops_hip": [float(x) for x in sg[4]],
+                                "tops_seq108": [float(x) for x in s108[4]],
+                                "abs_dscore_hip_vs_seq108": _hist(got - ref108),
+                                "flipped_cells_tree_vs_seq108": {"pairs": 24, "cells": cells, "flipped": flipped,
+                                                                 "fraction": flipped / max(1, cells)}})
+
+
+def test_seq108_at_T2000(ctx):
+    import oracle
+    from acoss_amd import synth
+    d = synth.rand_set(24, T=2000, seed=1234)
+    ctx.upload_pool(d["frames"], d["offsets"])
+    rng = np.random.default_rng(1)
+    iu, ju = np.triu_indices(24, 1)
+    sel = rng.choice(len(iu), 64, replace=False)
+    pairs = np.stack([iu[sel], ju[sel]], 1).astype(np.int32)
+    got = ctx.serra09_pairs(pairs)
+    tree = oracle.serra09_pairs_mt(d["frames"], d["offsets"], pairs, chunk=1)
+    assert np.array_equal(got, tree)
+    ref108 = oracle.serra09_pairs_mt(d["frames"], d["offsets"], pairs, oracle.serra09_params(arith="seq108"), chunk=1)
+    assert np.max(np.abs(got - ref108)) <= 2.0, np.max(np.abs(got - ref108))
+    _record("rand_T2000", {"pairs": 64, "abs_dscore_hip_vs_seq108": _hist(got - ref108)})
+    # structured tracks of the same length (cover versions align over long stretches)
+    c = synth.cover_set(n_works=4, versions=3, seed=2000, t_range=(1700, 2040))
+    ctx.upload_pool(c["frames"], c["offsets"])
+    n = len(c["offsets"]) - 1
+    pairs = oracle.all_pairs(n, True).astype(np.int32)
+    got = ctx.serra09_pairs(pairs)
+    assert np.array_equal(got, oracle.serra09_pairs_mt(c["frames"], c["offsets"], pairs, chunk=1))
+    ref108 = oracle.serra09_pairs_mt(c["frames"], c["offsets"], pairs, oracle.serra09_params(arith="seq108"), chunk=1)
+    assert np.max(np.abs(got - ref108)) <= 2.0, np.max(np.abs(got - ref108))
+    sg, s108 = _stats(oracle, c, pairs, got), _stats(oracle, c, pairs, ref108)
+    assert abs(sg[3] - s108[3]) <= 1e-4 and sg[0] == s108[0]
+    _record("covers_T2000", {"pairs": int(len(pairs)), "abs_dscore_hip_vs_seq108": _hist(got - ref108),
+                             "MAP_hip": float(sg[3]), "MAP_seq108": float(s108[3])})
+
+
+def test_pool_scale_15000_tracks(ctx):
+    """The DA-TACOS-size pool: 15 000 x 2000 frames.  frames 1.44 GB, rotated pool 4.32 GB, norm
+    table 1.43 GB -- device offsets beyond 2^31 bytes and 2^30 floats."""
+    import oracle
+    from acoss_amd import synth
+    N, T = 15000, 2000
+    rng = np.random.default_rng(1234)
+    frames = rng.random((N * T, 12), dtype=np.float32)
+    frames /= frames.max(axis=1, keepdims=True)
+    offsets = np.arange(N + 1, dtype=np.int64) * T
+    ctx.upload_pool(frames, offsets)
+    pairs = rng.integers(0, N, (20000, 2)).astype(np.int32)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    pairs[:64, 0] = N - 1 - np.arange(64)            # the far end of the pool is covered for sure
+    got = ctx.serra09_pairs(pairs)
+    assert got.shape == (len(pairs),) and np.all(got >= 1.0) and np.all(got < 200.0)
+    # (1) bit-exact vs the oracle on 64 sampled pairs (32 of them at the far end)
+    sel = np.concatenate([np.arange(32), rng.choice(np.arange(64, len(pairs)), 32, replace=False)])
+    ref = oracle.serra09_pairs_mt(frames, offsets, pairs[sel], chunk=1)
+    assert np.array_equal(got[sel], ref), (got[sel], ref)
+    # (2) self pairs at both ends: full diagonal, T - 9 - 2
+    selfp = np.array([[0, 0], [N // 2, N // 2], [N - 1, N - 1]], np.int32)
+    assert np.array_equal(ctx.serra09_pairs(selfp), np.full(3, T - 11, np.float32))
+    # (3) a score does not depend on where the tracks sit in the pool: the last 48 tracks as a pool of their own
+    tail = np.arange(N - 48, N)
+    iu, ju = np.triu_indices(48, 1)
+    big = ctx.serra09_pairs(np.stack([tail[iu], tail[ju]], 1).astype(np.int32))
+    ctx.upload_pool(frames[(N - 48) * T:], np.arange(49, dtype=np.int64) * T)
+    small = ctx.serra09_pairs(np.stack([iu, ju], 1).astype(np.int32))
+    assert np.array_equal(big, small)
+    _record("pool_15000x2000", {"pairs_run": int(len(pairs)), "oracle_checked": 64, "tail_pool_pairs": int(len(iu)),
+                                "result": "bit-identical"})

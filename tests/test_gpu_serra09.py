@@ -45,11 +45,16 @@ def _compare_pair(ctx, d, i, j, gp, op, tag=""):
     br = np.nonzero(g["eps_r"] != it["eps_r"])[0]
     assert len(bq) == 0, "%s row thresholds differ at %s: %s vs %s" % (tag, bq[:5], g["eps_q"][bq[:5]], it["eps_q"][bq[:5]])
     assert len(br) == 0, "%s col thresholds differ at %s: %s vs %s" % (tag, br[:5], g["eps_r"][br[:5]], it["eps_r"][br[:5]])
-    incl = bool(op.inclusive)
-    if incl:
-        Rg = (g["d2"] <= g["thr_q"][:, None]) & (g["d2"] <= g["thr_r"][None, :])
+    # the device compares SQUARED distances against thresholds moved to the d2 domain: thr = the
+    # largest f32 x with sqrt(x) <= eps (inclusive) or sqrt(x) < eps (exclusive), so `d2 <= thr` is the
+    # test in both modes; it must reproduce the oracle's comparison of d = sqrt(d2) with eps
+    Rg = (g["d2"] <= g["thr_q"][:, None]) & (g["d2"] <= g["thr_r"][None, :])
+    if op.inclusive:
+        Rd = (dg <= g["eps_q"][:, None]) & (dg <= g["eps_r"][None, :])
     else:
-        Rg = (g["d2"] <= g["thr_q"][:, None]) & (g["d2"] <= g["thr_r"][None, :])
+        Rd = (dg < g["eps_q"][:, None]) & (dg < g["eps_r"][None, :])
+    assert np.array_equal(Rg, Rd), "%s d2-domain thresholds disagree with d-domain comparison in %d cells" % (
+        tag, int(np.sum(Rg != Rd)))
     assert np.array_equal(Rg.astype(np.uint8), it["R"]), "%s recurrence plot differs in %d cells" % (
         tag, int(np.sum(Rg.astype(np.uint8) != it["R"])))
     assert g["score"] == s, "%s score %r vs %r" % (tag, g["score"], s)
@@ -218,21 +223,139 @@ def test_full_size_properties_without_the_oracle(ctx):
     assert np.array_equal(qd[:, 0], big[:6]) and np.all(qd[:, 1] >= qd[:, 0])
 
 
-def test_maximum_track_length(ctx):
-    """The device limit: 2041 embedded frames (T = 2050 with the default stack).  At the limit
-    the score equals the oracle's; one frame more is refused loudly (NotImplementedError)."""
-    from acoss_amd import synth
+def test_band_limit_and_long_tracks(ctx):
+    """Rows of up to 2041 cells (T = 2050 with the default stack) run in the band kernel; longer
+    tracks take the streaming kernels (serra09_long_kernels.hpp).  Both sides of the boundary, a
+    mixed batch, and every intermediate of a long pair: bit-exact vs the oracle."""
+    from acoss_amd import synth, _lib
     oracle = _oracle()
     rng = np.random.default_rng(17)
-    tracks = [synth._frame_max_normalise(rng.random((T, 12))) for T in (2050, 2050, 2051, 1200)]
+    lens = (2050, 2050, 2051, 1200, 2300, 100)
+    tracks = [synth._frame_max_normalise(rng.random((T, 12))) for T in lens]
     frames, offsets = synth.pack(tracks)
+    d = dict(frames=frames, offsets=offsets)
     ctx.upload_pool(frames, offsets)
-    pairs = np.array([[0, 1], [1, 0], [3, 0], [0, 3]], np.int32)
+    pairs = np.array([[0, 1], [1, 0], [3, 0], [0, 3], [2, 0], [0, 2], [2, 4], [4, 3], [5, 4], [4, 5], [3, 5]], np.int32)
     got = ctx.serra09_pairs(pairs)
     ref = oracle.serra09_pairs(frames, offsets, pairs)
     assert np.array_equal(got, ref), (got, ref)
-    with pytest.raises(NotImplementedError):
-        ctx.serra09_pairs(np.array([[2, 0]], np.int32))
+    _compare_pair(ctx, d, 2, 4, _lib.serra09_params(), oracle.serra09_params(), "long(2051,2300)")
+    _compare_pair(ctx, d, 5, 2, _lib.serra09_params(pct_mode=1, inclusive=0), oracle.serra09_params(pct_mode=1, inclusive=0), "long(100,2051)")
+
+
+def test_long_tracks_5000(ctx):
+    """T = 5 000 pooled frames (40 minutes of audio at the default profile): three DP strips of
+    2048 columns, Qmax and Dmax, equal and distinct gap penalties, structured and i.i.d. chroma."""
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    rng = np.random.default_rng(5000)
+    cov = synth.cover_set(n_works=1, versions=2, seed=50, t_range=(4300, 4400))
+    tracks = [synth._frame_max_normalise(rng.random((5000, 12))), synth._frame_max_normalise(rng.random((4200, 12))),
+              cov["frames"][cov["offsets"][0]:cov["offsets"][1]], cov["frames"][cov["offsets"][1]:cov["offsets"][2]],
+              synth._frame_max_normalise(rng.random((700, 12)))]
+    frames, offsets = synth.pack(tracks)
+    ctx.upload_pool(frames, offsets)
+    pairs = np.array([[0, 1], [1, 0], [2, 3], [3, 2], [4, 0], [0, 4], [2, 0]], np.int32)
+    for kw in (dict(), dict(dmax=1), dict(gamma_o=1.0, gamma_e=0.25), dict(dmax=1, gamma_o=0.25, gamma_e=1.5, dp_start=3)):
+        got = ctx.serra09_pairs(pairs, _lib.serra09_params(**kw))
+        ref = oracle.serra09_pairs(frames, offsets, pairs, oracle.serra09_params(**kw))
+        assert np.array_equal(got, ref), (kw, got, ref)
+    both = ctx.chenfusion_pairs(pairs[:4])
+    assert np.array_equal(both[:, 0], oracle.serra09_pairs(frames, offsets, pairs[:4]))
+    assert np.array_equal(both[:, 1], oracle.serra09_pairs(frames, offsets, pairs[:4], oracle.serra09_params(dmax=1)))
+    assert both[2, 0] > 50.0          # the two versions of one work align over a long stretch
+
+
+@pytest.mark.parametrize("kw", [dict(tau=2), dict(tau=3, m=5), dict(tau=2, embed_full=1), dict(m=17), dict(m=24, kappa=0.2),
+                                dict(m=33), dict(m=20, tau=2, dmax=1)])
+def test_stack_stride_and_large_stacks(ctx, kw):
+    """frameStackStride > 1 (the pool decimated on the device) and stacks of more than 16 frames
+    (streaming kernels with a run-time m): every intermediate bit-exact vs the oracle."""
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    d = synth.cover_set(n_works=2, versions=2, seed=61, t_range=(150, 330))
+    ctx.upload_pool(d["frames"], d["offsets"])
+    for (i, j) in [(0, 1), (2, 1), (3, 0)]:
+        _compare_pair(ctx, d, i, j, _lib.serra09_params(**kw), oracle.serra09_params(**kw), "%s (%d,%d)" % (kw, i, j))
+    ctx.upload_pool(d["frames"], d["offsets"])        # a later default call sees the undecimated pool again
+    pr = np.array([[0, 1], [1, 2]], np.int32)
+    a = ctx.serra09_pairs(pr, _lib.serra09_params(**kw))
+    b = ctx.serra09_pairs(pr)
+    assert np.array_equal(a, oracle.serra09_pairs(d["frames"], d["offsets"], pr, oracle.serra09_params(**kw)))
+    assert np.array_equal(b, oracle.serra09_pairs(d["frames"], d["offsets"], pr))
+
+
+def _planted(M, N, gaps=(), shift=0):
+    R = np.zeros((M, N), np.uint8)
+    for i in range(M):
+        j = i + shift
+        if 0 <= j < N and i not in gaps:
+            R[i, j] = 1
+    return R
+
+
+@pytest.mark.parametrize("M,N", [(40, 40), (300, 280), (700, 900), (1500, 2041), (2600, 2300), (64, 4500)])
+def test_qmax_analytic_known_answers(ctx, M, N):
+    """Oracle-independent known answers of the alignment (hand-derived from the recurrences of
+    Serra et al. 2009 eq. 8 / Chen et al. 2017 with gamma_o = gamma_e = 0.5; first two rows and
+    columns of Q are zero):
+      * full main diagonal of L = min(M, N) ones: Q[i][i] = i - 1  ->  L - 2;
+      * the same with ONE missing cell in the interior: that cell scores Q - 0.5 instead of Q + 1
+        ->  L - 3.5;
+      * TWO adjacent missing cells (k, k), (k+1, k+1): the best path leaves the diagonal through the
+        gap cell (k, k+1), reached from (k-1, k-1) by the (i-1, j-2) step at the price of one onset
+        penalty (Q = k - 2 - 0.5), and rejoins it at (k+2, k+2) by the (i-2, j-1) step: 2 matches
+        lost and 0.5 paid  ->  L - 4.5 (with gamma_o = 1: L - 5);
+      * an empty plot -> 0; a single isolated one at (5, 7) -> 1;
+      * Dmax on a plot whose only ones are a full diagonal equals Qmax (the extra terms read
+        off-diagonal cells, all zero);
+      * all ones: Q[i][j] = min(i, j) - 1 -> min(M, N) - 2 (Qmax)."""
+    from acoss_amd import _lib
+    L = min(M, N)
+    P = _lib.serra09_params
+    assert ctx.qmax_binary(_planted(M, N)) == L - 2
+    assert ctx.qmax_binary(_planted(M, N, gaps=(L // 2,))) == L - 3.5
+    assert ctx.qmax_binary(_planted(M, N, gaps=(L // 2, L // 2 + 1))) == L - 4.5
+    assert ctx.qmax_binary(np.zeros((M, N), np.uint8)) == 0.0
+    one = np.zeros((M, N), np.uint8)
+    one[5, 7] = 1
+    assert ctx.qmax_binary(one) == 1.0
+    assert ctx.qmax_binary(_planted(M, N), P(dmax=1)) == L - 2
+    assert ctx.qmax_binary(np.ones((M, N), np.uint8)) == L - 2
+    # distinct penalties: the detour pays the onset penalty only
+    assert ctx.qmax_binary(_planted(M, N, gaps=(L // 2, L // 2 + 1)), P(gamma_o=1.0, gamma_e=0.25)) == L - 5
+    # a diagonal shifted off the main one, far enough from the first two columns to count fully
+    if N >= M + 3:
+        assert ctx.qmax_binary(_planted(M, N, shift=3)) == M - 2
+
+
+def test_qmax_binary_random_vs_oracle(ctx):
+    """The DP alone on random plots of every size class (8 / 16 / 32 columns per lane, strips)."""
+    from acoss_amd import _lib
+    oracle = _oracle()
+    rng = np.random.default_rng(9)
+    for (M, N, dens) in [(30, 50, 0.3), (400, 505, 0.1), (506, 300, 0.2), (1000, 1017, 0.1), (900, 1500, 0.15),
+                         (2041, 700, 0.1), (1200, 2049, 0.1), (2500, 4100, 0.12), (3, 3, 0.5), (2, 9, 0.9), (1, 1, 1.0)]:
+        R = (rng.random((M, N)) < dens).astype(np.uint8)
+        for kw in (dict(), dict(dmax=1), dict(gamma_o=1.0, gamma_e=0.25), dict(dmax=1, gamma_o=0.25, gamma_e=2.0)):
+            got = ctx.qmax_binary(R, _lib.serra09_params(**kw))
+            ref = oracle.qmax_binary(R, kw.get("gamma_o", 0.5), kw.get("gamma_e", 0.5), bool(kw.get("dmax", 0)))
+            assert got == ref, (M, N, kw, got, ref)
+
+
+def test_self_pairs_score_full_diagonal(ctx):
+    """Chain-level known answer, no oracle: a track against itself has d = 0 on the whole main
+    diagonal (identical operands through identical arithmetic), every threshold is >= 0, so the
+    diagonal is recurrent and the score is at least M - 2 = T - 11; i.i.d. tracks have no longer
+    path, so it is exactly that."""
+    from acoss_amd import synth
+    rng = np.random.default_rng(404)
+    lens = (60, 333, 1000, 2000, 2050, 2200)
+    tracks = [synth._frame_max_normalise(rng.random((T, 12))) for T in lens]
+    frames, offsets = synth.pack(tracks)
+    ctx.upload_pool(frames, offsets)
+    got = ctx.serra09_pairs(np.array([[i, i] for i in range(len(lens))], np.int32))
+    assert np.array_equal(got, np.array([T - 9 - 2 for T in lens], np.float32)), got
 
 
 def test_batching_is_invisible(ctx):
@@ -260,7 +383,9 @@ def test_error_behaviour(ctx):
     with pytest.raises(_lib.AcxError):                      # essentia raises on inputs shorter than the stack
         ctx.serra09_pairs(np.array([[0, 1]], np.int32))
     with pytest.raises(NotImplementedError):
-        ctx.serra09_pairs(np.array([[1, 1]], np.int32), _lib.serra09_params(tau=2))
+        ctx.serra09_pairs(np.array([[1, 1]], np.int32), _lib.serra09_params(m=34))
+    with pytest.raises(_lib.AcxError):                      # 40 frames, stride 5: shorter than the stack
+        ctx.serra09_pairs(np.array([[1, 1]], np.int32), _lib.serra09_params(tau=5))
     with pytest.raises(ValueError):
         ctx.serra09_pairs(np.array([[1, 7]], np.int32))
     assert ctx.serra09_pairs(np.zeros((0, 2), np.int32)).shape == (0,)

@@ -114,3 +114,43 @@ def test_map_identical_between_arithmetics():
         res.append(oracle.eval_statistics(D, list(cl.values()), topsidx=(1, 5)))
     assert res[0][3] == res[1][3] and res[0][0] == res[1][0]           # MAP, MR identical
     assert res[0][3] > 0.8                                             # and the set is recoverable
+
+
+def test_qmax_analytic_known_answers():
+    """Hand-derived known answers of the alignment (gamma_o = gamma_e = 0.5; derivations in
+    tests/test_gpu_serra09.py::test_qmax_analytic_known_answers, which holds the device to the
+    same numbers): they pin the oracle's DP independently of any implementation."""
+    import oracle
+
+    def planted(M, N, gaps=(), shift=0):
+        R = np.zeros((M, N), np.uint8)
+        for i in range(M):
+            j = i + shift
+            if 0 <= j < N and i not in gaps:
+                R[i, j] = 1
+        return R
+    for M, N in [(40, 40), (300, 280), (120, 400)]:
+        L = min(M, N)
+        assert oracle.qmax_binary(planted(M, N)) == L - 2
+        assert oracle.qmax_binary(planted(M, N, (L // 2,))) == L - 3.5
+        assert oracle.qmax_binary(planted(M, N, (L // 2, L // 2 + 1))) == L - 4.5
+        assert oracle.qmax_binary(planted(M, N, (L // 2, L // 2 + 1)), 1.0, 0.25) == L - 5
+        assert oracle.qmax_binary(np.zeros((M, N), np.uint8)) == 0.0
+        assert oracle.qmax_binary(planted(M, N), dmax=True) == L - 2
+        assert oracle.qmax_binary(np.ones((M, N), np.uint8)) == L - 2
+        if N >= M + 3:
+            assert oracle.qmax_binary(planted(M, N, shift=3)) == M - 2
+    one = np.zeros((30, 30), np.uint8)
+    one[5, 7] = 1
+    assert oracle.qmax_binary(one) == 1.0
+
+
+def test_self_pair_scores_full_diagonal():
+    """Chain-level known answer: a track against itself scores M - 2 (full main diagonal)."""
+    import oracle
+    from acoss_amd import synth
+    rng = np.random.default_rng(404)
+    for T in (60, 333):
+        x = synth._frame_max_normalise(rng.random((T, 12)))
+        assert oracle.serra09_pair(x, x) == T - 9 - 2
+        assert oracle.serra09_pair(x, x, oracle.serra09_params(arith="seq108")) == T - 9 - 2
