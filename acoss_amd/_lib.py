@@ -27,7 +27,11 @@ EXPORTS = [
     "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
     "acx_chenfusion_pairs", "acx_csm_binary_sw", "acx_upload_raw_pool", "acx_download_pool",
     "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse", "acx_qmax_binary",
+    "acx_grid_plan", "acx_pool_lengths", "acx_grid_run", "acx_grid_scatter", "acx_pair_grid",
 ]
+
+ALGO_SERRA09, ALGO_CHENFUSION, ALGO_SIMPLE, ALGO_EARLYFUSION = 0, 1, 2, 3
+GRID_PLANES = {ALGO_SERRA09: 1, ALGO_CHENFUSION: 2, ALGO_SIMPLE: 1, ALGO_EARLYFUSION: 4}
 
 
 class AcxError(RuntimeError):
@@ -37,6 +41,24 @@ class AcxError(RuntimeError):
 class EfParams(ctypes.Structure):
     """acx_ef_params (include/acx.h); defaults = EarlyFusion ctor, earlyfusion_traile.py:44-45."""
     _fields_ = [("kappa", ctypes.c_double), ("K", ctypes.c_int32)]
+
+
+class GridSpec(ctypes.Structure):
+    """acx_grid_spec (include/acx.h)."""
+    _fields_ = [("algo", ctypes.c_int32), ("symmetric", ctypes.c_int32), ("tile", ctypes.c_int32),
+                ("world", ctypes.c_int32)]
+
+
+class GridTile(ctypes.Structure):
+    """acx_grid_tile (include/acx.h)."""
+    _fields_ = [("row0", ctypes.c_int32), ("col0", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("rank", ctypes.c_int32), ("diagonal", ctypes.c_int32), ("offset", ctypes.c_int64),
+                ("cost", ctypes.c_double)]
+
+
+class SimpleParams(ctypes.Structure):
+    """acx_simple_params (include/acx.h); defaults = Simple ctor, simple_silva.py:26-27."""
+    _fields_ = [("sslen", ctypes.c_int32), ("oti", ctypes.c_int32)]
 
 
 class Serra09Params(ctypes.Structure):
@@ -107,6 +129,13 @@ def load():
                                ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
     L.acx_csm_binary_sw.argtypes = [vp, fp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, fp]
     L.acx_qmax_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, pp, fp]
+    gp = ctypes.POINTER(GridSpec)
+    L.acx_grid_plan.argtypes = [lp, ctypes.c_int32, gp, ctypes.POINTER(GridTile), ctypes.c_int64, lp, lp, dp]
+    L.acx_pool_lengths.argtypes = [vp, ctypes.c_int32, lp, ctypes.c_int32, ip]
+    L.acx_grid_run.argtypes = [vp, gp, vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, vp]
+    L.acx_grid_scatter.argtypes = [lp, ctypes.c_int32, gp, fp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                   ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int32]
+    L.acx_pair_grid.argtypes = [vp, gp, vp, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int32]
     _lib = L
     return L
 
@@ -119,6 +148,50 @@ def serra09_params(m=9, tau=1, kappa=0.095, oti=True, gamma_o=0.5, gamma_e=0.5, 
 
 def _fptr(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _lptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+
+
+def grid_plan(lengths, algo, symmetric, world=1, tile=0, want_tiles=False):
+    """acx_grid_plan: the tile plan of the N x N pair grid -- a pure host function, no GPU needed.
+    Returns dict(spec, n_tiles, floats_per_rank (world,) int64, cost_per_rank (world,) f64[, tiles])."""
+    L = load()
+    lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+    spec = GridSpec(int(algo), int(bool(symmetric)), int(tile), int(world))
+    nt = ctypes.c_int64(0)
+    fl = np.zeros(world, np.int64)
+    co = np.zeros(world, np.float64)
+    rc = L.acx_grid_plan(_lptr(lengths), len(lengths), ctypes.byref(spec), None, 0, ctypes.byref(nt), _lptr(fl),
+                         co.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    if rc != ACX_OK:
+        raise ValueError("acx_grid_plan: bad argument")
+    out = dict(spec=spec, n_tiles=int(nt.value), floats_per_rank=fl, cost_per_rank=co)
+    if want_tiles:
+        tiles = (GridTile * nt.value)()
+        rc = L.acx_grid_plan(_lptr(lengths), len(lengths), ctypes.byref(spec), tiles, nt.value, None, None, None)
+        if rc != ACX_OK:
+            raise ValueError("acx_grid_plan: bad argument")
+        out["tiles"] = tiles
+    return out
+
+
+def grid_scatter(lengths, spec, gathered, rank_stride, planes, mirror, first=0, count=-1):
+    """acx_grid_scatter: gathered rank buffers (host f32) -> the (N, N) float32 planes (numpy arrays or
+    memmaps, C-contiguous rows with a common leading dimension).  Pure host function."""
+    L = load()
+    lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+    gathered = np.ascontiguousarray(gathered, dtype=np.float32)
+    n = len(lengths)
+    for P in planes:
+        if P.dtype != np.float32 or P.shape != (n, n) or not P.flags["C_CONTIGUOUS"]:
+            raise ValueError("grid_scatter: planes must be C-contiguous (N, N) float32")
+    ptrs = (ctypes.c_void_p * len(planes))(*[P.ctypes.data for P in planes])
+    rc = L.acx_grid_scatter(_lptr(lengths), n, ctypes.byref(spec), _fptr(gathered), int(rank_stride), int(first),
+                            int(count), ptrs, n, int(bool(mirror)))
+    if rc != ACX_OK:
+        raise ValueError("acx_grid_scatter: bad argument")
 
 
 class Context(object):
@@ -290,6 +363,36 @@ class Context(object):
         self._check(self._L.acx_snf_fuse(self._h, arr(Ws), arr(Js), arr(Vs), m, n, K, int(niters), float(reg_diag),
                                          out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return out
+
+    # ------------------------------------------------------------------ the N x N pair grid
+    def torch_device(self):
+        """Where the caller allocates the tile-score buffer handed to grid_run."""
+        import torch
+        return torch.device("cuda", self.device)
+
+    def pool_lengths(self, algo):
+        n = ctypes.c_int32(0)
+        self._check(self._L.acx_pool_lengths(self._h, int(algo), None, 0, ctypes.byref(n)))
+        out = np.zeros(n.value, np.int64)
+        self._check(self._L.acx_pool_lengths(self._h, int(algo), _lptr(out), n.value, ctypes.byref(n)))
+        return out
+
+    def grid_run(self, spec, params, rank, dev_ptr, first=0, count=-1):
+        """acx_grid_run: this rank's tiles [first, first + count) into the DEVICE buffer at `dev_ptr`
+        (e.g. torch_tensor.data_ptr()) of floats_per_rank[rank] floats."""
+        self._check(self._L.acx_grid_run(self._h, ctypes.byref(spec), ctypes.cast(ctypes.byref(params), ctypes.c_void_p),
+                                         int(rank), int(first), int(count), ctypes.c_void_p(int(dev_ptr))))
+
+    def pair_grid(self, algo, symmetric, params, planes, mirror, tile=0):
+        """acx_pair_grid: the whole grid on this GPU into the (N, N) float32 planes."""
+        spec = GridSpec(int(algo), int(bool(symmetric)), int(tile), 1)
+        n = planes[0].shape[0]
+        for P in planes:
+            if P.dtype != np.float32 or P.shape != (n, n) or not P.flags["C_CONTIGUOUS"]:
+                raise ValueError("pair_grid: planes must be C-contiguous (N, N) float32")
+        ptrs = (ctypes.c_void_p * len(planes))(*[P.ctypes.data for P in planes])
+        self._check(self._L.acx_pair_grid(self._h, ctypes.byref(spec), ctypes.cast(ctypes.byref(params), ctypes.c_void_p),
+                                          ptrs, n, int(bool(mirror))))
 
     def serra09_pairs(self, pairs, params=None):
         p = params or serra09_params()

@@ -14,14 +14,20 @@ Differences from the reference, all deliberate:
   * cleanup_memmap really removes the memmap files (the reference calls rmtree on a file
     and always fails);
   * the distance matrices are saved as <prefix>_Ds.npz (no deepdish/h5py offline);
-  * under torch.distributed (one process per GPU) all_pairwise shards the pair list over
-    the ranks and performs one all-gather of the scores.
+  * device-backed subclasses (those with a _grid() method) never build the pair list at all:
+    libacx enumerates the N x N grid itself in cost-balanced tiles (acx_pair_grid; under
+    torch.distributed, one process per GPU, acx_grid_run + ONE all-gather of the tile scores,
+    scattered into the matrices by rank 0).  User subclasses that implement similarity()
+    themselves keep the reference's chunked pair-list loop (sharded by pair count over the ranks).
+  * under torch.distributed rank 0 owns the result: it alone holds the filled matrices, writes
+    the cache / results files and computes the statistics, which are broadcast to the others.
 """
 import os
 import warnings
 
 import numpy as np
 
+from .. import _lib
 from .. import dist as _dist
 from ..featurestore import load_track
 from ..utils import create_dataset_filepaths
@@ -55,6 +61,10 @@ class CoverAlgorithm(object):
         if not os.path.exists(cachedir):
             os.makedirs(cachedir, exist_ok=True)
         self.Ds = {}
+        # the file names are fixed here: rank 0 owns the reference's names, other ranks (whose matrices
+        # stay empty) get a suffix even if the process group is initialised or torn down later
+        self._dmat_rank = _dist.world()[0]
+        self._dmat_paths = {}
         for s in similarity_types:
             self.Ds[s] = np.memmap(self._dmat_path(s), shape=(self.N, self.N), mode="w+", dtype="float32")
         print("Initialized %s algorithm on %i songs in dataset %s" % (name, self.N, shortname))
@@ -64,9 +74,10 @@ class CoverAlgorithm(object):
         return "%s/%s_%s" % (self.cachedir, self.name, self.shortname)
 
     def _dmat_path(self, s):
-        rank, _ = _dist.world()
-        # one process per GPU: every rank keeps its own memmap (rank 0 owns the reference's file name)
-        return "%s_%s_dmat%s" % (self.get_cacheprefix(), s, "" if rank == 0 else ".rank%d" % rank)
+        if s not in self._dmat_paths:
+            rank = self._dmat_rank
+            self._dmat_paths[s] = "%s_%s_dmat%s" % (self.get_cacheprefix(), s, "" if rank == 0 else ".rank%d" % rank)
+        return self._dmat_paths[s]
 
     def _register_label(self, i, label):
         self.cliques.setdefault(label, set()).add(int(i))
@@ -80,18 +91,22 @@ class CoverAlgorithm(object):
     def get_all_clique_ids(self, verbose=False):
         """Clique membership of every track, cached in <prefix>_clique_info.txt ("i,label")."""
         path = "%s_clique_info.txt" % self.get_cacheprefix()
-        if not os.path.exists(path):
-            with open(path, "w") as fout:
+        rank, ws = _dist.world()
+        if rank == 0 and not os.path.exists(path):
+            # written to a temporary name and renamed: nobody ever sees half a file
+            tmp = "%s.tmp%d" % (path, os.getpid())
+            with open(tmp, "w") as fout:
                 for i in range(len(self.filepaths)):
                     feats = CoverAlgorithm.load_features(self, i)
                     if verbose:
                         print(i)
                     fout.write("%i,%s\n" % (i, feats["label"]))
-        else:
-            with open(path) as fin:
-                for line in fin:
-                    i, label = line.split(",", 1)
-                    self._register_label(int(i), label.strip())
+            os.replace(tmp, path)
+        _dist.barrier()
+        with open(path) as fin:
+            for line in fin:
+                i, label = line.split(",", 1)
+                self._register_label(int(i), label.strip())
 
     # ------------------------------------------------------------------ pairwise
     def similarity(self, idxs):
@@ -124,26 +139,51 @@ class CoverAlgorithm(object):
                         self.Ds[s] = z[s]
             self.get_all_clique_ids()
             return
-        pairs = self.pair_list(self.N, symmetric)
         rank, ws = _dist.world()
-        lo, hi = _dist.shard_bounds(len(pairs), rank, ws)
-        mine = pairs[lo:hi]
-        for chunk in np.array_split(mine, max(1, min(self.n_chunks, len(mine)))):
-            if len(chunk):
-                self.similarity(chunk)
-        if ws > 1:
-            keys = list(self.Ds.keys())
-            local = np.stack([np.asarray(self.Ds[s][mine[:, 0], mine[:, 1]]) for s in keys], axis=1)
-            full = _dist.gather_scores(local, len(pairs))
-            for c, s in enumerate(keys):
-                self.Ds[s][pairs[:, 0], pairs[:, 1]] = full[:, c]
+        if hasattr(self, "_grid"):
+            self._all_pairwise_grid(symmetric)
+        else:
+            pairs = self.pair_list(self.N, symmetric)
+            lo, hi = _dist.shard_bounds(len(pairs), rank, ws)
+            mine = pairs[lo:hi]
+            for chunk in np.array_split(mine, max(1, min(self.n_chunks, len(mine)))):
+                if len(chunk):
+                    self.similarity(chunk)
+            if ws > 1:
+                keys = list(self.Ds.keys())
+                local = np.stack([np.asarray(self.Ds[s][mine[:, 0], mine[:, 1]]) for s in keys], axis=1)
+                full = _dist.gather_scores(local, len(pairs))
+                if rank == 0:
+                    for c, s in enumerate(keys):
+                        self.Ds[s][pairs[:, 0], pairs[:, 1]] = full[:, c]
+            if symmetric and rank == 0:
+                for s in self.Ds:
+                    self.Ds[s] += self.Ds[s].T
         if not self.cliques:
             self.get_all_clique_ids()
-        if symmetric:
-            for s in self.Ds:
-                self.Ds[s] += self.Ds[s].T
         if rank == 0:
             np.savez(npz, **{s: np.asarray(self.Ds[s]) for s in self.Ds})
+
+    def _all_pairwise_grid(self, symmetric):
+        """Device-backed classes: `self._grid()` -> (context with the pool uploaded, ACX_ALGO_*, params
+        struct, similarity types in plane order).  One GPU: acx_pair_grid straight into the memmaps.
+        N GPUs: every rank runs its tiles into a device buffer, one all-gather, rank 0 scatters."""
+        ctx, algo, params, keys = self._grid()
+        planes = [self.Ds[k] for k in keys]
+        rank, ws = _dist.world()
+        if ws == 1:
+            ctx.pair_grid(algo, symmetric, params, planes, mirror=symmetric)
+            return
+        import torch
+        lengths = ctx.pool_lengths(algo)
+        plan = _lib.grid_plan(lengths, algo, symmetric, world=ws)
+        stride = int(max(1, plan["floats_per_rank"].max()))
+        # (torch.empty launches nothing: libacx works on its own stream and zeroes what it owns)
+        local = torch.empty(stride, dtype=torch.float32, device=ctx.torch_device())
+        ctx.grid_run(plan["spec"], params, rank, local.data_ptr())
+        gathered = _dist.gather_tiles(local, stride)
+        if rank == 0:
+            _lib.grid_scatter(lengths, plan["spec"], gathered, stride, planes, mirror=symmetric)
 
     def cleanup_memmap(self):
         """Remove the memmap files behind the similarity matrices."""
@@ -162,8 +202,14 @@ class CoverAlgorithm(object):
         """MR, MRR, MDR, MAP and Top-k of one similarity matrix; appends a row to
         results_<shortname>_<name>.csv.  Same definitions as the reference (:205-290),
         including MRR's division by ALL N songs and the %.3g CSV format."""
-        D = np.array(self.Ds[similarity_type], dtype=np.float32)
-        MR, MRR, MDR, MAP, tops = eval_statistics(D, [sorted(self.cliques[s]) for s in self.cliques], topsidx)
+        rank, ws = _dist.world()
+        res = None
+        if rank == 0:
+            D = np.array(self.Ds[similarity_type], dtype=np.float32)
+            res = eval_statistics(D, [sorted(self.cliques[s]) for s in self.cliques], topsidx)
+        MR, MRR, MDR, MAP, tops = _dist.broadcast_object(res)
+        if rank != 0:
+            return MR, MRR, MDR, MAP, tops
         print("%s %s STATS\n-------------------------\nMR = %.3g\nMRR = %.3g\nMDR = %.3g\nMAP = %.3g"
               % (self.name, similarity_type, MR, MRR, MDR, MAP))
         for t, v in zip(topsidx, tops):

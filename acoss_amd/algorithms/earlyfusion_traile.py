@@ -153,6 +153,10 @@ class EarlyFusion(CoverAlgorithm):
             self._pool_ready = True
         return self._ctx
 
+    def _grid(self):
+        return (self._context(), _lib.ALGO_EARLYFUSION, _lib.EfParams(float(self.kappa), int(self.K)),
+                ["mfccs", "ssms", "chromas", "early"])
+
     def similarity(self, idxs, do_plot=False):
         idxs = np.asarray(idxs).reshape(-1, 2)
         if len(idxs) == 0:

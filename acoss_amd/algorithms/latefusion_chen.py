@@ -30,8 +30,12 @@ class ChenFusion(Serra09):
         self._engine = dict(engine or {})
         self._ctx = None
         self._pool_ready = False
+        self._pooled_len = None
         CoverAlgorithm.__init__(self, dataset_csv=dataset_csv, name="LateFusionChen", datapath=datapath,
                                 shortname=shortname, similarity_types=["qmax", "dmax"])
+
+    def _grid(self):
+        return self._context(), _lib.ALGO_CHENFUSION, self._params(), ["qmax", "dmax"]
 
     def similarity(self, idxs):
         idxs = np.asarray(idxs).reshape(-1, 2)

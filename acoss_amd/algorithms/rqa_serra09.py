@@ -103,6 +103,10 @@ class Serra09(CoverAlgorithm):
             return self._pooled_len
         return np.array([self.load_features(j).shape[0] for j in range(self.N)], dtype=np.int64)
 
+    def _grid(self):
+        """all_pairwise runs the whole N x N grid inside libacx (algorithm_template._all_pairwise_grid)."""
+        return self._context(), _lib.ALGO_SERRA09, self._params(), ["main"]
+
     def similarity(self, idxs):
         idxs = np.asarray(idxs).reshape(-1, 2)
         if len(idxs) == 0:

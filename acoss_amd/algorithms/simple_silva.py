@@ -117,6 +117,9 @@ class Simple(CoverAlgorithm):
         finally:
             ctx.close()
 
+    def _grid(self):
+        return self._context(), _lib.ALGO_SIMPLE, _lib.SimpleParams(int(self.SSLEN), 1), ["main"]
+
     def similarity(self, idxs):
         idxs = np.asarray(idxs).reshape(-1, 2)
         if len(idxs) == 0:

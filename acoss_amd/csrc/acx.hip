@@ -20,6 +20,7 @@
 #include "snf_kernels.hpp"
 #include "simple_kernels.hpp"
 #include "ef_kernels.hpp"
+#include "grid.hpp"
 
 using acx::PairDesc;
 
@@ -48,6 +49,8 @@ struct Serra09Slot {
     PairDesc *d_pd = nullptr; size_t pd_cap = 0;
     float *d_out = nullptr;   size_t out_cap = 0;
     float *h_out = nullptr;   size_t h_cap = 0;      // pinned
+    int64_t *h_idx = nullptr; size_t hidx_cap = 0;   // pinned: destinations of the batch's scores (grid runs)
+    int64_t *d_idx = nullptr; size_t didx_cap = 0;
     hipEvent_t done = nullptr;
     bool busy = false;
     int B = 0, w = 1;
@@ -337,16 +340,30 @@ int collect_slot(acx_ctx *c, Serra09Slot &s, float *out)
 {
     if (!s.busy) return ACX_OK;
     ACX_HIP(c, hipEventSynchronize(s.done));
-    for (int k2 = 0; k2 < s.B; ++k2)
+    for (int k2 = 0; out && k2 < s.B; ++k2)
         for (int e = 0; e < s.w; ++e) out[(size_t)s.w * (s.k0 + s.perm[k2]) + e] = s.h_out[(size_t)s.w * k2 + e];
     s.busy = false;
     drain_profile(c);
     return ACX_OK;
 }
 
+// Scores go to a DEVICE buffer instead of the host: pair k's `w` values to base[idx[k] .. + w)
+struct DevDst {
+    float *base;
+    const int64_t *idx;
+};
+
+static __global__ void scatter_scores_kernel(const float *__restrict__ src, const int64_t *__restrict__ idx,
+                                             float *__restrict__ dst, int B, int w)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    for (int e = 0; e < w; ++e) dst[idx[k] + e] = src[(size_t)k * w + e];
+}
+
 // Runs the chain over `K` pairs in scratch-sized batches.
 int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params &p_in, float *out,
-                const DebugOut *dbg, bool both = false)
+                const DebugOut *dbg, bool both = false, const DevDst *dd = nullptr)
 {
     if (!c->d_frames0) return fail(c, ACX_ERR_STATE, "serra09: feature pool not uploaded (acx_upload_pool)");
     if (c->dim != acx::NBIN) return fail(c, ACX_ERR_INVALID, "serra09: pool dim must be 12");
@@ -520,7 +537,22 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             else sweep(p.dmax != 0, S.d_out);
         }
         ACX_HIP(c, hipGetLastError());
-        ACX_HIP(c, hipMemcpyAsync(S.h_out, S.d_out, sizeof(float) * B * w, hipMemcpyDeviceToHost, c->stream));
+        if (dd) {
+            if ((size_t)B > S.hidx_cap) {
+                if (S.h_idx) ACX_HIP(c, hipHostFree(S.h_idx));
+                S.h_idx = nullptr; S.hidx_cap = 0;
+                ACX_HIP(c, hipHostMalloc((void **)&S.h_idx, sizeof(int64_t) * (size_t)B, hipHostMallocDefault));
+                S.hidx_cap = (size_t)B;
+            }
+            if ((rc = ensure(c, S.d_idx, S.didx_cap, (size_t)B)) != ACX_OK) return rc;
+            for (int k2 = 0; k2 < B; ++k2) S.h_idx[k2] = dd->idx[k0 + perm[k2]];
+            ACX_HIP(c, hipMemcpyAsync(S.d_idx, S.h_idx, sizeof(int64_t) * B, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(scatter_scores_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream,
+                               S.d_out, S.d_idx, dd->base, B, w);
+            ACX_HIP(c, hipGetLastError());
+        } else {
+            ACX_HIP(c, hipMemcpyAsync(S.h_out, S.d_out, sizeof(float) * B * w, hipMemcpyDeviceToHost, c->stream));
+        }
         ACX_HIP(c, hipEventRecord(S.done, c->stream));
         S.busy = true; S.B = B; S.w = w; S.k0 = k0;
 
@@ -762,6 +794,8 @@ void acx_destroy(acx_ctx *c)
         if (sl.d_pd) (void)hipFree(sl.d_pd);
         if (sl.d_out) (void)hipFree(sl.d_out);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.h_idx) (void)hipHostFree(sl.h_idx);
+        if (sl.d_idx) (void)hipFree(sl.d_idx);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (c->d_out) (void)hipFree(c->d_out);
@@ -1372,6 +1406,174 @@ int acx_snf_fuse(acx_ctx *c, const double *const *Ws, const int32_t *const *Js, 
     ACX_HIPC(hipStreamSynchronize(c->stream));
 #undef ACX_HIPC
     cleanup();
+    return ACX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// the N x N pair grid
+// ---------------------------------------------------------------------------------------
+static int pool_lengths(acx_ctx *c, int algo, std::vector<int64_t> &len)
+{
+    const std::vector<int64_t> *off = nullptr;
+    int n = 0;
+    switch (algo) {
+    case ACX_ALGO_SERRA09: case ACX_ALGO_CHENFUSION:
+        if (!c->d_frames0) return fail(c, ACX_ERR_STATE, "grid: feature pool not uploaded (acx_upload_pool)");
+        off = &c->h_off0; n = c->n_tracks; break;
+    case ACX_ALGO_SIMPLE:
+        if (!c->d_frames64) return fail(c, ACX_ERR_STATE, "grid: f64 feature pool not uploaded (acx_upload_pool_f64)");
+        off = &c->h_off64; n = c->n_tracks64; break;
+    case ACX_ALGO_EARLYFUSION:
+        if (!c->d_ef[0]) return fail(c, ACX_ERR_STATE, "grid: block-feature pool not uploaded (acx_ef_upload_pool)");
+        off = &c->h_efoff; n = c->ef_ntracks; break;
+    default: return fail(c, ACX_ERR_INVALID, "grid: unknown algorithm");
+    }
+    len.resize(n);
+    for (int i = 0; i < n; ++i) len[i] = (*off)[i + 1] - (*off)[i];
+    return ACX_OK;
+}
+
+int acx_grid_plan(const int64_t *lengths, int32_t n_tracks, const acx_grid_spec *spec, acx_grid_tile *tiles,
+                  int64_t capacity, int64_t *n_tiles, int64_t *floats_per_rank, double *cost_per_rank)
+{
+    if (!lengths || n_tracks < 1 || !acx::grid_spec_ok(spec)) return ACX_ERR_INVALID;
+    std::vector<acx_grid_tile> t;
+    std::vector<int64_t> fl;
+    std::vector<double> co;
+    acx::grid_plan(lengths, n_tracks, *spec, t, fl, co);
+    if (n_tiles) *n_tiles = (int64_t)t.size();
+    if (tiles) {
+        if (capacity < (int64_t)t.size()) return ACX_ERR_INVALID;
+        std::copy(t.begin(), t.end(), tiles);
+    }
+    for (int r = 0; r < spec->world; ++r) {
+        if (floats_per_rank) floats_per_rank[r] = fl[r];
+        if (cost_per_rank) cost_per_rank[r] = co[r];
+    }
+    return ACX_OK;
+}
+
+int acx_pool_lengths(acx_ctx *c, int32_t algo, int64_t *lengths, int32_t capacity, int32_t *n_tracks)
+{
+    if (!c) return ACX_ERR_INVALID;
+    std::vector<int64_t> len;
+    const int rc = pool_lengths(c, algo, len);
+    if (rc != ACX_OK) return rc;
+    if (n_tracks) *n_tracks = (int32_t)len.size();
+    if (lengths) {
+        if (capacity < (int32_t)len.size()) return fail(c, ACX_ERR_INVALID, "pool_lengths: buffer too small");
+        std::copy(len.begin(), len.end(), lengths);
+    }
+    return ACX_OK;
+}
+
+int acx_grid_run(acx_ctx *c, const acx_grid_spec *spec, const void *params, int32_t rank, int64_t first, int64_t count,
+                 float *d_scores)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!acx::grid_spec_ok(spec) || !params || !d_scores || rank < 0 || rank >= spec->world || first < 0)
+        return fail(c, ACX_ERR_INVALID, "grid_run: bad argument");
+    std::vector<int64_t> len;
+    int rc = pool_lengths(c, spec->algo, len);
+    if (rc != ACX_OK) return rc;
+    ACX_HIP(c, hipSetDevice(c->device));
+    std::vector<acx_grid_tile> tiles;
+    std::vector<int64_t> fl;
+    std::vector<double> co;
+    acx::grid_plan(len.data(), (int)len.size(), *spec, tiles, fl, co);
+    const std::vector<acx_grid_tile> mine = acx::grid_slice(tiles, rank, first, count);
+    if (mine.empty()) return ACX_OK;
+    const int w = acx::grid_planes(spec->algo);
+    {   // blocks of one rank are contiguous in deal order: zero the slice (diagonal blocks keep zeros)
+        const int64_t lo = mine.front().offset;
+        const int64_t hi = mine.back().offset + (int64_t)mine.back().rows * mine.back().cols * w;
+        ACX_HIP(c, hipMemsetAsync(d_scores + lo, 0, sizeof(float) * (size_t)(hi - lo), c->stream));
+    }
+    const int64_t CHUNK_PAIRS = (int64_t)1 << 20;
+    std::vector<int32_t> pairs;
+    std::vector<int64_t> idx;
+    std::vector<float> host;          // SiMPle / EarlyFusion: scores come back through the host
+    std::vector<double> host64;
+    size_t t0 = 0;
+    while (t0 < mine.size()) {
+        pairs.clear(); idx.clear();
+        size_t t1 = t0;
+        while (t1 < mine.size() && (t1 == t0 || (int64_t)idx.size() + (int64_t)mine[t1].rows * mine[t1].cols <= CHUNK_PAIRS)) {
+            acx::grid_tile_pairs(mine[t1], spec->symmetric, w, pairs, idx);
+            ++t1;
+        }
+        const int64_t K = (int64_t)idx.size();
+        if (K > 0) {
+            if (spec->algo == ACX_ALGO_SERRA09 || spec->algo == ACX_ALGO_CHENFUSION) {
+                DevDst dd{d_scores, idx.data()};
+                rc = run_serra09(c, pairs.data(), K, *static_cast<const acx_serra09_params *>(params), nullptr, nullptr,
+                                 spec->algo == ACX_ALGO_CHENFUSION, &dd);
+                if (rc != ACX_OK) return rc;
+            } else {
+                // list-based drivers deliver host scores; they go back up block by block
+                host.assign((size_t)K * w, 0.0f);
+                if (spec->algo == ACX_ALGO_SIMPLE) {
+                    const acx_simple_params *sp = static_cast<const acx_simple_params *>(params);
+                    host64.resize((size_t)K);
+                    rc = acx_simple_pairs(c, pairs.data(), K, sp->sslen, sp->oti, host64.data());
+                    if (rc != ACX_OK) return rc;
+                    for (int64_t k = 0; k < K; ++k) host[(size_t)k] = (float)host64[(size_t)k];
+                } else {
+                    rc = acx_earlyfusion_pairs(c, pairs.data(), K, static_cast<const acx_ef_params *>(params), host.data());
+                    if (rc != ACX_OK) return rc;
+                }
+                const int64_t lo = mine[t0].offset;
+                const int64_t hi = mine[t1 - 1].offset + (int64_t)mine[t1 - 1].rows * mine[t1 - 1].cols * w;
+                std::vector<float> stage((size_t)(hi - lo), 0.0f);
+                for (int64_t k = 0; k < K; ++k)
+                    for (int e = 0; e < w; ++e) stage[(size_t)(idx[(size_t)k] - lo) + e] = host[(size_t)k * w + e];
+                ACX_HIP(c, hipMemcpy(d_scores + lo, stage.data(), sizeof(float) * stage.size(), hipMemcpyHostToDevice));
+            }
+        }
+        t0 = t1;
+    }
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    return ACX_OK;
+}
+
+int acx_grid_scatter(const int64_t *lengths, int32_t n_tracks, const acx_grid_spec *spec, const float *gathered,
+                     int64_t rank_stride, int64_t first, int64_t count, float *const *D, int64_t ld, int32_t mirror)
+{
+    if (!lengths || n_tracks < 1 || !acx::grid_spec_ok(spec) || !gathered || !D || ld < n_tracks || first < 0) return ACX_ERR_INVALID;
+    for (int e = 0; e < acx::grid_planes(spec->algo); ++e) if (!D[e]) return ACX_ERR_INVALID;
+    std::vector<acx_grid_tile> tiles;
+    std::vector<int64_t> fl;
+    std::vector<double> co;
+    acx::grid_plan(lengths, n_tracks, *spec, tiles, fl, co);
+    for (int r = 0; r < spec->world; ++r) if (fl[r] > rank_stride) return ACX_ERR_INVALID;
+    acx::grid_scatter(tiles, *spec, gathered, rank_stride, first, count, D, ld, mirror);
+    return ACX_OK;
+}
+
+int acx_pair_grid(acx_ctx *c, const acx_grid_spec *spec, const void *params, float *const *D, int64_t ld, int32_t mirror)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!acx::grid_spec_ok(spec) || spec->world != 1 || !params || !D) return fail(c, ACX_ERR_INVALID, "pair_grid: bad argument (world must be 1)");
+    std::vector<int64_t> len;
+    int rc = pool_lengths(c, spec->algo, len);
+    if (rc != ACX_OK) return rc;
+    if (ld < (int64_t)len.size()) return fail(c, ACX_ERR_INVALID, "pair_grid: leading dimension smaller than the number of tracks");
+    int64_t fl = 0, nt = 0;
+    if ((rc = acx_grid_plan(len.data(), (int32_t)len.size(), spec, nullptr, 0, &nt, &fl, nullptr)) != ACX_OK) return rc;
+    ACX_HIP(c, hipSetDevice(c->device));
+    float *d = nullptr;
+    ACX_HIP(c, hipMalloc((void **)&d, sizeof(float) * (size_t)std::max<int64_t>(1, fl)));
+    rc = acx_grid_run(c, spec, params, 0, 0, -1, d);
+    std::vector<float> host;
+    if (rc == ACX_OK) {
+        host.resize((size_t)fl);
+        const hipError_t e = hipMemcpy(host.data(), d, sizeof(float) * (size_t)fl, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, ACX_ERR_HIP, std::string("pair_grid: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    if (rc != ACX_OK) return rc;
+    rc = acx_grid_scatter(len.data(), (int32_t)len.size(), spec, host.data(), fl, 0, -1, D, ld, mirror);
+    if (rc != ACX_OK) return fail(c, rc, "pair_grid: scatter failed");
     return ACX_OK;
 }
 

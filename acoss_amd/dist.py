@@ -1,12 +1,14 @@
 """
-Multi-GPU sharding of the pair list: one process per GPU under torch.distributed
-(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).  Pairs are
-independent, so the only exchange on the path is ONE gather of the score vectors at the
-end; there is no data-path collective inside the kernels.
+Multi-GPU execution of the pair grid: one process per GPU under torch.distributed (backend
+"nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).  Pairs are independent; the grid is
+cut into B x B track tiles that libacx deals to the ranks by cost (acx_grid_plan), every rank
+writes the scores of its tiles into ONE dense device buffer (acx_grid_run), and the only exchange
+on the path is ONE all-gather of those buffers -- device to device under
+RCCL, no host staging.  Rank 0 then scatters the tiles into the N x N matrices.
 """
 import numpy as np
 
-__all__ = ["world", "shard_bounds", "gather_scores"]
+__all__ = ["world", "barrier", "broadcast_object", "shard_bounds", "gather_scores", "gather_tiles"]
 
 
 def world():
@@ -20,6 +22,46 @@ def world():
     return 0, 1
 
 
+def barrier():
+    rank, ws = world()
+    if ws > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def broadcast_object(obj, src=0):
+    """Small picklable object from rank `src` to every rank."""
+    rank, ws = world()
+    if ws == 1:
+        return obj
+    import torch.distributed as dist
+    box = [obj if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def gather_tiles(local, stride):
+    """All-gather of the per-rank tile-score buffers: `local` is a torch tensor of `stride` float32
+    (on the rank's GPU under nccl).  Returns the gathered (world * stride,) float32 numpy array.
+    Under nccl the collective runs on the device buffers themselves (one D2H copy of the result);
+    under gloo (CPU tests, ranks sharing one GPU) the buffer is moved to the host first."""
+    import torch
+    import torch.distributed as dist
+    rank, ws = world()
+    assert local.dtype == torch.float32 and local.numel() == stride
+    if ws == 1:
+        return local.cpu().numpy()
+    if dist.get_backend() == "nccl":
+        out = torch.empty(ws * stride, dtype=torch.float32, device=local.device)
+        dist.all_gather_into_tensor(out, local)
+        return out.cpu().numpy()
+    loc = local.cpu()
+    outs = [torch.empty_like(loc) for _ in range(ws)]
+    dist.all_gather(outs, loc)
+    return torch.cat(outs).numpy()
+
+
+# ---- pair-LIST sharding: the CPU loop of user subclasses that implement similarity() themselves
 def shard_bounds(n_items, rank, world_size):
     """Contiguous, balanced [lo, hi) slice of range(n_items) for this rank."""
     base, rem = divmod(int(n_items), int(world_size))

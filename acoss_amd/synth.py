@@ -49,8 +49,10 @@ def _triads():
     return t
 
 
-def cover_set(n_works=None, versions=5, seed=4321, t_range=(300, 600), clique_sizes=None):
-    """clique_sizes overrides (n_works, versions).  Returns frames/offsets/labels."""
+def cover_set(n_works=None, versions=5, seed=4321, t_range=(300, 600), clique_sizes=None, noise=0.05, segment_keep=1.0):
+    """clique_sizes overrides (n_works, versions).  Returns frames/offsets/labels.
+    noise: amplitude of the uniform noise added to every version; segment_keep < 1: every version keeps
+    only a random contiguous part of the work (harder sets, so that MAP is not trivially 1)."""
     rng = np.random.default_rng(seed)
     tri = _triads()
     if clique_sizes is None:
@@ -74,7 +76,11 @@ def cover_set(n_works=None, versions=5, seed=4321, t_range=(300, 600), clique_si
             hi = np.minimum(lo + 1, T - 1)
             fr = (pos - lo)[:, None]
             x = (1 - fr) * base[lo] + fr * base[hi]
-            x = np.roll(x, shift, axis=1) + 0.05 * rng.random((Tv, NBINS))
+            x = np.roll(x, shift, axis=1) + noise * rng.random((Tv, NBINS))
+            if segment_keep < 1.0:
+                keep = max(32, int(round(Tv * segment_keep)))
+                st = int(rng.integers(0, Tv - keep + 1))
+                x = x[st:st + keep]
             tracks.append(_frame_max_normalise(x))
             labels.append("w%d" % w)
     frames, offsets = pack(tracks)
@@ -84,8 +90,8 @@ def cover_set(n_works=None, versions=5, seed=4321, t_range=(300, 600), clique_si
 COVERS80_CLIQUES = [2] * 77 + [3] * 2 + [4]   # 164 tracks / 80 works (covers80_annotations.csv)
 
 
-def covers80_shaped(seed=4321, t_range=(300, 600)):
-    return cover_set(clique_sizes=COVERS80_CLIQUES, seed=seed, t_range=t_range)
+def covers80_shaped(seed=4321, t_range=(300, 600), noise=0.05, segment_keep=1.0):
+    return cover_set(clique_sizes=COVERS80_CLIQUES, seed=seed, t_range=t_range, noise=noise, segment_keep=segment_keep)
 
 
 def simple_raw_set(n_works, versions=3, seed=4321, t0_range=(15000, 25000)):

@@ -243,6 +243,79 @@ int acx_sw_binary(acx_ctx *ctx, const uint8_t *B, int32_t M, int32_t N, float *s
 int acx_snf_fuse(acx_ctx *ctx, const double *const *Ws, const int32_t *const *Js, const double *const *Vs,
                  int32_t m, int32_t n, int32_t K, int32_t niters, double reg_diag, double *out);
 
+/* ---- the N x N pair grid -------------------------------------------------- */
+
+/*
+ * CoverAlgorithm.all_pairwise (algorithm_template.py:142-192) builds the list of all pairs
+ * (itertools.combinations for symmetric algorithms, permutations otherwise, :168-171), cuts it into
+ * 45 chunks for joblib (:172-177) and mirrors the result (D += D.T, :189-191).  Here the grid is cut
+ * into tile x tile blocks of tracks (upper triangle incl. the diagonal blocks when symmetric),
+ * each block costed by the sum of len_i * len_j over its pairs, and the blocks are dealt to `world`
+ * ranks longest-processing-time-first.  A rank writes the scores of its blocks into one dense
+ * buffer (block after block in deal order; a block is rows x cols x planes floats, planes
+ * fastest); the only exchange of the whole path is one all-gather of those buffers.
+ */
+enum { ACX_ALGO_SERRA09 = 0, ACX_ALGO_CHENFUSION = 1, ACX_ALGO_SIMPLE = 2, ACX_ALGO_EARLYFUSION = 3 };
+
+typedef struct {
+    int32_t algo;       /* ACX_ALGO_*: 1 / 2 (qmax, dmax) / 1 / 4 (mfccs, ssms, chromas, early) score planes */
+    int32_t symmetric;  /* 1: unordered pairs i < j   0: ordered pairs i != j (all_pairwise's `symmetric`) */
+    int32_t tile;       /* tracks per block edge; 0: 128, halved while a rank would get fewer than 32 blocks */
+    int32_t world;      /* number of ranks */
+} acx_grid_spec;
+
+typedef struct {
+    int32_t row0, col0;   /* first track of the block's rows / columns */
+    int32_t rows, cols;   /* tracks per side */
+    int32_t rank;         /* owner */
+    int32_t diagonal;     /* row0 == col0: only i < j (symmetric) or i != j is computed; the rest stays 0 */
+    int64_t offset;       /* float offset of the block in its owner's buffer */
+    double cost;          /* sum of len_i * len_j over the block's pairs */
+} acx_grid_tile;
+
+typedef struct {
+    int32_t sslen;        /* SSLEN (Simple ctor, simple_silva.py:26-27), default 10 */
+    int32_t oti;          /* 1: transpose the second track toward the first (Simple.oti) */
+} acx_simple_params;
+
+/*
+ * The plan: pure host function of (track lengths, spec), identical on every rank.  `tiles` (may be
+ * NULL) receives up to `capacity` blocks in deal order (cost descending), *n_tiles their number,
+ * floats_per_rank[world] the size of every rank's score buffer, cost_per_rank[world] (may be NULL)
+ * the dealt cost.  No device needed.
+ */
+int acx_grid_plan(const int64_t *lengths, int32_t n_tracks, const acx_grid_spec *spec, acx_grid_tile *tiles,
+                  int64_t capacity, int64_t *n_tiles, int64_t *floats_per_rank, double *cost_per_rank);
+
+/* Track lengths the grid of `algo` is planned on: pooled frames (Serra09 / ChenFusion: the f32
+ * pool; SiMPle: the f64 pool) or blocks (EarlyFusion).  lengths: room for `capacity` entries. */
+int acx_pool_lengths(acx_ctx *ctx, int32_t algo, int64_t *lengths, int32_t capacity, int32_t *n_tracks);
+
+/*
+ * Scores of blocks [first, first + count) of rank `rank`'s deal (count < 0: all of them) into
+ * d_scores, a DEVICE buffer of floats_per_rank[rank] floats owned by the caller (e.g. the
+ * storage of a torch tensor that is handed to the all-gather next).  The slice's part of the
+ * buffer is zeroed first.  params: acx_serra09_params (Serra09, ChenFusion), acx_simple_params,
+ * acx_ef_params.  Replaces the similarity(idxs) fan-out of algorithm_template.py:172-187.
+ */
+int acx_grid_run(acx_ctx *ctx, const acx_grid_spec *spec, const void *params, int32_t rank, int64_t first,
+                 int64_t count, float *d_scores);
+
+/*
+ * Gathered rank buffers (HOST memory: `world` segments of rank_stride floats) -> the planes of
+ * D: D[e][i * ld + j] = score plane e of pair (i, j), for the blocks [first, first + count) of
+ * every rank; mirror != 0 also stores D[e][j * ld + i] (the D += D.T of
+ * algorithm_template.py:189-191 on a matrix whose other triangle is zero).  Pure host function.
+ */
+int acx_grid_scatter(const int64_t *lengths, int32_t n_tracks, const acx_grid_spec *spec, const float *gathered,
+                     int64_t rank_stride, int64_t first, int64_t count, float *const *D, int64_t ld,
+                     int32_t mirror);
+
+/* One GPU, whole grid: plan (world must be 1) + run + scatter into the caller's N x N host planes
+ * (e.g. the float32 memmaps CoverAlgorithm.Ds holds). */
+int acx_pair_grid(acx_ctx *ctx, const acx_grid_spec *spec, const void *params, float *const *D, int64_t ld,
+                  int32_t mirror);
+
 /* ---- measurement -------------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on the library's own stream around

@@ -1,7 +1,12 @@
 """
-CPU suite, part 5: the N > 1 path.  Two processes under torch.distributed (gloo,
-127.0.0.1) shard the pair list, compute their slices with a CPU similarity() (a user
-subclass), and all-gather the scores: every rank must end with the single-process matrix.
+CPU suite, part 5: the N > 1 path.  Two processes under torch.distributed (gloo, 127.0.0.1).
+  * user subclasses (their own CPU similarity()): the pair list is sharded, the scores gathered;
+  * device-backed classes: the tile plan of libacx (acx_grid_plan), every rank fills the score
+    buffer of ITS tiles, one all-gather of the buffers, rank 0 scatters (acx_grid_scatter).  The GPU
+    context is replaced by a stand-in that writes f(i, j) into the tiles, so that plan, gather and
+    scatter -- everything but the kernels -- run here; the real thing is tests/test_gpu_grid.py.
+Rank 0 owns the result: it must end with the single-process matrices; the statistics are the same
+on every rank.
 """
 import os
 import socket
@@ -21,14 +26,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, ws, port, workdir, sym, out):
+def _worker(rank, ws, port, workdir, sym, out, kind):
     sys.path.insert(0, ROOT)
     os.chdir(workdir)
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=ws)
     try:
-        D = _run_toy(workdir, sym)
+        D, stats = (_run_grid if kind == "grid" else _run_toy)(workdir, sym)
         np.save(os.path.join(out, "D_rank%d.npy" % rank), D)
+        np.save(os.path.join(out, "S_rank%d.npy" % rank), np.array(stats[:4]))
     finally:
         dist.destroy_process_group()
 
@@ -47,31 +53,160 @@ def _run_toy(workdir, sym):
     toy = Toy(os.path.join(workdir, "toy.csv"), name="Toy", datapath=workdir + "/", shortname="t",
               similarity_types=["main", "aux"])
     toy.all_pairwise(symmetric=sym)
-    return np.stack([np.array(toy.Ds["main"]), np.array(toy.Ds["aux"])])
+    stats = toy.getEvalStatistics("main", topsidx=[1, 10])
+    return np.stack([np.array(toy.Ds["main"]), np.array(toy.Ds["aux"])]), stats
 
 
-@pytest.mark.parametrize("sym", [True, False])
-def test_two_ranks_equal_one(tmp_path, sym):
-    import torch.multiprocessing as mp
+class _FakeContext(object):
+    """Stand-in for acoss_amd._lib.Context in the grid path: same methods, CPU memory, and the
+    'kernel' is score(i, j, plane) = 1000 plane + 37 i + j (+ 0.5 for ordered pairs with i > j)."""
+    device = 0
+
+    def __init__(self, lengths):
+        self.lengths = np.asarray(lengths, np.int64)
+
+    def torch_device(self):
+        import torch
+        return torch.device("cpu")
+
+    def pool_lengths(self, algo):
+        return self.lengths
+
+    @staticmethod
+    def score(i, j, e):
+        return 1000.0 * e + 37.0 * i + j + (0.5 if i > j else 0.0)
+
+    def _fill(self, plan, rank, buf):
+        from acoss_amd import _lib
+        w = _lib.GRID_PLANES[plan["spec"].algo]
+        sym = plan["spec"].symmetric
+        for t in plan["tiles"]:
+            if t.rank != rank:
+                continue
+            blk = np.zeros((t.rows, t.cols, w), np.float32)
+            for a in range(t.rows):
+                for b in range(t.cols):
+                    i, j = t.row0 + a, t.col0 + b
+                    if t.diagonal and ((sym and not i < j) or (not sym and i == j)):
+                        continue
+                    blk[a, b] = [self.score(i, j, e) for e in range(w)]
+            buf[t.offset:t.offset + blk.size] = blk.ravel()
+
+    def grid_run(self, spec, params, rank, dev_ptr, first=0, count=-1):
+        import ctypes
+        from acoss_amd import _lib
+        plan = _lib.grid_plan(self.lengths, spec.algo, spec.symmetric, world=spec.world, tile=spec.tile, want_tiles=True)
+        n = int(plan["floats_per_rank"][rank])
+        buf = np.ctypeslib.as_array(ctypes.cast(dev_ptr, ctypes.POINTER(ctypes.c_float)), shape=(n,))
+        self._fill(plan, rank, buf)
+
+    def pair_grid(self, algo, symmetric, params, planes, mirror, tile=0):
+        from acoss_amd import _lib
+        plan = _lib.grid_plan(self.lengths, algo, symmetric, world=1, tile=tile, want_tiles=True)
+        buf = np.zeros(int(plan["floats_per_rank"][0]), np.float32)
+        self._fill(plan, 0, buf)
+        _lib.grid_scatter(self.lengths, plan["spec"], buf, len(buf), planes, mirror)
+
+
+def _run_grid(workdir, sym):
+    from acoss_amd import _lib
+    from acoss_amd.algorithms.algorithm_template import CoverAlgorithm
+    n = 75
+    lengths = np.random.default_rng(3).integers(40, 900, n)
+
+    class Dev(CoverAlgorithm):
+        def _grid(self):
+            return _FakeContext(lengths), _lib.ALGO_CHENFUSION, _lib.serra09_params(), ["qmax", "dmax"]
+
+    dev = Dev(os.path.join(workdir, "grid.csv"), name="Dev", datapath=workdir + "/", shortname="g",
+              similarity_types=["qmax", "dmax"])
+    dev.all_pairwise(symmetric=sym)
+    stats = dev.getEvalStatistics("qmax", topsidx=[1, 10])
+    return np.stack([np.array(dev.Ds["qmax"]), np.array(dev.Ds["dmax"])]), stats
+
+
+def _expected_grid(n, sym):
+    D = np.zeros((2, n, n), np.float32)
+    for e in range(2):
+        for i in range(n):
+            for j in range(n):
+                if i == j:
+                    continue
+                if sym:
+                    D[e, i, j] = _FakeContext.score(min(i, j), max(i, j), e)
+                else:
+                    D[e, i, j] = _FakeContext.score(i, j, e)
+    return D
+
+
+def _dataset(wd, name, n, nworks):
     from acoss_amd.featurestore import save_track
-    wd = str(tmp_path)
-    with open(os.path.join(wd, "toy.csv"), "w") as f:
+    with open(os.path.join(wd, name), "w") as f:
         f.write("work_id,track_id\n")
-        for k in range(11):
-            f.write("w%d,t%d\n" % (k % 4, k))
-            save_track(os.path.join(wd, "w%d/t%d.h5" % (k % 4, k)), {"label": "w%d" % (k % 4), "track_id": "t%d" % k})
+        for k in range(n):
+            f.write("w%d,t%d\n" % (k % nworks, k))
+            save_track(os.path.join(wd, "w%d/t%d.h5" % (k % nworks, k)), {"label": "w%d" % (k % nworks), "track_id": "t%d" % k})
+
+
+@pytest.mark.parametrize("kind,sym", [("toy", True), ("toy", False), ("grid", True), ("grid", False)])
+def test_two_ranks_equal_one(tmp_path, kind, sym):
+    import torch.multiprocessing as mp
+    wd = str(tmp_path)
+    _dataset(wd, "toy.csv", 11, 4)
+    _dataset(wd, "grid.csv", 75, 20)
     cwd = os.getcwd()
     os.chdir(wd)
     try:
-        single = _run_toy(wd, sym)
+        single, sstats = (_run_grid if kind == "grid" else _run_toy)(wd, sym)
     finally:
         os.chdir(cwd)
+    if kind == "grid":
+        assert np.array_equal(single, _expected_grid(75, sym))
     out = str(tmp_path / "out")
     os.makedirs(out)
-    mp.spawn(_worker, args=(2, _free_port(), wd, sym, out), nprocs=2, join=True)
+    for stale in ("results_t_Toy.csv", "results_g_Dev.csv"):
+        if os.path.exists(os.path.join(wd, stale)):
+            os.remove(os.path.join(wd, stale))
+    mp.spawn(_worker, args=(2, _free_port(), wd, sym, out, kind), nprocs=2, join=True)
+    D0 = np.load(os.path.join(out, "D_rank0.npy"))
+    assert np.array_equal(D0, single), "rank 0 differs from the single-process result"
     for r in range(2):
-        D = np.load(os.path.join(out, "D_rank%d.npy" % r))
-        assert np.array_equal(D, single), "rank %d differs" % r
+        assert np.array_equal(np.load(os.path.join(out, "S_rank%d.npy" % r)), np.array(sstats[:4])), "statistics differ on rank %d" % r
+    # rank 0 alone wrote the results file: one header, one row
+    res = [f for f in os.listdir(wd) if f.startswith("results_")]
+    assert len(res) == 1 and len(open(os.path.join(wd, res[0])).read().strip().split("\n")) == 2
+
+
+def test_grid_plan_is_cost_balanced_on_ragged_lengths():
+    """acx_grid_plan on ragged track lengths (cost ~ len_i * len_j varies 100 x): the dealt cost of
+    the fullest rank is within 2 % of the mean; every pair belongs to exactly one tile."""
+    from acoss_amd import _lib
+    rng = np.random.default_rng(0)
+    for n, ws, sym in [(5000, 8, True), (1200, 8, True), (900, 4, False), (164, 8, True), (333, 3, True)]:
+        L = np.concatenate([rng.integers(150, 700, n - n // 10), rng.integers(1500, 5000, n // 10)])
+        rng.shuffle(L)
+        pl = _lib.grid_plan(L, _lib.ALGO_SERRA09, sym, world=ws, want_tiles=True)
+        c = pl["cost_per_rank"]
+        assert c.max() / c.mean() <= 1.02, (n, ws, c.max() / c.mean())
+        total = sum(t.cost for t in pl["tiles"])
+        S, Q = float(L.sum()), float((L.astype(np.float64) ** 2).sum())
+        want = (S * S - Q) / 2 if sym else (S * S - Q)
+        assert abs(total - want) <= 1e-9 * want
+        seen = np.zeros((n, n), np.int32)
+        for t in pl["tiles"]:
+            seen[t.row0:t.row0 + t.rows, t.col0:t.col0 + t.cols] += 1
+        if sym:
+            assert np.all(seen[np.triu_indices(n, 1)] == 1)       # every unordered pair in exactly one tile
+        else:
+            assert np.all(seen == 1)
+        # offsets of a rank's tiles are disjoint and dense
+        for r in range(ws):
+            mine = [t for t in pl["tiles"] if t.rank == r]
+            off = 0
+            for t in mine:
+                assert t.offset == off
+                off += t.rows * t.cols
+            assert off == pl["floats_per_rank"][r]
 
 
 def test_shard_bounds_cover_everything():

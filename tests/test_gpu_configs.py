@@ -102,6 +102,35 @@ def test_covers80_shaped_all_pairs(ctx):
                                                                  "fraction": flipped / max(1, cells)}})
 
 
+def test_covers80_shaped_hard_set(ctx):
+    """The same shape with cover versions that are hard to tell apart (noise as loud as the chords,
+    every version a random half of its work: MAP ~ 0.6 instead of 1.0), so that the comparison of the
+    rank statistics means something: HIP == oracle bit for bit and therefore identical statistics;
+    against seq108 the measured |dMAP| is recorded (a handful of scores move by 0.5 - 1)."""
+    import oracle
+    from acoss_amd import synth
+    d = synth.covers80_shaped(seed=99, t_range=(600, 1200), noise=1.0, segment_keep=0.5)
+    n = len(d["offsets"]) - 1
+    ctx.upload_pool(d["frames"], d["offsets"])
+    pairs = oracle.all_pairs(n, True).astype(np.int32)
+    got = ctx.serra09_pairs(pairs)
+    ref = oracle.serra09_pairs_mt(d["frames"], d["offsets"], pairs)
+    assert np.array_equal(got, ref), "scores differ for %d / %d pairs" % (int(np.sum(got != ref)), len(ref))
+    sg, sr = _stats(oracle, d, pairs, got), _stats(oracle, d, pairs, ref)
+    assert sg[:4] == sr[:4] and np.array_equal(sg[4], sr[4])
+    assert 0.2 < sg[3] < 0.95, sg[3]
+    ref108 = oracle.serra09_pairs_mt(d["frames"], d["offsets"], pairs, oracle.serra09_params(arith="seq108"))
+    s108 = _stats(oracle, d, pairs, ref108)
+    assert np.max(np.abs(got - ref108)) <= 2.0
+    assert abs(sg[3] - s108[3]) <= 5e-3, (sg[3], s108[3])
+    _record("covers80_shaped_hard", {"tracks": n, "pairs": int(len(pairs)), "hip_vs_tree_oracle": "bit-identical",
+                                     "MR_MRR_MDR_MAP_hip": [float(x) for x in sg[:4]],
+                                     "MR_MRR_MDR_MAP_seq108": [float(x) for x in s108[:4]],
+                                     "abs_dMAP_hip_vs_seq108": abs(float(sg[3]) - float(s108[3])),
+                                     "tops_hip": [float(x) for x in sg[4]], "tops_seq108": [float(x) for x in s108[4]],
+                                     "abs_dscore_hip_vs_seq108": _hist(got - ref108)})
+
+
 def test_seq108_at_T2000(ctx):
     import oracle
     from acoss_amd import synth
@@ -147,7 +176,7 @@ def test_pool_scale_15000_tracks(ctx):
     pairs = pairs[pairs[:, 0] != pairs[:, 1]]
     pairs[:64, 0] = N - 1 - np.arange(64)            # the far end of the pool is covered for sure
     got = ctx.serra09_pairs(pairs)
-    assert got.shape == (len(pairs),) and np.all(got >= 1.0) and np.all(got < 200.0)
+    assert got.shape == (len(pairs),) and np.all(got >= 1.0) and np.all(got <= T - 11)
     # (1) bit-exact vs the oracle on 64 sampled pairs (32 of them at the far end)
     sel = np.concatenate([np.arange(32), rng.choice(np.arange(64, len(pairs)), 32, replace=False)])
     ref = oracle.serra09_pairs_mt(frames, offsets, pairs[sel], chunk=1)

@@ -1,0 +1,148 @@
+"""
+GPU tests of the N x N pair grid (run with -m gpu on a real MI355X): acx_pair_grid / acx_grid_run
+against the pair-list entry points, through the real host classes, and on two ranks.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from acoss_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _from_pairs(n, pairs, scores, mirror):
+    D = np.zeros((n, n), np.float32)
+    D[pairs[:, 0], pairs[:, 1]] = scores
+    if mirror:
+        D += D.T
+    return D
+
+
+@pytest.mark.parametrize("tile", [0, 7, 64])
+def test_pair_grid_equals_pair_list_serra09(ctx, tile):
+    import oracle
+    from acoss_amd import synth, _lib
+    d = synth.cover_set(clique_sizes=[2] * 9 + [3, 1], seed=31, t_range=(60, 420))
+    n = len(d["offsets"]) - 1
+    ctx.upload_pool(d["frames"], d["offsets"])
+    for sym in (True, False):
+        pairs = oracle.all_pairs(n, sym).astype(np.int32)
+        want = _from_pairs(n, pairs, ctx.serra09_pairs(pairs), sym)
+        D = np.zeros((n, n), np.float32)
+        ctx.pair_grid(_lib.ALGO_SERRA09, sym, _lib.serra09_params(), [D], mirror=sym, tile=tile)
+        assert np.array_equal(D, want)
+    # two planes from one recurrence plot
+    pairs = oracle.all_pairs(n, True).astype(np.int32)
+    both = ctx.chenfusion_pairs(pairs)
+    Q, Dm = np.zeros((n, n), np.float32), np.zeros((n, n), np.float32)
+    ctx.pair_grid(_lib.ALGO_CHENFUSION, True, _lib.serra09_params(), [Q, Dm], mirror=True, tile=tile)
+    assert np.array_equal(Q, _from_pairs(n, pairs, both[:, 0], True))
+    assert np.array_equal(Dm, _from_pairs(n, pairs, both[:, 1], True))
+
+
+def test_grid_run_ranks_and_slices(ctx):
+    """acx_grid_run for every rank of a 3-rank plan into torch device buffers (the all-gather's operands),
+    in one call and tile by tile; acx_grid_scatter of the concatenation equals the one-GPU grid."""
+    import torch
+    from acoss_amd import synth, _lib
+    d = synth.cover_set(clique_sizes=[2] * 14, seed=5, t_range=(60, 300))
+    n = len(d["offsets"]) - 1
+    ctx.upload_pool(d["frames"], d["offsets"])
+    want = np.zeros((n, n), np.float32)
+    ctx.pair_grid(_lib.ALGO_SERRA09, True, _lib.serra09_params(), [want], mirror=True)
+    lengths = ctx.pool_lengths(_lib.ALGO_SERRA09)
+    assert np.array_equal(lengths, np.diff(d["offsets"]))
+    ws = 3
+    plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=ws, tile=5, want_tiles=True)
+    stride = int(plan["floats_per_rank"].max())
+    for sliced in (False, True):
+        bufs = []
+        for r in range(ws):
+            t = torch.full((stride,), -7.0, dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            if sliced:
+                ntile = sum(1 for tl in plan["tiles"] if tl.rank == r)
+                for k in range(ntile):
+                    ctx.grid_run(plan["spec"], _lib.serra09_params(), r, t.data_ptr(), first=k, count=1)
+            else:
+                ctx.grid_run(plan["spec"], _lib.serra09_params(), r, t.data_ptr())
+            bufs.append(t.cpu().numpy())
+        D = np.zeros((n, n), np.float32)
+        _lib.grid_scatter(lengths, plan["spec"], np.concatenate(bufs), stride, [D], mirror=True)
+        assert np.array_equal(D, want)
+
+
+def test_pair_grid_simple_and_earlyfusion(ctx):
+    from acoss_amd import synth, _lib
+    import oracle
+    rng = np.random.default_rng(8)
+    feats = [rng.random((int(rng.integers(40, 120)), 12)) for _ in range(9)]
+    feats = [f / np.linalg.norm(f, axis=1, keepdims=True) for f in feats]
+    offs = np.concatenate([[0], np.cumsum([len(f) for f in feats])]).astype(np.int64)
+    ctx.upload_pool_f64(np.concatenate(feats), offs)
+    n = len(feats)
+    pairs = oracle.all_pairs(n, False).astype(np.int32)
+    want = _from_pairs(n, pairs, ctx.simple_pairs(pairs, 10).astype(np.float32), False)
+    D = np.zeros((n, n), np.float32)
+    ctx.pair_grid(_lib.ALGO_SIMPLE, False, _lib.SimpleParams(10, 1), [D], mirror=False, tile=4)
+    assert np.array_equal(D, want)
+    tracks = synth.earlyfusion_set(6, seed=3, nb_range=(40, 90))
+    ctx.ef_upload_pool(tracks)
+    pairs = oracle.all_pairs(6, True).astype(np.int32)
+    sc = ctx.earlyfusion_pairs(pairs, kappa=0.1, K=10)
+    planes = [np.zeros((6, 6), np.float32) for _ in range(4)]
+    ctx.pair_grid(_lib.ALGO_EARLYFUSION, True, _lib.EfParams(0.1, 10), planes, mirror=True, tile=4)
+    for e in range(4):
+        assert np.array_equal(planes[e], _from_pairs(6, pairs, sc[:, e], True))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_share_one_gpu(tmp_path):
+    """The real Serra09 and ChenFusion classes under torch.distributed (gloo, two ranks on GPU 0):
+    rank 0's matrices are bit-identical to the single-process run, the statistics agree on all ranks."""
+    from acoss_amd.featurestore import save_track
+    wd = str(tmp_path)
+    with open(os.path.join(wd, "grid.csv"), "w") as f:
+        f.write("work_id,track_id\n")
+        for k in range(32):
+            f.write("w%d,t%d\n" % (k, k))
+            save_track(os.path.join(wd, "w%d/t%d.h5" % (k, k)), {"label": "w%d" % k, "track_id": "t%d" % k})
+    out = os.path.join(wd, "out")
+    os.makedirs(out)
+    worker = os.path.join(ROOT, "tests", "_grid_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    subprocess.run([sys.executable, worker, wd, out], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, wd, out],
+                   check=True, env=env, timeout=900)
+    one = np.load(os.path.join(out, "world1_rank0.npz"))
+    two0 = np.load(os.path.join(out, "world2_rank0.npz"))
+    two1 = np.load(os.path.join(out, "world2_rank1.npz"))
+    mats = [k for k in one.files if not k.endswith("_stats")]
+    assert len(mats) == 3
+    for k in one.files:
+        assert np.array_equal(one[k], two0[k], equal_nan=True), k
+        if k.endswith("_stats"):
+            assert np.array_equal(one[k], two1[k], equal_nan=True), k
+    assert float(one["serra09_main"].max()) > 10.0
