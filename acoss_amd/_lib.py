@@ -83,6 +83,13 @@ def load():
         raise ImportError(
             "libacx.so is not built (%s). Build it with `make -C acoss_amd/csrc` or "
             "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime: when both live in one process (the multi-GPU path hands
+    # torch device buffers to libacx) torch's copy has to be the one that is loaded -- libacx then binds
+    # to it by soname.  The other order leaves torch without a device ("No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     fp = ctypes.POINTER(ctypes.c_float)
     ip = ctypes.POINTER(ctypes.c_int32)

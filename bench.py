@@ -1,28 +1,40 @@
 #!/usr/bin/env python3
 """
 bench.py -- headline benchmark: track-pairs/sec of the Serra09 chain
-(OTI -> embedded CSM -> mutual-kappa thresholds -> Qmax) on synthetic HPCP of
-T = 2000 pooled frames (BASELINE.json metric; per-track shape of configs[2]).
+(OTI -> embedded CSM -> mutual-kappa thresholds -> Qmax) on BASELINE.json configs[2]: a synthetic
+pool of 5 000 tracks x 2000 pooled HPCP frames, the pair grid tiled over the GPUs.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of PAIRS_PER_RANK track pairs per GPU
-(weak scaling: the pair grid grows with N; pairs are independent, the only exchange is one
-all-gather of the scores per pass over RCCL).  The feature pool is uploaded to HBM before
-the timed region.  Rank 0 prints ONE JSON line.
+The 5000 x 5000 grid is cut into 64 x 64 track tiles and dealt to the N ranks by libacx's
+cost-balanced plan (acx_grid_plan, the scheduler all_pairwise uses).  A "step" is one pass of the
+hot path over the next TILES_PER_STEP tiles of every rank's deal (2 tiles = 8192 pairs per GPU per
+step, different tracks every step; weak scaling: per-GPU work is fixed) into a device buffer
+(acx_grid_run), followed, for N > 1, by the one collective of the path: an all-gather of the tile
+scores over RCCL on the device buffers themselves.  The pool is resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
 
 Also in the line:
-  roofline      dominant kernel (by accumulated HIP-event time on the library's own
-                stream) against the HBM roofline, with the algorithmic bytes of DESIGN.md
-  cpu_baseline  the CPU oracle (a C port of the same chain, 1 thread) timed on the box's
-                host cores on a bounded sample of the same pairs -- and checked bit-for-bit
-                against the GPU scores of those pairs.
+  roofline      the dominant kernel (accumulated HIP-event time on the library's own stream)
+                against the byte model SURVEY.md 8d fixes (10 B/cell: f32 distance matrix written
+                once + read once, 1-byte recurrence matrix written once + read once) and the
+                8 TB/s HBM peak -- a THROUGHPUT PROXY: the production pipeline keeps the distance
+                matrix out of HBM, so the kernel is bound by SIMD issue (VALU + f32 MFMA share the
+                issue port), which `bound` / `real_bound` say (utilisations from the committed
+                rocprofv3 counter run, profiles/r02_real_bound.json); `traffic` = HBM bytes per
+                launch from the committed PMC run (profiles/pmc_traffic.json), scaled by cells.
+  cpu_baseline  the CPU oracle (a C port of the same chain) on ALL host cores through a process
+                fan-out over max(45, cores) chunks (the reference's joblib scheme,
+                algorithm_template.py:172-177, has 45), on a bounded sample of the same workload;
+                its scores are checked bit-for-bit against the GPU's.  Timed BEFORE the GPU is
+                initialised (the worker processes are forks).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,20 +44,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 T_FRAMES = 2000
-N_TRACKS = 384                 # C(384, 2) = 73 536 pairs >= 8 ranks x 8192
-PAIRS_PER_RANK = 8192
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+N_TRACKS = 5000
+TILE = 64
+TILES_PER_STEP = 2             # per rank: 2 x 64 x 64 = 8192 pairs per GPU per step
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 M_STACK = 9
 
-# algorithmic bytes per matrix cell by kernel (DESIGN.md "Roofline model"; SURVEY.md 8d:
-# 10 B/cell = f32 distance matrix written once + read once, 1-byte recurrence matrix
-# written once + read once)
+# algorithmic bytes per matrix cell by kernel (DESIGN.md "Roofline model").
 # band_kernel is launched twice per batch (role 1: column thresholds, role 0: row thresholds +
-# recurrence bitmap); each launch carries one 4 B/cell pass over the distance matrix of the
-# model (write / read-back), together the 8 B/cell of v1's csm_tile_kernel + rowsel_kernel;
-# qmax_kernel = the DP over the recurrence plot.
+# recurrence bitmap); each launch carries one 4 B/cell pass over the distance matrix of the model
+# (write / read-back); qmax_bits_kernel = the DP over the recurrence plot (write + read, 1 B each).
 ALGO_BYTES_PER_CELL = {"band_kernel": 4.0, "csm_long_kernel": 4.0, "rowsel_long_kernel": 4.0, "qmax_bits_kernel": 2.0,
                        "oti_kernel": 0.0, "norms_kernel": 0.0}
+
+_CPU = {}
 
 
 def chain_bytes_per_pair(Tq, Tr, m=M_STACK):
@@ -53,83 +65,162 @@ def chain_bytes_per_pair(Tq, Tr, m=M_STACK):
     return 10.0 * Mq * Mr + 48.0 * (Tq + Tr) + 4.0
 
 
+def make_pool(n, T, seed=1234):
+    """SURVEY 8d 'rand' set: i.i.d. U[0,1) frames, each divided by its max."""
+    rng = np.random.default_rng(seed)
+    frames = rng.random((n * T, 12), dtype=np.float32)
+    frames /= frames.max(axis=1, keepdims=True)
+    return frames, np.arange(n + 1, dtype=np.int64) * T
+
+
+def _cpu_chunk(chunk):
+    import oracle
+    return oracle.serra09_pairs(_CPU["frames"], _CPU["offsets"], chunk)
+
+
+def cpu_baseline(frames, offsets, pairs, budget_s=15.0):
+    """Oracle on all host cores, process fan-out (fork: no GPU state exists yet)."""
+    import multiprocessing as mp
+    import oracle
+    oracle.lib()
+    _CPU["frames"], _CPU["offsets"] = frames, offsets
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    one = oracle.serra09_pairs(frames, offsets, pairs[:2])
+    t_pair = (time.perf_counter() - t0) / 2
+    n = int(min(len(pairs), max(cores, budget_s * cores / t_pair)))
+    nchunks = max(45, cores)
+    n = max(nchunks, n - n % nchunks)
+    sample = np.ascontiguousarray(pairs[:n])
+    chunks = [c for c in np.array_split(sample, nchunks) if len(c)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_cpu_chunk, [c[:1] for c in chunks[:cores]])          # workers up, library loaded
+        t0 = time.perf_counter()
+        parts = pool.map(_cpu_chunk, chunks, chunksize=1)
+        dt = time.perf_counter() - t0
+    scores = np.concatenate(parts)
+    assert np.array_equal(scores[:2], one)
+    model = ""
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True).stdout.splitlines():
+            if line.startswith("Model name"):
+                model = line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return sample, scores, {
+        "value": round(n / dt, 3), "unit": "track-pairs/s", "cores": cores, "kind": "port",
+        "sample": "first %d pairs of step 0's tiles of the same workload (T=%d), C oracle -O2, %d worker "
+                  "processes over %d chunks (reference scheme: 45 joblib chunks); scores bit-identical to the GPU's"
+                  % (n, T_FRAMES, cores, len(chunks)),
+        "value_1core": round(1.0 / t_pair, 3), "cpu_model": model, "host_cpus": cores}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs-per-rank", type=int, default=PAIRS_PER_RANK)
-    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on ONE thread of the CPU oracle (0 = skip the CPU leg)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tracks", type=int, default=N_TRACKS)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from acoss_amd import _lib, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    from acoss_amd import _lib
+    frames, offsets = make_pool(args.tracks, T_FRAMES)
+    lengths = np.diff(offsets)
+    plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=world, tile=TILE, want_tiles=True)
+    spec = plan["spec"]
+    mine = [t for t in plan["tiles"] if t.rank == rank]
+    nslices = len(mine) // TILES_PER_STEP
+    assert nslices >= 1
+
+    def slice_of(step):
+        k = (step % nslices) * TILES_PER_STEP
+        return k, mine[k:k + TILES_PER_STEP]
+
+    def pairs_of(tiles):
+        out = []
+        for t in tiles:
+            i, j = np.meshgrid(np.arange(t.row0, t.row0 + t.rows), np.arange(t.col0, t.col0 + t.cols), indexing="ij")
+            keep = (i < j) if t.diagonal else np.ones_like(i, bool)
+            out.append(np.stack([i[keep], j[keep]], 1))
+        return np.concatenate(out).astype(np.int32)
+
+    # ---- CPU baseline first: worker processes are forked before any GPU state exists
+    cpu = cpu_sample = cpu_scores = None
+    if world == 1 and rank == 0 and not args.no_cpu:
+        cpu_sample, cpu_scores, cpu = cpu_baseline(frames, offsets, pairs_of(slice_of(args.warmup)[1]))
+
+    import torch
+    import torch.distributed as dist
     # ACX_BENCH_BACKEND=gloo (development): functional run of the N > 1 path on a box with fewer
-    # GPUs than ranks -- ranks share the devices and the score gather goes through host memory
+    # GPUs than ranks -- ranks share the devices and the gather goes through host memory
     backend = os.environ.get("ACX_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+    dev = torch.device("cuda", local_rank)
 
-    # ---- synthetic pool (SURVEY 8d "rand" set), resident in HBM before timing
-    data = synth.rand_set(N_TRACKS, T=T_FRAMES, seed=1234)
     ctx = _lib.Context(local_rank)
-    ctx.upload_pool(data["frames"], data["offsets"])
-    iu, ju = np.triu_indices(N_TRACKS, 1)
-    all_pairs = np.stack([iu, ju], 1).astype(np.int32)
-    ppr = args.pairs_per_rank
-    assert world * ppr <= len(all_pairs)
-    mine = np.ascontiguousarray(all_pairs[rank * ppr:(rank + 1) * ppr])
+    ctx.upload_pool(frames, offsets)                 # pool resident in HBM before timing
     params = _lib.serra09_params()
+    slice_floats = max(sum(t.rows * t.cols for t in mine[k:k + TILES_PER_STEP]) for k in range(0, nslices * TILES_PER_STEP, TILES_PER_STEP))
+    local = torch.zeros(slice_floats, dtype=torch.float32, device=dev)
+    gathered = torch.zeros(world * slice_floats, dtype=torch.float32, device=dev) if world > 1 else None
+    torch.cuda.synchronize()
+    pairs_per_step = []
 
-    def step():
-        sc = ctx.serra09_pairs(mine, params)
-        if world > 1:
-            t = torch.from_numpy(sc).to(dev)
-            outs = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(outs, t)            # the one collective of the path
-            return sc, outs
-        return sc, None
+    def step(s):
+        k, tiles = slice_of(s)
+        # acx_grid_run writes tile t at d_scores + t.offset: rebase so that the slice starts at local[0]
+        ctx.grid_run(spec, params, rank, local.data_ptr() - 4 * tiles[0].offset, first=k, count=TILES_PER_STEP)
+        if world > 1:                               # the one collective of the path, device to device
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, local)
+            else:
+                outs = [torch.empty(slice_floats) for _ in range(world)]
+                dist.all_gather(outs, local.cpu())
+        return sum((t.rows * (t.rows - 1)) // 2 if t.diagonal else t.rows * t.cols for t in tiles)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for s in range(args.warmup):
+        step(s)
     ctx.profile_enable(True)
     ctx.profile_reset()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        scores, _ = step()
+    for s in range(args.warmup, args.warmup + args.steps):
+        pairs_per_step.append(step(s))
     fence()
     elapsed = time.perf_counter() - t0
+    my_pairs = float(sum(pairs_per_step))
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        pp = torch.tensor([my_pairs], dtype=torch.float64, device=cdev)
+        dist.all_reduce(pp, op=dist.ReduceOp.SUM)
+        total_pairs = float(pp.item())
+    else:
+        total_pairs = my_pairs
     prof = ctx.profile()
 
     if rank == 0:
-        total_pairs = world * ppr * args.steps
         value = total_pairs / elapsed
         # ---- roofline of the dominant kernel (HIP events on the library's stream)
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        kname, kst = dom
+        kname, kst = max(prof.items(), key=lambda kv: kv[1]["ms"])
         launches = max(1, kst["launches"])
         cells_per_launch = kst["cells"] / launches
         avg_ms = kst["ms"] / launches
@@ -137,62 +228,51 @@ def main():
         if kname in ("csm_long_kernel", "band_kernel"):
             algo_bytes += 48.0 * 2 * T_FRAMES * (cells_per_launch / float((T_FRAMES - M_STACK) ** 2))
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source, real_bound = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if kname in tj and tj[kname].get("cells_per_launch"):
                     traffic = tj[kname]["hbm_bytes_per_launch"] * cells_per_launch / tj[kname]["cells_per_launch"]
+                    traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in a separate run "
+                                      "(%s), scaled by cells per launch; not measured in this run" % tj.get("source", "round 1"))
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        rpath = os.path.join(ROOT, "profiles", "r02_real_bound.json")
+        if os.path.exists(rpath):
+            try:
+                real_bound = json.load(open(rpath)).get(kname)
+            except Exception:
+                real_bound = None
+        bpp = chain_bytes_per_pair(T_FRAMES, T_FRAMES)
+        roofline = {"bound": "simd-issue (valu + f32 mfma)", "model": "hbm byte model of SURVEY 8d (throughput proxy, not a memory bound)",
+                    "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": traffic_source, "real_bound": real_bound,
                     "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
                     "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
-                    "chain": {"algorithmic_bytes_per_pair": chain_bytes_per_pair(T_FRAMES, T_FRAMES),
-                              "achieved": round(value / world * chain_bytes_per_pair(T_FRAMES, T_FRAMES) / 1e9, 1),
-                              "frac": round(value / world * chain_bytes_per_pair(T_FRAMES, T_FRAMES) / 1e9 / HBM_PEAK_GBS, 4)}}
-        # ---- CPU baseline: the oracle on a bounded sample of the same pairs (rank 0, N = 1 only)
-        cpu = None
-        if world == 1 and args.cpu_pairs > 0:
-            import oracle
-            from concurrent.futures import ThreadPoolExecutor
-            # one thread first (per-core figure), then the same C routine on up to 32 host threads
-            # (ctypes releases the GIL; the oracle keeps no global state)
-            ncpu = min(args.cpu_pairs, ppr)
-            sample = mine[:ncpu]
-            tc = time.perf_counter()
-            ref = oracle.serra09_pairs(data["frames"], data["offsets"], sample)
-            tcpu = time.perf_counter() - tc
-            if not np.array_equal(ref, scores[:ncpu]):
+                    "chain": {"algorithmic_bytes_per_pair": bpp,
+                              "achieved": round(value / world * bpp / 1e9, 1),
+                              "frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 4)}}
+        if cpu is not None:
+            got = ctx.serra09_pairs(cpu_sample, params)
+            if not np.array_equal(got, cpu_scores):
                 raise SystemExit("bench: GPU scores differ from the CPU oracle on the sampled pairs")
-            cores = max(1, min(32, os.cpu_count() or 1))
-            nmt = min(ppr, 4 * cores)
-            chunks = [mine[a:a + 4] for a in range(0, nmt, 4)]
-            tc = time.perf_counter()
-            with ThreadPoolExecutor(cores) as ex:
-                parts = list(ex.map(lambda ch: oracle.serra09_pairs(data["frames"], data["offsets"], ch), chunks))
-            tmt = time.perf_counter() - tc
-            if not np.array_equal(np.concatenate(parts), scores[:nmt]):
-                raise SystemExit("bench: GPU scores differ from the CPU oracle on the sampled pairs (threaded leg)")
-            cpu = {"value": round(nmt / tmt, 3), "unit": "track-pairs/s", "cores": cores, "kind": "port",
-                   "sample": "first %d pairs of the same workload (T=%d), C oracle -O2 on %d threads; "
-                             "scores bit-identical to the GPU's" % (nmt, T_FRAMES, cores),
-                   "value_1core": round(ncpu / tcpu, 3), "sample_1core": "first %d pairs, 1 thread" % ncpu,
-                   "host_cpus": os.cpu_count()}
         line = {
             "metric": "track-pairs/sec on N x N Serra09 Qmax (HPCP, T=2000)",
             "value": round(value, 1), "unit": "track-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "synthetic %d tracks x %d-frame HPCP (seed 1234), Serra09 Qmax "
-                                   "(m=9, tau=1, kappa=0.095, OTI), %d pairs per GPU per step, "
-                                   "one all-gather of the scores per step"
-                                   % (N_TRACKS, T_FRAMES, ppr),
-                       "pairs_per_step": world * ppr, "frames_per_track": T_FRAMES,
-                       "parallelism": "pair-grid sharded over %d GPU(s)" % world},
+            "config": {"workload": "configs[2]: synthetic %d tracks x %d-frame HPCP (seed 1234), Serra09 Qmax "
+                                   "(m=9, tau=1, kappa=0.095, OTI); the %d x %d pair grid in %d x %d tiles dealt to %d rank(s) "
+                                   "by cost (acx_grid_plan); %d tiles = %d pairs per GPU per step, different tiles every "
+                                   "step; one all-gather of the tile scores per step"
+                                   % (args.tracks, T_FRAMES, args.tracks, args.tracks, TILE, TILE, world, TILES_PER_STEP,
+                                      int(pairs_per_step[0])),
+                       "pairs_per_step": int(round(total_pairs / args.steps)), "frames_per_track": T_FRAMES,
+                       "pool_tracks": args.tracks, "parallelism": "pair-grid tiles over %d GPU(s)" % world},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
