@@ -82,6 +82,8 @@ struct acx_ctx {
     double *d_frames64 = nullptr;
     int64_t *d_toff64 = nullptr;
     double *d_prof64 = nullptr;
+    double *d_wn64 = nullptr;     // window norms of the f64 pool for subsequence length wn64_L (SiMPle)
+    int wn64_L = 0;
     std::vector<int64_t> h_off64;
     int32_t n_tracks64 = 0;
     int32_t *d_pairs = nullptr; size_t pairs_cap = 0;
@@ -742,7 +744,26 @@ int launch_simple(acx_ctx *c, int n, size_t smem, int oti)
 {
     auto kern = acx::simple_kernel<L>;
     ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(n), dim3(256), smem, c->stream, c->d_frames64, c->d_toff64, c->d_prof64, c->d_pairs, c->d_out64, oti);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(64), smem, c->stream, c->d_frames64, c->d_toff64, c->d_prof64, c->d_wn64, c->d_pairs,
+                       c->d_out64, oti);
+    return ACX_OK;
+}
+
+// |x_t|^2 summed over every window of `sslen` frames of the f64 pool: built on first use per (pool, SSLEN)
+static int ensure_winnorm(acx_ctx *c, int sslen)
+{
+    if (c->d_wn64 && c->wn64_L == sslen) return ACX_OK;
+    if (c->d_wn64) { ACX_HIP(c, hipFree(c->d_wn64)); c->d_wn64 = nullptr; }
+    const int64_t total = c->h_off64[c->n_tracks64];
+    int maxn = 1;
+    for (int t = 0; t < c->n_tracks64; ++t) maxn = std::max<int>(maxn, (int)(c->h_off64[t + 1] - c->h_off64[t]));
+    ACX_HIP(c, hipMalloc((void **)&c->d_wn64, sizeof(double) * std::max<int64_t>(1, total)));
+    ACX_HIP(c, hipMemsetAsync(c->d_wn64, 0, sizeof(double) * std::max<int64_t>(1, total), c->stream));
+    // (grid.x = tracks: up to 2^31 - 1)
+    hipLaunchKernelGGL(acx::simple_winnorm_kernel, dim3(c->n_tracks64, std::min(64, (maxn + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_frames64, c->d_toff64, c->d_wn64, sslen);
+    ACX_HIP(c, hipGetLastError());
+    c->wn64_L = sslen;
     return ACX_OK;
 }
 
@@ -803,6 +824,7 @@ void acx_destroy(acx_ctx *c)
     if (c->d_frames64) (void)hipFree(c->d_frames64);
     if (c->d_toff64) (void)hipFree(c->d_toff64);
     if (c->d_prof64) (void)hipFree(c->d_prof64);
+    if (c->d_wn64) (void)hipFree(c->d_wn64);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_out64) (void)hipFree(c->d_out64);
     for (int k = 0; k < 3; ++k) if (c->d_ef[k]) (void)hipFree(c->d_ef[k]);
@@ -1055,6 +1077,8 @@ int acx_upload_pool_f64(acx_ctx *c, const double *frames, const int64_t *offsets
     if (c->d_frames64) { (void)hipFree(c->d_frames64); c->d_frames64 = nullptr; }
     if (c->d_toff64) { (void)hipFree(c->d_toff64); c->d_toff64 = nullptr; }
     if (c->d_prof64) { (void)hipFree(c->d_prof64); c->d_prof64 = nullptr; }
+    if (c->d_wn64) { (void)hipFree(c->d_wn64); c->d_wn64 = nullptr; }
+    c->wn64_L = 0;
     const int64_t total = offsets[n_tracks];
     c->h_off64.assign(offsets, offsets + n_tracks + 1);
     c->n_tracks64 = n_tracks;
@@ -1084,7 +1108,6 @@ int acx_simple_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_
     std::vector<int64_t> poff((size_t)n_tracks + 1, 0);
     for (int t = 0; t < n_tracks; ++t) {
         const int64_t n = (raw_offsets[t + 1] - raw_offsets[t]) / skip;          // int(T0 / SKIP), simple_silva.py:37
-        if (n > acx::SIMPLE_PREP_MAXN) return fail(c, ACX_ERR_UNSUPPORTED, "simple_upload_raw_pool: tracks with more than 512 pooled frames are not supported on the device yet");
         poff[t + 1] = poff[t] + n;
     }
     // scipy.signal.get_window('hann', n, fftbins=False) / sum  (simple_silva.py:58-60)
@@ -1173,11 +1196,13 @@ int acx_simple_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, int32_t sslen,
             if (t < 0 || t >= c->n_tracks64) return fail(c, ACX_ERR_INVALID, "simple_pairs: track index out of range in pair " + std::to_string(k));
             const int n = (int)(c->h_off64[t + 1] - c->h_off64[t]);
             if (n < sslen) return fail(c, ACX_ERR_SHORT, "simple_pairs: track shorter than SSLEN (pair " + std::to_string(k) + ")");
-            if (n > acx::SIMPLE_MAXN) return fail(c, ACX_ERR_UNSUPPORTED, "simple_pairs: tracks with more than 512 pooled frames are not supported on the device yet");
+            if (n > acx::SIMPLE_MAXN) return fail(c, ACX_ERR_UNSUPPORTED, "simple_pairs: tracks with more than 6000 pooled frames are not supported on the device");
             maxn = std::max(maxn, n);
         }
     }
-    const size_t smem = 32 + sizeof(double) * ((size_t)2 * maxn * 12 + 3 * (size_t)maxn);
+    const size_t smem = 64 + sizeof(double) * 3 * (size_t)maxn;        // two edge rows + the profile keys
+    int rcw = ensure_winnorm(c, sslen);
+    if (rcw != ACX_OK) return rcw;
     const int64_t chunk = 1 << 22;
     int rc;
     if ((rc = ensure(c, c->d_pairs, c->pairs_cap, (size_t)2 * std::min(K, chunk))) != ACX_OK) return rc;

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void pool_median_kernel(const float *__restric
 // LDS as f64.  Stage 2: 'same' convolution along time with the normalised Hann window (nw taps,
 // zero fill), then every frame divided by its L2 norm over the 12 bins (norm < tiny: unscaled).
 // ------------------------------------------------------------------------------------
-constexpr int SIMPLE_PREP_MAXN = 512;
+constexpr int SIMPLE_PREP_CHUNK = 480;     // output frames per pass; + 2 x 16 frames of halo = 512 pooled frames in LDS
 constexpr int SIMPLE_PREP_MAXW = 16;
 
 struct SmoothWin { double w[SIMPLE_PREP_MAXW]; int nw; };
@@ -97,40 +97,48 @@ __global__ __launch_bounds__(256) void simple_prep_kernel(const float *__restric
                                                           int t_begin, int win, int skip, SmoothWin sw,
                                                           double *__restrict__ feats, int64_t p_base)
 {
-    __shared__ double pooled[SIMPLE_PREP_MAXN * 12];
+    __shared__ double pooled[(SIMPLE_PREP_CHUNK + 2 * SIMPLE_PREP_MAXW) * 12];
     const int t = t_begin + blockIdx.x;
     const int64_t r0 = roff[t], T0 = roff[t + 1] - r0;
     const int n = (int)(poff[t + 1] - poff[t]);
     const float *x = raw + (r0 - raw_base) * 12;
-    for (int k = threadIdx.x; k < n * 12; k += 256) {
-        const int i = k / 12, c = k - 12 * i;
-        const int64_t a = (int64_t)i * skip;
-        int64_t e = a + win;
-        if (e > T0) e = T0;
-        float acc = 0.0f;
-        for (int64_t f = a; f < e; ++f) acc = acc + x[f * 12 + c];
-        pooled[k] = (double)(acc / (float)(e - a));
-    }
-    __syncthreads();
     const int off = (sw.nw - 1) / 2;
     double *out = feats + (poff[t] - p_base) * 12;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        double v[12];
-        double ss = 0.0;
-#pragma unroll
-        for (int c = 0; c < 12; ++c) {
-            double acc = 0.0;
-            for (int k = 0; k < sw.nw; ++k) {
-                const int src = i + off - k;
-                if (src >= 0 && src < n) acc = acc + pooled[src * 12 + c] * sw.w[k];
-            }
-            v[c] = acc;
-            ss = ss + acc * acc;
+    // a track of any length: SIMPLE_PREP_CHUNK output frames per pass, their pooled neighbours as halo
+    for (int i0 = 0; i0 < n; i0 += SIMPLE_PREP_CHUNK) {
+        const int lo = i0 - SIMPLE_PREP_MAXW < 0 ? 0 : i0 - SIMPLE_PREP_MAXW;
+        int hi = i0 + SIMPLE_PREP_CHUNK + SIMPLE_PREP_MAXW;
+        hi = hi > n ? n : hi;
+        for (int k = threadIdx.x; k < (hi - lo) * 12; k += 256) {
+            const int i = lo + k / 12, c = k % 12;
+            const int64_t a = (int64_t)i * skip;
+            int64_t e = a + win;
+            if (e > T0) e = T0;
+            float acc = 0.0f;
+            for (int64_t f = a; f < e; ++f) acc = acc + x[f * 12 + c];
+            pooled[k] = (double)(acc / (float)(e - a));
         }
-        double nrm = __builtin_sqrt(ss);
-        if (nrm < 2.2250738585072014e-308) nrm = 1.0;
+        __syncthreads();
+        const int i1 = i0 + SIMPLE_PREP_CHUNK > n ? n : i0 + SIMPLE_PREP_CHUNK;
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+            double v[12];
+            double ss = 0.0;
 #pragma unroll
-        for (int c = 0; c < 12; ++c) out[i * 12 + c] = v[c] / nrm;
+            for (int c = 0; c < 12; ++c) {
+                double acc = 0.0;
+                for (int k = 0; k < sw.nw; ++k) {
+                    const int src = i + off - k;
+                    if (src >= 0 && src < n) acc = acc + pooled[(src - lo) * 12 + c] * sw.w[k];
+                }
+                v[c] = acc;
+                ss = ss + acc * acc;
+            }
+            double nrm = __builtin_sqrt(ss);
+            if (nrm < 2.2250738585072014e-308) nrm = 1.0;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) out[i * 12 + c] = v[c] / nrm;
+        }
+        __syncthreads();
     }
 }
 

@@ -1,4 +1,4 @@
-// SiMPle device kernel for gfx950 (reference: acoss/algorithms/simple_silva.py:45-54, 68-126).
+// SiMPle device kernels for gfx950 (reference: acoss/algorithms/simple_silva.py:45-54, 68-126).
 //
 // Per ORDERED pair (i, j) (the reference runs permutations, coverid.py:135):
 //   OTI      shift = last argmax_s <sum_t A, roll(sum_t B, s)>       simple_silva.py:45-54
@@ -6,21 +6,29 @@
 //            evaluated like the reference as |a|^2 + |b|^2 - 2 <a, b>, all in f64
 //   score    D[i, j] = -median(MP)                                    simple_silva.py:118,125
 //
-// <a, b> for subsequences starting at (a, b) is the length-L window sum, along the diagonal
-// b - a, of the frame Gram G[t][u] = sum_c A[c,t] B'[c,u] -- the reference's STOMP update
-// (simple_silva.py:107-110) walks exactly these diagonals.  One workgroup per pair: both
-// tracks live in LDS (time-major, 12 f64 per frame), thread d walks diagonal d keeping the
-// last L Gram values in registers (window sum re-added from scratch every step: no drift),
-// row minima are merged with 64-bit LDS atomics on order-preserving keys, and the median is
-// taken by rank counting.  The whole pair is ~40 KB: the kernel is LDS/VALU resident, HBM
-// traffic is the two feature reads.
+// One WAVE per ordered pair, no workgroup barriers, the distance matrix never exists:
+//   * lane = row a of the profile (subsequence start in A), rows in groups of 64; the wave steps
+//     through the columns b.  Everything that belongs to the column -- the two frames of B that
+//     enter and leave the window, |b|^2 -- is wave-uniform and arrives through the SCALAR cache;
+//     the lane's two frames of A (entering / leaving, already rotated by the OTI shift) and |a|^2
+//     sit in registers for the whole sweep: the 12-dim frame products are v_fma_f64 with an SGPR
+//     operand, no LDS, no MFMA operand staging;
+//   * <a, b> slides down the diagonal exactly as the reference's STOMP update does
+//     (simple_silva.py:107-110): dot[a][b] = dot[a-1][b-1] - <A[a-1], B'[b-1]> + <A[a+L-1], B'[b+L-1]>;
+//     dot[a-1][b-1] is the neighbour lane's value of the previous step (one 64-bit lane shift),
+//     for lane 0 the value the previous row group's lane 63 left in LDS; row 0 (and column 0) are
+//     evaluated in full (120 products) up front;
+//   * the row minimum is a running v_min_f64 in the lane's own register -- no atomics, no reduction;
+//   * the median of the profile is an exact binary search on order-preserving 64-bit keys, counted
+//     with ballots.
+// LDS per pair: 8 (2 nb + na) bytes -- tracks of thousands of pooled frames fit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace acx {
 
-constexpr int SIMPLE_MAXN = 512;     // pooled frames per track supported on the device
+constexpr int SIMPLE_MAXN = 6000;    // pooled frames per track (LDS: 8 (2 nb + na) + 64 bytes <= 160 KB)
 constexpr int SIMPLE_MAXL = 16;      // subsequence length
 
 __device__ __forceinline__ unsigned long long f64_key(double v)
@@ -34,113 +42,154 @@ __device__ __forceinline__ double key_f64(unsigned long long k)
     return __longlong_as_double((long long)b);
 }
 
-// pool: (sum n_t, 12) f64 time-major; prof: (n_tracks, 12) f64 = sum over time of every bin
+// |x_t|^2 + ... + |x_{t+L-1}|^2 for every window start t of every track, once per (pool, L):
+// wn[toff[track] + t], t <= n - L (np.sum(np.square(seq[:, t:t+L])), simple_silva.py:85-89).
+static __global__ void simple_winnorm_kernel(const double *__restrict__ pool, const int64_t *__restrict__ toff,
+                                             double *__restrict__ wn, int L)
+{
+    const int track = blockIdx.x;
+    const int64_t t0 = toff[track];
+    const int n = (int)(toff[track + 1] - t0);
+    for (int t = blockIdx.y * 256 + threadIdx.x; t <= n - L; t += 256 * gridDim.y) {
+        double acc = 0.0;
+        for (int k = 0; k < L; ++k)
+            for (int c = 0; c < 12; ++c) {
+                const double v = pool[(t0 + t + k) * 12 + c];
+                acc += v * v;
+            }
+        wn[t0 + t] = acc;
+    }
+}
+
+// k-th smallest (0-based) of the m keys in LDS: binary search on the key value, every probe counted
+// with ballots.  Exact; ties are harmless (the answer is a value, not a position).
+__device__ __forceinline__ unsigned long long simple_select_key(const unsigned long long *keys, int m, int k, int lane)
+{
+    unsigned long long lo = 0ull, hi = 0xffffffffffffffffull;      // answer in [lo, hi]
+    while (lo < hi) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        int tot = 0;
+        for (int i0 = 0; i0 < m; i0 += 64) {                       // wave-uniform trip count
+            const int i = i0 + lane;
+            const bool le = i < m && keys[i] <= mid;
+            tot += __popcll(__ballot(le));
+        }
+        if (tot >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// pool: (sum n_t, 12) f64 time-major; prof: (n_tracks, 12) f64 = sum over time of every bin;
+// wn: window norms (simple_winnorm_kernel, same L).  One 64-thread workgroup per ordered pair.
 template <int L>
-__global__ __launch_bounds__(256) void simple_kernel(const double *__restrict__ pool,
-                                                     const int64_t *__restrict__ toff,
-                                                     const double *__restrict__ prof,
-                                                     const int32_t *__restrict__ pairs,
-                                                     double *__restrict__ out, int do_oti)
+__global__ __launch_bounds__(64) void simple_kernel(const double *__restrict__ pool,
+                                                    const int64_t *__restrict__ toff,
+                                                    const double *__restrict__ prof,
+                                                    const double *__restrict__ wn,
+                                                    const int32_t *__restrict__ pairs,
+                                                    double *__restrict__ out, int do_oti)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int ti = pairs[2 * blockIdx.x], tj = pairs[2 * blockIdx.x + 1];
-    const int na = (int)(toff[ti + 1] - toff[ti]), nb = (int)(toff[tj + 1] - toff[tj]);
-    const int ma = na - L + 1, mb = nb - L + 1;      // profile lengths
-    int &s_shift = *reinterpret_cast<int *>(smem_raw);          // first 32 bytes: scalars
-    double *s_med = reinterpret_cast<double *>(smem_raw + 8);
-    double *A = reinterpret_cast<double *>(smem_raw + 32);     // na x 12
-    double *B = A + (size_t)na * 12;                            // nb x 12 (rolled)
-    double *a2 = B + (size_t)nb * 12;                           // ma
-    double *b2 = a2 + ma;                                       // mb
-    unsigned long long *mp = reinterpret_cast<unsigned long long *>(b2 + mb);   // ma keys
+    const int64_t oa = toff[ti], ob = toff[tj];
+    const int na = (int)(toff[ti + 1] - oa), nb = (int)(toff[tj + 1] - ob);
+    const int ma = na - L + 1, mb = nb - L + 1;      // profile length, columns
+    double *edge0 = reinterpret_cast<double *>(smem_raw);       // mb: dot of the last lane, even row groups (and row 0 before the sweep)
+    double *edge1 = edge0 + mb;                                  // mb: odd row groups
+    unsigned long long *mp = reinterpret_cast<unsigned long long *>(edge1 + mb);   // ma keys of the profile
 
-    // ---- OTI (simple_silva.py:45-54): v[s] = <pa, roll(pb, s)>; np.argsort(v)[-1]
-    if (tid == 0) {
+    // ---- OTI (simple_silva.py:45-54): v[s] = <pa, roll(pb, s)>; np.argsort(v)[-1]  (wave-uniform)
+    int shift = 0;
+    if (do_oti) {
         const double *pa = prof + (size_t)ti * 12, *pb = prof + (size_t)tj * 12;
-        int best = 0;
         double bestv = 0.0;
         for (int s = 0; s < 12; ++s) {
             double acc = 0.0;
             for (int c = 0; c < 12; ++c) acc += pa[c] * pb[(c - s + 12) % 12];
-            if (s == 0 || acc >= bestv) { bestv = acc; best = s; }     // ties: highest index (stable sort order)
+            if (s == 0 || acc >= bestv) { bestv = acc; shift = s; }     // ties: highest index (stable sort order)
         }
-        s_shift = do_oti ? best : 0;
     }
-    __syncthreads();
-    const int shift = s_shift;
-    const double *ga = pool + toff[ti] * 12, *gb = pool + toff[tj] * 12;
-    for (int idx = tid; idx < na * 12; idx += 256) A[idx] = ga[idx];
-    for (int idx = tid; idx < nb * 12; idx += 256) {
-        const int t = idx / 12, c = idx - 12 * t;
-        int cs = c + shift; if (cs >= 12) cs -= 12;
-        B[t * 12 + cs] = gb[idx];                  // np.roll(seq_b, shift, axis=0): bin c -> c + shift
-    }
-    __syncthreads();
-    // ---- windowed squared norms
-    for (int i = tid; i < ma; i += 256) {
+    // B' = roll(B, shift): B'[u][c] = B[u][(c - shift) mod 12], so <A[t], B'[u]> = sum_c A[t][(c + shift) mod 12] B[u][c]:
+    // the lane's frames of A are loaded rotated, the frames of B are used as stored (scalar loads)
+    const double *ga = pool + oa * 12, *gb = pool + ob * 12;
+    const double *wa = wn + oa, *wb = wn + ob;
+    auto load_a = [&](int t, double (&v)[12]) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            int cs = c + shift; if (cs >= 12) cs -= 12;
+            v[c] = ga[(size_t)t * 12 + cs];
+        }
+    };
+    auto dot12 = [&](const double (&a)[12], const double *brow) {
         double acc = 0.0;
-        for (int k = 0; k < L; ++k)
-            for (int c = 0; c < 12; ++c) acc += A[(i + k) * 12 + c] * A[(i + k) * 12 + c];
-        a2[i] = acc;
-        mp[i] = 0xffffffffffffffffull;
-    }
-    for (int j = tid; j < mb; j += 256) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) acc = __builtin_fma(a[c], brow[c], acc);
+        return acc;
+    };
+
+    // ---- row 0 in full: top[b] = sum_k <A[k], B'[b + k]>  (lanes over b), kept in edge1 until group 0 is done
+    for (int b = lane; b < mb; b += 64) {
         double acc = 0.0;
-        for (int k = 0; k < L; ++k)
-            for (int c = 0; c < 12; ++c) acc += B[(j + k) * 12 + c] * B[(j + k) * 12 + c];
-        b2[j] = acc;
-    }
-    __syncthreads();
-    // ---- diagonals d = b - a in [-(ma-1), mb-1]
-    const int ndiag = ma + mb - 1;
-    for (int dd = tid; dd < ndiag; dd += 256) {
-        const int d = dd - (ma - 1);
-        int a = d < 0 ? -d : 0, b = d < 0 ? 0 : d;
-        // Gram values of the first window
-        double g[L];
 #pragma unroll
         for (int k = 0; k < L; ++k) {
-            double acc = 0.0;
-#pragma unroll
-            for (int c = 0; c < 12; ++c) acc += A[(a + k) * 12 + c] * B[(b + k) * 12 + c];
-            g[k] = acc;
+            double ak[12];
+            load_a(k, ak);                                   // wave-uniform address: scalar loads
+            acc += dot12(ak, gb + (size_t)(b + k) * 12);
         }
-        while (true) {
-            double dot = 0.0;
-#pragma unroll
-            for (int k = 0; k < L; ++k) dot += g[k];
-            const double dist = b2[b] + a2[a] - 2.0 * dot;
-            atomicMin(&mp[a], f64_key(dist));
-            ++a; ++b;
-            if (a >= ma || b >= mb) break;
-            // slide: drop G[a-1][b-1], append G[a+L-1][b+L-1]
-#pragma unroll
-            for (int k = 0; k < L - 1; ++k) g[k] = g[k + 1];
-            double acc = 0.0;
-#pragma unroll
-            for (int c = 0; c < 12; ++c) acc += A[(a + L - 1) * 12 + c] * B[(b + L - 1) * 12 + c];
-            g[L - 1] = acc;
-        }
+        edge1[b] = acc;
     }
-    __syncthreads();
-    // ---- median by rank counting (np.median: mean of the two middle values for even counts)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int ngroups = (ma + 63) / 64;
+    for (int g = 0; g < ngroups; ++g) {
+        const int a = 64 * g + lane;
+        const bool valid = a < ma;
+        const int ac = valid ? a : ma - 1;                      // clamp: results of the idle lanes are dropped
+        const double *ein = (g & 1) ? edge0 : edge1;            // written by group g - 1 (group 0: the row-0 values)
+        double *eout = (g & 1) ? edge1 : edge0;
+        const bool more = g + 1 < ngroups;
+        double An[12], Ao[12];
+        load_a(ac + L - 1, An);                                 // frame entering the window of row a
+        load_a(ac > 0 ? ac - 1 : 0, Ao);                        // frame that left it (row a - 1's first)
+        const double a2 = wa[ac];
+        // column 0 in full: dot[a][0] = sum_k <A[a + k], B'[k]>
+        double dot = 0.0;
+        {
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                double ak[12];
+                load_a(ac + k, ak);
+                dot += dot12(ak, gb + (size_t)k * 12);
+            }
+        }
+        if (g == 0 && lane == 0) dot = ein[0];
+        double mn = (a2 + wb[0]) - 2.0 * dot;
+        if (more && lane == 63) eout[0] = dot;
+        for (int b = 1; b < mb; ++b) {
+            const double *bn = gb + (size_t)(b + L - 1) * 12;   // wave-uniform: scalar loads
+            const double *bo = gb + (size_t)(b - 1) * 12;
+            double prev = __shfl_up(dot, 1, 64);
+            const double e = ein[b - 1 + (g == 0 ? 1 : 0)];     // group 0: row 0's own value top[b]; else dot[a - 1][b - 1] of the last lane
+            if (lane == 0) prev = e;
+            double nd = prev - dot12(Ao, bo);
+            nd += dot12(An, bn);
+            if (g == 0 && lane == 0) nd = e;
+            dot = nd;
+            const double dist = (a2 + wb[b]) - 2.0 * dot;
+            mn = dist < mn ? dist : mn;
+            if (more && lane == 63) eout[b] = dot;
+        }
+        if (valid) mp[a] = f64_key(mn);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- median (np.median: mean of the two middle values for even counts)
     const int r_lo = (ma - 1) / 2, r_hi = ma / 2;
-    for (int i = tid; i < ma; i += 256) {
-        const unsigned long long me = mp[i];
-        int rank = 0;
-        for (int k = 0; k < ma; ++k) {
-            const unsigned long long o = mp[k];
-            rank += (o < me || (o == me && k < i)) ? 1 : 0;
-        }
-        if (rank == r_lo) s_med[0] = key_f64(me);
-        if (rank == r_hi) s_med[1] = key_f64(me);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const double med = (r_lo == r_hi) ? s_med[0] : (s_med[0] + s_med[1]) * 0.5;
-        out[blockIdx.x] = -med;
-    }
+    const double vlo = key_f64(simple_select_key(mp, ma, r_lo, lane));
+    const double vhi = (r_hi == r_lo) ? vlo : key_f64(simple_select_key(mp, ma, r_hi, lane));
+    if (lane == 0) out[blockIdx.x] = -((r_lo == r_hi) ? vlo : (vlo + vhi) * 0.5);
 }
 
 }  // namespace acx

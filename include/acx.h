@@ -179,7 +179,7 @@ int acx_download_pool_f64(acx_ctx *ctx, double *frames, int64_t capacity);
  * out[k] = -median(matrix profile) of the ORDERED pair (pairs[2k], pairs[2k+1]): OTI of the
  * second track toward the first, then simple_sim -- the value Simple.similarity() stores into
  * Ds['main'][i, j] (simple_silva.py:45-54, 68-126).  f64 like the reference.  sslen = SSLEN
- * (default 10, <= 16); tracks need sslen <= n_i <= 512 pooled frames.  oti = 0 skips the
+ * (default 10, <= 16); tracks need sslen <= n_i <= 6000 pooled frames.  oti = 0 skips the
  * transposition (Simple.simple_sim alone, simple_silva.py:68).
  */
 int acx_simple_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, int32_t sslen, int32_t oti,

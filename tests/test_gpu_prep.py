@@ -99,5 +99,11 @@ def test_errors(ctx):
         ctx.upload_raw_pool(raw, roff, 0)
     with pytest.raises(ValueError):
         ctx.upload_raw_pool(raw, roff[::-1].copy(), 40)
-    with pytest.raises(NotImplementedError):
-        ctx.simple_upload_raw_pool(*_pack(_raw_tracks(rng, [51300])))       # 513 pooled frames
+    # long tracks: pooled / smoothed in chunks of 480 frames with a halo (no length limit)
+    import oracle
+    tracks = _raw_tracks(rng, [51300, 97001, 480 * 100, 481 * 100 + 7])
+    raw, roff = _pack(tracks)
+    poff = ctx.simple_upload_raw_pool(raw, roff)
+    want = [oracle.simple_smooth(oracle.simple_pool(t, 200, 100), 4).T for t in tracks]
+    assert np.array_equal(np.diff(poff), [513, 970, 480, 481])
+    np.testing.assert_allclose(ctx.download_pool_f64(poff[-1]), np.concatenate(want), rtol=1e-13, atol=1e-16)

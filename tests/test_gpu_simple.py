@@ -65,10 +65,11 @@ def test_large_and_ragged_tracks(ctx):
     import oracle
     rng = np.random.default_rng(4)
     S = type("S", (), {})
-    feats = [oracle.simple_smooth(rng.random((12, n))) for n in (10, 11, 64, 257, 512)]
+    feats = [oracle.simple_smooth(rng.random((12, n))) for n in (10, 11, 64, 257, 512, 73, 74, 137, 1500, 1203)]
     fr, offs = _pool(feats)
     ctx.upload_pool_f64(fr, offs)
-    pairs = np.array([[0, 1], [1, 0], [0, 4], [4, 0], [2, 3], [3, 4], [4, 3]], np.int32)
+    pairs = np.array([[0, 1], [1, 0], [0, 4], [4, 0], [2, 3], [3, 4], [4, 3], [5, 6], [6, 5], [7, 2], [2, 7], [5, 5],
+                      [8, 9], [9, 8], [8, 0], [0, 8], [3, 8]], np.int32)
     got = ctx.simple_pairs(pairs, 10)
     ref = np.array([oracle.simple_pair(feats[i], feats[j]) for i, j in pairs])
     np.testing.assert_allclose(got, ref, rtol=RTOL, atol=1e-13)
@@ -77,12 +78,12 @@ def test_large_and_ragged_tracks(ctx):
 def test_errors(ctx):
     from acoss_amd import _lib
     rng = np.random.default_rng(1)
-    fr, offs = _pool([rng.random((12, 9)), rng.random((12, 30)), rng.random((12, 600))])
+    fr, offs = _pool([rng.random((12, 9)), rng.random((12, 30)), rng.random((12, 6001))])
     ctx.upload_pool_f64(fr, offs)
     with pytest.raises(_lib.AcxError):
         ctx.simple_pairs(np.array([[0, 1]], np.int32), 10)          # shorter than SSLEN
     with pytest.raises(NotImplementedError):
-        ctx.simple_pairs(np.array([[1, 2]], np.int32), 10)          # > 512 pooled frames
+        ctx.simple_pairs(np.array([[1, 2]], np.int32), 10)          # > 6000 pooled frames (10 hours of audio)
     with pytest.raises(ValueError):
         ctx.simple_pairs(np.array([[1, 5]], np.int32), 10)
 
