@@ -27,7 +27,7 @@ EXPORTS = [
     "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
     "acx_chenfusion_pairs", "acx_csm_binary_sw", "acx_upload_raw_pool", "acx_download_pool",
     "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse", "acx_qmax_binary",
-    "acx_grid_plan", "acx_pool_lengths", "acx_grid_run", "acx_grid_scatter", "acx_pair_grid",
+    "acx_ef_block_features", "acx_ef_upload_raw_pool", "acx_grid_plan", "acx_pool_lengths", "acx_grid_run", "acx_grid_scatter", "acx_pair_grid",
 ]
 
 ALGO_SERRA09, ALGO_CHENFUSION, ALGO_SIMPLE, ALGO_EARLYFUSION = 0, 1, 2, 3
@@ -59,6 +59,11 @@ class GridTile(ctypes.Structure):
 class SimpleParams(ctypes.Structure):
     """acx_simple_params (include/acx.h); defaults = Simple ctor, simple_silva.py:26-27."""
     _fields_ = [("sslen", ctypes.c_int32), ("oti", ctypes.c_int32)]
+
+
+class EfPrepParams(ctypes.Structure):
+    """acx_ef_prep_params (include/acx.h); defaults = EarlyFusion ctor, earlyfusion_traile.py:44-45."""
+    _fields_ = [("blocksize", ctypes.c_int32), ("mfccs_per_block", ctypes.c_int32), ("chromas_per_block", ctypes.c_int32)]
 
 
 class Serra09Params(ctypes.Structure):
@@ -136,6 +141,10 @@ def load():
                                ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
     L.acx_csm_binary_sw.argtypes = [vp, fp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, fp]
     L.acx_qmax_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, pp, fp]
+    epp = ctypes.POINTER(EfPrepParams)
+    L.acx_ef_block_features.argtypes = [vp, fp, ctypes.c_int64, fp, ctypes.c_int64, ctypes.c_int32, lp, ctypes.c_int32, epp,
+                                        fp, fp, fp, dp]
+    L.acx_ef_upload_raw_pool.argtypes = [vp, fp, lp, fp, lp, ctypes.c_int32, lp, lp, ctypes.c_int32, epp, lp]
     gp = ctypes.POINTER(GridSpec)
     L.acx_grid_plan.argtypes = [lp, ctypes.c_int32, gp, ctypes.POINTER(GridTile), ctypes.c_int64, lp, lp, dp]
     L.acx_pool_lengths.argtypes = [vp, ctypes.c_int32, lp, ctypes.c_int32, ip]
@@ -318,6 +327,43 @@ class Context(object):
                                                med.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                                offs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(tracks), dims))
         self.ef_blocks = nb
+
+    def ef_block_features(self, chroma, mfcc, onsets, blocksize=20, mfccs_per_block=50, chromas_per_block=40):
+        """EarlyFusion.load_features for one track on the device (acx_ef_block_features): chroma (T, 12),
+        mfcc (T', ncoef) TIME-major, onsets (beat frame indices).  Returns the dict of block features."""
+        chroma = np.ascontiguousarray(chroma, dtype=np.float32)
+        mfcc = np.ascontiguousarray(mfcc, dtype=np.float32)
+        onsets = np.ascontiguousarray(onsets, dtype=np.int64)
+        ncoef = mfcc.shape[1]
+        nb = max(0, len(onsets) - int(blocksize))
+        out = dict(mfccs=np.zeros((nb, mfccs_per_block * ncoef), np.float32),
+                   ssms=np.zeros((nb, mfccs_per_block * (mfccs_per_block - 1) // 2), np.float32),
+                   chromas=np.zeros((nb, chromas_per_block * 12), np.float32), chroma_med=np.zeros(12, np.float64))
+        p = EfPrepParams(int(blocksize), int(mfccs_per_block), int(chromas_per_block))
+        self._check(self._L.acx_ef_block_features(
+            self._h, _fptr(chroma), chroma.shape[0], _fptr(mfcc), mfcc.shape[0], ncoef, _lptr(onsets), len(onsets),
+            ctypes.byref(p), _fptr(out["mfccs"]), _fptr(out["ssms"]), _fptr(out["chromas"]),
+            out["chroma_med"].ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return out
+
+    def ef_upload_raw_pool(self, tracks, blocksize=20, mfccs_per_block=50, chromas_per_block=40):
+        """tracks: list of dicts with chroma (T, 12), mfcc (T', ncoef) time-major and onsets -- the block
+        features of the whole collection are built and kept on the device (acx_ef_upload_raw_pool).
+        Returns the block offsets."""
+        def pack(key, dtype, width=None):
+            arrs = [np.ascontiguousarray(t[key], dtype=dtype) for t in tracks]
+            offs = np.concatenate([[0], np.cumsum([len(a) for a in arrs])]).astype(np.int64)
+            return (np.ascontiguousarray(np.concatenate(arrs, axis=0)) if len(arrs) else np.zeros(0, dtype)), offs
+        ch, coff = pack("chroma", np.float32)
+        mf, moff = pack("mfcc", np.float32)
+        on, ooff = pack("onsets", np.int64)
+        ncoef = mf.shape[1]
+        boff = np.zeros(len(tracks) + 1, np.int64)
+        p = EfPrepParams(int(blocksize), int(mfccs_per_block), int(chromas_per_block))
+        self._check(self._L.acx_ef_upload_raw_pool(self._h, _fptr(ch), _lptr(coff), _fptr(mf), _lptr(moff), ncoef,
+                                                   _lptr(on), _lptr(ooff), len(tracks), ctypes.byref(p), _lptr(boff)))
+        self.ef_blocks = np.diff(boff)
+        return boff
 
     def earlyfusion_pairs(self, pairs, kappa=0.1, K=10):
         """(n, 4) scores: mfccs, ssms, chromas, early."""

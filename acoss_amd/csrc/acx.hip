@@ -20,6 +20,7 @@
 #include "snf_kernels.hpp"
 #include "simple_kernels.hpp"
 #include "ef_kernels.hpp"
+#include "ef_prep_kernels.hpp"
 #include "grid.hpp"
 
 using acx::PairDesc;
@@ -721,6 +722,8 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
     return ACX_OK;
 }
 
+static void ef_free_pool(acx_ctx *c);
+
 static void free_pool(acx_ctx *c)
 {
     if (c->d_frames && c->d_frames != c->d_frames0) (void)hipFree(c->d_frames);
@@ -827,10 +830,7 @@ void acx_destroy(acx_ctx *c)
     if (c->d_wn64) (void)hipFree(c->d_wn64);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_out64) (void)hipFree(c->d_out64);
-    for (int k = 0; k < 3; ++k) if (c->d_ef[k]) (void)hipFree(c->d_ef[k]);
-    for (int k = 0; k < 2; ++k) if (c->d_efn[k]) (void)hipFree(c->d_efn[k]);
-    if (c->d_efmed) (void)hipFree(c->d_efmed);
-    if (c->d_efoff) (void)hipFree(c->d_efoff);
+    ef_free_pool(c);
     if (c->d_efpd) (void)hipFree(c->d_efpd);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1228,6 +1228,39 @@ int acx_simple_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, int32_t sslen,
     return ACX_OK;
 }
 
+static void ef_free_pool(acx_ctx *c)
+{
+    for (int k = 0; k < 3; ++k) if (c->d_ef[k]) { (void)hipFree(c->d_ef[k]); c->d_ef[k] = nullptr; }
+    for (int k = 0; k < 2; ++k) if (c->d_efn[k]) { (void)hipFree(c->d_efn[k]); c->d_efn[k] = nullptr; }
+    if (c->d_efmed) { (void)hipFree(c->d_efmed); c->d_efmed = nullptr; }
+    if (c->d_efoff) { (void)hipFree(c->d_efoff); c->d_efoff = nullptr; }
+    c->ef_ntracks = 0;
+}
+
+// The block features are on the device (d_ef[0..2], d_efmed): unit-norm chroma rows in place
+// (X / XNorm with zero norms -> 1, cross_recurrence.py:66-71) and the squared row norms of the
+// Euclidean features (np.sum(X**2, 1), :46; f64 accumulation), once per pool.
+static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, const int32_t *dims)
+{
+    const int64_t nb = offsets[n_tracks];
+    c->h_efoff.assign(offsets, offsets + n_tracks + 1);
+    c->ef_ntracks = n_tracks;
+    for (int k = 0; k < 3; ++k) c->ef_dims[k] = dims[k];
+    ACX_HIP(c, hipMalloc((void **)&c->d_efoff, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIP(c, hipMemcpy(c->d_efoff, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    for (int k = 0; k < 2; ++k)
+        ACX_HIP(c, hipMalloc((void **)&c->d_efn[k], sizeof(float) * std::max<int64_t>(1, nb)));
+    if (nb > 0) {
+        const unsigned g = (unsigned)((nb + 3) / 4);
+        hipLaunchKernelGGL(acx::ef_rownorm_kernel, dim3(g), dim3(256), 0, c->stream, c->d_ef[2], nb, dims[2], 1, (float *)nullptr);
+        for (int k = 0; k < 2; ++k)
+            hipLaunchKernelGGL(acx::ef_rownorm_kernel, dim3(g), dim3(256), 0, c->stream, c->d_ef[k], nb, dims[k], 0, c->d_efn[k]);
+        ACX_HIP(c, hipGetLastError());
+    }
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    return ACX_OK;
+}
+
 int acx_ef_upload_pool(acx_ctx *c, const float *mfccs, const float *ssms, const float *chromas,
                        const double *chroma_med, const int64_t *offsets, int32_t n_tracks, const int32_t *dims)
 {
@@ -1240,46 +1273,154 @@ int acx_ef_upload_pool(acx_ctx *c, const float *mfccs, const float *ssms, const 
     for (int i = 0; i < n_tracks; ++i)
         if (offsets[i + 1] < offsets[i]) return fail(c, ACX_ERR_INVALID, "ef_upload_pool: offsets must be non-decreasing");
     ACX_HIP(c, hipSetDevice(c->device));
-    for (int k = 0; k < 3; ++k) if (c->d_ef[k]) { (void)hipFree(c->d_ef[k]); c->d_ef[k] = nullptr; }
-    for (int k = 0; k < 2; ++k) if (c->d_efn[k]) { (void)hipFree(c->d_efn[k]); c->d_efn[k] = nullptr; }
-    if (c->d_efmed) { (void)hipFree(c->d_efmed); c->d_efmed = nullptr; }
-    if (c->d_efoff) { (void)hipFree(c->d_efoff); c->d_efoff = nullptr; }
+    ef_free_pool(c);
     const int64_t nb = offsets[n_tracks];
-    c->h_efoff.assign(offsets, offsets + n_tracks + 1);
-    c->ef_ntracks = n_tracks;
-    for (int k = 0; k < 3; ++k) c->ef_dims[k] = dims[k];
     const float *src[3] = {mfccs, ssms, chromas};
-    // squared row norms of the Euclidean features (np.sum(X**2, 1), cross_recurrence.py:46) and
-    // unit-norm chroma rows (X / XNorm with zero norms -> 1, :66-71), once per pool
-    std::vector<float> cn((size_t)nb * dims[2]);
-    for (int64_t b = 0; b < nb; ++b) {
-        double acc = 0.0;
-        for (int k = 0; k < dims[2]; ++k) { double v = chromas[b * dims[2] + k]; acc += v * v; }
-        float nr = (float)std::sqrt(acc);
-        if (nr == 0.0f) nr = 1.0f;
-        for (int k = 0; k < dims[2]; ++k) cn[(size_t)b * dims[2] + k] = chromas[b * dims[2] + k] / nr;
-    }
-    src[2] = cn.data();
     for (int k = 0; k < 3; ++k) {
         ACX_HIP(c, hipMalloc((void **)&c->d_ef[k], sizeof(float) * std::max<int64_t>(1, nb) * dims[k]));
         ACX_HIP(c, hipMemcpy(c->d_ef[k], src[k], sizeof(float) * nb * dims[k], hipMemcpyHostToDevice));
     }
-    for (int k = 0; k < 2; ++k) {
-        std::vector<float> nrm((size_t)nb);
-        for (int64_t b = 0; b < nb; ++b) {
-            double acc = 0.0;      // f64 accumulation: as close as numpy's pairwise f32 sum gets to exact
-            const float *x = src[k] + b * dims[k];
-            for (int e = 0; e < dims[k]; ++e) acc += (double)x[e] * (double)x[e];
-            nrm[(size_t)b] = (float)acc;
-        }
-        ACX_HIP(c, hipMalloc((void **)&c->d_efn[k], sizeof(float) * std::max<int64_t>(1, nb)));
-        ACX_HIP(c, hipMemcpy(c->d_efn[k], nrm.data(), sizeof(float) * nb, hipMemcpyHostToDevice));
-    }
     ACX_HIP(c, hipMalloc((void **)&c->d_efmed, sizeof(double) * 12 * n_tracks));
     ACX_HIP(c, hipMemcpy(c->d_efmed, chroma_med, sizeof(double) * 12 * n_tracks, hipMemcpyHostToDevice));
-    ACX_HIP(c, hipMalloc((void **)&c->d_efoff, sizeof(int64_t) * (n_tracks + 1)));
-    ACX_HIP(c, hipMemcpy(c->d_efoff, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    return ef_finish_pool(c, offsets, n_tracks, dims);
+}
+
+// Block features of tracks [0, n_tracks) into fresh device arrays (caller frees / adopts them).
+static int ef_build_blocks(acx_ctx *c, const float *chroma, const int64_t *coff, const float *mfcc, const int64_t *moff,
+                           int32_t ncoef, const int64_t *onsets, const int64_t *ooff, int32_t n_tracks,
+                           const acx_ef_prep_params &pp, std::vector<int64_t> &boff, float *d_out[3], double *&d_med)
+{
+    if (pp.blocksize < 1 || pp.mfccs_per_block < 2 || pp.chromas_per_block < 1 || ncoef < 1)
+        return fail(c, ACX_ERR_INVALID, "ef block features: bad parameter");
+    if (pp.mfccs_per_block > acx::EFP_MAXROWS || pp.chromas_per_block > acx::EFP_MAXROWS || ncoef > acx::EFP_MAXDIM ||
+        pp.mfccs_per_block * ncoef > acx::EFP_MAXROWS * acx::EFP_MAXDIM || pp.chromas_per_block * 12 > acx::EFP_MAXROWS * acx::EFP_MAXDIM)
+        return fail(c, ACX_ERR_UNSUPPORTED, "ef block features: at most 64 rows per block and 40 coefficients per frame on the device");
+    boff.assign((size_t)n_tracks + 1, 0);
+    for (int t = 0; t < n_tracks; ++t) {
+        if (coff[t + 1] < coff[t] || moff[t + 1] < moff[t] || ooff[t + 1] < ooff[t])
+            return fail(c, ACX_ERR_INVALID, "ef block features: offsets must be non-decreasing");
+        const int64_t nbeat = ooff[t + 1] - ooff[t];
+        boff[t + 1] = boff[t] + std::max<int64_t>(0, nbeat - pp.blocksize);
+    }
+    const int64_t nb = boff[n_tracks];
+    const int dims[3] = {pp.mfccs_per_block * ncoef, pp.mfccs_per_block * (pp.mfccs_per_block - 1) / 2, pp.chromas_per_block * 12};
+    d_out[0] = d_out[1] = d_out[2] = nullptr; d_med = nullptr;
+    float *d_ch = nullptr, *d_mf = nullptr;
+    int64_t *d_on = nullptr, *d_coff = nullptr, *d_moff = nullptr, *d_ooff = nullptr, *d_boff = nullptr;
+    auto cleanup_in = [&]() {
+        if (d_ch) (void)hipFree(d_ch);
+        if (d_mf) (void)hipFree(d_mf);
+        if (d_on) (void)hipFree(d_on);
+        if (d_coff) (void)hipFree(d_coff);
+        if (d_moff) (void)hipFree(d_moff);
+        if (d_ooff) (void)hipFree(d_ooff);
+        if (d_boff) (void)hipFree(d_boff);
+        d_ch = d_mf = nullptr; d_on = d_coff = d_moff = d_ooff = d_boff = nullptr;
+    };
+    auto cleanup_all = [&]() {
+        cleanup_in();
+        for (int k = 0; k < 3; ++k) if (d_out[k]) { (void)hipFree(d_out[k]); d_out[k] = nullptr; }
+        if (d_med) { (void)hipFree(d_med); d_med = nullptr; }
+    };
+#define ACX_HIPC(expr_) do { const hipError_t ec_ = (expr_); if (ec_ != hipSuccess) { cleanup_all(); ACX_HIP(c, ec_); } } while (0)
+    for (int k = 0; k < 3; ++k) ACX_HIPC(hipMalloc((void **)&d_out[k], sizeof(float) * std::max<int64_t>(1, nb) * dims[k]));
+    ACX_HIPC(hipMalloc((void **)&d_med, sizeof(double) * 12 * n_tracks));
+    // whole tracks in slices of about 1 GiB of raw features
+    for (int t0 = 0; t0 < n_tracks;) {
+        int t1 = t0 + 1;
+        auto slice_floats = [&](int a, int b2) { return (coff[b2] - coff[a]) * 12 + (moff[b2] - moff[a]) * ncoef; };
+        while (t1 < n_tracks && t1 - t0 < 65535 && slice_floats(t0, t1 + 1) <= RAW_SLICE_FLOATS) ++t1;
+        const int nt = t1 - t0;
+        const int64_t nch = coff[t1] - coff[t0], nmf = moff[t1] - moff[t0], non = ooff[t1] - ooff[t0], nbs = boff[t1] - boff[t0];
+        std::vector<int64_t> lc(nt + 1), lm(nt + 1), lo(nt + 1), lb(nt + 1);
+        for (int t = 0; t <= nt; ++t) {
+            lc[t] = coff[t0 + t] - coff[t0]; lm[t] = moff[t0 + t] - moff[t0];
+            lo[t] = ooff[t0 + t] - ooff[t0]; lb[t] = boff[t0 + t] - boff[t0];
+        }
+        ACX_HIPC(hipMalloc((void **)&d_ch, sizeof(float) * std::max<int64_t>(1, nch) * 12));
+        ACX_HIPC(hipMalloc((void **)&d_mf, sizeof(float) * std::max<int64_t>(1, nmf) * ncoef));
+        ACX_HIPC(hipMalloc((void **)&d_on, sizeof(int64_t) * std::max<int64_t>(1, non)));
+        ACX_HIPC(hipMalloc((void **)&d_coff, sizeof(int64_t) * (nt + 1)));
+        ACX_HIPC(hipMalloc((void **)&d_moff, sizeof(int64_t) * (nt + 1)));
+        ACX_HIPC(hipMalloc((void **)&d_ooff, sizeof(int64_t) * (nt + 1)));
+        ACX_HIPC(hipMalloc((void **)&d_boff, sizeof(int64_t) * (nt + 1)));
+        ACX_HIPC(hipMemcpyAsync(d_ch, chroma + coff[t0] * 12, sizeof(float) * nch * 12, hipMemcpyHostToDevice, c->stream));
+        ACX_HIPC(hipMemcpyAsync(d_mf, mfcc + moff[t0] * ncoef, sizeof(float) * nmf * ncoef, hipMemcpyHostToDevice, c->stream));
+        ACX_HIPC(hipMemcpyAsync(d_on, onsets + ooff[t0], sizeof(int64_t) * non, hipMemcpyHostToDevice, c->stream));
+        ACX_HIPC(hipMemcpyAsync(d_coff, lc.data(), sizeof(int64_t) * (nt + 1), hipMemcpyHostToDevice, c->stream));
+        ACX_HIPC(hipMemcpyAsync(d_moff, lm.data(), sizeof(int64_t) * (nt + 1), hipMemcpyHostToDevice, c->stream));
+        ACX_HIPC(hipMemcpyAsync(d_ooff, lo.data(), sizeof(int64_t) * (nt + 1), hipMemcpyHostToDevice, c->stream));
+        ACX_HIPC(hipMemcpyAsync(d_boff, lb.data(), sizeof(int64_t) * (nt + 1), hipMemcpyHostToDevice, c->stream));
+        if (nbs > 0) {
+            acx::EfPrepParams kp{pp.blocksize, pp.mfccs_per_block, pp.chromas_per_block, ncoef};
+            hipLaunchKernelGGL(acx::ef_blocks_kernel, dim3((unsigned)nbs), dim3(256), 0, c->stream,
+                               d_ch, d_coff, d_mf, d_moff, d_on, d_ooff, d_boff, nt, kp,
+                               d_out[0] + boff[t0] * dims[0], d_out[1] + boff[t0] * dims[1], d_out[2] + boff[t0] * dims[2]);
+        }
+        hipLaunchKernelGGL(acx::ef_chroma_median_kernel, dim3(nt, 12), dim3(64), 0, c->stream, d_ch, d_coff, d_med + (size_t)t0 * 12);
+        ACX_HIPC(hipGetLastError());
+        ACX_HIPC(hipStreamSynchronize(c->stream));
+        cleanup_in();
+        t0 = t1;
+    }
+#undef ACX_HIPC
     return ACX_OK;
+}
+
+static int ef_check_raw(acx_ctx *c, const char *who, const float *chroma, const float *mfcc, const int64_t *onsets,
+                        const acx_ef_prep_params *prep)
+{
+    if (!chroma || !mfcc || !onsets || !prep) return fail(c, ACX_ERR_INVALID, std::string(who) + ": bad argument");
+    return ACX_OK;
+}
+
+int acx_ef_block_features(acx_ctx *c, const float *chroma, int64_t n_chroma, const float *mfcc, int64_t n_mfcc, int32_t ncoef,
+                          const int64_t *onsets, int32_t n_beats, const acx_ef_prep_params *prep, float *mfccs, float *ssms,
+                          float *chromas, double *chroma_med)
+{
+    if (!c) return ACX_ERR_INVALID;
+    int rc = ef_check_raw(c, "ef_block_features", chroma, mfcc, onsets, prep);
+    if (rc != ACX_OK) return rc;
+    if (n_chroma < 0 || n_mfcc < 0 || n_beats < 0) return fail(c, ACX_ERR_INVALID, "ef_block_features: bad argument");
+    ACX_HIP(c, hipSetDevice(c->device));
+    const int64_t coff[2] = {0, n_chroma}, moff[2] = {0, n_mfcc}, ooff[2] = {0, n_beats};
+    std::vector<int64_t> boff;
+    float *d_out[3];
+    double *d_med;
+    if ((rc = ef_build_blocks(c, chroma, coff, mfcc, moff, ncoef, onsets, ooff, 1, *prep, boff, d_out, d_med)) != ACX_OK) return rc;
+    const int64_t nb = boff[1];
+    const int dims[3] = {prep->mfccs_per_block * ncoef, prep->mfccs_per_block * (prep->mfccs_per_block - 1) / 2, prep->chromas_per_block * 12};
+    float *dst[3] = {mfccs, ssms, chromas};
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 3 && e == hipSuccess; ++k)
+        if (dst[k] && nb > 0) e = hipMemcpy(dst[k], d_out[k], sizeof(float) * nb * dims[k], hipMemcpyDeviceToHost);
+    if (e == hipSuccess && chroma_med) e = hipMemcpy(chroma_med, d_med, sizeof(double) * 12, hipMemcpyDeviceToHost);
+    for (int k = 0; k < 3; ++k) (void)hipFree(d_out[k]);
+    (void)hipFree(d_med);
+    ACX_HIP(c, e);
+    return ACX_OK;
+}
+
+int acx_ef_upload_raw_pool(acx_ctx *c, const float *chroma, const int64_t *chroma_offsets, const float *mfcc,
+                           const int64_t *mfcc_offsets, int32_t ncoef, const int64_t *onsets, const int64_t *onset_offsets,
+                           int32_t n_tracks, const acx_ef_prep_params *prep, int64_t *block_offsets_out)
+{
+    if (!c) return ACX_ERR_INVALID;
+    int rc = ef_check_raw(c, "ef_upload_raw_pool", chroma, mfcc, onsets, prep);
+    if (rc != ACX_OK) return rc;
+    if (!chroma_offsets || !mfcc_offsets || !onset_offsets || n_tracks <= 0) return fail(c, ACX_ERR_INVALID, "ef_upload_raw_pool: bad argument");
+    ACX_HIP(c, hipSetDevice(c->device));
+    ef_free_pool(c);
+    std::vector<int64_t> boff;
+    float *d_out[3];
+    double *d_med;
+    if ((rc = ef_build_blocks(c, chroma, chroma_offsets, mfcc, mfcc_offsets, ncoef, onsets, onset_offsets, n_tracks, *prep, boff,
+                              d_out, d_med)) != ACX_OK) return rc;
+    for (int k = 0; k < 3; ++k) c->d_ef[k] = d_out[k];
+    c->d_efmed = d_med;
+    const int32_t dims[3] = {prep->mfccs_per_block * ncoef, prep->mfccs_per_block * (prep->mfccs_per_block - 1) / 2, prep->chromas_per_block * 12};
+    if (block_offsets_out) memcpy(block_offsets_out, boff.data(), sizeof(int64_t) * (n_tracks + 1));
+    return ef_finish_pool(c, boff.data(), n_tracks, dims);
 }
 
 int acx_earlyfusion_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params *params, float *out)

@@ -167,17 +167,41 @@ __global__ __launch_bounds__(64) void simple_kernel(const double *__restrict__ p
         if (g == 0 && lane == 0) dot = ein[0];
         double mn = (a2 + wb[0]) - 2.0 * dot;
         if (more && lane == 63) eout[0] = dot;
+        // The column's frames of B are wave-uniform: scalar loads.  The frame that ENTERS the window
+        // (bn, first touched here: a scalar-cache miss) is requested half a step ahead, right after
+        // its registers became free; the frame that LEAVES (bo, touched L steps ago: a hit) at the top
+        // of its step, behind the first dozen v_fma_f64.
+        double bn[12];
+        if (mb > 1) {
+            const double *pn = gb + (size_t)L * 12;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) bn[c] = pn[c];
+        }
         for (int b = 1; b < mb; ++b) {
-            const double *bn = gb + (size_t)(b + L - 1) * 12;   // wave-uniform: scalar loads
-            const double *bo = gb + (size_t)(b - 1) * 12;
-            double prev = __shfl_up(dot, 1, 64);
+            const double *po = gb + (size_t)(b - 1) * 12;
+            double bo[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) bo[c] = po[c];
+            const double w = wb[b];
+            double prev = __shfl_up(dot, 1, 64);                // dot[a - 1][b - 1] of the neighbour lane
             const double e = ein[b - 1 + (g == 0 ? 1 : 0)];     // group 0: row 0's own value top[b]; else dot[a - 1][b - 1] of the last lane
+            double gnew = 0.0;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) gnew = __builtin_fma(An[c], bn[c], gnew);
+            asm volatile("" : "+v"(gnew));                      // bn is dead from here: its registers take the next frame
+            if (b + 1 < mb) {
+                const double *pn = gb + (size_t)(b + L) * 12;
+#pragma unroll
+                for (int c = 0; c < 12; ++c) bn[c] = pn[c];
+            }
+            double gold = 0.0;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) gold = __builtin_fma(Ao[c], bo[c], gold);
             if (lane == 0) prev = e;
-            double nd = prev - dot12(Ao, bo);
-            nd += dot12(An, bn);
+            double nd = (prev - gold) + gnew;
             if (g == 0 && lane == 0) nd = e;
             dot = nd;
-            const double dist = (a2 + wb[b]) - 2.0 * dot;
+            const double dist = (a2 + w) - 2.0 * dot;
             mn = dist < mn ? dist : mn;
             if (more && lane == 63) eout[b] = dot;
         }

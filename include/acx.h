@@ -197,6 +197,41 @@ int acx_ef_upload_pool(acx_ctx *ctx, const float *mfccs, const float *ssms, cons
                        const double *chroma_med, const int64_t *offsets, int32_t n_tracks,
                        const int32_t *dims);
 
+/* Block-feature parameters of EarlyFusion.load_features (ctor arguments blocksize,
+ * mfccs_per_block, chromas_per_block; earlyfusion_traile.py:44-45): defaults 20, 50, 40. */
+typedef struct {
+    int32_t blocksize;          /* beats per block                                  */
+    int32_t mfccs_per_block;    /* rows an MFCC block is resized to   (<= 64)        */
+    int32_t chromas_per_block;  /* rows a chroma block is resized to  (<= 64)        */
+} acx_ef_prep_params;
+
+/*
+ * EarlyFusion.load_features(i) for ONE track on the device (earlyfusion_traile.py:100-140, with
+ * resize_block :214-247): from the track's chroma (n_chroma, 12) f32, MFCCs (n_mfcc, ncoef) f32
+ * TIME-major (feats['mfcc_htk'].T; NaN -> 0 as at :108) and beat onsets (frame indices), the
+ * n_blocks = n_beats - blocksize block features
+ *   mfccs (n_blocks, mfccs_per_block * ncoef), ssms (n_blocks, mfccs_per_block (mfccs_per_block - 1) / 2),
+ *   chromas (n_blocks, chromas_per_block * 12)  f32 row-major, chroma_med (12) f64
+ * into host buffers (any may be NULL).  The anti-aliased resize restates skimage.transform.resize
+ * (see acoss_amd/csrc/ef_prep_kernels.hpp; unpinned: skimage is absent from the reference's tree).
+ */
+int acx_ef_block_features(acx_ctx *ctx, const float *chroma, int64_t n_chroma, const float *mfcc, int64_t n_mfcc,
+                          int32_t ncoef, const int64_t *onsets, int32_t n_beats, const acx_ef_prep_params *prep,
+                          float *mfccs, float *ssms, float *chromas, double *chroma_med);
+
+/*
+ * The block-feature pool of a whole collection built on the device and kept there: the same as
+ * acx_ef_block_features for every track followed by acx_ef_upload_pool, without the features
+ * ever visiting the host.  chroma (sum n_chroma_i, 12), mfcc (sum n_mfcc_i, ncoef), onsets
+ * (sum n_beats_i) packed, track i at *_offsets[i] .. *_offsets[i+1].  block_offsets_out
+ * (n_tracks + 1, may be NULL) receives the block offsets.  Tracks with fewer than blocksize + 1
+ * beats have no block.
+ */
+int acx_ef_upload_raw_pool(acx_ctx *ctx, const float *chroma, const int64_t *chroma_offsets, const float *mfcc,
+                           const int64_t *mfcc_offsets, int32_t ncoef, const int64_t *onsets,
+                           const int64_t *onset_offsets, int32_t n_tracks, const acx_ef_prep_params *prep,
+                           int64_t *block_offsets_out);
+
 typedef struct {
     double kappa;     /* csm_to_binary neighbourhood (EarlyFusion ctor kappa = 0.1)  */
     int32_t K;        /* getWCSM neighbours (ctor K = 10)                            */

@@ -488,3 +488,64 @@ def snf_fuse(Scores, K=5, niters=5, reg_diag=1):
     for Pt in Pts:
         F += Pt
     return Ws, F / m
+
+
+# ----------------------------------------------------------------------------
+# EarlyFusion block features (earlyfusion_traile.py:100-140, resize_block :214-247)
+# ----------------------------------------------------------------------------
+
+def ef_resize(x, rows):
+    """skimage.transform.resize(x, (rows, d), anti_aliasing=True, mode='constant') along the first
+    axis, restated from the primitives skimage calls (scipy.ndimage.gaussian_filter with
+    sigma = max(0, (n / rows - 1) / 2) truncated at 4 sigma, then an order-1 scipy.ndimage.zoom on the
+    pixel-centre grid, zeros outside) -- tests/test_oracle_golden.py checks it against those scipy
+    calls.  UNPINNED against skimage itself (absent).  NaN / inf results -> 0 (:245-246)."""
+    x = np.asarray(x, dtype=np.float64)
+    n, d = x.shape
+    if n == 0:
+        return np.zeros((rows, d))
+    factor = n / float(rows)
+    sigma = max(0.0, (factor - 1.0) / 2.0)
+    r = int(4.0 * sigma + 0.5)
+    filt = x
+    if r > 0:
+        k = np.arange(-r, r + 1, dtype=np.float64)
+        w = np.exp(-0.5 * k * k / (sigma * sigma))
+        w /= w.sum()
+        padded = np.concatenate([np.zeros((r, d)), x, np.zeros((r, d))])
+        filt = np.stack([np.convolve(padded[:, c], w[::-1], mode="valid") for c in range(d)], axis=1)
+    pos = (np.arange(rows) + 0.5) * factor - 0.5
+    t0 = np.floor(pos).astype(np.int64)
+    f = (pos - t0)[:, None]
+    ext = np.concatenate([np.zeros((2, d)), filt, np.zeros((2, d))])       # index t -> ext[t + 2], t in [-2, n + 1]
+    a = ext[np.clip(t0, -2, n + 1) + 2]
+    b = ext[np.clip(t0 + 1, -2, n + 1) + 2]
+    out = (1.0 - f) * a + f * b
+    out[~np.isfinite(out)] = 0
+    return out
+
+
+def ef_block_features(chroma, mfcc_tm, onsets, blocksize=20, mfccs_per_block=50, chromas_per_block=40):
+    """EarlyFusion.load_features (earlyfusion_traile.py:100-140): chroma (T, 12), mfcc_tm (T', ncoef)
+    time-major (= feats['mfcc_htk'].T), onsets = beat frame indices."""
+    chroma = np.asarray(chroma)
+    mfcc = np.array(mfcc_tm, dtype=np.float64)
+    mfcc[np.isnan(mfcc)] = 0
+    onsets = np.asarray(onsets).astype(np.int64)
+    nb = max(0, len(onsets) - blocksize)
+    R = mfccs_per_block
+    rr, cc = np.nonzero(np.tri(R, k=-1, dtype=bool))           # cells (r, c) with c < r, row-major
+    out = dict(mfccs=np.zeros((nb, R * mfcc.shape[1]), np.float32), ssms=np.zeros((nb, R * (R - 1) // 2), np.float32),
+               chromas=np.zeros((nb, chromas_per_block * chroma.shape[1]), np.float32),
+               chroma_med=np.median(chroma, axis=0))
+    for b in range(nb):
+        blk = ef_resize(mfcc[onsets[b]:onsets[b + blocksize - 1]], R)
+        blk = blk - blk.mean(axis=0, keepdims=True)
+        nrm = np.linalg.norm(blk, axis=1, keepdims=True)
+        blk = blk / np.where(nrm == 0, 1.0, nrm)
+        out["mfccs"][b] = blk.ravel()
+        sq = np.sum(blk * blk, axis=1)
+        d2 = np.maximum(sq[:, None] + sq[None, :] - 2.0 * blk.dot(blk.T), 0.0)
+        out["ssms"][b] = np.sqrt(d2)[rr, cc]
+        out["chromas"][b] = ef_resize(np.asarray(chroma[onsets[b]:onsets[b + blocksize]], np.float64), chromas_per_block).ravel()
+    return out

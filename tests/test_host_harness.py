@@ -249,53 +249,48 @@ def test_earlyfusion_class_surface(tmp_path, monkeypatch):
     assert np.all(np.isfinite(big.Ds["late"]))
 
 
-def test_earlyfusion_block_feature_preparation(tmp_path, monkeypatch):
-    """earlyfusion_traile.py:100-154, 214-247 on the host.  skimage is neither pinned by the
-    reference nor installed, so resize_block is checked through the properties of the algorithm
-    it restates (identity at scale 1, constants and linear ramps preserved away from the zero
-    border, range clipping) and block_features through the reference's own definitions."""
-    from acoss_amd.algorithms.earlyfusion_traile import EarlyFusion, resize_block, block_features
+def test_earlyfusion_block_feature_oracle():
+    """The checker of the device's block-feature kernels (oracle.ef_resize / ef_block_features;
+    earlyfusion_traile.py:100-140, 214-247).  skimage is neither pinned by the reference nor
+    installed, so the resize is held (1) to the scipy.ndimage primitives skimage.transform.resize
+    calls, and (2) to the properties of the algorithm: identity at scale 1, constants and linear
+    ramps preserved away from the zero border, no blur when upsampling."""
+    import scipy.ndimage as ndi
     rng = np.random.default_rng(11)
     X = rng.random((400, 5))
-    np.testing.assert_allclose(resize_block(X, 30, 80, 50), X[30:80], atol=1e-12)          # scale 1: identity
-    r = resize_block(np.full((300, 2), 3.0), 0, 240, 40)
-    assert r.shape == (40, 2) and np.allclose(r[6:-6], 3.0) and r.max() <= 3.0 and r[0, 0] < 3.0   # zero border leaks in
+    for (i1, i2, rows) in [(30, 80, 50), (0, 240, 40), (100, 399, 50), (10, 35, 50), (0, 400, 7), (5, 6, 3)]:
+        x = X[i1:i2]
+        n = len(x)
+        sigma = max(0.0, (n / rows - 1) / 2)
+        filt = ndi.gaussian_filter(x, (sigma, 0.0), cval=0.0, mode="constant") if sigma > 0 else x
+        want = ndi.zoom(filt, (rows / n, 1.0), order=1, mode="grid-constant", cval=0.0, grid_mode=True)
+        np.testing.assert_allclose(oracle.ef_resize(x, rows), want, atol=1e-12)
+    np.testing.assert_allclose(oracle.ef_resize(X[30:80], 50), X[30:80], atol=1e-12)          # scale 1: identity
+    r = oracle.ef_resize(np.full((240, 2), 3.0), 40)
+    assert r.shape == (40, 2) and np.allclose(r[6:-6], 3.0) and r.max() <= 3.0 + 1e-12 and r[0, 0] < 3.0   # zero border leaks in
     ramp = np.arange(600, dtype=np.float64)[:, None] * np.ones((1, 2))
-    r = resize_block(ramp, 100, 500, 50)                                                   # 8 : 1
-    want = 100 + (np.arange(50) + 0.5) * 8 - 0.5                                           # pixel centres
-    np.testing.assert_allclose(r[8:-8, 0], want[8:-8], atol=1e-6)
-    up = resize_block(X, 10, 35, 50)                                                       # upsampling: no blur
-    assert up.shape == (50, 5) and up.min() >= min(X[10:35].min(), 0) and up.max() <= X[10:35].max()
-    bad = X.copy(); bad[50, 0] = np.nan
-    assert np.all(np.isfinite(resize_block(bad, 40, 90, 20)))
+    r = oracle.ef_resize(ramp[100:500], 50)                                                # 8 : 1
+    np.testing.assert_allclose(r[8:-8, 0], (100 + (np.arange(50) + 0.5) * 8 - 0.5)[8:-8], atol=1e-6)
+    up = oracle.ef_resize(X[10:35], 50)                                                    # upsampling: no blur
+    assert up.shape == (50, 5) and up.min() >= 0 and up.max() <= X[10:35].max() + 1e-12
 
     T = 2600
-    feats = {"hpcp": rng.random((T, 12)).astype(np.float32), "mfcc_htk": rng.standard_normal((13, T)),
-             "madmom_features": {"onsets": np.sort(rng.choice(T - 100, 48, replace=False))}}
-    feats["mfcc_htk"][3, 77] = np.nan
-    bf = block_features(feats)
+    hpcp = rng.random((T, 12)).astype(np.float32)
+    mfcc = rng.standard_normal((T, 13))
+    mfcc[77, 3] = np.nan
+    on = np.sort(rng.choice(T - 100, 48, replace=False))
+    bf = oracle.ef_block_features(hpcp, mfcc, on)
     nb = 48 - 20
     assert bf["mfccs"].shape == (nb, 650) and bf["ssms"].shape == (nb, 1225) and bf["chromas"].shape == (nb, 480)
-    assert bf["mfccs"].dtype == np.float32 and bf["chroma_med"].shape == (12,)
-    np.testing.assert_array_equal(bf["chroma_med"], np.median(feats["hpcp"], axis=0))
+    assert bf["mfccs"].dtype == np.float32 and np.all(np.isfinite(bf["mfccs"]))
+    np.testing.assert_array_equal(bf["chroma_med"], np.median(hpcp, axis=0))
     blk = bf["mfccs"][5].reshape(50, 13).astype(np.float64)
     np.testing.assert_allclose(np.linalg.norm(blk, axis=1), 1.0, atol=1e-6)               # z-normalised rows
-    pix = np.arange(50); I, J = np.meshgrid(pix, pix)
+    np.testing.assert_allclose(blk.mean(axis=0), 0.0, atol=0.05)
+    pix = np.arange(50)
+    I, J = np.meshgrid(pix, pix)                                                          # the reference's D[I < J]
     np.testing.assert_allclose(bf["ssms"][5], oracle.get_csm(blk.astype(np.float32), blk.astype(np.float32))[I < J], atol=2e-3)
-    on = feats["madmom_features"]["onsets"]
-    np.testing.assert_allclose(bf["chromas"][7], resize_block(feats["hpcp"], on[7], on[27], 40).flatten(), rtol=1e-6)
-
-    # class path: a track file with raw features only
-    labels = ["a", "a"]
-    csv, root = _toy_dataset(tmp_path, labels)
-    for k, l in enumerate(labels):
-        save_track(root + "%s/t%d.h5" % (l, k), {"label": l, "track_id": "t%d" % k, "hpcp": feats["hpcp"],
-                                                 "mfcc_htk": np.nan_to_num(feats["mfcc_htk"]),
-                                                 "madmom_features": {"onsets": on}})
-    monkeypatch.chdir(tmp_path)
-    ef = EarlyFusion(csv, root, chroma_type="hpcp", shortname="toy", log_times=True)
-    got = ef.load_features(1)
-    assert got["mfccs"].shape == (nb, 650) and ef.load_features(1) is got and len(ef.times["features"]) == 1
+    np.testing.assert_allclose(bf["chromas"][7], oracle.ef_resize(hpcp[on[7]:on[27]].astype(np.float64), 40).ravel(), rtol=1e-6)
 
 
 def test_snf_neighbour_lists_equal_the_stable_sort():
