@@ -27,7 +27,7 @@ EXPORTS = [
     "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
     "acx_chenfusion_pairs", "acx_csm_binary_sw", "acx_upload_raw_pool", "acx_download_pool",
     "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse", "acx_qmax_binary",
-    "acx_ef_block_features", "acx_ef_upload_raw_pool", "acx_grid_plan", "acx_pool_lengths", "acx_grid_run", "acx_grid_scatter", "acx_pair_grid",
+    "acx_ef_block_features", "acx_ef_upload_raw_pool", "acx_snf_fuse_dists", "acx_grid_plan", "acx_pool_lengths", "acx_grid_run", "acx_grid_scatter", "acx_pair_grid",
 ]
 
 ALGO_SERRA09, ALGO_CHENFUSION, ALGO_SIMPLE, ALGO_EARLYFUSION = 0, 1, 2, 3
@@ -139,6 +139,9 @@ def load():
     L.acx_snf_fuse.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    L.acx_snf_fuse_dists.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                     ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_void_p)]
     L.acx_csm_binary_sw.argtypes = [vp, fp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, fp]
     L.acx_qmax_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, pp, fp]
     epp = ctypes.POINTER(EfPrepParams)
@@ -446,6 +449,20 @@ class Context(object):
         ptrs = (ctypes.c_void_p * len(planes))(*[P.ctypes.data for P in planes])
         self._check(self._L.acx_pair_grid(self._h, ctypes.byref(spec), ctypes.cast(ctypes.byref(params), ctypes.c_void_p),
                                           ptrs, n, int(bool(mirror))))
+
+    def snf_fuse_dists(self, Ds, K=20, niters=20, reg_diag=1.0, mu=0.5, want_ws=False):
+        """doSimilarityFusion on the device (acx_snf_fuse_dists): Ds = list of (n, n) distance matrices.
+        Returns (Ws or None, fused (n, n) f64)."""
+        m = len(Ds)
+        Ds = [np.ascontiguousarray(D, dtype=np.float64) for D in Ds]
+        n = Ds[0].shape[0]
+        out = np.empty((n, n), np.float64)
+        Ws = [np.empty((n, n), np.float64) for _ in range(m)] if want_ws else None
+        arr = lambda xs: (ctypes.c_void_p * m)(*[x.ctypes.data for x in xs])
+        self._check(self._L.acx_snf_fuse_dists(self._h, arr(Ds), m, n, int(K), int(niters), float(reg_diag), float(mu),
+                                               out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                               arr(Ws) if want_ws else None))
+        return Ws, out
 
     def serra09_pairs(self, pairs, params=None):
         p = params or serra09_params()

@@ -122,14 +122,13 @@ class EarlyFusion(CoverAlgorithm):
             self._ctx = _lib.Context(dev if dev is not None else int(os.environ.get("LOCAL_RANK", "0")))
         return self._ctx
 
-    def do_late_fusion(self, host=False):
-        """SNF of 1/(1+D) over the three / four score matrices (earlyfusion_traile.py:200-206).  The
-        cross-diffusion loop runs on the GPU (acx_snf_fuse; no device -> the call fails);
-        host=True asks explicitly for the dense numpy form of the same definitions (small N, checks)."""
+    def do_late_fusion(self):
+        """SNF of 1/(1+D) over the three / four score matrices (earlyfusion_traile.py:200-206), on the
+        GPU (acx_snf_fuse_dists; no device -> the call fails)."""
         def inv(s):
             return 1.0 / (1.0 + np.array(self.Ds[s], dtype=np.float64))
-        ctx = None if host else self._fusion_context()
+        ctx = self._fusion_context()
         self.Ds["late"] = doSimilarityFusion([inv(s) for s in ("chromas", "ssms", "mfccs")],
-                                             K=20, niters=20, reg_diag=1, ctx=ctx)[1]
+                                             K=20, niters=20, reg_diag=1, ctx=ctx, want_ws=False)[1]
         self.Ds["early+late"] = doSimilarityFusion([inv(s) for s in ("chromas", "ssms", "mfccs", "early")],
-                                                   K=20, niters=20, reg_diag=1, ctx=ctx)[1]
+                                                   K=20, niters=20, reg_diag=1, ctx=ctx, want_ws=False)[1]

@@ -56,17 +56,15 @@ class ChenFusion(Serra09):
                     j1 = min(self.N, j0 + 2048)
                     D[:, j0:j1] = (norm[None, j0:j1] / D[:, j0:j1]).astype(np.float32)
 
-    def do_late_fusion(self, host=False):
+    def do_late_fusion(self):
         """SNF of the two distance matrices (latefusion_chen.py:87-91): Ds["Late"] = fused
-        similarity; the two inputs are negated so that larger = closer everywhere.  The loop runs on
-        the GPU (acx_snf_fuse); host=True asks explicitly for the dense numpy form (small N, checks)."""
-        ctx = None
-        if not host:
-            if self._ctx is None:
-                import os
-                self._ctx = _lib.Context(self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0")))
-            ctx = self._ctx
-        DLate = doSimilarityFusion([self.Ds[s] for s in self.Ds], K=20, niters=20, reg_diag=1, ctx=ctx)[1]
+        similarity; the two inputs are negated so that larger = closer everywhere.  Runs on the GPU
+        (acx_snf_fuse_dists)."""
+        if self._ctx is None:
+            import os
+            self._ctx = _lib.Context(self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0")))
+        DLate = doSimilarityFusion([self.Ds[s] for s in self.Ds], K=20, niters=20, reg_diag=1, ctx=self._ctx,
+                                   want_ws=False)[1]
         for key in self.Ds:
             self.Ds[key] *= -1
         self.Ds["Late"] = DLate

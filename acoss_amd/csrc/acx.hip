@@ -1495,6 +1495,90 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
     return ACX_OK;
 }
 
+// Device state of one similarity-network-fusion run: P matrices (two generations), the kNN kernels,
+// two N x N work buffers.
+struct SnfRun {
+    int m = 0, n = 0, K = 0;
+    std::vector<double *> cur, nxt, dV;
+    std::vector<int32_t *> dJ;
+    double *acc = nullptr, *ut = nullptr, *md = nullptr;
+    void release()
+    {
+        for (double *p : cur) if (p) (void)hipFree(p);
+        for (double *p : nxt) if (p) (void)hipFree(p);
+        for (double *p : dV) if (p) (void)hipFree(p);
+        for (int32_t *p : dJ) if (p) (void)hipFree(p);
+        if (acc) (void)hipFree(acc);
+        if (ut) (void)hipFree(ut);
+        if (md) (void)hipFree(md);
+        cur.clear(); nxt.clear(); dV.clear(); dJ.clear();
+        acc = ut = md = nullptr;
+    }
+};
+
+static int snf_alloc(acx_ctx *c, SnfRun &R, int m, int n, int K)
+{
+    const size_t nn = (size_t)n * n;
+    const size_t need = ((size_t)2 * m + 2) * nn * sizeof(double) + (size_t)m * n * K * (sizeof(double) + sizeof(int32_t));
+    if (need > (size_t)(0.8 * (double)c->total_mem)) return fail(c, ACX_ERR_NOMEM, "snf_fuse: matrices do not fit the device");
+    R.m = m; R.n = n; R.K = K;
+    R.cur.assign(m, nullptr); R.nxt.assign(m, nullptr); R.dV.assign(m, nullptr); R.dJ.assign(m, nullptr);
+#define ACX_HIPC(expr_) do { const hipError_t ec_ = (expr_); if (ec_ != hipSuccess) { R.release(); ACX_HIP(c, ec_); } } while (0)
+    ACX_HIPC(hipMalloc((void **)&R.acc, nn * sizeof(double)));
+    ACX_HIPC(hipMalloc((void **)&R.ut, nn * sizeof(double)));
+    ACX_HIPC(hipMalloc((void **)&R.md, (size_t)n * sizeof(double)));
+    for (int i = 0; i < m; ++i) {
+        ACX_HIPC(hipMalloc((void **)&R.cur[i], nn * sizeof(double)));
+        ACX_HIPC(hipMalloc((void **)&R.nxt[i], nn * sizeof(double)));
+        ACX_HIPC(hipMalloc((void **)&R.dV[i], (size_t)n * K * sizeof(double)));
+        ACX_HIPC(hipMalloc((void **)&R.dJ[i], (size_t)n * K * sizeof(int32_t)));
+    }
+#undef ACX_HIPC
+    return ACX_OK;
+}
+
+// The cross-diffusion loop of doSimilarityFusionWs (similarity_fusion.py:146-186) on matrices that are
+// already on the device: cur[i] = row-normalised W_i, (dJ[i], dV[i]) = its kNN kernel.
+static int snf_loop(acx_ctx *c, SnfRun &R, int niters, double reg_diag, double *out)
+{
+    const int m = R.m, n = R.n, K = R.K;
+    const size_t nn = (size_t)n * n;
+    const bool ldsrow = (size_t)n * sizeof(double) <= 160 * 1024 - 1024;
+    if (ldsrow)
+        ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::snf_ast_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)n * sizeof(double))));
+    for (int it = 0; it < niters; ++it) {
+        // from the second sweep on the reference's two work lists alias: a matrix updated earlier in the
+        // sweep is already seen by the later ones (similarity_fusion.py:179)
+        std::vector<double *> &src = it == 0 ? R.cur : R.nxt;
+        for (int i = 0; i < m; ++i) {
+            acx::SnfSrc sp;
+            sp.count = 0;
+            for (int k = 0; k < m; ++k)
+                if (k != i) sp.p[sp.count++] = src[k];
+            hipLaunchKernelGGL(acx::snf_mean_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream,
+                               sp, 1.0 / (double)(m - 1), R.acc, (int64_t)nn);
+            if (ldsrow)
+                hipLaunchKernelGGL((acx::snf_ast_kernel<true>), dim3(n), dim3(256), (size_t)n * sizeof(double), c->stream,
+                                   R.acc, R.dJ[i], R.dV[i], R.ut, n, K);
+            else
+                hipLaunchKernelGGL((acx::snf_ast_kernel<false>), dim3(n), dim3(256), 0, c->stream, R.acc, R.dJ[i], R.dV[i], R.ut, n, K);
+            hipLaunchKernelGGL(acx::snf_sut_kernel, dim3(n), dim3(256), 0, c->stream, R.ut, R.dJ[i], R.dV[i], R.nxt[i], n, K, reg_diag);
+        }
+    }
+    {
+        acx::SnfSrc sp;
+        sp.count = m;
+        for (int k = 0; k < m; ++k) sp.p[k] = R.nxt[k];
+        hipLaunchKernelGGL(acx::snf_mean_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream,
+                           sp, 1.0 / (double)m, R.acc, (int64_t)nn);
+    }
+    ACX_HIP(c, hipGetLastError());
+    ACX_HIP(c, hipMemcpyAsync(out, R.acc, nn * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    return ACX_OK;
+}
+
 int acx_snf_fuse(acx_ctx *c, const double *const *Ws, const int32_t *const *Js, const double *const *Vs, int32_t m,
                  int32_t n, int32_t K, int32_t niters, double reg_diag, double *out)
 {
@@ -1507,72 +1591,58 @@ int acx_snf_fuse(acx_ctx *c, const double *const *Ws, const int32_t *const *Js, 
         for (int64_t e = 0; e < (int64_t)n * K; ++e)
             if (Js[i][e] < 0 || Js[i][e] >= n) return fail(c, ACX_ERR_INVALID, "snf_fuse: neighbour index out of range");
     ACX_HIP(c, hipSetDevice(c->device));
+    SnfRun R;
+    int rc = snf_alloc(c, R, m, n, K);
+    if (rc != ACX_OK) return rc;
     const size_t nn = (size_t)n * n;
-    const size_t need = ((size_t)2 * m + 2) * nn * sizeof(double) + (size_t)m * n * K * (sizeof(double) + sizeof(int32_t));
-    if (need > (size_t)(0.8 * (double)c->total_mem)) return fail(c, ACX_ERR_NOMEM, "snf_fuse: matrices do not fit the device");
-    std::vector<double *> cur(m, nullptr), nxt(m, nullptr), dV(m, nullptr);
-    std::vector<int32_t *> dJ(m, nullptr);
-    double *acc = nullptr, *ut = nullptr;
-    auto cleanup = [&]() {
-        for (int i = 0; i < m; ++i) {
-            if (cur[i]) (void)hipFree(cur[i]);
-            if (nxt[i]) (void)hipFree(nxt[i]);
-            if (dV[i]) (void)hipFree(dV[i]);
-            if (dJ[i]) (void)hipFree(dJ[i]);
-        }
-        if (acc) (void)hipFree(acc);
-        if (ut) (void)hipFree(ut);
-    };
-#define ACX_HIPC(expr_) do { const hipError_t ec_ = (expr_); if (ec_ != hipSuccess) { cleanup(); ACX_HIP(c, ec_); } } while (0)
-    ACX_HIPC(hipMalloc((void **)&acc, nn * sizeof(double)));
-    ACX_HIPC(hipMalloc((void **)&ut, nn * sizeof(double)));
-    for (int i = 0; i < m; ++i) {
-        ACX_HIPC(hipMalloc((void **)&cur[i], nn * sizeof(double)));
-        ACX_HIPC(hipMalloc((void **)&nxt[i], nn * sizeof(double)));
-        ACX_HIPC(hipMalloc((void **)&dV[i], (size_t)n * K * sizeof(double)));
-        ACX_HIPC(hipMalloc((void **)&dJ[i], (size_t)n * K * sizeof(int32_t)));
-        ACX_HIPC(hipMemcpyAsync(dV[i], Vs[i], (size_t)n * K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        ACX_HIPC(hipMemcpyAsync(dJ[i], Js[i], (size_t)n * K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < m && e == hipSuccess; ++i) {
+        e = hipMemcpyAsync(R.dV[i], Vs[i], (size_t)n * K * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(R.dJ[i], Js[i], (size_t)n * K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
         // P_i = row-normalised W_i (getP, similarity_fusion.py:101-122); `acc` is the staging buffer
-        ACX_HIPC(hipMemcpyAsync(acc, Ws[i], nn * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(acx::snf_rownorm_kernel, dim3(n), dim3(256), 0, c->stream, acc, cur[i], n);
+        if (e == hipSuccess) e = hipMemcpyAsync(R.acc, Ws[i], nn * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) hipLaunchKernelGGL(acx::snf_rownorm_kernel, dim3(n), dim3(256), 0, c->stream, R.acc, R.cur[i], n);
     }
-    const bool ldsrow = (size_t)n * sizeof(double) <= 160 * 1024 - 1024;
-    if (ldsrow)
-        ACX_HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(acx::snf_ast_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)n * sizeof(double))));
-    for (int it = 0; it < niters; ++it) {
-        // from the second sweep on the reference's two work lists alias: a matrix updated earlier in
-        // the sweep is already seen by the later ones (similarity_fusion.py:179)
-        std::vector<double *> &src = it == 0 ? cur : nxt;
-        for (int i = 0; i < m; ++i) {
-            acx::SnfSrc sp;
-            sp.count = 0;
-            for (int k = 0; k < m; ++k)
-                if (k != i) sp.p[sp.count++] = src[k];
-            hipLaunchKernelGGL(acx::snf_mean_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream,
-                               sp, 1.0 / (double)(m - 1), acc, (int64_t)nn);
-            if (ldsrow)
-                hipLaunchKernelGGL((acx::snf_ast_kernel<true>), dim3(n), dim3(256), (size_t)n * sizeof(double), c->stream,
-                                   acc, dJ[i], dV[i], ut, n, K);
-            else
-                hipLaunchKernelGGL((acx::snf_ast_kernel<false>), dim3(n), dim3(256), 0, c->stream, acc, dJ[i], dV[i], ut, n, K);
-            hipLaunchKernelGGL(acx::snf_sut_kernel, dim3(n), dim3(256), 0, c->stream, ut, dJ[i], dV[i], nxt[i], n, K, reg_diag);
-        }
+    if (e != hipSuccess) { R.release(); ACX_HIP(c, e); }
+    rc = snf_loop(c, R, niters, reg_diag, out);
+    R.release();
+    return rc;
+}
+
+int acx_snf_fuse_dists(acx_ctx *c, const double *const *Ds, int32_t m, int32_t n, int32_t K, int32_t niters, double reg_diag,
+                       double mu, double *out, double *const *Ws_out)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!Ds || !out || m < 2 || m > 8 || n < 1 || K < 1 || K > n || niters < 1 || !(mu > 0.0))
+        return fail(c, ACX_ERR_INVALID, "snf_fuse_dists: bad argument (2 <= m <= 8, 1 <= K <= n, niters >= 1, mu > 0)");
+    if (K > 64) return fail(c, ACX_ERR_UNSUPPORTED, "snf_fuse_dists: more than 64 neighbours are not supported on the device");
+    for (int i = 0; i < m; ++i)
+        if (!Ds[i]) return fail(c, ACX_ERR_INVALID, "snf_fuse_dists: null matrix");
+    ACX_HIP(c, hipSetDevice(c->device));
+    SnfRun R;
+    int rc = snf_alloc(c, R, m, n, K);
+    if (rc != ACX_OK) return rc;
+    const size_t nn = (size_t)n * n;
+    hipError_t e = hipSuccess;
+    const dim3 tg((n + 31) / 32, (n + 31) / 32);
+    const unsigned rows4 = (unsigned)((n + 3) / 4);
+    for (int i = 0; i < m && e == hipSuccess; ++i) {
+        e = hipMemcpyAsync(R.acc, Ds[i], nn * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) break;
+        // getW (similarity_fusion.py:15-36): symmetrise, local scale from the K + 1 nearest, Gaussian kernel
+        hipLaunchKernelGGL(acx::snf_sym_kernel, tg, dim3(256), 0, c->stream, R.acc, R.ut, n);
+        hipLaunchKernelGGL(acx::snf_localscale_kernel, dim3(rows4), dim3(256), 0, c->stream, R.ut, R.md, n, K);
+        hipLaunchKernelGGL(acx::snf_affinity_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream, R.ut, R.md, n, mu);
+        if (Ws_out && Ws_out[i]) e = hipMemcpyAsync(Ws_out[i], R.ut, nn * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        // getS (:124-144) as neighbour lists, getP (:101-122)
+        hipLaunchKernelGGL(acx::snf_knn_kernel, dim3(rows4), dim3(256), 0, c->stream, R.ut, R.dJ[i], R.dV[i], n, K);
+        hipLaunchKernelGGL(acx::snf_rownorm_kernel, dim3(n), dim3(256), 0, c->stream, R.ut, R.cur[i], n);
+        if (e == hipSuccess) e = hipGetLastError();
     }
-    {
-        acx::SnfSrc sp;
-        sp.count = m;
-        for (int k = 0; k < m; ++k) sp.p[k] = nxt[k];
-        hipLaunchKernelGGL(acx::snf_mean_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream,
-                           sp, 1.0 / (double)m, acc, (int64_t)nn);
-    }
-    ACX_HIPC(hipGetLastError());
-    ACX_HIPC(hipMemcpyAsync(out, acc, nn * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    ACX_HIPC(hipStreamSynchronize(c->stream));
-#undef ACX_HIPC
-    cleanup();
-    return ACX_OK;
+    if (e != hipSuccess) { R.release(); ACX_HIP(c, e); }
+    rc = snf_loop(c, R, niters, reg_diag, out);
+    R.release();
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -202,7 +202,8 @@ __global__ __launch_bounds__(64) void ef_chroma_median_kernel(const float *__res
     };
     const double a = select((T - 1) / 2);
     const double b = (T & 1) ? a : select(T / 2);
-    if (lane == 0) med[(size_t)track * 12 + bin] = (T & 1) ? a : (a + b) * 0.5;
+    // np.median of float32 data is float32: the mean of the two middle values is taken in f32
+    if (lane == 0) med[(size_t)track * 12 + bin] = (T & 1) ? a : (double)(((float)a + (float)b) / 2.0f);
 }
 
 // unit-norm chroma rows in place (X / |X| with zero norms -> 1, cross_recurrence.py:66-71) and the

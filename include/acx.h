@@ -278,6 +278,17 @@ int acx_sw_binary(acx_ctx *ctx, const uint8_t *B, int32_t M, int32_t N, float *s
 int acx_snf_fuse(acx_ctx *ctx, const double *const *Ws, const int32_t *const *Js, const double *const *Vs,
                  int32_t m, int32_t n, int32_t K, int32_t niters, double reg_diag, double *out);
 
+/*
+ * The whole of doSimilarityFusion (similarity_fusion.py:188-196) on the device: from m distance
+ * matrices Ds[i] (n, n) f64 row-major -- getW (:15-36: symmetrise, zero diagonal, local scale =
+ * mean of the K + 1 smallest of a row x (K + 1) / K, W = exp(-D^2 / (2 (mu eps)^2))), the kNN
+ * kernels (getS, ties at the cut in column order), getP and the cross-diffusion loop as in
+ * acx_snf_fuse.  out (n, n) f64: the fused matrix; Ws_out (may be NULL, entries may be NULL): the m
+ * affinity matrices.  K <= 64.
+ */
+int acx_snf_fuse_dists(acx_ctx *ctx, const double *const *Ds, int32_t m, int32_t n, int32_t K, int32_t niters,
+                       double reg_diag, double mu, double *out, double *const *Ws_out);
+
 /* ---- the N x N pair grid -------------------------------------------------- */
 
 /*

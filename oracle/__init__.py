@@ -445,6 +445,16 @@ def snf_getW(D, K, Mu=0.5):
     return np.exp(-DSym ** 2 / Denom)
 
 
+def snf_knn_lists(W, K):
+    """getS (similarity_fusion.py:124-144) as K (column, weight) pairs per row: the K largest of a
+    row, ties in column order (stable descending sort), weights divided by their sum."""
+    J = np.argsort(-W, 1, kind="stable")[:, :K]
+    V = np.take_along_axis(W, J, 1)
+    sn = np.sum(V, 1)
+    sn[sn == 0] = 1
+    return J.astype(np.int32), V / sn[:, None]
+
+
 def snf_fuse(Scores, K=5, niters=5, reg_diag=1):
     """similarity_fusion.py:146-196 (doSimilarityFusion -> fused matrix).  Dense
     restatement of the kNN-truncated cross-diffusion; the neighbour set of each row is
