@@ -14,7 +14,7 @@ from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = sys.argv[2] if len(sys.argv) > 2 else os.path.join("gpurun_out", "prof_" + tag)
-cells_per_launch = float(sys.argv[3]) if len(sys.argv) > 3 else 2048 * 1991.0 * 1991.0
+cells_per_launch = float(sys.argv[3]) if len(sys.argv) > 3 else 8192 * 1991.0 * 1991.0
 
 
 def short(name):
@@ -40,8 +40,8 @@ for sub in sorted(os.listdir(src)):
             pmc[k]["_lds"] = [float(row["LDS_Block_Size"])]
 
 lines = ["# rocprofv3 summary `%s`" % tag, "",
-         "Command: `python bench.py --steps 2 --warmup 1 --cpu-pairs 0 --pairs-per-rank 2048` "
-         "(2048 pairs of 1991 x 1991 cells per launch); one `--kernel-trace --stats` pass and separate "
+         "Command: `python bench.py --no-cpu --steps 2 --warmup 1 --tracks 640` "
+         "(8192 pairs of 1991 x 1991 cells per launch); one `--kernel-trace --stats` pass and separate "
          "`--pmc` passes (scripts/profile.sh).", "",
          "| kernel | calls | avg ms | % time | VGPR | LDS B | FETCH KiB | WRITE KiB | HBM GB (2 x fetch + write) | GB/s |",
          "|---|---|---|---|---|---|---|---|---|---|"]
@@ -78,9 +78,43 @@ for k in sorted(stats, key=lambda kk: -stats[kk]["avg_ms"]):
         v = pmc[k].get(n)
         vals.append("%.3g" % (sum(v) / len(v)) if v else "-")
     lines.append("| %s | " % k + " | ".join(vals) + " |")
+# ---- what the kernels are really bound by: pipe utilisations from the SQ counters (MI355X_MICROARCH.md:
+# SQ_ACTIVE_INST_* count quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs,
+# SQ_LDS_IDX_ACTIVE cycles summed over CUs; GRBM_GUI_ACTIVE = the kernel's own clock ticks)
+N_SIMD, N_CU = 1024.0, 256.0
+real = {}
+lines += ["", "## Pipe utilisation (real bound)", "",
+          "| kernel | clock GHz (GRBM_GUI_ACTIVE / wall) | VALU busy | f32-MFMA busy | LDS busy | HBM util (corrected traffic / 8 TB/s) |", "|---|---|---|---|---|---|"]
+for k in sorted(stats, key=lambda kk: -stats[kk]["avg_ms"]):
+    c = pmc.get(k, {})
+    if "GRBM_GUI_ACTIVE" not in c:
+        continue
+    mean = lambda name: sum(c[name]) / len(c[name]) if name in c and len(c[name]) else 0.0
+    gui = mean("GRBM_GUI_ACTIVE")
+    wall = stats[k]["avg_ms"] * 1e-3
+    fl, wl = c.get("FETCH_SIZE", [0]), c.get("WRITE_SIZE", [0])
+    hbm = (2 * sum(fl) / max(1, len(fl)) + sum(wl) / max(1, len(wl))) * 1024.0
+    r = dict(clock_ghz=gui / wall / 1e9 if wall > 0 else 0.0,
+             valu_busy=4.0 * mean("SQ_ACTIVE_INST_VALU") / (gui * N_SIMD) if gui else 0.0,
+             mfma_busy=mean("SQ_VALU_MFMA_BUSY_CYCLES") / (gui * N_SIMD) if gui else 0.0,
+             lds_busy=mean("SQ_LDS_IDX_ACTIVE") / (gui * N_CU) if gui else 0.0,
+             hbm_util=hbm / wall / 8e12 if wall > 0 else 0.0)
+    lines.append("| %s | %.2f | %.3f | %.3f | %.3f | %.4f |" % (k, r["clock_ghz"], r["valu_busy"], r["mfma_busy"], r["lds_busy"], r["hbm_util"]))
+    base = k.split("<")[0]
+    acc = real.setdefault(base, dict(n=0))
+    for key, val in r.items():
+        acc[key] = (acc.get(key, 0.0) * acc["n"] + val) / (acc["n"] + 1)
+    acc["n"] += 1
+for v in real.values():
+    v.pop("n", None)
+    for key in list(v):
+        v[key] = round(v[key], 4)
+    v["source"] = "profiles/%s_summary.md (rocprofv3 --pmc, separate passes; not measured in the bench run)" % tag
 os.makedirs("profiles", exist_ok=True)
 open(os.path.join("profiles", tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
+json.dump(real, open(os.path.join("profiles", "r02_real_bound.json"), "w"), indent=1)
 for t in traffic.values():
     t.pop("_calls", None)
+traffic["source"] = tag
 json.dump(traffic, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
