@@ -624,8 +624,6 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                 d.N = (int)(c->h_efoff[d.r + 1] - c->h_efoff[d.r]);
             }
             if (d.M < 1 || d.N < 1) return fail(c, ACX_ERR_SHORT, "earlyfusion: track without blocks (pair " + std::to_string(k) + ")");
-            if (d.M > acx::EF_MAXNB || d.N > acx::EF_MAXNB)
-                return fail(c, ACX_ERR_UNSUPPORTED, "earlyfusion: tracks with more than 1024 blocks are not supported on the device yet");
             d.oti = 0;
             d.pitchC = round_up(d.N, 64);
             d.pitchT = round_up(d.M, 64);
@@ -640,7 +638,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             d.offC = used;
             d.offS = used_s;
             used += need;
-            used_s += 4 * acx::ef_s_stride(d);
+            used_s += acx::ef_s_total(d);
             maxM = std::max(maxM, d.M);
             maxN = std::max(maxN, d.N);
             cells += (int64_t)d.M * d.N;
@@ -669,10 +667,14 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
         }
         const int nfeat = ext_matrix ? 1 : 3;
         // rows of more than 512 cells take the wide variants (16 values / columns per lane)
+        // more than 1024: a row no longer fits a wave's registers -- the streaming variants (any length)
         const bool wide_rows = std::max(maxM, maxN) > 512, wide_cols = maxN > 512;
-#define ACX_ROWSTAT(grid_, mode_) do { if (wide_rows) hipLaunchKernelGGL((acx::ef_rowstat_kernel<4>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); \
+        const bool long_rows = std::max(maxM, maxN) > acx::EF_MAXNB, long_cols = maxN > acx::EF_MAXNB;
+#define ACX_ROWSTAT(grid_, mode_) do { if (long_rows) hipLaunchKernelGGL(acx::ef_rowstat_long_kernel, grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); \
+                                       else if (wide_rows) hipLaunchKernelGGL((acx::ef_rowstat_kernel<4>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); \
                                        else hipLaunchKernelGGL((acx::ef_rowstat_kernel<2>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); } while (0)
-#define ACX_SW(grid_, src_) do { if (wide_cols) hipLaunchKernelGGL((acx::sw_kernel<16>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); \
+#define ACX_SW(grid_, src_) do { if (long_cols) hipLaunchKernelGGL(acx::sw_long_kernel, grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); \
+                                 else if (wide_cols) hipLaunchKernelGGL((acx::sw_kernel<16>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); \
                                  else hipLaunchKernelGGL((acx::sw_kernel<8>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); } while (0)
         {
             ProfScope ps(c, KS_EFSTAT, cells);
@@ -1448,8 +1450,6 @@ int acx_csm_binary_sw(acx_ctx *c, const float *D, int32_t M, int32_t N, double k
 {
     if (!c) return ACX_ERR_INVALID;
     if (!D || !score || M < 1 || N < 1) return fail(c, ACX_ERR_INVALID, "csm_binary_sw: bad argument");
-    if (M > acx::EF_MAXNB || N > acx::EF_MAXNB)
-        return fail(c, ACX_ERR_UNSUPPORTED, "csm_binary_sw: matrices larger than 1024 are not supported on the device yet");
     acx_ef_params p{kappa, 1};
     float sc[4] = {0, 0, 0, 0};
     const int rc = run_ef(c, nullptr, 1, p, sc, nullptr, D, M, N);
@@ -1461,7 +1461,6 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
 {
     if (!c) return ACX_ERR_INVALID;
     if (!B || !score || M < 1 || N < 1) return fail(c, ACX_ERR_INVALID, "sw_binary: bad argument");
-    if (M > acx::EF_MAXNB || N > acx::EF_MAXNB) return fail(c, ACX_ERR_UNSUPPORTED, "sw_binary: matrices larger than 1024 are not supported on the device yet");
     std::vector<float> Cm((size_t)M * N);
     for (size_t k = 0; k < Cm.size(); ++k) {
         if (B[k] > 1) return fail(c, ACX_ERR_INVALID, "Non-binary elements found in input");
@@ -1477,7 +1476,7 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
     int rc;
     ACX_HIP(c, hipSetDevice(c->device));
     if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)M * d.pitchC)) != ACX_OK) return rc;
-    if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)4 * acx::ef_s_stride(d))) != ACX_OK) return rc;
+    if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)acx::ef_s_total(d))) != ACX_OK) return rc;
     if ((rc = ensure(c, c->d_efpd, c->efpd_cap, (size_t)1)) != ACX_OK) return rc;
     if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)4)) != ACX_OK) return rc;
     ACX_HIP(c, hipMemcpyAsync(c->d_efpd, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
@@ -1485,7 +1484,8 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
                                 hipMemcpyHostToDevice, c->stream));
     ACX_HIP(c, hipMemsetAsync(c->d_thr, 0, sizeof(float) * M, c->stream));
     ACX_HIP(c, hipMemsetAsync(c->d_thr + acx::ef_jcut_off(d, 0), 0x7f, sizeof(int) * M, c->stream));   // every tie counts
-    if (N > 512) hipLaunchKernelGGL((acx::sw_kernel<16>), dim3(1, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
+    if (N > acx::EF_MAXNB) hipLaunchKernelGGL(acx::sw_long_kernel, dim3(1, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
+    else if (N > 512) hipLaunchKernelGGL((acx::sw_kernel<16>), dim3(1, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
     else hipLaunchKernelGGL((acx::sw_kernel<8>), dim3(1, 1), dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, 0);
     ACX_HIP(c, hipGetLastError());
     ACX_HIP(c, hipMemcpyAsync(sc, c->d_out, sizeof(float) * 4, hipMemcpyDeviceToHost, c->stream));

@@ -25,7 +25,8 @@
 
 namespace acx {
 
-constexpr int EF_MAXNB = 1024;    // blocks per track supported on the device (rows of <= 512 take the narrow kernels)
+constexpr int EF_MAXNB = 1024;    // blocks per track of the register-resident kernels (rows of <= 512 take the narrow ones);
+                                  // longer tracks: ef_rowstat_long_kernel / sw_long_kernel (any length)
 
 struct EfPair {
     int32_t q, r;          // track indices
@@ -53,6 +54,9 @@ __device__ __forceinline__ int64_t ef_f_off(const EfPair &P)
 // Binarisation rule (csm_to_binary keeps exactly k cells per row): B_ij = C_ij < t_i, or C_ij == t_i
 // and j <= jcut_i -- ties at the k-th value are taken in column order until k cells are set.
 __host__ __device__ __forceinline__ int64_t ef_s_stride(const EfPair &P) { return 3 * (int64_t)P.pitchT + P.pitchC; }
+// strip-boundary records of the long Smith-Waterman: behind the four vector blocks, 4 pitchT ints per matrix
+__host__ __device__ __forceinline__ int64_t ef_rec_off(const EfPair &P, int src) { return 4 * ef_s_stride(P) + (int64_t)src * 4 * P.pitchT; }
+__host__ __device__ __forceinline__ int64_t ef_s_total(const EfPair &P) { return 4 * ef_s_stride(P) + 16 * (int64_t)P.pitchT; }
 __host__ __device__ __forceinline__ int64_t ef_jcut_off(const EfPair &P, int src)
 {
     return src < 3 ? 2 * (int64_t)P.pitchT + P.pitchC : (int64_t)P.pitchT;
@@ -453,6 +457,194 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
                 U2[e] = U1[e];
                 U1[e] = Tn[e] + (b[e] ? 0 : -7);
             }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int t = __shfl_xor(best, o, 64);
+            best = best > t ? best : t;
+        }
+        result = (float)best / 10.0f;
+    }
+    if (lane == 0) out[(size_t)blockIdx.x * 4 + src] = result;
+}
+
+// ------------------------------------------------------------------------------------
+// E2 / E4 for tracks of any length (more than 1024 blocks: a row no longer fits a wave's registers).
+// Same results as the register-resident kernels, rows streamed from HBM / L2.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ef_key(float v)
+{
+    const unsigned u = __float_as_uint(v);
+    return (u >> 31) ? ~u : (u | 0x80000000u);         // monotone: smaller float -> smaller key
+}
+__device__ __forceinline__ float ef_unkey(unsigned k)
+{
+    return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k);
+}
+// k-th smallest (0-based) of a row of n floats: binary search on the key, ballots count
+__device__ __forceinline__ float ef_select_stream(const float *__restrict__ v, int n, int k, int lane)
+{
+    unsigned lo = 0u, hi = 0xffffffffu;
+    while (lo < hi) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int tot = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            tot += __popcll(__ballot(j < n && ef_key(v[j]) <= mid));
+        }
+        if (tot >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    return ef_unkey(lo);
+}
+
+__global__ __launch_bounds__(256) void ef_rowstat_long_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
+                                                              float *__restrict__ stat, int mode, int kw)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const EfPair P = pd[blockIdx.y];
+    const int s = blockIdx.z;
+    const int nrows = mode == 1 ? P.N : P.M;
+    const int n = mode == 1 ? P.M : P.N;
+    const int pitch = mode == 1 ? P.pitchT : P.pitchC;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= nrows) return;
+    const int64_t base = mode == 0 ? ef_c_off(P, s) : (mode == 1 ? ef_ct_off(P, s) : ef_f_off(P));
+    const float *v = scratch + base + (size_t)row * pitch;
+    const float INF = __builtin_inff();
+    float *S = stat + P.offS + (mode == 2 ? 3 * ef_s_stride(P) : s * ef_s_stride(P));
+    if (mode != 1) {
+        const int kb = P.kbin;
+        float t;
+        int jcut = 0x7fffffff;
+        if (kb <= 0) t = -INF;
+        else if (kb >= n) t = INF;
+        else {
+            t = ef_select_stream(v, n, kb - 1, lane);
+            int lt = 0, eq = 0;
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                const float x = j < n ? v[j] : INF;
+                lt += __popcll(__ballot(j < n && x < t));
+                eq += __popcll(__ballot(j < n && x == t));
+            }
+            const int budget = kb - lt;
+            if (eq > budget) {                       // ties at the k-th value: taken in column order
+                int seen = 0;
+                for (int j0 = 0; j0 < n; j0 += 64) {
+                    const int j = j0 + lane;
+                    const unsigned long long m = __ballot(j < n && v[j] == t);
+                    const int c = __popcll(m);
+                    if (seen + c >= budget) {
+                        // the (budget - seen)-th set bit of m
+                        unsigned long long mm = m;
+                        for (int q = 1; q < budget - seen; ++q) mm &= mm - 1;
+                        jcut = j0 + (__ffsll((long long)mm) - 1);
+                        break;
+                    }
+                    seen += c;
+                }
+            }
+        }
+        if (lane == 0) {
+            S[row] = t;
+            reinterpret_cast<int *>(S)[ef_jcut_off(P, mode == 2 ? 3 : s) + row] = jcut;
+        }
+    }
+    if (mode != 2) {
+        const int kk = kw < n ? kw : n;
+        const float vk = ef_select_stream(v, n, kk - 1, lane);
+        float acc = 0.0f;
+        int cnt = 0;
+        for (int j = lane; j < n; j += 64) {
+            const float x = v[j];
+            if (x < vk) { acc += x; ++cnt; }
+        }
+        const int tot = wave_sum_i(cnt);
+        float sm = acc;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        const float m = (sm + (float)(kk - tot) * vk) / (float)kk;
+        if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
+    }
+}
+
+// Constrained Smith-Waterman in strips of 64 x 16 = 1024 columns; for every row a strip leaves
+// U[i][c - 1], U[i][c - 2] (c = first column of the next strip) in the pair's record area, which
+// lane 0 of the next strip reads in place of the matrix edge.  Records: rec[(strip & 1)][row] (int2).
+__global__ __launch_bounds__(64) void sw_long_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
+                                                     float *__restrict__ stat, float *__restrict__ out, int src_base)
+{
+    constexpr int CPL = 16;
+    const int lane = threadIdx.x;
+    const EfPair P = pd[blockIdx.x];
+    const int src = src_base + blockIdx.y;
+    const int M = P.M, N = P.N, pitch = P.pitchC;
+    const float *C = scratch + (src < 3 ? ef_c_off(P, src) : ef_f_off(P));
+    const float *thr = stat + P.offS + src * ef_s_stride(P);
+    const int *jcut = reinterpret_cast<const int *>(thr) + ef_jcut_off(P, src);
+    int2 *rec = reinterpret_cast<int2 *>(stat + P.offS + ef_rec_off(P, src));
+    float result = 0.0f;
+    if (M >= 4 && N >= 4) {
+        const int nstrips = (N + 64 * CPL - 1) / (64 * CPL);
+        const int prev = (lane + 63) & 63;
+        int best = 0;
+        for (int st = 0; st < nstrips; ++st) {
+            const int j0 = st * 64 * CPL + CPL * lane;
+            const int2 *rin = rec + (size_t)((st + 1) & 1) * P.pitchT;
+            int2 *rout = rec + (size_t)(st & 1) * P.pitchT;
+            const bool more = st + 1 < nstrips;
+            int U1[CPL], U2[CPL];
+            auto load_b = [&](int row, bool (&b)[CPL]) {
+                const float t = thr[row];
+                const int jc = jcut[row];
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) {
+                    const int j = j0 + e;
+                    const float d = j < N ? C[(size_t)row * pitch + j] : 0.0f;
+                    b[e] = (j < N) && (d < t || (d == t && j <= jc));
+                }
+            };
+            bool b[CPL];
+            load_b(0, b);
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) U2[e] = b[e] ? 0 : -7;
+            if (more && lane == 63) rout[0] = make_int2(U2[CPL - 1], U2[CPL - 2]);
+            load_b(1, b);
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) U1[e] = b[e] ? 0 : -7;
+            if (more && lane == 63) rout[1] = make_int2(U1[CPL - 1], U1[CPL - 2]);
+            int2 recB = make_int2(0, 0);                        // record of row i - 2
+            if (st > 0) recB = rin[0];
+            for (int i = 2; i <= M - 2; ++i) {
+                load_b(i, b);
+                int l1a = __shfl(U1[CPL - 1], prev, 64), l1b = __shfl(U1[CPL - 2], prev, 64), l2a = __shfl(U2[CPL - 1], prev, 64);
+                int2 recA = make_int2(0, 0);                    // record of row i - 1
+                if (st > 0) recA = rin[i - 1];
+                if (lane == 0) { l1a = recA.x; l1b = recA.y; l2a = recB.x; }
+                recB = recA;
+                int Tn[CPL];
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) {
+                    const int c2 = (e >= 1) ? U1[e - 1] : l1a;
+                    const int c3 = (e >= 1) ? U2[e - 1] : l2a;
+                    const int c4 = (e >= 2) ? U1[e - 2] : (e == 1 ? l1a : l1b);
+                    int mx = c2 > c3 ? c2 : c3;
+                    mx = mx > c4 ? mx : c4;
+                    int t = (b[e] ? 10 : -10) + mx;
+                    t = t > 0 ? t : 0;
+                    const int j = j0 + e;
+                    if (j < 2) t = 0;
+                    Tn[e] = t;
+                    if (j <= N - 2) best = best > t ? best : t;
+                }
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) {
+                    U2[e] = U1[e];
+                    U1[e] = Tn[e] + (b[e] ? 0 : -7);
+                }
+                if (more && lane == 63) rout[i] = make_int2(U1[CPL - 1], U1[CPL - 2]);
+            }
+            __threadfence();                                    // the next strip reads this one's records
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {

@@ -81,7 +81,7 @@ for k in sorted(stats, key=lambda kk: -stats[kk]["avg_ms"]):
 # ---- what the kernels are really bound by: pipe utilisations from the SQ counters (MI355X_MICROARCH.md:
 # SQ_ACTIVE_INST_* count quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs,
 # SQ_LDS_IDX_ACTIVE cycles summed over CUs; GRBM_GUI_ACTIVE = the kernel's own clock ticks)
-N_SIMD, N_CU = 1024.0, 256.0
+N_SIMD, N_CU, N_XCD = 1024.0, 256.0, 8.0      # (GRBM_GUI_ACTIVE comes back summed over the 8 XCDs)
 real = {}
 lines += ["", "## Pipe utilisation (real bound)", "",
           "| kernel | clock GHz (GRBM_GUI_ACTIVE / wall) | VALU busy | f32-MFMA busy | LDS busy | HBM util (corrected traffic / 8 TB/s) |", "|---|---|---|---|---|---|"]
@@ -90,7 +90,7 @@ for k in sorted(stats, key=lambda kk: -stats[kk]["avg_ms"]):
     if "GRBM_GUI_ACTIVE" not in c:
         continue
     mean = lambda name: sum(c[name]) / len(c[name]) if name in c and len(c[name]) else 0.0
-    gui = mean("GRBM_GUI_ACTIVE")
+    gui = mean("GRBM_GUI_ACTIVE") / N_XCD
     wall = stats[k]["avg_ms"] * 1e-3
     fl, wl = c.get("FETCH_SIZE", [0]), c.get("WRITE_SIZE", [0])
     hbm = (2 * sum(fl) / max(1, len(fl)) + sum(wl) / max(1, len(wl))) * 1024.0
@@ -101,6 +101,8 @@ for k in sorted(stats, key=lambda kk: -stats[kk]["avg_ms"]):
              hbm_util=hbm / wall / 8e12 if wall > 0 else 0.0)
     lines.append("| %s | %.2f | %.3f | %.3f | %.3f | %.4f |" % (k, r["clock_ghz"], r["valu_busy"], r["mfma_busy"], r["lds_busy"], r["hbm_util"]))
     base = k.split("<")[0]
+    if not base.endswith("_kernel") or "::" in base:
+        continue
     acc = real.setdefault(base, dict(n=0))
     for key, val in r.items():
         acc[key] = (acc.get(key, 0.0) * acc["n"] + val) / (acc["n"] + 1)
@@ -109,7 +111,9 @@ for v in real.values():
     v.pop("n", None)
     for key in list(v):
         v[key] = round(v[key], 4)
-    v["source"] = "profiles/%s_summary.md (rocprofv3 --pmc, separate passes; not measured in the bench run)" % tag
+    v["source"] = ("profiles/%s_summary.md (rocprofv3 --pmc, separate passes; not measured in the bench run); "
+                   "valu_busy = 4 x SQ_ACTIVE_INST_VALU / (clock ticks x 1024 SIMDs) reads 1.32 for the pure-VALU qmax_bits_kernel, "
+                   "i.e. it over-counts by up to a third" % tag)
 os.makedirs("profiles", exist_ok=True)
 open(os.path.join("profiles", tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(real, open(os.path.join("profiles", "r02_real_bound.json"), "w"), indent=1)

@@ -44,7 +44,8 @@ def test_smith_waterman_random_shapes_vs_oracle(ctx):
     import oracle
     rng = np.random.default_rng(9)
     for (m, n) in [(4, 4), (5, 64), (64, 5), (65, 65), (300, 511), (512, 512), (129, 8), (8, 500),
-                   (513, 513), (700, 40), (40, 700), (1024, 1024), (600, 1023)]:       # > 512 columns: wide kernel
+                   (513, 513), (700, 40), (40, 700), (1024, 1024), (600, 1023),        # > 512 columns: wide kernel
+                   (700, 1025), (1500, 2100), (30, 3000), (2049, 600)]:                 # > 1024 columns: strips
         for dens in (0.05, 0.3, 0.8):
             B = (rng.random((m, n)) < dens).astype(np.uint8)
             assert round(ctx.sw_binary(B) * 10) == oracle.sw_constrained_i32(B), (m, n, dens)
@@ -59,7 +60,7 @@ def test_binarise_with_ties_keeps_k_cells_in_column_order(ctx):
     import oracle
     rng = np.random.default_rng(21)
     cases = []
-    for (m, n) in [(40, 50), (64, 257), (130, 512), (75, 68), (9, 300), (33, 777), (600, 1024)]:
+    for (m, n) in [(40, 50), (64, 257), (130, 512), (75, 68), (9, 300), (33, 777), (600, 1024), (90, 1300), (1100, 2500)]:
         cases.append(rng.integers(0, 4, (m, n)).astype(np.float32))                       # 4 distinct values
         cases.append(np.ones((m, n), np.float32))                                         # one value
         D = np.ones((m, n), np.float32)
@@ -157,9 +158,28 @@ def test_chain_long_tracks_wide_kernels(ctx):
     pairs = np.array([[0, 1], [1, 2], [2, 0], [3, 2], [2, 3], [3, 0]], np.int32)
     a = ctx.earlyfusion_pairs(pairs)
     assert np.array_equal(a[0], d["scores"])
-    with pytest.raises(NotImplementedError):
-        ctx.ef_upload_pool(tracks[:1] + synth.earlyfusion_set(1, seed=11, nb_range=(1025, 1025)))
-        ctx.earlyfusion_pairs(np.array([[0, 1]], np.int32))
+
+
+def test_chain_tracks_of_2000_blocks(ctx):
+    """More than 1024 blocks (a 17-minute track at 120 bpm): the streaming row statistics and the
+    Smith-Waterman in column strips; every intermediate against the oracle, both orientations, mixed
+    with short tracks in one batch."""
+    from acoss_amd import synth
+    rng = np.random.default_rng(16)
+    tracks = synth.earlyfusion_set(1, seed=11, nb_range=(2000, 2000)) + synth.earlyfusion_set(1, seed=12, nb_range=(1025, 1025)) \
+        + synth.earlyfusion_set(1, seed=13, nb_range=(300, 300))
+    for key in ("mfccs", "ssms", "chromas"):
+        n = 400
+        tracks[1][key][500:500 + n] = tracks[0][key][1200:1200 + n] + 0.02 * rng.standard_normal((n, tracks[0][key].shape[1])).astype(np.float32)
+    ctx.ef_upload_pool(tracks)
+    d = _check_pair(ctx, 0, 1, tracks[0], tracks[1])
+    assert d["scores"].max() > 100.0
+    for (i, j) in [(1, 0), (2, 0), (0, 2), (1, 2)]:
+        _check_pair(ctx, i, j, tracks[i], tracks[j])
+    pairs = np.array([[0, 1], [1, 0], [2, 0], [2, 1]], np.int32)
+    a = ctx.earlyfusion_pairs(pairs)
+    assert np.array_equal(a[0], d["scores"])
+    assert np.array_equal(a[3], ctx.earlyfusion_pairs(pairs[3:])[0])       # the short pair alone: narrow kernels, same scores
 
 
 def test_errors(ctx):
