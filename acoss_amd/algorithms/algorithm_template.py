@@ -29,7 +29,7 @@ import numpy as np
 
 from .. import _lib
 from .. import dist as _dist
-from ..featurestore import load_track
+from ..featurestore import load_track, load_matrices_h5, save_matrices_h5
 from ..utils import create_dataset_filepaths
 
 __all__ = ["CoverAlgorithm"]
@@ -130,13 +130,18 @@ class CoverAlgorithm(object):
         compatibility; the fan-out unit here is the GPU (one process per GPU under
         torch.distributed), not joblib workers."""
         npz = "%s_Ds.npz" % self.get_cacheprefix()
+        h5 = "%s_Ds.h5" % self.get_cacheprefix()          # the reference's cache file (algorithm_template.py:163-166,192)
         if precomputed:
-            with np.load(npz) as z:
-                for s in z.files:
-                    if s in self.Ds:
-                        self.Ds[s][:] = z[s]
-                    else:
-                        self.Ds[s] = z[s]
+            if os.path.exists(npz):
+                with np.load(npz) as z:
+                    loaded = {s: z[s] for s in z.files}
+            else:
+                loaded = load_matrices_h5(h5)                  # a cache written by acoss itself (needs h5py)
+            for s, M in loaded.items():
+                if s in self.Ds:
+                    self.Ds[s][:] = M
+                else:
+                    self.Ds[s] = M
             self.get_all_clique_ids()
             return
         rank, ws = _dist.world()
@@ -163,6 +168,7 @@ class CoverAlgorithm(object):
             self.get_all_clique_ids()
         if rank == 0:
             np.savez(npz, **{s: np.asarray(self.Ds[s]) for s in self.Ds})
+            save_matrices_h5(h5, self.Ds)                      # also in the reference's own format when h5py exists
 
     def _all_pairwise_grid(self, symmetric):
         """Device-backed classes: `self._grid()` -> (context with the pool uploaded, ACX_ALGO_*, params

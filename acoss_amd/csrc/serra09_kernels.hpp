@@ -390,23 +390,25 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
     static_assert(DPL >= 4 && DPL <= 16 && (DPL & (DPL - 1)) == 0, "BINS must be 256, 512 or 1024");
     static_assert(BPL >= 1 && (COPIES & (COPIES - 1)) == 0 && COPIES <= 8, "COPIES must be 1, 2, 4 or 8 with >= 64 bins");
     const float INF = __builtin_inff();
-    // ---- value range over the finite cells
-    unsigned mnu = 0xFFFFFFFFu;
+    // ---- value range over the finite cells.  NEGPAD rows (squared distances, >= +0): the range starts
+    // at 0 -- no minimum pass at all; the bins below the row's true minimum stay empty (a sixth of
+    // them on i.i.d. chroma, fewer on real tracks, whose best matches are near 0), which costs less
+    // than 32 v_min_u32 and a wave reduction.
+    unsigned mnu = NEGPAD ? 0u : 0xFFFFFFFFu;
     int mxb = (int)0x80000000;
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         const unsigned b = __float_as_uint(x[t]);
-        mnu = b < mnu ? b : mnu;
+        if constexpr (!NEGPAD) mnu = b < mnu ? b : mnu;
         const int bb = NEGPAD ? (int)b : (int)(b + 0x00800000u);
         mxb = bb > mxb ? bb : mxb;
     }
-    mnu = (unsigned)__builtin_amdgcn_readlane(wave_scan_bits((int)mnu, -1, OpMinU()), 63);
+    if constexpr (!NEGPAD) mnu = (unsigned)__builtin_amdgcn_readlane(wave_scan_bits((int)mnu, -1, OpMinU()), 63);
     mxb = __builtin_amdgcn_readlane(wave_scan_bits(mxb, (int)0x80000000, OpMaxI()), 63);
     const float mn = __uint_as_float(mnu);
     const float mx = __uint_as_float(NEGPAD ? (unsigned)mxb : (unsigned)mxb - 0x00800000u);
     if (mxb < 0) return false;                       // no finite cell at all
-    if (NEGPAD && (int)mnu < 0) return false;        // (only pads: cannot happen for a row of the matrix)
-    if (!(mn < mx)) { slo = mn; shi = mn; return true; }   // every finite cell equal
+    if (!(mn < mx)) { slo = mn; shi = mn; return true; }   // every finite cell equal (NEGPAD: every cell 0)
     const float range = mx - mn;
     // y = fma(x, scale4, off4) is monotone in x; the rounding of off4 shifts every y by the same
     // amount, at most 2^-24 * mn * scale4 -- kept below one quarter-bin unit by the guard (the top
@@ -1121,17 +1123,23 @@ __device__ __forceinline__ void qmax_cells(unsigned wraw, unsigned colmask, unsi
         float c4 = (e >= 2) ? QA[e - 2] : (e == 1 ? l1a : l1b);               // (i-1, j-2)
         if constexpr (DMAX) { c3 += x3; c4 += x4; }
         const float mx = fmaxf(fmaxf(c2, c3), c4);
-        float vgap;
+        float q;
         if constexpr (EQG) {
-            vgap = fmaxf(mx - go, 0.0f);
+            // match: mx + 1; gap: max(mx - g, 0).  mx >= 0, so both are max(mx + t, 0) with t = +1 or -g
+            // picked by the recurrence bit: sign-extend the bit, blend the two constants (v_bfe_i32 +
+            // v_bfi_b32 instead of and / compare / select), one add, one max -- same f32 operations on
+            // the same values as the two-branch form
+            const int m = __builtin_amdgcn_sbfe((int)w, e, 1);
+            const float t = __int_as_float((m & __float_as_int(1.0f)) | (~m & __float_as_int(-go)));
+            q = fmaxf(mx + t, 0.0f);
         } else {
             const float a2 = (e >= 1) ? PA[e - 1] : p1a;
             float a3 = (e >= 1) ? PB[e - 1] : p2a;
             float a4 = (e >= 2) ? PA[e - 2] : (e == 1 ? p1a : p1b);
             if constexpr (DMAX) { a3 += x3; a4 += x4; }
-            vgap = fmaxf(fmaxf(fmaxf(a2, a3), a4), 0.0f);
+            const float vgap = fmaxf(fmaxf(fmaxf(a2, a3), a4), 0.0f);
+            q = r ? (mx + 1.0f) : vgap;
         }
-        float q = r ? (mx + 1.0f) : vgap;
         // Columns 0, 1 and the columns right of the matrix must not count.  For Qmax the masked
         // recurrence bit does it alone: such a cell takes the gap branch, so it is <= a value an
         // existing cell already reported (never a new maximum), it feeds only cells further

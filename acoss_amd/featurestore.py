@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-__all__ = ["load_track", "save_track"]
+__all__ = ["load_track", "save_track", "save_matrices_h5", "load_matrices_h5"]
 
 
 def _load_h5(path):
@@ -65,3 +65,24 @@ def save_track(path, feats):
         else:
             flat[k] = np.asarray(v)
     np.savez(stem + ".npz", **flat)
+
+
+def save_matrices_h5(path, Ds):
+    """{name: (N, N) array} -> one HDF5 file with a dataset per name -- what the reference's
+    dd.io.save("<prefix>_Ds.h5", self.Ds) leaves on disk (algorithm_template.py:192; deepdish stores
+    plain ndarrays as plain datasets).  Returns False when h5py is not installed (the .npz cache is
+    always written)."""
+    try:
+        import h5py
+    except ImportError:
+        return False
+    with h5py.File(path, "w") as f:
+        for k, v in Ds.items():
+            f.create_dataset(k, data=np.asarray(v))
+    return True
+
+
+def load_matrices_h5(path):
+    """The reference's <prefix>_Ds.h5 (dd.io.load, algorithm_template.py:163-166) -> {name: array}."""
+    d = _load_h5(path)
+    return {k: np.asarray(v) for k, v in d.items() if isinstance(v, np.ndarray) or np.ndim(v) == 2}

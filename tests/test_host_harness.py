@@ -284,3 +284,88 @@ def test_earlyfusion_block_feature_oracle():
     np.testing.assert_allclose(bf["chromas"][7], oracle.ef_resize(hpcp[on[7]:on[27]].astype(np.float64), 40).ravel(), rtol=1e-6)
 
 
+
+
+class _FakeH5(object):
+    """A stand-in for the h5py module (absent here) over an in-memory tree: just enough of File /
+    Group / Dataset / attrs for acoss_amd.featurestore's HDF5 branch -- deepdish layout: arrays are
+    datasets, sub-dictionaries are groups, scalars and strings sit in attributes."""
+    store = {}
+
+    class Dataset(object):
+        def __init__(self, a):
+            self.a = np.asarray(a)
+
+        def __getitem__(self, key):
+            return self.a[key] if key != () else (self.a if self.a.ndim else self.a[()])
+
+    class Group(object):
+        def __init__(self, tree=None):
+            self.tree = tree if tree is not None else {"__attrs__": {}}
+            self.attrs = self.tree.setdefault("__attrs__", {})
+
+        def items(self):
+            for k, v in self.tree.items():
+                if k == "__attrs__":
+                    continue
+                yield k, (_FakeH5.Group(v) if isinstance(v, dict) else _FakeH5.Dataset(v))
+
+        def create_dataset(self, name, data):
+            self.tree[name] = np.array(data)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    @classmethod
+    def File(cls, path, mode="r"):
+        if mode == "w":
+            cls.store[path] = {"__attrs__": {}}
+        return cls.Group(cls.store[path])
+
+
+def test_hdf5_feature_store_and_cache_branch(tmp_path, monkeypatch):
+    """The .h5 paths of the feature store and of the distance-matrix cache (reference README.md:116-150,
+    algorithm_template.py:90,163-166,192) through a stand-in h5py: track files in deepdish layout are
+    read (nested groups, attribute scalars, byte strings), <prefix>_Ds.h5 is written next to the .npz
+    and read back by all_pairwise(precomputed=True) when only the reference's file exists."""
+    import sys
+    from acoss_amd import featurestore
+    from acoss_amd.algorithms.algorithm_template import CoverAlgorithm
+    monkeypatch.setitem(sys.modules, "h5py", _FakeH5)
+    rng = np.random.default_rng(0)
+    labels = ["a", "a", "b"]
+    csv, root = _toy_dataset(tmp_path, labels)
+    for k, l in enumerate(labels):
+        os.remove(root + "%s/t%d.npz" % (l, k))
+        path = root + "%s/t%d.h5" % (l, k)
+        open(path, "wb").close()
+        _FakeH5.store[path] = {"__attrs__": {"label": l.encode(), "track_id": ("t%d" % k).encode()},
+                               "hpcp": rng.random((50, 12)).astype(np.float32),
+                               "madmom_features": {"__attrs__": {}, "onsets": np.arange(5)}}
+    d = featurestore.load_track(root + "a/t0.h5")
+    assert d["label"] == "a" and d["track_id"] == "t0" and d["hpcp"].shape == (50, 12)
+    assert np.array_equal(d["madmom_features"]["onsets"], np.arange(5))
+    monkeypatch.chdir(tmp_path)
+
+    class Toy(CoverAlgorithm):
+        def similarity(self, idxs):
+            self.Ds["main"][idxs[:, 0], idxs[:, 1]] = 1.0 + idxs[:, 0] + 10.0 * idxs[:, 1]
+
+    toy = Toy(csv, name="Toy", datapath=root, shortname="h5")
+    toy.all_pairwise(symmetric=True)
+    assert toy.cliques == {"a": {0, 1}, "b": {2}}
+    want = np.array(toy.Ds["main"])
+    assert os.path.exists("cache/Toy_h5_Ds.npz") and "cache/Toy_h5_Ds.h5" in _FakeH5.store
+    assert np.array_equal(_FakeH5.store["cache/Toy_h5_Ds.h5"]["main"], want)
+    os.remove("cache/Toy_h5_Ds.npz")
+    open("cache/Toy_h5_Ds.h5", "wb").close()
+    again = Toy(csv, name="Toy", datapath=root, shortname="h5")
+    again.all_pairwise(symmetric=True, precomputed=True)
+    assert np.array_equal(np.array(again.Ds["main"]), want)
+    # without h5py the HDF5 branch fails loudly and names the converter
+    monkeypatch.setitem(sys.modules, "h5py", None)
+    with pytest.raises(IOError):
+        featurestore.load_track(root + "a/t0.h5")
