@@ -390,25 +390,25 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
     static_assert(DPL >= 4 && DPL <= 16 && (DPL & (DPL - 1)) == 0, "BINS must be 256, 512 or 1024");
     static_assert(BPL >= 1 && (COPIES & (COPIES - 1)) == 0 && COPIES <= 8, "COPIES must be 1, 2, 4 or 8 with >= 64 bins");
     const float INF = __builtin_inff();
-    // ---- value range over the finite cells.  NEGPAD rows (squared distances, >= +0): the range starts
-    // at 0 -- no minimum pass at all; the bins below the row's true minimum stay empty (a sixth of
-    // them on i.i.d. chroma, fewer on real tracks, whose best matches are near 0), which costs less
-    // than 32 v_min_u32 and a wave reduction.
-    unsigned mnu = NEGPAD ? 0u : 0xFFFFFFFFu;
+    // ---- value range over the finite cells
+    // (measured: starting the NEGPAD range at 0 instead of the row minimum saves the 32 v_min_u32 but
+    // leaves a sixth of the bins empty -- 100.5 vs 99.7 ms per 8192 pairs, no gain)
+    unsigned mnu = 0xFFFFFFFFu;
     int mxb = (int)0x80000000;
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         const unsigned b = __float_as_uint(x[t]);
-        if constexpr (!NEGPAD) mnu = b < mnu ? b : mnu;
+        mnu = b < mnu ? b : mnu;
         const int bb = NEGPAD ? (int)b : (int)(b + 0x00800000u);
         mxb = bb > mxb ? bb : mxb;
     }
-    if constexpr (!NEGPAD) mnu = (unsigned)__builtin_amdgcn_readlane(wave_scan_bits((int)mnu, -1, OpMinU()), 63);
+    mnu = (unsigned)__builtin_amdgcn_readlane(wave_scan_bits((int)mnu, -1, OpMinU()), 63);
     mxb = __builtin_amdgcn_readlane(wave_scan_bits(mxb, (int)0x80000000, OpMaxI()), 63);
     const float mn = __uint_as_float(mnu);
     const float mx = __uint_as_float(NEGPAD ? (unsigned)mxb : (unsigned)mxb - 0x00800000u);
     if (mxb < 0) return false;                       // no finite cell at all
-    if (!(mn < mx)) { slo = mn; shi = mn; return true; }   // every finite cell equal (NEGPAD: every cell 0)
+    if (NEGPAD && (int)mnu < 0) return false;        // (only pads: cannot happen for a row of the matrix)
+    if (!(mn < mx)) { slo = mn; shi = mn; return true; }   // every finite cell equal
     const float range = mx - mn;
     // y = fma(x, scale4, off4) is monotone in x; the rounding of off4 shifts every y by the same
     // amount, at most 2^-24 * mn * scale4 -- kept below one quarter-bin unit by the guard (the top
