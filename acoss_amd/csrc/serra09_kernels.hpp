@@ -1259,6 +1259,98 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
     if (lane == 0) out[(size_t)blockIdx.x * out_stride] = best;
 }
 
+// ------------------------------------------------------------------------------------
+// K3c: Qmax with the default penalties (gamma_o = gamma_e = 0.5) in PACKED 16-bit integers.  Every Q
+// value is a multiple of 0.5 and at most min(M, N) - 2 <= 2039: in half-units it fits int16, and one
+// v_pk_* instruction updates two cells.  A lane still owns CPL contiguous columns; register k holds
+// the columns k (low half) and k + CPL/2 (high half), so that the (i-1, j-1), (i-2, j-1), (i-1, j-2)
+// predecessors of register k are simply registers k-1 / k-2 of the previous rows (the first two are
+// stitched from the neighbour lane with one funnel shift each).  A cell is max(mx + t, 0) with
+// t = +2 (match) / -1 (gap) half-units = 3 bit - 1, the bits of both halves spread by one shift + and.
+// Exactly the arithmetic of qmax_bits_kernel<true, false, CPL>: integers instead of exact floats.
+// ------------------------------------------------------------------------------------
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i16x2 as_i16x2(unsigned v) { return __builtin_bit_cast(i16x2, v); }
+__device__ __forceinline__ unsigned as_u32(i16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+template <int CPL>
+__global__ __launch_bounds__(64) void qmax_bits_h16_kernel(const PairDesc *__restrict__ pd,
+                                                           const unsigned long long *__restrict__ bits,
+                                                           float *__restrict__ out, int out_stride, int dp_start)
+{
+    constexpr int NR = CPL / 2;                                  // packed registers per row
+    const int lane = threadIdx.x;
+    const PairDesc P = pd[blockIdx.x];
+    int Me = P.Mq, Ne = P.Mr;
+    if (dp_start == 3) { Me -= 1; Ne -= 1; }
+    const int ndw = 2 * P.nw;
+    const unsigned *rows = reinterpret_cast<const unsigned *>(bits + P.offT);
+    unsigned colmask = 0u;
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+        const int j = CPL * lane + e;
+        if (j >= 2 && j < Ne) colmask |= (1u << e);
+    }
+    unsigned Q1[NR], Q2[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { Q1[k] = 0u; Q2[k] = 0u; }
+    i16x2 best = {0, 0};
+    const int prev = (lane + 63) & 63;
+    const int dw0 = (CPL * lane) >> 5, bit0 = (CPL * lane) & 31;
+    const bool has0 = dw0 < ndw, has1 = dw0 + 1 < ndw;
+    auto load_row = [&](int i, unsigned &d0, unsigned &d1) {
+        d0 = 0u; d1 = 0u;
+        if (i < Me) {
+            const unsigned *r = rows + (size_t)i * ndw;
+            if (has0) d0 = r[dw0];
+            if (has1) d1 = r[dw0 + 1];
+        }
+    };
+    const i16x2 three = {3, 3}, minus1 = {-1, -1}, zero = {0, 0};
+    // One DP row: QA = row i-1, QB = row i-2 (overwritten with row i)
+    auto dp_row = [&](int i, unsigned d0, unsigned d1, unsigned (&QA)[NR], unsigned (&QB)[NR]) {
+        const int sh = (BAND - 1) - (i & (BAND - 1));
+        const unsigned w = __builtin_amdgcn_alignbit(d1, d0, bit0 + sh) & colmask;
+        // neighbour lane's last registers: its columns CPL-1 / CPL-2 are the HIGH halves of registers NR-1 / NR-2
+        unsigned nA1 = (unsigned)__shfl((int)QA[NR - 1], prev, 64), nA2 = (unsigned)__shfl((int)QA[NR - 2], prev, 64);
+        unsigned nB1 = (unsigned)__shfl((int)QB[NR - 1], prev, 64);
+        if (lane == 0) { nA1 = 0u; nA2 = 0u; nB1 = 0u; }
+        // register "-1": low half = column -1 (neighbour's high half of NR-1), high half = column NR-1 (own low half of NR-1)
+        const unsigned a_m1 = __builtin_amdgcn_alignbit(QA[NR - 1], nA1, 16);
+        const unsigned a_m2 = __builtin_amdgcn_alignbit(QA[NR - 2], nA2, 16);
+        const unsigned b_m1 = __builtin_amdgcn_alignbit(QB[NR - 1], nB1, 16);
+#pragma unroll
+        for (int k = NR - 1; k >= 0; --k) {
+            const i16x2 c2 = as_i16x2(k >= 1 ? QA[k - 1] : a_m1);                          // (i-1, j-1)
+            const i16x2 c3 = as_i16x2(k >= 1 ? QB[k - 1] : b_m1);                          // (i-2, j-1)
+            const i16x2 c4 = as_i16x2(k >= 2 ? QA[k - 2] : (k == 1 ? a_m1 : a_m2));        // (i-1, j-2)
+            const i16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(c2, c3), c4);
+            unsigned sp;                                     // recurrence bit of column k -> low half, of column k + NR -> high half
+            if constexpr (NR == 16) sp = (w >> k) & 0x00010001u;
+            else sp = ((w >> k) & 1u) | (((w >> (k + NR)) & 1u) << 16);
+            const i16x2 t = as_i16x2(sp) * three + minus1;
+            const i16x2 q = __builtin_elementwise_max(mx + t, zero);
+            QB[k] = as_u32(q);
+            best = __builtin_elementwise_max(best, q);
+        }
+    };
+    unsigned a0, a1, b0, b1, c0, c1, d0, d1;
+    load_row(2, a0, a1); load_row(3, b0, b1); load_row(4, c0, c1); load_row(5, d0, d1);
+    for (int i = 2; i < Me; i += 4) {
+        unsigned n0, n1;
+        if (i < Me) { load_row(i + 4, n0, n1); dp_row(i, a0, a1, Q1, Q2); a0 = n0; a1 = n1; }
+        if (i + 1 < Me) { load_row(i + 5, n0, n1); dp_row(i + 1, b0, b1, Q2, Q1); b0 = n0; b1 = n1; }
+        if (i + 2 < Me) { load_row(i + 6, n0, n1); dp_row(i + 2, c0, c1, Q1, Q2); c0 = n0; c1 = n1; }
+        if (i + 3 < Me) { load_row(i + 7, n0, n1); dp_row(i + 3, d0, d1, Q2, Q1); d0 = n0; d1 = n1; }
+    }
+    int bh = best.x > best.y ? best.x : best.y;
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int t = __shfl_xor(bh, o, 64);
+        bh = bh > t ? bh : t;
+    }
+    if (lane == 0) out[(size_t)blockIdx.x * out_stride] = 0.5f * (float)bh;
+}
+
 static __global__ void sqrt_probe_kernel(const float *in, float *out, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
