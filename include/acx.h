@@ -93,7 +93,13 @@ typedef struct {
     float gamma_o;       /* disOnset, default 0.5 */
     float gamma_e;       /* disExtension, default 0.5 */
     int32_t embed_full;  /* 0: M = T - m*tau   1: M = T - (m-1)*tau */
-    int32_t pct_mode;    /* 0 linear  1 essentia d0+d1  2 lower  3 nearest */
+    int32_t pct_mode;    /* 0 linear  1 essentia d0+d1  2 lower  3 nearest.  Position k = (n - 1) kappa; 0 and 1 both
+                            interpolate d_(floor k) (ceil k - k) + d_(ceil k) (k - floor k) and differ only when k is an
+                            exact integer: 1 evaluates the formula as recalled from essentia -- both weights are 0, the
+                            threshold is 0 and the row stays empty (rows of n - 1 = 200, 400, ... cells at kappa =
+                            0.095) --, 0 (the default, a DELIBERATE deviation until the pin kit says otherwise)
+                            returns d_(k), the value the interpolation converges to.
+                            tests/test_oracle_serra09.py::test_integer_percentile_position pins both. */
     int32_t oti_target;  /* 0 rotate reference  1 rotate query */
     int32_t dp_start;    /* 2 or 3 */
     int32_t inclusive;   /* 1: d <= eps  0: d < eps */

@@ -285,6 +285,23 @@ def test_stack_stride_and_large_stacks(ctx, kw):
     assert np.array_equal(b, oracle.serra09_pairs(d["frames"], d["offsets"], pr))
 
 
+def test_integer_percentile_position(ctx):
+    """n - 1 = 200 cells per row: the percentile position is an exact integer, where pct_mode 0 and 1
+    differ (include/acx.h); both modes bit-exact vs the oracle, mode 1 yields empty plots."""
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    rng = np.random.default_rng(200)
+    tracks = [synth._frame_max_normalise(rng.random((T, 12))) for T in (210, 210, 410, 211)]
+    frames, offsets = synth.pack(tracks)
+    d = dict(frames=frames, offsets=offsets)
+    ctx.upload_pool(frames, offsets)
+    for mode in (0, 1):
+        for (i, j) in [(0, 1), (2, 0), (0, 2), (3, 0), (0, 3)]:
+            _compare_pair(ctx, d, i, j, _lib.serra09_params(pct_mode=mode), oracle.serra09_params(pct_mode=mode), "pct%d(%d,%d)" % (mode, i, j))
+    assert ctx.serra09_pairs(np.array([[0, 1]], np.int32), _lib.serra09_params(pct_mode=1))[0] == 0.0
+    assert ctx.serra09_pairs(np.array([[0, 1]], np.int32))[0] > 0.0
+
+
 def _planted(M, N, gaps=(), shift=0):
     R = np.zeros((M, N), np.uint8)
     for i in range(M):

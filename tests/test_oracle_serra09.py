@@ -154,3 +154,26 @@ def test_self_pair_scores_full_diagonal():
         x = synth._frame_max_normalise(rng.random((T, 12)))
         assert oracle.serra09_pair(x, x) == T - 9 - 2
         assert oracle.serra09_pair(x, x, oracle.serra09_params(arith="seq108")) == T - 9 - 2
+
+
+def test_integer_percentile_position():
+    """kappa = 0.095 and n - 1 = 200 cells per row put the percentile position k = 19.0 on an order
+    statistic.  pct_mode 0 (default) takes d_(19); pct_mode 1 evaluates the interpolation formula as
+    recalled from essentia, whose two weights are both 0 there: threshold 0, an empty recurrence plot
+    for rows of that length (include/acx.h documents the deliberate deviation of the default)."""
+    import oracle
+    from acoss_amd import synth
+    rng = np.random.default_rng(200)
+    q = synth._frame_max_normalise(rng.random((210, 12)))      # 201 embedded frames
+    r = synth._frame_max_normalise(rng.random((210, 12)))
+    s0, i0 = oracle.serra09_pair(q, r, oracle.serra09_params(pct_mode=0), want_intermediates=True)
+    s1, i1 = oracle.serra09_pair(q, r, oracle.serra09_params(pct_mode=1), want_intermediates=True)
+    d = np.sort(i0["d"], axis=1)
+    assert np.array_equal(i0["eps_q"], d[:, 19])
+    assert np.all(i1["eps_q"] == 0.0) and np.all(i1["eps_r"] == 0.0) and i1["R"].sum() == 0 and s1 == 0.0
+    assert i0["R"].sum() > 0 and s0 > 0.0
+    # one frame more: k = 19.095, both modes interpolate alike
+    q2 = synth._frame_max_normalise(rng.random((211, 12)))
+    a = oracle.serra09_pair(q2, q2[::-1].copy(), oracle.serra09_params(pct_mode=0))
+    b = oracle.serra09_pair(q2, q2[::-1].copy(), oracle.serra09_params(pct_mode=1))
+    assert a == b
