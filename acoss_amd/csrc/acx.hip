@@ -665,7 +665,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
         } else {
             hipLaunchKernelGGL(acx::ef_oti_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream, c->d_efpd, B, c->d_efmed);
             {
-                const int tiles_x = (maxN + 63) / 64, tiles_y = (maxM + 63) / 64;
+                const int tiles_x = (maxN + acx::EF_TILE - 1) / acx::EF_TILE, tiles_y = (maxM + acx::EF_TILE - 1) / acx::EF_TILE;
                 ProfScope ps(c, KS_EFGEMM, cells);
                 hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 3), dim3(256), 0, c->stream,
                                    c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,

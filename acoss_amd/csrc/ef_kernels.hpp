@@ -79,16 +79,20 @@ __global__ void ef_oti_kernel(EfPair *pd, int B, const double *__restrict__ med)
 }
 
 // ------------------------------------------------------------------------------------
-// E1: C[i][j] = epilogue( sum_k A[i][perm(k)] * B[j][k] ), 64 x 64 tile per workgroup,
-// 4 waves as 2 x 2, each wave 32 x 32 = 2 x 2 MFMA tiles.  K is walked in blocks of 48
-// (a multiple of the 12-bin chroma roll): the next block's 16-byte global loads are in flight
-// in registers while the current one is multiplied out of LDS (k-major, conflict-free operand
-// reads), two barriers per 48 k.  The blocked-OTI roll of the first song's chroma is applied as
-// a permutation of the LDS k-row on the way in.
+// E1: C[i][j] = epilogue( sum_k A[i][perm(k)] * B[j][k] ), 128 x 128 tile per workgroup,
+// 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles (16 accumulator tiles: every operand
+// read from LDS feeds four MFMAs -- an f32 MFMA blocks VALU / LDS issue on its SIMD, so the
+// instructions AROUND the MFMAs are what the GEMM loses time to).  K is walked in blocks of 24 (two
+// 12-bin groups of the chroma roll): the next block's 16-byte global loads are in flight in registers
+// while the current one is multiplied out of LDS (k-major, conflict-free operand reads), two
+// barriers per 24 k.  16 x 16 sub-tiles that lie entirely outside the matrix are skipped (wave-uniform),
+// so padding costs at most 15 rows / columns.  The blocked-OTI roll of the first song's chroma
+// is applied as a permutation of the LDS k-row on the way in.
 // feat: 0 mfcc (euclid), 1 ssm (euclid), 2 chroma (cosine, A rolled by oti).
 // ------------------------------------------------------------------------------------
-constexpr int EF_BK = 48;
-constexpr int EF_LP = 80;      // LDS pitch (k-major, 64 rows + pad; 80 % 32 == 16)
+constexpr int EF_BK = 24;
+constexpr int EF_TILE = 128;
+constexpr int EF_LP = 144;     // LDS pitch (k-major, 128 rows + pad; 144 % 32 == 16)
 
 __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ feat0, const float *__restrict__ feat1,
                                                       const float *__restrict__ feat2,
@@ -102,39 +106,40 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
     const EfPair P = pd[blockIdx.y];
     const int s = blockIdx.z;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int i0 = ty * 64, j0 = tx * 64;
+    const int i0 = ty * EF_TILE, j0 = tx * EF_TILE;
     if (i0 >= P.M || j0 >= P.N) return;
     const int K = s == 0 ? K0 : (s == 1 ? K1 : K2);
     const float *F = s == 0 ? feat0 : (s == 1 ? feat1 : feat2);
     const int rot = (s == 2) ? P.oti : 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int lr = lane & 15, lk = lane >> 4;
+    // 16-row / 16-column sub-tiles of this wave that hold at least one cell of the matrix
+    int na = (P.M - (i0 + 64 * wr) + 15) / 16, nb = (P.N - (j0 + 64 * wc) + 15) / 16;
+    na = na < 0 ? 0 : (na > 4 ? 4 : na);
+    nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
 
-    f32x4 acc[2][2];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging: thread -> (row = tid / 4, 12 consecutive k = 12 * (tid % 4) ...) as three float4
-    const int srow = tid >> 2, sk = (tid & 3) * 12;
+    // staging: thread -> (row = tid / 2, 12 consecutive k = 12 * (tid % 2) ...) as three float4 per operand
+    const int srow = tid >> 1, sk = (tid & 1) * 12;
     const bool rowa = i0 + srow < P.M, rowb = j0 + srow < P.N;
-    const float *Ap = F + (boff[P.q] + (rowa ? i0 + srow : 0)) * K + sk;
-    const float *Bp = F + (boff[P.r] + (rowb ? j0 + srow : 0)) * K + sk;
+    const float *ap = F + (boff[P.q] + (rowa ? i0 + srow : 0)) * K + sk;      // (rows past the matrix read row 0; never stored)
+    const float *bp = F + (boff[P.r] + (rowb ? j0 + srow : 0)) * K + sk;
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     float ra[12], rb[12];
-    // Every instruction here competes with the MFMAs for the SIMD (an f32 MFMA blocks VALU and LDS
-    // issue), so the staging is kept to the bare loads / stores: full 48-k blocks take the unchecked
-    // path (three dwordx4 per operand off a running pointer), only the last partial block checks k.
-    const float *ap = Ap, *bp = Bp;                   // start of the block being loaded
     auto gload_full = [&]() {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const f32x4 va = *reinterpret_cast<const f32x4u *>(ap + 4 * q);
             const f32x4 vb = *reinterpret_cast<const f32x4u *>(bp + 4 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { ra[4 * q + e] = va[e]; rb[4 * q + e] = vb[e]; }   // (rows past the matrix read row 0; never stored)
+            for (int e = 0; e < 4; ++e) { ra[4 * q + e] = va[e]; rb[4 * q + e] = vb[e]; }
         }
         ap += EF_BK;
         bp += EF_BK;
@@ -151,11 +156,10 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
         if (k0 + EF_BK <= K) gload_full();            // workgroup-uniform
         else gload_tail(k0);
     };
-    // k-row k of the LDS tiles keeps its 64 rows XORed with 16 (k / 12 mod 4): the four threads that
-    // stage one row (k = 12 q + e, q = 0..3) then land in four different bank groups -- without it all
-    // four hit the same bank (12 * 80 = 0 mod 64) and half the LDS cycles were conflicts -- while the
-    // operand reads (one k / 12 group per MFMA step) stay conflict free
-    const int swrow = srow ^ (16 * (tid & 3));
+    // k-rows of the second 12-group keep their 128 rows XORed with 16: the two threads that stage one
+    // row then land in different bank groups (12 * 144 = 0 mod 32), the operand reads (one group per
+    // MFMA step) stay conflict free
+    const int swrow = srow ^ (16 * (tid & 1));
     float *as0 = As + sk * EF_LP + swrow, *bs0 = Bs + sk * EF_LP + swrow;
     auto lstore = [&]() {
         if (rot == 0) {                                // workgroup-uniform: all offsets are immediates
@@ -178,46 +182,58 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
         if (k0 + EF_BK < K) gload(k0 + EF_BK);           // in flight during the MFMAs below
 #pragma unroll
         for (int kb = 0; kb < EF_BK / 4; ++kb) {
-            float av[2], bv[2];
+            const int sw = 16 * (kb / 3);                 // the XOR of this k-group
+            float av[4], bv[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) av[a] = As[(4 * kb + lk) * EF_LP + ((32 * wr + 16 * a + lr) ^ (16 * ((kb / 3) & 3)))];
+            for (int a = 0; a < 4; ++a) av[a] = As[(4 * kb + lk) * EF_LP + ((64 * wr + 16 * a + lr) ^ sw)];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bv[b] = Bs[(4 * kb + lk) * EF_LP + ((32 * wc + 16 * b + lr) ^ (16 * ((kb / 3) & 3)))];
+            for (int b = 0; b < 4; ++b) bv[b] = Bs[(4 * kb + lk) * EF_LP + ((64 * wc + 16 * b + lr) ^ sw)];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 4; ++a)
+                if (a < na) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < 4; ++b)
+                        if (b < nb) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                }
         }
         __syncthreads();
     }
-    // epilogue + stores (C row-major and C^T)
+    // epilogue + stores: C row-major (a lane's 16 lanes-in-a-row write 64 contiguous bytes) and C^T
+    // (a lane's four accumulator rows are four consecutive columns of C^T: one 16-byte store)
     const float *nrm = s == 0 ? nrm0 : nrm1;
     float *C = scratch + ef_c_off(P, s);
     float *CT = scratch + ef_ct_off(P, s);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b) {
+            if (!(a < na && b < nb)) continue;
+            const int ib = i0 + 64 * wr + 16 * a + 4 * lk;
+            const int j = j0 + 64 * wc + 16 * b + lr;
+            float v[4];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int i = i0 + 32 * wr + 16 * a + 4 * lk + reg;
-                const int j = j0 + 32 * wc + 16 * b + lr;
-                if (i < P.M && j < P.N) {
-                    const float dot = acc[a][b][reg];
-                    float v;
-                    if (s == 2) {
-                        v = 1.0f - dot;
-                    } else {
-                        const float nx = nrm[boff[P.q] + i], ny = nrm[boff[P.r] + j];
-                        float t = (nx + ny) - 2.0f * dot;
-                        if (t < 0.0f) t = 0.0f;
-                        v = __builtin_sqrtf(t);
-                    }
-                    C[(size_t)i * P.pitchC + j] = v;
-                    CT[(size_t)j * P.pitchT + i] = v;
+                const int i = ib + reg;
+                const float dot = acc[a][b][reg];
+                if (s == 2) {
+                    v[reg] = 1.0f - dot;
+                } else {
+                    const float nx = (i < P.M) ? nrm[boff[P.q] + i] : 0.0f, ny = (j < P.N) ? nrm[boff[P.r] + j] : 0.0f;
+                    float t = (nx + ny) - 2.0f * dot;
+                    if (t < 0.0f) t = 0.0f;
+                    v[reg] = __builtin_sqrtf(t);
                 }
+                if (i < P.M && j < P.N) C[(size_t)i * P.pitchC + j] = v[reg];
             }
+            if (j < P.N) {
+                float *ct = CT + (size_t)j * P.pitchT + ib;
+                if (ib + 3 < P.M) *reinterpret_cast<float4 *>(ct) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        if (ib + reg < P.M) ct[reg] = v[reg];
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------

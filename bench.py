@@ -78,8 +78,16 @@ def _cpu_chunk(chunk):
     return oracle.serra09_pairs(_CPU["frames"], _CPU["offsets"], chunk)
 
 
-def cpu_baseline(frames, offsets, pairs, budget_s=15.0):
-    """Oracle on all host cores, process fan-out (fork: no GPU state exists yet)."""
+def _cpu_init():
+    import oracle
+    oracle.lib()
+
+
+def cpu_baseline(frames, offsets, pairs, budget_s=20.0):
+    """Oracle on all host cores, process fan-out (fork: no GPU state exists yet).  Bounded: a pilot round of
+    one pair per worker measures the rate under full load (the oracle streams ~100 MB per pair: with
+    every core busy it is memory-bound and far slower per core than alone), the timed round is sized
+    from it to about `budget_s` seconds -- or is the pilot itself when that already took longer."""
     import multiprocessing as mp
     import oracle
     oracle.lib()
@@ -88,17 +96,24 @@ def cpu_baseline(frames, offsets, pairs, budget_s=15.0):
     t0 = time.perf_counter()
     one = oracle.serra09_pairs(frames, offsets, pairs[:2])
     t_pair = (time.perf_counter() - t0) / 2
-    n = int(min(len(pairs), max(cores, budget_s * cores / t_pair)))
-    nchunks = max(45, cores)
-    n = max(nchunks, n - n % nchunks)
-    sample = np.ascontiguousarray(pairs[:n])
-    chunks = [c for c in np.array_split(sample, nchunks) if len(c)]
-    with mp.get_context("fork").Pool(cores) as pool:
-        pool.map(_cpu_chunk, [c[:1] for c in chunks[:cores]])          # workers up, library loaded
+    with mp.get_context("fork").Pool(cores, initializer=_cpu_init) as pool:
+        nchunks = max(45, cores)                                  # the reference's joblib scheme has 45 chunks
+        pilot = np.ascontiguousarray(pairs[:nchunks])
         t0 = time.perf_counter()
-        parts = pool.map(_cpu_chunk, chunks, chunksize=1)
+        parts = pool.map(_cpu_chunk, [pilot[k:k + 1] for k in range(len(pilot))], chunksize=1)
         dt = time.perf_counter() - t0
-    scores = np.concatenate(parts)
+        sample, scores = pilot, np.concatenate(parts)
+        per_chunk = int(budget_s / dt) if dt > 0 else 0
+        if per_chunk >= 2:                                         # room for a longer timed round
+            n = min(len(pairs), nchunks * per_chunk)
+            n -= n % nchunks
+            sample = np.ascontiguousarray(pairs[:n])
+            chunks = [c for c in np.array_split(sample, nchunks) if len(c)]
+            t0 = time.perf_counter()
+            parts = pool.map(_cpu_chunk, chunks, chunksize=1)
+            dt = time.perf_counter() - t0
+            scores = np.concatenate(parts)
+    n = len(sample)
     assert np.array_equal(scores[:2], one)
     model = ""
     try:
@@ -110,8 +125,8 @@ def cpu_baseline(frames, offsets, pairs, budget_s=15.0):
     return sample, scores, {
         "value": round(n / dt, 3), "unit": "track-pairs/s", "cores": cores, "kind": "port",
         "sample": "first %d pairs of step 0's tiles of the same workload (T=%d), C oracle -O2, %d worker "
-                  "processes over %d chunks (reference scheme: 45 joblib chunks); scores bit-identical to the GPU's"
-                  % (n, T_FRAMES, cores, len(chunks)),
+                  "processes over %d chunks (reference scheme: 45 joblib chunks), %.1f s; scores bit-identical to the GPU's"
+                  % (n, T_FRAMES, cores, max(45, cores), dt),
         "value_1core": round(1.0 / t_pair, 3), "cpu_model": model, "host_cpus": cores}
 
 

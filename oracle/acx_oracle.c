@@ -36,7 +36,7 @@
  * dominate (measured on the 256-core bench host: 21 pairs/s for 256 workers vs 2 pairs/s for one). */
 __attribute__((constructor)) static void acx_o_init(void)
 {
-    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024);      /* glibc's maximum: the 16 MB matrices of a T = 2000 pair stay below it */
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     mallopt(M_TOP_PAD, 64 << 20);
 }

@@ -102,7 +102,9 @@ def _check_pair(ctx, i, j, f1, f2, ref_csms=None, ref_fused=None, ref_scores=Non
     ws = np.zeros_like(d["csm"][0])
     for k in range(3):
         ws += oracle.get_wcsm(d["csm"][k], 10, 10)
-    np.testing.assert_allclose(d["fused"], np.exp(-ws), rtol=2e-3, atol=1e-6)
+    # f32 on both sides; the kernel weights are exp(-C^2 / (2 (eps / 2)^2)) with exponents of up to ~100, so a
+    # 1e-7 relative difference in the neighbourhood means (summation order) shows as ~1e-5 in W
+    np.testing.assert_allclose(d["fused"], np.exp(-ws), rtol=2e-4, atol=1e-6)
     assert round(oracle.sw_constrained(oracle.csm_to_binary(d["fused"], 0.1)) * 10) == round(float(d["scores"][3]) * 10)
     want = ref_scores if ref_scores is not None else np.array([oscores[s] for s in ("mfccs", "ssms", "chromas", "early")])
     assert np.all(np.abs(d["scores"] - want) <= 2.0), (d["scores"], want)
