@@ -1,4 +1,5 @@
-"""Ad-hoc timing of the device SNF loop (acx_snf_fuse).  usage: bench_snf.py [n] [m]"""
+"""Ad-hoc timing of the similarity-network-fusion post-step (acx_snf_fuse_dists) at DA-TACOS size.
+usage: python scripts/bench_snf.py [n] [m]"""
 import sys
 import time
 
@@ -6,19 +7,17 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from acoss_amd import _lib  # noqa: E402
-from acoss_amd.algorithms import similarity_fusion as sf  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-m = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 12000
+m = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rng = np.random.default_rng(0)
+Ds = []
+for _ in range(m):
+    D = rng.random((n, n), dtype=np.float32).astype(np.float64)
+    Ds.append(D + D.T)
 ctx = _lib.Context(0)
-Scores = [rng.random((n, n)) for _ in range(m)]
-t0 = time.time()
-Ws = [sf.getW(D, 20) for D in Scores]
-t1 = time.time()
-lists = [sf._knn_lists(W, 20) for W in Ws]
-t2 = time.time()
-out = ctx.snf_fuse(Ws, [l[0] for l in lists], [l[1] for l in lists], 20, 1.0)
-t3 = time.time()
-print("n=%d m=%d: getW %.2f s, neighbour lists %.2f s (host), device loop (20 sweeps, incl. transfers) %.2f s" % (n, m, t1 - t0, t2 - t1, t3 - t2))
-print("checksum %.6f" % float(out.sum()))
+for rep in range(2):
+    t0 = time.time()
+    _, F = ctx.snf_fuse_dists(Ds, K=20, niters=20, reg_diag=1.0)
+    print("n=%d m=%d: %.2f s (affinity matrices, kNN lists, 20 sweeps, transfers)" % (n, m, time.time() - t0))
+ctx.close()
