@@ -193,3 +193,59 @@ def test_pool_scale_15000_tracks(ctx):
     assert np.array_equal(big, small)
     _record("pool_15000x2000", {"pairs_run": int(len(pairs)), "oracle_checked": 64, "tail_pool_pairs": int(len(iu)),
                                 "result": "bit-identical"})
+
+
+def test_simple_dataset_scale_15000(ctx):
+    """BASELINE configs[3] at dataset scale: 15 000 tracks of 150-250 pooled frames, ALL 224 985 000
+    ordered pairs through the pair grid into a 15 000 x 15 000 matrix (acx_pair_grid: the pair list
+    never exists on the host); 64 sampled cells against the oracle, 1e-11 relative (f32 store)."""
+    import time
+    import oracle
+    from acoss_amd import _lib
+    N = 15000
+    rng = np.random.default_rng(15000)
+    lens = rng.integers(150, 251, N)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    frames = rng.random((int(offs[-1]), 12))
+    frames /= np.linalg.norm(frames, axis=1, keepdims=True)          # unit frames, like Simple.smooth leaves them
+    ctx.upload_pool_f64(frames, offs)
+    D = np.zeros((N, N), np.float32)
+    t0 = time.time()
+    ctx.pair_grid(_lib.ALGO_SIMPLE, False, _lib.SimpleParams(10, 1), [D], mirror=False)
+    dt = time.time() - t0
+    assert np.all(np.isfinite(D)) and np.all(np.diag(D) == 0.0)
+    off_diag = D[~np.eye(N, dtype=bool)] if N <= 2000 else D[0, 1:]
+    assert np.all(off_diag < 0.0)                                     # -median of squared distances
+    ii = rng.integers(0, N, 64)
+    jj = (ii + rng.integers(1, N, 64)) % N
+    for i, j in zip(ii, jj):
+        ref = oracle.simple_pair(frames[offs[i]:offs[i + 1]].T, frames[offs[j]:offs[j + 1]].T)
+        assert abs(float(D[i, j]) - ref) <= 2e-7 * abs(ref), (i, j, D[i, j], ref)      # f32 store of an f64 result
+    pr = np.stack([ii, jj], 1).astype(np.int32)
+    np.testing.assert_array_equal(D[ii, jj], ctx.simple_pairs(pr, 10).astype(np.float32))
+    _record("simple_15000", {"tracks": N, "ordered_pairs": N * (N - 1), "seconds_grid_incl_scatter": round(dt, 2),
+                             "pairs_per_s": round(N * (N - 1) / dt), "oracle_checked": 64})
+
+
+def test_earlyfusion_scale_1200(ctx):
+    """BASELINE configs[4] per-track shape at a pool that no longer fits any cache (1 200 tracks of
+    300-500 blocks: 4.5 GB of block features): 30 000 random pairs; 6 against the oracle (scores
+    within +-2 tenths-exact units like the chain tests), the rest through oracle-free properties."""
+    import oracle
+    from acoss_amd import synth
+    tracks = synth.earlyfusion_set(1200, seed=77, nb_range=(300, 500))
+    ctx.ef_upload_pool(tracks)
+    rng = np.random.default_rng(3)
+    pairs = rng.integers(0, 1200, (30000, 2)).astype(np.int32)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    sc = ctx.earlyfusion_pairs(pairs)
+    assert sc.shape == (len(pairs), 4) and np.all(np.isfinite(sc)) and np.all(sc >= 0.0)
+    assert np.all(np.abs(sc * 10 - np.round(sc * 10)) < 1e-3)         # Smith-Waterman scores are tenths
+    for k in range(6):
+        i, j = pairs[k]
+        o = oracle.earlyfusion_pair(tracks[i], tracks[j], kappa=0.1, K=10)[0]
+        want = np.array([o[s] for s in ("mfccs", "ssms", "chromas", "early")])
+        assert np.all(np.abs(sc[k] - want) <= 2.0), (sc[k], want)
+    again = ctx.earlyfusion_pairs(pairs[:500][::-1].copy())
+    assert np.array_equal(again, sc[:500][::-1])
+    _record("earlyfusion_1200", {"tracks": 1200, "pairs_run": int(len(pairs)), "oracle_checked": 6})
