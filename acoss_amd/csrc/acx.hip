@@ -755,9 +755,12 @@ template <int L>
 int launch_simple(acx_ctx *c, int n, size_t smem, int oti)
 {
     auto kern = acx::simple_kernel<L>;
-    ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(n), dim3(64), smem, c->stream, c->d_frames64, c->d_toff64, c->d_prof64, c->d_wn64, c->d_pairs,
-                       c->d_out64, oti);
+    // waves (= pairs) per workgroup: SIMPLE_WPB, fewer when the tracks are long enough for their LDS to run out
+    int wpb = acx::SIMPLE_WPB;
+    while (wpb > 1 && smem * wpb > 160 * 1024) --wpb;
+    ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem * wpb)));
+    hipLaunchKernelGGL(kern, dim3((n + wpb - 1) / wpb), dim3(64 * wpb), smem * wpb, c->stream, c->d_frames64, c->d_toff64,
+                       c->d_prof64, c->d_wn64, c->d_pairs, c->d_out64, oti, n, (int)smem);
     return ACX_OK;
 }
 
@@ -1214,16 +1217,28 @@ int acx_simple_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, int32_t sslen,
             maxn = std::max(maxn, n);
         }
     }
-    const size_t smem = 64 + sizeof(double) * 3 * (size_t)maxn;        // two edge rows + the profile keys
+    const size_t smem = 64 + sizeof(double) * 3 * (size_t)maxn;        // per wave: two edge rows + the profile keys
     int rcw = ensure_winnorm(c, sslen);
     if (rcw != ACX_OK) return rcw;
     const int64_t chunk = 1 << 22;
     int rc;
     if ((rc = ensure(c, c->d_pairs, c->pairs_cap, (size_t)2 * std::min(K, chunk))) != ACX_OK) return rc;
     if ((rc = ensure(c, c->d_out64, c->out64_cap, (size_t)std::min(K, chunk))) != ACX_OK) return rc;
+    std::vector<int32_t> order, sorted, bucket;
+    std::vector<double> tmp;
     for (int64_t k0 = 0; k0 < K; k0 += chunk) {
         const int n = (int)std::min(chunk, K - k0);
-        ACX_HIP(c, hipMemcpyAsync(c->d_pairs, pairs + 2 * k0, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, c->stream));
+        // sorted by the second track (then the first): neighbouring waves share the frames of B (scalar cache)
+        // (stable counting sort on the second index: O(n))
+        order.resize(n);
+        const int32_t *pp = pairs + 2 * k0;
+        bucket.assign((size_t)c->n_tracks64 + 1, 0);
+        for (int k = 0; k < n; ++k) ++bucket[(size_t)pp[2 * k + 1] + 1];
+        for (int t = 0; t < c->n_tracks64; ++t) bucket[t + 1] += bucket[t];
+        for (int k = 0; k < n; ++k) order[bucket[pp[2 * k + 1]]++] = k;
+        sorted.resize((size_t)2 * n);
+        for (int k = 0; k < n; ++k) { sorted[2 * k] = pp[2 * order[k]]; sorted[2 * k + 1] = pp[2 * order[k] + 1]; }
+        ACX_HIP(c, hipMemcpyAsync(c->d_pairs, sorted.data(), sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, c->stream));
         {
             ProfScope ps(c, KS_SIMPLE, n);
             switch (sslen) {
@@ -1235,8 +1250,10 @@ int acx_simple_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, int32_t sslen,
             if (rc != ACX_OK) return rc;
         }
         ACX_HIP(c, hipGetLastError());
-        ACX_HIP(c, hipMemcpyAsync(out + k0, c->d_out64, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        tmp.resize(n);
+        ACX_HIP(c, hipMemcpyAsync(tmp.data(), c->d_out64, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
         ACX_HIP(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < n; ++k) out[k0 + order[k]] = tmp[k];
         drain_profile(c);
     }
     return ACX_OK;

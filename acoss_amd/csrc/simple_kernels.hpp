@@ -80,18 +80,27 @@ __device__ __forceinline__ unsigned long long simple_select_key(const unsigned l
 }
 
 // pool: (sum n_t, 12) f64 time-major; prof: (n_tracks, 12) f64 = sum over time of every bin;
-// wn: window norms (simple_winnorm_kernel, same L).  One 64-thread workgroup per ordered pair.
+// wn: window norms (simple_winnorm_kernel, same L).  One WAVE per ordered pair, SIMPLE_WPB independent
+// waves per workgroup (no barrier anywhere): the host hands the pairs over sorted by their second
+// track, so the waves of a workgroup -- and of its neighbours on the CU -- walk the SAME frames of B at
+// about the same time and share their scalar-cache misses.
+constexpr int SIMPLE_WPB = 4;
 template <int L>
-__global__ __launch_bounds__(64) void simple_kernel(const double *__restrict__ pool,
-                                                    const int64_t *__restrict__ toff,
-                                                    const double *__restrict__ prof,
-                                                    const double *__restrict__ wn,
-                                                    const int32_t *__restrict__ pairs,
-                                                    double *__restrict__ out, int do_oti)
+__global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *__restrict__ pool,
+                                                                 const int64_t *__restrict__ toff,
+                                                                 const double *__restrict__ prof,
+                                                                 const double *__restrict__ wn,
+                                                                 const int32_t *__restrict__ pairs,
+                                                                 double *__restrict__ out, int do_oti, int npairs,
+                                                                 int smem_per_wave)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x;
-    const int ti = pairs[2 * blockIdx.x], tj = pairs[2 * blockIdx.x + 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pidx = blockIdx.x * (int)(blockDim.x >> 6) + wave;       // (long tracks: fewer waves per workgroup, LDS)
+    if (pidx >= npairs) return;                                  // wave-uniform
+    unsigned char *smem_raw = smem_all + (size_t)wave * smem_per_wave;
+    const int ti = pairs[2 * pidx], tj = pairs[2 * pidx + 1];
     const int64_t oa = toff[ti], ob = toff[tj];
     const int na = (int)(toff[ti + 1] - oa), nb = (int)(toff[tj + 1] - ob);
     const int ma = na - L + 1, mb = nb - L + 1;      // profile length, columns
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(64) void simple_kernel(const double *__restrict__ p
     const int r_lo = (ma - 1) / 2, r_hi = ma / 2;
     const double vlo = key_f64(simple_select_key(mp, ma, r_lo, lane));
     const double vhi = (r_hi == r_lo) ? vlo : key_f64(simple_select_key(mp, ma, r_hi, lane));
-    if (lane == 0) out[blockIdx.x] = -((r_lo == r_hi) ? vlo : (vlo + vhi) * 0.5);
+    if (lane == 0) out[pidx] = -((r_lo == r_hi) ? vlo : (vlo + vhi) * 0.5);
 }
 
 }  // namespace acx
