@@ -82,15 +82,15 @@ __global__ void ef_oti_kernel(EfPair *pd, int B, const double *__restrict__ med)
 // E1: C[i][j] = epilogue( sum_k A[i][perm(k)] * B[j][k] ), 128 x 128 tile per workgroup,
 // 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles (16 accumulator tiles: every operand
 // read from LDS feeds four MFMAs -- an f32 MFMA blocks VALU / LDS issue on its SIMD, so the
-// instructions AROUND the MFMAs are what the GEMM loses time to).  K is walked in blocks of 12 (one
-// 12-bin group of the chroma roll): the next block's global loads are in flight in registers while
-// the current one is multiplied out of LDS (k-major, conflict-free operand reads); the LDS tiles are
-// double-buffered, ONE barrier per block.  16 x 16 sub-tiles that lie entirely outside the matrix are skipped (wave-uniform),
+// instructions AROUND the MFMAs are what the GEMM loses time to).  K is walked in blocks of 24 (two
+// 12-bin groups of the chroma roll): the next block's 16-byte global loads are in flight in registers
+// while the current one is multiplied out of LDS (k-major, conflict-free operand reads), two
+// barriers per 24 k.  16 x 16 sub-tiles that lie entirely outside the matrix are skipped (wave-uniform),
 // so padding costs at most 15 rows / columns.  The blocked-OTI roll of the first song's chroma
 // is applied as a permutation of the LDS k-row on the way in.
 // feat: 0 mfcc (euclid), 1 ssm (euclid), 2 chroma (cosine, A rolled by oti).
 // ------------------------------------------------------------------------------------
-constexpr int EF_BK = 12;      // one 12-bin chroma group per block
+constexpr int EF_BK = 24;
 constexpr int EF_TILE = 128;
 constexpr int EF_LP = 144;     // LDS pitch (k-major, 128 rows + pad; 144 % 32 == 16)
 
@@ -101,12 +101,8 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
                                                       const EfPair *__restrict__ pd, float *__restrict__ scratch,
                                                       int K0, int K1, int K2, int tiles_x)
 {
-    // two generations of the operand tiles: a block is written while the previous one is still being
-    // multiplied by slower waves, so ONE barrier per block suffices (a wave reaches the barrier of
-    // block n + 1 only after it finished multiplying block n, hence nobody still reads the buffer
-    // that block n + 2 overwrites)
-    __shared__ float As[2][EF_BK * EF_LP];
-    __shared__ float Bs[2][EF_BK * EF_LP];
+    __shared__ float As[EF_BK * EF_LP];
+    __shared__ float Bs[EF_BK * EF_LP];
     const EfPair P = pd[blockIdx.y];
     const int s = blockIdx.z;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -130,27 +126,27 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging: thread -> (row = tid / 2, 6 consecutive k = 6 * (tid % 2) ...) as three 8-byte loads per operand
-    const int srow = tid >> 1, sk = (tid & 1) * 6;
+    // staging: thread -> (row = tid / 2, 12 consecutive k = 12 * (tid % 2) ...) as three float4 per operand
+    const int srow = tid >> 1, sk = (tid & 1) * 12;
     const bool rowa = i0 + srow < P.M, rowb = j0 + srow < P.N;
     const float *ap = F + (boff[P.q] + (rowa ? i0 + srow : 0)) * K + sk;      // (rows past the matrix read row 0; never stored)
     const float *bp = F + (boff[P.r] + (rowb ? j0 + srow : 0)) * K + sk;
-    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-    float ra[6], rb[6];
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    float ra[12], rb[12];
     auto gload_full = [&]() {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const f32x2u va = *reinterpret_cast<const f32x2u *>(ap + 2 * q);
-            const f32x2u vb = *reinterpret_cast<const f32x2u *>(bp + 2 * q);
-            ra[2 * q] = va.x; ra[2 * q + 1] = va.y;
-            rb[2 * q] = vb.x; rb[2 * q + 1] = vb.y;
+            const f32x4 va = *reinterpret_cast<const f32x4u *>(ap + 4 * q);
+            const f32x4 vb = *reinterpret_cast<const f32x4u *>(bp + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ra[4 * q + e] = va[e]; rb[4 * q + e] = vb[e]; }
         }
         ap += EF_BK;
         bp += EF_BK;
     };
     auto gload_tail = [&](int k0) {                   // the block that crosses K: element-wise, zeros beyond K
 #pragma unroll
-        for (int e = 0; e < 6; ++e) {
+        for (int e = 0; e < 12; ++e) {
             const bool ok = k0 + sk + e < K;
             ra[e] = ok ? ap[e] : 0.f;
             rb[e] = ok ? bp[e] : 0.f;
@@ -160,30 +156,38 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
         if (k0 + EF_BK <= K) gload_full();            // workgroup-uniform
         else gload_tail(k0);
     };
-    auto lstore = [&](int buf) {
-        float *as0 = As[buf] + srow, *bs0 = Bs[buf] + sk * EF_LP + srow;
+    // k-rows of the second 12-group keep their 128 rows XORed with 16: the two threads that stage one
+    // row then land in different bank groups (12 * 144 = 0 mod 32), the operand reads (one group per
+    // MFMA step) stay conflict free
+    const int swrow = srow ^ (16 * (tid & 1));
+    float *as0 = As + sk * EF_LP + swrow, *bs0 = Bs + sk * EF_LP + swrow;
+    auto lstore = [&]() {
+        if (rot == 0) {                                // workgroup-uniform: all offsets are immediates
 #pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            // A[k] multiplies B[k'] with k' = k - c + (c + rot) mod 12, c = k mod 12 = sk + e here
-            int ea = sk + e + rot; ea = ea >= 12 ? ea - 12 : ea;
-            as0[ea * EF_LP] = ra[e];
-            bs0[e * EF_LP] = rb[e];
+            for (int e = 0; e < 12; ++e) { as0[e * EF_LP] = ra[e]; bs0[e * EF_LP] = rb[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                // A[k] multiplies B[k'] with k' = k - c + (c + rot) mod 12, c = k mod 12 = e here
+                int ea = e + rot; ea = ea >= 12 ? ea - 12 : ea;
+                as0[ea * EF_LP] = ra[e];
+                bs0[e * EF_LP] = rb[e];
+            }
         }
     };
     gload(0);
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += EF_BK, buf ^= 1) {
-        lstore(buf);
-        if (k0 + EF_BK < K) gload(k0 + EF_BK);           // in flight during the MFMAs below
+    for (int k0 = 0; k0 < K; k0 += EF_BK) {
+        lstore();
         __syncthreads();
-        const float *Ab = As[buf], *Bb = Bs[buf];
+        if (k0 + EF_BK < K) gload(k0 + EF_BK);           // in flight during the MFMAs below
 #pragma unroll
         for (int kb = 0; kb < EF_BK / 4; ++kb) {
+            const int sw = 16 * (kb / 3);                 // the XOR of this k-group
             float av[4], bv[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = Ab[(4 * kb + lk) * EF_LP + 64 * wr + 16 * a + lr];
+            for (int a = 0; a < 4; ++a) av[a] = As[(4 * kb + lk) * EF_LP + ((64 * wr + 16 * a + lr) ^ sw)];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = Bb[(4 * kb + lk) * EF_LP + 64 * wc + 16 * b + lr];
+            for (int b = 0; b < 4; ++b) bv[b] = Bs[(4 * kb + lk) * EF_LP + ((64 * wc + 16 * b + lr) ^ sw)];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
                 if (a < na) {
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
                         if (b < nb) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
                 }
         }
+        __syncthreads();
     }
     // epilogue + stores: C row-major (a lane's 16 lanes-in-a-row write 64 contiguous bytes) and C^T
     // (a lane's four accumulator rows are four consecutive columns of C^T: one 16-byte store)
