@@ -216,7 +216,7 @@ bool launch_band(acx_ctx *c, int m, const PairDesc *dpd, int B, int maxRows, int
 template <int M>
 void launch_normtab(acx_ctx *c, int maxM, int span)
 {
-    hipLaunchKernelGGL((acx::normtab_kernel<M>), dim3((maxM + 255) / 256, c->n_tracks, acx::NBIN), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL((acx::normtab_kernel<M>), dim3(c->n_tracks, (maxM + 255) / 256, acx::NBIN), dim3(256), 0, c->stream,
                        c->d_frames, c->d_toff, c->d_noff, c->d_normtab, span);
 }
 
@@ -293,7 +293,6 @@ int ensure_normtab(acx_ctx *c, const acx_serra09_params &p)
 {
     const int span = p.embed_full ? (p.m - 1) : p.m;           // (active pool: tau == 1)
     if (c->d_normtab && c->normtab_m == p.m && c->normtab_span == span) return ACX_OK;
-    if (c->n_tracks > 65535) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: pools of more than 65535 tracks are not supported");
     if (c->d_normtab) { ACX_HIP(c, hipFree(c->d_normtab)); c->d_normtab = nullptr; }
     if (c->d_noff) { ACX_HIP(c, hipFree(c->d_noff)); c->d_noff = nullptr; }
     std::vector<int64_t> noff((size_t)c->n_tracks + 1);

@@ -582,11 +582,11 @@ __global__ __launch_bounds__(256) void normtab_kernel(const float *__restrict__ 
                                                       const int64_t *__restrict__ noff,
                                                       float *__restrict__ tab, int span)
 {
-    const int track = blockIdx.y, rot = blockIdx.z;
+    const int track = blockIdx.x, rot = blockIdx.z;            // (tracks on grid.x: any pool size)
     const int64_t t0 = toff[track];
     const int T = (int)(toff[track + 1] - t0);
     const int Me = T - span;                                   // embedded frames (tau == 1)
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y * 256 + threadIdx.x;
     if (i >= Me) return;
     const float *f = pool + (t0 + i) * NBIN;
     float s[M];
