@@ -47,3 +47,17 @@ bool launch_band_kernel(const BandLaunch &L, int m, const PairDesc *dpd, int B, 
 
 
 }  // namespace acx
+
+#ifdef ACX_TIMING
+// development builds: per-phase clock totals of band_kernel (slots 0-7; slot 15 = waves); reset != 0 clears them
+extern "C" int acx_dev_band_timing(unsigned long long *out, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(acx::g_band_clk), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(acx::g_band_clk), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -556,12 +556,225 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
     return true;
 }
 
+// ------------------------------------------------------------------------------------
+// Pivot-filtered variant of the fast path (band kernel, negative pads).  Only the smallest ~10 % of a
+// row decide its kappa-percentile, so the histogram need not see the rest: a PIVOT g is chosen such
+// that a little more than k + 2 cells lie at or below it, the bins cover [row minimum, g] only, and a
+// lane adds a cell to the histogram only if its bin exists -- the LDS atomic runs under an exec mask
+// with a fifth of the lanes active (4.3 instead of 10.9 LDS cycles per instruction on gfx950,
+// scripts/ubench/lds_masked_add.hip) and the pass over the row for its maximum disappears.
+//   * pivot: a lane's minimum over its NV consecutive positions is about the 1/(NV+1) quantile of
+//     the row, the largest of the 64 / GRP group minima (GRP neighbouring lanes = one group; only
+//     groups without pads take part) sits near the (ln 64) / (NV GRP) quantile; g = that maximum
+//     pushed up by `delta` of its distance to the row minimum.  Every group then holds a cell <= g;
+//     whether k + 2 cells do is CHECKED by the histogram total -- the function returns false when
+//     they do not (or on anything else unusual) and the caller falls back to the unfiltered pass.
+//   * bin = cvt_u32(fma(x, scale, off)) is monotone in x and a cell takes part iff bin < NB, so the
+//     cells that take part are exactly the smallest ones and the histogram is a monotone partition
+//     of them: ranks below the total are exact whatever the rounding.
+// `hist_addr` = LDS byte address of this wave's zeroed BINS-dword histogram; `cand` = 64 floats.
+// ------------------------------------------------------------------------------------
+// Pads must be -inf here (they take no part: k is the plain rank among the cells).
+template <int NV, int BINS, int GRP>
+__device__ __forceinline__ bool wave_select_pivot(const float (&x)[NV], int k, bool want_next, unsigned hist_addr,
+                                                  float *cand, int lane, float &slo, float &shi, bool lane_has_data,
+                                                  bool group_full, float delta)
+{
+    constexpr int NB = BINS;                // logical bins
+    constexpr int DPL = BINS / 64;          // dwords per lane in the scan
+    constexpr int NQ = DPL / 4;             // 16-byte pieces per lane
+    constexpr int BPL = DPL;
+    static_assert(DPL >= 4 && DPL <= 16 && (DPL & (DPL - 1)) == 0, "BINS must be 256, 512 or 1024");
+    static_assert(GRP == 1 || GRP == 2 || GRP == 4, "groups of 1, 2 or 4 lanes");
+    const float INF = __builtin_inff();
+    // ---- row minimum and the largest group minimum (unsigned order: the -1 pads are invisible)
+    unsigned mnl = 0xFFFFFFFFu;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const unsigned b = __float_as_uint(x[t]);
+        mnl = b < mnl ? b : mnl;
+    }
+    unsigned gmn = mnl;
+    if constexpr (GRP >= 2) {
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)gmn, (int)gmn, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        gmn = o < gmn ? o : gmn;
+    }
+    if constexpr (GRP >= 4) {
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)gmn, (int)gmn, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+        gmn = o < gmn ? o : gmn;
+    }
+    const unsigned mnu = (unsigned)__builtin_amdgcn_readlane(wave_scan_bits((int)mnl, -1, OpMinU()), 63);
+    const int mxg = __builtin_amdgcn_readlane(wave_scan_bits(group_full ? (int)gmn : (int)0x80000000, (int)0x80000000, OpMaxI()), 63);
+    if (mxg < 0 || (int)mnu < 0) return false;       // no complete group / no cell
+    const float mn = __uint_as_float(mnu);
+    const float gm = __uint_as_float((unsigned)mxg);
+    const float range = __builtin_fmaf(delta, gm - mn, gm) - mn;
+    if (!(range >= 1e-30f) || !(range <= 1e30f) || !(mn <= 2048.0f * range)) return false;
+    // bin units; the pivot lands in bin NB - 2.  The bin comes out of the fma itself: with 2^23 + 1 folded into
+    // the offset the sum is rounded to an integer by the addition (ulp = 1 above 2^23), so the float's bit
+    // pattern is MAGIC + bin -- no conversion instruction, and v_fma_f32 issues at twice the rate of v_cvt.
+    // offm is exact up to 0.57 (its own rounding + that of mn * scale <= 2^20), so the row minimum and every
+    // cell above it land at or above MAGIC: `pattern < MAGIC + NB` alone decides who takes part.  Pads are
+    // -inf (pattern 0xff800000, out), huge cells and +inf compare above; the lanes that hold nothing but
+    // pads get an offset of +inf.
+    constexpr unsigned MAGIC = 0x4B000000u;            // 2^23
+    const float scale = ((float)NB - 3.0f) * __builtin_amdgcn_rcpf(range);
+    const float offm = lane_has_data ? (8388609.0f - mn * scale) : INF;
+    // ---- histogram of the cells whose bin exists
+    unsigned off[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) off[t] = __float_as_uint(__builtin_fmaf(x[t], scale, offm));
+    // The atomics run under exec = [bin < NB].  Written out by hand, four cells per statement: the compiler
+    // wraps every exec-masked LDS instruction in a branch of its own (v_cmp, s_and_saveexec, s_cbranch_execz,
+    // ..., s_or exec), 32 serialised round trips per row.  exec is put back before the statement ends.
+    {
+        const unsigned nb = __builtin_amdgcn_readfirstlane(MAGIC + NB);
+        const unsigned hb = __builtin_amdgcn_readfirstlane(hist_addr - 4u * MAGIC);      // (mod 2^32, like the shift)
+        unsigned one = 1u;
+        asm volatile("" : "+v"(one));
+        static_assert(NV % 4 == 0, "atomics go in groups of 4");
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            unsigned long long m0, m1, m2, m3, sv;
+            unsigned a0, a1, a2, a3;
+            asm volatile("v_cmp_gt_u32_e64 %[m0], %[nb], %[q0]\n\t"
+                         "v_cmp_gt_u32_e64 %[m1], %[nb], %[q1]\n\t"
+                         "v_cmp_gt_u32_e64 %[m2], %[nb], %[q2]\n\t"
+                         "v_cmp_gt_u32_e64 %[m3], %[nb], %[q3]\n\t"
+                         "v_lshl_add_u32 %[a0], %[q0], 2, %[hb]\n\t"
+                         "v_lshl_add_u32 %[a1], %[q1], 2, %[hb]\n\t"
+                         "v_lshl_add_u32 %[a2], %[q2], 2, %[hb]\n\t"
+                         "v_lshl_add_u32 %[a3], %[q3], 2, %[hb]\n\t"
+                         "s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b64 exec, %[m0]\n\t"
+                         "ds_add_u32 %[a0], %[one]\n\t"
+                         "s_mov_b64 exec, %[m1]\n\t"
+                         "ds_add_u32 %[a1], %[one]\n\t"
+                         "s_mov_b64 exec, %[m2]\n\t"
+                         "ds_add_u32 %[a2], %[one]\n\t"
+                         "s_mov_b64 exec, %[m3]\n\t"
+                         "ds_add_u32 %[a3], %[one]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [sv] "=&s"(sv),
+                           [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+                         : [q0] "v"(off[t]), [q1] "v"(off[t + 1]), [q2] "v"(off[t + 2]), [q3] "v"(off[t + 3]),
+                           [nb] "s"(nb), [hb] "s"(hb), [one] "v"(one)
+                         : "memory");
+        }
+    }
+    wave_lds_fence();
+    // ---- scan: lane owns bins [BPL lane, +BPL); pieces read in a staggered order (conflict-free)
+    int lsum = 0;
+    {
+        const int rot = (NQ > 1) ? ((lane >> (NQ == 2 ? 3 : 2)) & (NQ - 1)) : 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int piece = (q + rot) & (NQ - 1);
+            const u32x4 h = *(const lds_u32x4 *)(hist_addr + (unsigned)(lane * DPL + 4 * piece) * 4u);
+            lsum += (int)(h.x + h.y) + (int)(h.z + h.w);
+        }
+    }
+    const int incl = wave_incl_scan_i(lsum);
+    const int L1 = __ffsll((long long)__ballot(incl > k)) - 1;
+    const int L2 = want_next ? __ffsll((long long)__ballot(incl > k + 1)) - 1 : L1;
+    if (L1 < 0 || L2 < 0) return false;              // fewer than k + 2 cells at or below the pivot
+    const int ex1 = __builtin_amdgcn_readlane(incl - lsum, L1);
+    const int ex2 = __builtin_amdgcn_readlane(incl - lsum, L2);
+    // second level: lanes 0..15 look at lane L1's bins, lanes 16..31 at lane L2's
+    const int e = lane & 15;
+    const bool lo16 = lane < 16;
+    int c = 0;
+    if (lane < 32 && e < BPL) c = (int)*(const lds_u32 *)(hist_addr + (unsigned)((lo16 ? L1 : L2) * BPL + e) * 4u);
+    int P = c;                                        // inclusive prefix inside each row of 16 lanes
+    P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, false);
+    P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, false);
+    P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xf, 0xf, false);
+    if (BPL > 8) P += __builtin_amdgcn_update_dpp(0, P, 0x118, 0xf, 0xf, false);
+    const int l1 = __ffsll((long long)__ballot(lo16 && e < BPL && ex1 + P > k)) - 1;
+    if (l1 < 0) return false;
+    const int cnt1 = __builtin_amdgcn_readlane(c, l1);
+    const int cum1 = ex1 + __builtin_amdgcn_readlane(P, l1) - cnt1;
+    const int bin1 = L1 * BPL + l1;
+    int bin2 = bin1, ncand = cnt1;
+    if (want_next) {
+        const int l2 = __ffsll((long long)__ballot(!lo16 && lane < 32 && e < BPL && ex2 + P > k + 1)) - 1;
+        if (l2 < 0) return false;
+        bin2 = L2 * BPL + (l2 - 16);
+        if (bin2 != bin1) ncand += __builtin_amdgcn_readlane(c, l2);    // the bins between are empty
+    }
+    if (ncand > 64) return false;
+    // ---- gather the members of [bin1, bin2]
+    // (the slots hold MAGIC + bin; pads and the lanes that stayed out of the histogram hold patterns no bin matches)
+    const unsigned a1 = MAGIC + (unsigned)bin1;
+    const unsigned span = (unsigned)(bin2 - bin1);
+    int n = 0;
+    auto put = [&](unsigned long long m, bool hit, float v) {
+        if (m != 0ull) {
+            if (hit) {
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                cand[(n + (int)pos) & 63] = v;
+            }
+            n += __popcll(m);
+        }
+    };
+    static_assert(NV % 4 == 0, "gather works in groups of 4");
+    if (span == 0u) {
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            const bool h0 = off[t] == a1, h1 = off[t + 1] == a1, h2 = off[t + 2] == a1, h3 = off[t + 3] == a1;
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            if ((m0 | m1 | m2 | m3) != 0ull) {       // most groups hold no member of the target bin
+                put(m0, h0, x[t]); put(m1, h1, x[t + 1]); put(m2, h2, x[t + 2]); put(m3, h3, x[t + 3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            const bool h0 = (off[t] - a1) <= span, h1 = (off[t + 1] - a1) <= span;
+            const bool h2 = (off[t + 2] - a1) <= span, h3 = (off[t + 3] - a1) <= span;
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            if ((m0 | m1 | m2 | m3) != 0ull) {
+                put(m0, h0, x[t]); put(m1, h1, x[t + 1]); put(m2, h2, x[t + 2]); put(m3, h3, x[t + 3]);
+            }
+        }
+    }
+    wave_lds_fence();
+    // ---- rank them (LDS broadcasts, four per 16-byte read; slots beyond ncand padded with +inf)
+    if (lane >= ncand) cand[lane] = INF;
+    wave_lds_fence();
+    const float mine = cand[lane];
+    int rank = 0;
+#pragma unroll 1
+    for (int t = 0; t < ncand; t += 4) {
+        const float4 o = *reinterpret_cast<const float4 *>(cand + t);
+        rank += (o.x < mine || (o.x == mine && t + 0 < lane)) ? 1 : 0;
+        rank += (o.y < mine || (o.y == mine && t + 1 < lane)) ? 1 : 0;
+        rank += (o.z < mine || (o.z == mine && t + 2 < lane)) ? 1 : 0;
+        rank += (o.w < mine || (o.w == mine && t + 3 < lane)) ? 1 : 0;
+    }
+    const int want = k - cum1;
+    const int s1 = __ffsll((long long)__ballot(lane < ncand && rank == want)) - 1;
+    if (s1 < 0) return false;
+    slo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), s1));
+    shi = slo;
+    if (want_next) {
+        const int s2 = __ffsll((long long)__ballot(lane < ncand && rank == want + 1)) - 1;
+        if (s2 < 0) return false;
+        shi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), s2));
+    }
+    wave_lds_fence();
+    return true;
+}
+
 // eps from the two order statistics d2_(ilo) <= d2_(ihi) (oracle percentile_f32)
 __device__ __forceinline__ float percentile_eps2(float slo, float shi, int pct_mode, int ilo, int ihi,
                                                  float kf, float fl, float ce)
 {
-    if (!(pct_mode == 0 || pct_mode == 1)) return __builtin_sqrtf(slo);
-    const float dlo = __builtin_sqrtf(slo), dhi = __builtin_sqrtf(shi);
+    // (slo and shi are wave-uniform: odd lanes root shi, even lanes slo -- one sqrt expansion instead of two)
+    const float dboth = __builtin_sqrtf((__lane_id() & 1u) ? shi : slo);
+    const float dlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dboth), 0));
+    const float dhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dboth), 1));
+    if (!(pct_mode == 0 || pct_mode == 1)) return dlo;
     if (pct_mode == 0 && ihi == ilo) return dlo;
     const float d0 = __fmul_rn(dlo, __fsub_rn(ce, kf));
     const float d1 = __fmul_rn(dhi, __fsub_rn(kf, fl));
@@ -678,6 +891,15 @@ struct BandLaunch {
 bool launch_band_kernel(const BandLaunch &L, int m, const struct PairDesc *dpd, int B, int maxRows, int maxCols, int role,
                         int write_d2);
 
+#ifdef ACX_TIMING   /* development builds only (scripts/ab_build.sh timing -DACX_TIMING; experiments/phase_timing.py) */
+__device__ unsigned long long g_band_clk[32];      // [0, 16): band_kernel (slot 15 = waves); [16, 32): spare
+struct StampT { unsigned long long t; int base; };
+#define ACX_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+        if (lane == 0) atomicAdd(&g_band_clk[tstamp_.base + (slot)], now_ - tstamp_.t); tstamp_.t = now_; } while (0)
+#else
+#define ACX_STAMP(slot) do { } while (0)
+#endif
+
 template <int M>
 struct BandGeom {
     static constexpr int NRT = (BAND + M - 1 + 15) / 16;            // 16-row MFMA tiles of row frames
@@ -701,6 +923,178 @@ __device__ __forceinline__ float percentile_eps(const SelectResult &sr, int pct_
     return __fadd_rn(d0, d1);
 }
 
+// Geometry of a complete band row in LDS (the exchange) and of the selection's histograms, by row width:
+// a row owner holds NV = 8 / 16 / 32 consecutive slots per lane.
+template <int NV>
+struct RowGeom {
+    static constexpr int LNP = NV + 4;          // floats per owner lane in an exchange row: its NV slots + 16 bytes of pad
+    static constexpr int ROWP = 64 * LNP;       // exchange pitch (floats)
+    // Fast selection: FBINS counters = FBINS / FCOPIES bins x FCOPIES copies.  (Copies spread
+    // same-address atomics -- they paid while one instruction handled 64 NEIGHBOURING columns; with
+    // the position-order rows one copy and twice the bins measure best on every workload.)
+    // For rows of >= 1024 slots the histogram lives in the upper part of the wave's OWN
+    // exchange row, free once the row sits in registers; the shortest rows (2 KB) keep a separate
+    // area behind the exchange rows.
+    static constexpr int FBINS = NV >= 32 ? 1024 : 512;
+    static constexpr int FCOPIES = 1;
+    static constexpr bool HIST_IN_ROW = ROWP >= 64 + 2 * FBINS;        // room for an FBINS-aligned block behind the 64 candidate slots
+    // Pivot-filtered pass (wave_select_pivot): bins, lanes per pivot group and the pivot's push-up, per row
+    // width -- groups of 32 cells put the pivot near the 0.13 ... 0.2 quantile of an i.i.d. row
+#ifndef ACX_PBINS
+#define ACX_PBINS 512
+#endif
+    static constexpr int PBINS = NV >= 32 ? ACX_PBINS : 256;
+    static constexpr int PGRP = NV >= 32 ? 1 : 2;
+    static constexpr float PDELTA = NV >= 32 ? 0.04f : (NV >= 16 ? 0.15f : 0.0f);
+    static constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
+    static constexpr int TAIL_FLOATS = BAND * ROWP + (HIST_IN_ROW ? 0 : 8 * FBINS);
+    static_assert(SelGeom<GBINS>::SLOTS + 64 + 4 <= ROWP, "generic selection must fit the wave's own exchange row");
+    static_assert(HIST_IN_ROW || (BAND * ROWP) % FBINS == 0, "fast histograms must be aligned to their size");
+    static_assert(NV == 8 || NV == 16 || NV == 32, "row owners hold 8, 16 or 32 consecutive slots");
+    // this wave's fast histogram: inside its own exchange row (the first FBINS-aligned block behind
+    // the 64 candidate slots), or in the separate area behind the rows
+    __device__ static __forceinline__ int hist_off(int wave)
+    {
+        return HIST_IN_ROW ? ((wave * ROWP + 64 + FBINS - 1) & ~(FBINS - 1)) : BAND * ROWP + wave * FBINS;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// The part of the band pipeline that follows the exchange: wave `wave` holds one complete row of the
+// pair's matrix in registers (xr[t] = slot NV lane + t; slot s <-> column s - cshift; slots without a
+// column hold -inf) and owns exchange row `wave` of `smem` as scratch.  Exact kappa-percentile of the
+// row (pivot-filtered histogram, unfiltered histogram, generic narrowing), eps and the d2-domain
+// threshold into the pair's threshold arena, and, when `bits` is given (rows = query frames, the
+// column thresholds are there already), the binarised row into the recurrence bitmap: bit = slot (bit b of
+// row i is column b - 7 + (i & 7), the band kernel's position order).
+// ------------------------------------------------------------------------------------
+#ifdef ACX_TIMING
+#define ACX_STAMP_PARM , StampT &tstamp_
+#define ACX_STAMP_ARG , tstamp_
+#else
+#define ACX_STAMP_PARM
+#define ACX_STAMP_ARG
+#endif
+template <int NV, int ROLE>
+__device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int wave, int lane, int row, int MA, int MB,
+                                              int cshift, const PairDesc &P, float *__restrict__ thr,
+                                              unsigned long long *__restrict__ bits, float kappa, int pct_mode,
+                                              int inclusive ACX_STAMP_PARM)
+{
+    using RG = RowGeom<NV>;
+    constexpr int ROWP = RG::ROWP, FBINS = RG::FBINS, FCOPIES = RG::FCOPIES, PBINS = RG::PBINS, PGRP = RG::PGRP, GBINS = RG::GBINS;
+    constexpr bool HIST_IN_ROW = RG::HIST_IN_ROW;
+    constexpr float PDELTA = RG::PDELTA;
+    constexpr int CH = NV / 4;           // 16-byte chunks per lane of a complete row
+    constexpr int role = ROLE;
+    const float INF = __builtin_inff();
+    const int hist_off = RG::hist_off(wave);
+    if (row >= MA) return;
+    const int n = MB;
+    const float kf = (n > 1) ? __fmul_rn((float)(n - 1), kappa) : __fmul_rn((float)n, kappa);
+    const float fl = floorf(kf), ce = ceilf(kf);
+    int ilo = (int)fl, ihi = (int)ce;
+    ilo = ilo < 0 ? 0 : (ilo > n - 1 ? n - 1 : ilo);
+    ihi = ihi < 0 ? 0 : (ihi > n - 1 ? n - 1 : ihi);
+    int k = ilo;
+    if (pct_mode == 3) {
+        k = (int)floorf(__fadd_rn(kf, 0.5f));
+        k = k > n - 1 ? n - 1 : k;
+    }
+    const bool interp = (pct_mode == 0 || pct_mode == 1);
+    float *myrow = smem + wave * ROWP;
+    float slo, shi;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + hist_off);
+    // Small kappa (the default 0.095): the pivot-filtered histogram first (wave_select_pivot); it gives up
+    // when fewer than k + 2 cells lie below its pivot, and the unfiltered pass takes over.
+    const bool use_pivot = (ihi + 2) * 9 <= n;
+    auto zero_hist = [&](int bins) {
+        float *h = smem + hist_off;
+        for (int q = 0; q < bins / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+        wave_lds_fence();
+    };
+    if constexpr (HIST_IN_ROW) zero_hist(use_pivot ? PBINS : FBINS);   // the row has left LDS: part of it becomes the zeroed histogram
+    bool done = false;
+    const int end_valid = MB + cshift;                                  // slots [cshift, end_valid) are cells
+    const bool lane_has_data = lane * NV < end_valid;                   // first slot of the lane is a cell or a low pad
+    // pads inside the lanes that take part in the histogram: the low ones of lane 0 and the tail of the
+    // last lane with cells; they sit in bin 0 and rank below every cell
+    const int npadc = cshift + (((end_valid + NV - 1) / NV) * NV - end_valid);
+    if (use_pivot) {
+        const int g0 = (lane & ~(PGRP - 1)) * NV;                       // first slot of the lane's group
+        const bool group_full = g0 >= cshift && g0 + PGRP * NV <= end_valid;
+        done = wave_select_pivot<NV, PBINS, PGRP>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi,
+                                                  lane_has_data, group_full, PDELTA);
+        if (!done) zero_hist(FBINS);
+    }
+    if (!done)
+        done = wave_select_fast<NV, FBINS, FCOPIES, true>(xr, k + npadc, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, lane_has_data);
+    if (!done) {
+        unsigned *ghist = reinterpret_cast<unsigned *>(myrow) + 64;
+        unsigned *counter = reinterpret_cast<unsigned *>(myrow) + 64 + SelGeom<GBINS>::SLOTS;
+        float xi[NV];                                   // the generic selection wants its pads at +inf
+#pragma unroll
+        for (int t = 0; t < NV; ++t) xi[t] = xr[t] < 0.0f ? INF : xr[t];
+        const SelectResult sr = wave_select_regs<NV, GBINS>(xi, k, ghist, myrow, counter, lane, interp);
+        slo = sr.value;
+        shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
+    }
+    ACX_STAMP(5);        // selection
+    const float eps = percentile_eps2(slo, shi, pct_mode, ilo, ihi, kf, fl, ce);
+    const float thr_row = d2_threshold(eps, inclusive);
+    ACX_STAMP(6);        // eps + threshold
+    float *X = thr + P.offX;
+    if (lane == 0) {
+        const int o = role ? P.pitchT + row : row;
+        X[o] = thr_row;
+        X[P.pitchT + P.pitchD + o] = eps;
+    }
+    // ---- rows = query frames (the column thresholds of the pair are already there): binarise the row the
+    // wave still holds in registers and emit it as a bitmap.  256 bytes per row instead of 8 KB of f32.
+    // A lane owns NV consecutive slots, i.e. NV consecutive bits: R = [d2 <= min(thr_row, thr_col)] is
+    // shifted into the lane's own word bit by bit (compare -> carry -> add-with-carry), no cross-lane traffic.
+    if (role == 0 && bits) {
+        // column thresholds (d2 domain): NV consecutive floats per lane, no bounds check (columns
+        // -7 .. 64 ntiles + 63 of the threshold arena are always inside the pair's arena)
+        const float *tc = X + P.pitchT + (lane * NV - cshift);
+        typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+        float tcv[NV];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const f32x4_u v = *reinterpret_cast<const f32x4_u *>(tc + 4 * j);
+            tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
+        }
+        // slots of this lane whose column exists: t in [lo, hi)
+        int lo = cshift - lane * NV, hi = MB + cshift - lane * NV;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > NV ? NV : hi;
+        unsigned valid = 0u;
+        if (hi > lo) valid = (hi - lo >= 32 ? ~0u : ((1u << (hi - lo)) - 1u)) << lo;
+        unsigned acc = 0u;
+#pragma unroll
+        for (int t = NV - 1; t >= 0; --t) {
+            float mthr;
+            asm("v_min_f32 %0, %1, %2" : "=v"(mthr) : "v"(tcv[t]), "v"(thr_row));
+            asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(xr[t]), "v"(mthr) : "vcc");
+        }
+        acc &= valid;
+        // NV < 32: neighbouring lanes complete a dword
+        if constexpr (NV == 16) {
+            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 16;
+        } else if constexpr (NV == 8) {
+            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 8;
+            acc |= (unsigned)__shfl_down((int)acc, 2, 64) << 16;
+        }
+        constexpr int LPD = 32 / NV;                                    // lanes per dword
+        unsigned *rowbits = reinterpret_cast<unsigned *>(bits + P.offT + (size_t)row * P.nw);
+        const int ndw = 2 * P.nw, d = lane / LPD;
+        if ((lane & (LPD - 1)) == 0 && d < ndw) rowbits[d] = acc;
+        for (int z = 2 * NV + lane; z < ndw; z += 64) rowbits[z] = 0u;  // words beyond this size class
+    }
+    ACX_STAMP(7);        // threshold store + bitmap
+}
+
 // (short-row variants: 6 waves / SIMD = 3 workgroups per CU; m >= 10 needs two MFMA row tiles and is LDS-limited anyway)
 constexpr int band_waves_per_simd(int m, int v4) { return (v4 <= 4 && m <= 9) ? 6 : 4; }
 template <int M, int V4, int ROLE>
@@ -719,23 +1113,11 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     constexpr int role = ROLE;           // 1: rows = reference frames (column thresholds); 0: rows = query frames
     constexpr int NV = 4 * V4;           // values per lane of a complete row
     constexpr int NSTEP = NV / 8;        // tiles per wave
-    constexpr int LNP = NV + 4;          // floats per owner lane in an exchange row: its NV positions + 16 bytes of pad
-    constexpr int ROWP = 64 * LNP;       // exchange pitch (floats)
-    // Fast selection: FBINS counters = FBINS / FCOPIES bins x FCOPIES copies.  (Copies spread
-    // same-address atomics -- they paid while one instruction handled 64 NEIGHBOURING columns; with
-    // the position-order rows below one copy and twice the bins measure best on every workload.)
-    // For rows of >= 1024 positions the histogram lives in the upper part of the wave's OWN
-    // exchange row, free once the row sits in registers; the shortest rows (2 KB) keep a separate
-    // area behind the exchange rows.
-    constexpr int FBINS = NV >= 32 ? 1024 : 512;
-    constexpr int FCOPIES = 1;
-    constexpr bool HIST_IN_ROW = ROWP >= 64 + 2 * FBINS;        // room for an FBINS-aligned block behind the 64 candidate slots
-    constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
+    using RG = RowGeom<NV>;
+    constexpr int LNP = RG::LNP, ROWP = RG::ROWP, FBINS = RG::FBINS;
+    constexpr bool HIST_IN_ROW = RG::HIST_IN_ROW;
     constexpr int SWEEP_FLOATS = 8 * G::AROWS * G::SP;          // one Gram tile per wave
-    constexpr int TAIL_FLOATS = BAND * ROWP + (HIST_IN_ROW ? 0 : 8 * FBINS);
-    constexpr int LDS_FLOATS = SWEEP_FLOATS > TAIL_FLOATS ? SWEEP_FLOATS : TAIL_FLOATS;
-    static_assert(SelGeom<GBINS>::SLOTS + 64 + 4 <= ROWP, "generic selection must fit the wave's own exchange row");
-    static_assert(HIST_IN_ROW || (BAND * ROWP) % FBINS == 0, "fast histograms must be aligned to their size");
+    constexpr int LDS_FLOATS = SWEEP_FLOATS > RG::TAIL_FLOATS ? SWEEP_FLOATS : RG::TAIL_FLOATS;
     __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
 
     const int bid_x = blockIdx.x, bid_y = blockIdx.y;
@@ -753,10 +1135,11 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     const float *nrow = normtab + noff[role ? P.r : P.q] + (int64_t)rota * MA;
     const float *ncol = normtab + noff[role ? P.q : P.r] + (int64_t)rotb * MB;
     const float INF = __builtin_inff();
-    // Cells outside the matrix travel through the exchange as -1: distances are >= +0, so a negative
+    // Cells outside the matrix travel through the exchange as -inf: distances are >= +0, so a negative
     // pad is the largest UNSIGNED and the smallest SIGNED bit pattern -- the selection's integer min /
-    // max skip it for free (a +inf pad needed a bias add per value for the max)
-    const float PADV = -1.0f;
+    // max skip it for free (a +inf pad needed a bias add per value for the max) -- and -inf stays -inf
+    // through the binning fma of the pivot-filtered pass, whatever the scale
+    const float PADV = -INF;
 
     // ---- MFMA operands come straight from the rotated frame pool (frot, see rotpool_kernel):
     // frame f holds, for each rotation r = 0..2 and residue class cls = 0..3, the three bins
@@ -785,6 +1168,10 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
 #pragma unroll
     for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : 0.0f;
     float *Sw = smem + wave * (G::AROWS * G::SP);               // this wave's Gram tile, [row frame][column frame]
+#ifdef ACX_TIMING
+    StampT tstamp_{__builtin_readcyclecounter(), 0};
+    if (lane == 0) atomicAdd(&g_band_clk[15], 1ull);
+#endif
 
     const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= NV by dispatch
     typedef float BvT[G::NCT][3];
@@ -960,7 +1347,9 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
             if (i0 + a < MA) D[a * pitchD + j] = INF;
         }
     }
+    ACX_STAMP(0);        // sweep
     __syncthreads();     // all slabs dead -> reuse LDS as the exchange rows + the fast histograms
+    ACX_STAMP(1);        // wait B1
     // ---- exchange: row a of the band becomes a row of LDS in POSITION order (position p = 64 tile +
     // lane <-> column p - 7 + a), so that the owner of the row can pick up NV CONSECUTIVE positions
     // per lane.  With that layout one instruction of the selection handles 64 columns that are NV
@@ -981,15 +1370,15 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
             for (int a = 0; a < BAND; ++a) dst[a * ROWP] = xv[a][st];
         }
     }
-    // this wave's fast histogram: inside its own exchange row (the first FBINS-aligned block behind
-    // the 64 candidate slots), or in the separate area behind the rows
-    const int hist_off = HIST_IN_ROW ? ((wave * ROWP + 64 + FBINS - 1) & ~(FBINS - 1)) : BAND * ROWP + wave * FBINS;
+    // this wave's fast histogram (RowGeom::hist_off): inside its own exchange row or in the separate area
     if constexpr (!HIST_IN_ROW) {   // zero it before the barrier: nobody else touches that area
-        float *h = smem + hist_off;
+        float *h = smem + RG::hist_off(wave);
 #pragma unroll
         for (int q = 0; q < FBINS / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    ACX_STAMP(2);        // exchange writes
     __syncthreads();
+    ACX_STAMP(3);        // wait B2
     float xr[NV];      // xr[t] = cell at position NV lane + t of band row `wave` (column = position - 7 + wave)
     {
         const float *mine = smem + wave * ROWP + lane * LNP;
@@ -1002,100 +1391,12 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     // From here on the waves are independent: wave w owns exchange row w (its cells are in
     // registers now) as private scratch, and its own fast histogram.
 
-    // ---- exact percentile selection: wave w owns band row w
-    const int row = i0 + wave;
-    if (row >= MA) return;
-    const int n = MB;
-    const float kf = (n > 1) ? __fmul_rn((float)(n - 1), kappa) : __fmul_rn((float)n, kappa);
-    const float fl = floorf(kf), ce = ceilf(kf);
-    int ilo = (int)fl, ihi = (int)ce;
-    ilo = ilo < 0 ? 0 : (ilo > n - 1 ? n - 1 : ilo);
-    ihi = ihi < 0 ? 0 : (ihi > n - 1 ? n - 1 : ihi);
-    int k = ilo;
-    if (pct_mode == 3) {
-        k = (int)floorf(__fadd_rn(kf, 0.5f));
-        k = k > n - 1 ? n - 1 : k;
-    }
-    const bool interp = (pct_mode == 0 || pct_mode == 1);
-    float *myrow = smem + wave * ROWP;
+    // ---- exact percentile selection, thresholds and (role 0) the recurrence bitmap: wave w owns band row w;
+    // slot s of the row = position s = column s - 7 + w
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row has left LDS
-    float slo, shi;
-    typedef __attribute__((address_space(3))) void lds_void;
-    const unsigned hist_addr = (unsigned)(uintptr_t)(lds_void *)(smem + hist_off);
-    if constexpr (HIST_IN_ROW) {    // the row has left LDS: part of it becomes the zeroed histogram
-        float *h = smem + hist_off;
-#pragma unroll
-        for (int q = 0; q < FBINS / 256; ++q) *reinterpret_cast<float4 *>(h + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
-        wave_lds_fence();
-    }
-    bool done = false;
-    const int end_valid = MB + (BAND - 1) - wave;                       // positions [7 - wave, end_valid) are cells
-    const bool lane_has_data = lane * NV < end_valid;                   // first position of the lane is a cell or a low pad
-    // pads inside the lanes that take part in the histogram: the low ones of lane 0 and the tail of the
-    // last lane with cells; they sit in bin 0 and rank below every cell
-    const int npadc = ((BAND - 1) - wave) + (((end_valid + NV - 1) / NV) * NV - end_valid);
-    done = wave_select_fast<NV, FBINS, FCOPIES, true>(xr, k + npadc, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, lane_has_data);
-    if (!done) {
-        unsigned *ghist = reinterpret_cast<unsigned *>(myrow) + 64;
-        unsigned *counter = reinterpret_cast<unsigned *>(myrow) + 64 + SelGeom<GBINS>::SLOTS;
-        float xi[NV];                                   // the generic selection wants its pads at +inf
-#pragma unroll
-        for (int t = 0; t < NV; ++t) xi[t] = xr[t] < 0.0f ? INF : xr[t];
-        const SelectResult sr = wave_select_regs<NV, GBINS>(xi, k, ghist, myrow, counter, lane, interp);
-        slo = sr.value;
-        shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
-    }
-    const float eps = percentile_eps2(slo, shi, pct_mode, ilo, ihi, kf, fl, ce);
-    const float thr_row = d2_threshold(eps, inclusive);
-    float *X = thr + P.offX;
-    if (lane == 0) {
-        const int o = role ? P.pitchT + row : row;
-        X[o] = thr_row;
-        X[P.pitchT + P.pitchD + o] = eps;
-    }
-    // ---- role 0 (the column thresholds of the pair are already there): binarise the row the
-    // wave still holds in registers and emit it as a bitmap -- bit p of the row = position p =
-    // column p - 7 + (row & 7).  256 bytes per row instead of 8 KB of f32.  A lane owns NV
-    // consecutive positions, i.e. NV consecutive bits: R = [d2 <= min(thr_row, thr_col)] is shifted
-    // into the lane's own word bit by bit (compare -> carry -> add-with-carry), no cross-lane traffic.
-    if (role == 0 && bits) {
-        // column thresholds (d2 domain): NV consecutive floats per lane, no bounds check (columns
-        // -7 .. 64 ntiles + 63 of the threshold arena are always inside the pair's arena)
-        const float *tc = X + P.pitchT + (lane * NV + wave - (BAND - 1));
-        typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-        float tcv[NV];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const f32x4_u v = *reinterpret_cast<const f32x4_u *>(tc + 4 * j);
-            tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
-        }
-        // positions of this lane whose column exists: t in [lo, hi)
-        int lo = (BAND - 1) - wave - lane * NV, hi = MB + (BAND - 1) - wave - lane * NV;
-        lo = lo < 0 ? 0 : lo;
-        hi = hi > NV ? NV : hi;
-        unsigned valid = 0u;
-        if (hi > lo) valid = (hi - lo >= 32 ? ~0u : ((1u << (hi - lo)) - 1u)) << lo;
-        unsigned acc = 0u;
-#pragma unroll
-        for (int t = NV - 1; t >= 0; --t) {
-            float mthr;
-            asm("v_min_f32 %0, %1, %2" : "=v"(mthr) : "v"(tcv[t]), "v"(thr_row));
-            asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(xr[t]), "v"(mthr) : "vcc");
-        }
-        acc &= valid;
-        // NV < 32: neighbouring lanes complete a dword
-        if constexpr (NV == 16) {
-            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 16;
-        } else if constexpr (NV == 8) {
-            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 8;
-            acc |= (unsigned)__shfl_down((int)acc, 2, 64) << 16;
-        }
-        constexpr int LPD = 32 / NV;                                    // lanes per dword
-        unsigned *rowbits = reinterpret_cast<unsigned *>(bits + P.offT + (size_t)row * P.nw);
-        const int ndw = 2 * P.nw, d = lane / LPD;
-        if ((lane & (LPD - 1)) == 0 && d < ndw) rowbits[d] = acc;
-        for (int z = 2 * NV + lane; z < ndw; z += 64) rowbits[z] = 0u;  // words beyond this size class
-    }
+    ACX_STAMP(4);        // row read
+    band_row_tail<NV, ROLE>(xr, smem, wave, lane, i0 + wave, MA, MB, (BAND - 1) - wave, P, thr, role == 0 ? bits : nullptr,
+                            kappa, pct_mode, inclusive ACX_STAMP_ARG);
 }
 
 // One DP row for the CPL columns of a lane (descending column order, in place): QA = row i-1,

@@ -1,5 +1,6 @@
 """Development aid: per-phase shader-clock breakdown of band_kernel from an -DACX_TIMING build.
-usage: ACX_LIB=build_ab/timing.so python scripts/phase_timing.py [n_tracks] [T]"""
+   scripts/ab_build.sh timing -DACX_TIMING
+   ACX_LIB=build_ab/libacx_timing.so python experiments/phase_timing.py [n_tracks] [T] [covers]"""
 import ctypes
 import sys
 
@@ -20,20 +21,19 @@ ctx.upload_pool(d["frames"], d["offsets"])
 i, j = np.triu_indices(n, 1)
 pairs = np.stack([i, j], 1).astype(np.int32)
 ctx.serra09_pairs(pairs[:64])
-L = _lib.load()
+L = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 32)()
-L.acx_debug_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-L.acx_debug_timing(ctx._h, buf, 1)
+L.acx_dev_band_timing(buf, 1)
 ctx.serra09_pairs(pairs)
-L.acx_debug_timing(ctx._h, buf, 1)
+L.acx_dev_band_timing(buf, 1)
 t = np.array(list(buf), dtype=np.float64)
-w = t[31]
-names = ["row operands + norms", "sweep", "wait B1", "exchange write + hist clear", "wait B2", "row read",
-         "selection", "eps + d2 threshold", "bitmap (role 0 only)"]
-tot = t[:9].sum()
-print("waves %d, mean cycles per wave %.0f" % (w, tot / w))
-for k, nm in enumerate(names):
-    print("  %-28s %8.0f  %5.1f %%" % (nm, t[k] / w, 100 * t[k] / tot))
-print("  sweep split: dma wait %.0f  gram %.0f  walk %.0f" % (t[16] / w, t[17] / w, t[18] / w))
-print("  fast selection split: range %.0f  bin+atomics %.0f  scan+find %.0f  gather %.0f  rank %.0f" % tuple(t[20:25] / w))
-print("  fast selection: %d rows decided, %d rows fell back to the generic selection" % (t[26], t[25]))
+names = ["operands + sweep / gather", "wait B1", "exchange writes", "wait B2", "row read (+ Z store)", "selection", "eps + d2 threshold",
+         "threshold store + bitmap (row pass)"]
+for title, o in (("band_kernel", 0), ("band_read_kernel", 16)):
+    w = t[o + 15]
+    if w == 0:
+        continue
+    tot = t[o:o + 8].sum()
+    print("%s: waves %d, mean clock ticks per wave %.0f" % (title, w, tot / w))
+    for k, nm in enumerate(names):
+        print("  %-36s %8.1f  %5.1f %%" % (nm, t[o + k] / w, 100 * t[o + k] / tot))

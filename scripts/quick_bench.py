@@ -21,6 +21,8 @@ for rep in range(2):
     t0 = time.time()
     out = ctx.serra09_pairs(pairs)
     dt = time.time() - t0
+    import zlib
+    print("   scores crc32 %08x" % zlib.crc32(np.ascontiguousarray(out, dtype=np.float32).tobytes()))
     print("n=%d T=%d pairs=%d  %.3f s  %.1f pairs/s  (max score %.1f)" % (n, T, len(pairs), dt, len(pairs) / dt, out.max()))
     for k, v in ctx.profile().items():
         if v["launches"]:

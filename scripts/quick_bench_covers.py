@@ -25,6 +25,8 @@ for rep in range(2):
     t0 = time.time()
     out = ctx.serra09_pairs(pairs)
     dt = time.time() - t0
+    import zlib
+    print("   scores crc32 %08x" % zlib.crc32(np.ascontiguousarray(out, dtype=np.float32).tobytes()))
     L = np.diff(d["offsets"]) - 9
     cells = float(np.sum(L[pairs[:, 0]] * L[pairs[:, 1]]))
     print("n=%d pairs=%d  %.3f s  %.1f pairs/s  %.1f Gcells/s" % (n, len(pairs), dt, len(pairs) / dt, cells / dt / 1e9))
