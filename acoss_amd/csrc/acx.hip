@@ -205,11 +205,16 @@ int check_params(acx_ctx *c, const acx_serra09_params &p)
     return ACX_OK;
 }
 
+// The band kernel's edge tiles read their operands and norms WITHOUT clamping the frame index (the cells
+// they feed are masked anyway): up to 7 frames before a track and 71 behind it.  Inside the pool that is
+// a neighbouring track; the two ends of the rotated pool and of the norm table carry this much zeroed slack.
+constexpr int64_t POOL_SLACK = 96;      // frames (rotated pool) / floats (norm table) on either side
+
 // band_kernel is launched from its own translation unit (acx_band.hip)
 bool launch_band(acx_ctx *c, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, const acx_serra09_params &p, int role, int write_d2)
 {
-    acx::BandLaunch L{c->stream, c->d_frot, c->d_toff, c->d_normtab, c->d_noff, c->d_scratch, c->d_thr, c->d_bits,
-                      p.kappa, p.pct_mode, p.inclusive, p.oti_target};
+    acx::BandLaunch L{c->stream, c->d_frot + POOL_SLACK * acx::FROT, c->d_toff, c->d_normtab + POOL_SLACK, c->d_noff, c->d_scratch, c->d_thr,
+                      c->d_bits, p.kappa, p.pct_mode, p.inclusive, p.oti_target};
     return acx::launch_band_kernel(L, m, dpd, B, maxRows, maxCols, role, write_d2);
 }
 
@@ -217,7 +222,7 @@ template <int M>
 void launch_normtab(acx_ctx *c, int maxM, int span)
 {
     hipLaunchKernelGGL((acx::normtab_kernel<M>), dim3(c->n_tracks, (maxM + 255) / 256, acx::NBIN), dim3(256), 0, c->stream,
-                       c->d_frames, c->d_toff, c->d_noff, c->d_normtab, span);
+                       c->d_frames, c->d_toff, c->d_noff, c->d_normtab + POOL_SLACK, span);
 }
 
 #ifdef ACX_FAST_BUILD   /* development builds: only the default stack size */
@@ -276,11 +281,13 @@ int ensure_tau(acx_ctx *c, int tau)
     const int64_t total = c->h_off[n];
     // rotated copy of the active pool: the band kernel loads its MFMA operands from it (12 bytes per
     // lane per 16-frame tile, already in the rotated chain order) -- 144 B per frame
-    ACX_HIP(c, hipMalloc((void **)&c->d_frot, sizeof(float) * std::max<int64_t>(1, total) * acx::FROT));
+    ACX_HIP(c, hipMalloc((void **)&c->d_frot, sizeof(float) * (std::max<int64_t>(1, total) + 2 * POOL_SLACK) * acx::FROT));
+    ACX_HIP(c, hipMemsetAsync(c->d_frot, 0, sizeof(float) * POOL_SLACK * acx::FROT, c->stream));
+    ACX_HIP(c, hipMemsetAsync(c->d_frot + (POOL_SLACK + total) * acx::FROT, 0, sizeof(float) * POOL_SLACK * acx::FROT, c->stream));
     if (total > 0) {
         const int64_t nout = total * acx::FROT;
         hipLaunchKernelGGL(acx::rotpool_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_frames, c->d_frot, total);
+                           c->d_frames, c->d_frot + POOL_SLACK * acx::FROT, total);
         ACX_HIP(c, hipGetLastError());
     }
     ACX_HIP(c, hipStreamSynchronize(c->stream));
@@ -302,10 +309,12 @@ int ensure_normtab(acx_ctx *c, const acx_serra09_params &p)
         noff[t] = tot;
         const int Me = std::max<int>(0, (int)(c->h_off[t + 1] - c->h_off[t]) - span);
         maxM = std::max(maxM, Me);
-        tot += (int64_t)acx::NBIN * Me;
+        tot += (int64_t)acx::NBIN * (Me + acx::NGUARD);      // + the +inf guard entries behind every rotation's row
     }
     noff[c->n_tracks] = tot;
-    ACX_HIP(c, hipMalloc((void **)&c->d_normtab, sizeof(float) * std::max<int64_t>(1, tot)));
+    ACX_HIP(c, hipMalloc((void **)&c->d_normtab, sizeof(float) * (std::max<int64_t>(1, tot) + 2 * POOL_SLACK)));
+    // +inf everywhere first: the guard entries and the slack are what the band kernel reads for columns outside a matrix
+    ACX_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_normtab, 0x7f800000, (size_t)(std::max<int64_t>(1, tot) + 2 * POOL_SLACK), c->stream));
     ACX_HIP(c, hipMalloc((void **)&c->d_noff, sizeof(int64_t) * noff.size()));
     ACX_HIP(c, hipMemcpy(c->d_noff, noff.data(), sizeof(int64_t) * noff.size(), hipMemcpyHostToDevice));
     bool handled = true;

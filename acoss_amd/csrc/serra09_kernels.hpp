@@ -29,6 +29,7 @@ namespace acx {
 constexpr int NBIN = 12;       // chroma bins
 constexpr int SEL_BINS = 2048; // histogram bins of the generic percentile selection
 constexpr int MAX_M = 16;      // largest stack size of the band kernel (larger m: long-track kernels)
+constexpr int NGUARD = 80;     // +inf entries behind every row of the embedded-norm table (normtab_kernel)
 
 struct PairDesc {
     int32_t q, r;          // track indices (query, reference)
@@ -574,7 +575,7 @@ __device__ __forceinline__ bool wave_select_fast(const float (&x)[NV], int k, bo
 //     of them: ranks below the total are exact whatever the rounding.
 // `hist_addr` = LDS byte address of this wave's zeroed BINS-dword histogram; `cand` = 64 floats.
 // ------------------------------------------------------------------------------------
-// Pads must be -inf here (they take no part: k is the plain rank among the cells).
+// Pads are +inf (they take no part: k is the plain rank among the cells).
 template <int NV, int BINS, int GRP>
 __device__ __forceinline__ bool wave_select_pivot(const float (&x)[NV], int k, bool want_next, unsigned hist_addr,
                                                   float *cand, int lane, float &slo, float &shi, bool lane_has_data,
@@ -587,7 +588,7 @@ __device__ __forceinline__ bool wave_select_pivot(const float (&x)[NV], int k, b
     static_assert(DPL >= 4 && DPL <= 16 && (DPL & (DPL - 1)) == 0, "BINS must be 256, 512 or 1024");
     static_assert(GRP == 1 || GRP == 2 || GRP == 4, "groups of 1, 2 or 4 lanes");
     const float INF = __builtin_inff();
-    // ---- row minimum and the largest group minimum (unsigned order: the -1 pads are invisible)
+    // ---- row minimum and the largest group minimum (unsigned bit patterns: +inf pads are above every cell)
     unsigned mnl = 0xFFFFFFFFu;
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
@@ -614,9 +615,8 @@ __device__ __forceinline__ bool wave_select_pivot(const float (&x)[NV], int k, b
     // the offset the sum is rounded to an integer by the addition (ulp = 1 above 2^23), so the float's bit
     // pattern is MAGIC + bin -- no conversion instruction, and v_fma_f32 issues at twice the rate of v_cvt.
     // offm is exact up to 0.57 (its own rounding + that of mn * scale <= 2^20), so the row minimum and every
-    // cell above it land at or above MAGIC: `pattern < MAGIC + NB` alone decides who takes part.  Pads are
-    // -inf (pattern 0xff800000, out), huge cells and +inf compare above; the lanes that hold nothing but
-    // pads get an offset of +inf.
+    // cell above it land at or above MAGIC: `pattern < MAGIC + NB` alone decides who takes part.  Huge cells
+    // and the +inf pads compare above; the lanes that hold nothing but pads get an offset of +inf.
     constexpr unsigned MAGIC = 0x4B000000u;            // 2^23
     const float scale = ((float)NB - 3.0f) * __builtin_amdgcn_rcpf(range);
     const float offm = lane_has_data ? (8388609.0f - mn * scale) : INF;
@@ -786,7 +786,9 @@ __device__ __forceinline__ float percentile_eps2(float slo, float shi, int pct_m
 // rotation rot = 0..11 and every embedded frame i: xx = tree over m frame norms, each a 12-term
 // fmaf chain over the bins in ROTATED order (rotated[c'] = src[(c' - rot) mod 12]) -- the chain
 // order is part of the arithmetic spec, so the norm depends on the rotation.  Layout:
-// tab[noff[track] + rot * Memb(track) + i].  A pair only picks two rows of it (query unrotated,
+// tab[noff[track] + rot * (Memb(track) + NGUARD) + i]; the NGUARD entries behind every row (and the slack in
+// front of the table) hold +inf: a band-kernel tile that reaches past the matrix reads them as the norms of its
+// nonexistent columns, so those cells come out as +inf -- the pad value -- without a single compare.  A pair only picks two rows of it (query unrotated,
 // reference rotated by its OTI, or the other way round).
 // ------------------------------------------------------------------------------------
 template <int M>
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(256) void normtab_kernel(const float *__restrict__ 
         }
         s[k] = acc;
     }
-    tab[noff[track] + (int64_t)rot * Me + i] = tree_sum<M>(s);
+    tab[noff[track] + (int64_t)rot * (Me + NGUARD) + i] = tree_sum<M>(s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -962,7 +964,7 @@ struct RowGeom {
 // ------------------------------------------------------------------------------------
 // The part of the band pipeline that follows the exchange: wave `wave` holds one complete row of the
 // pair's matrix in registers (xr[t] = slot NV lane + t; slot s <-> column s - cshift; slots without a
-// column hold -inf) and owns exchange row `wave` of `smem` as scratch.  Exact kappa-percentile of the
+// column hold +inf) and owns exchange row `wave` of `smem` as scratch.  Exact kappa-percentile of the
 // row (pivot-filtered histogram, unfiltered histogram, generic narrowing), eps and the d2-domain
 // threshold into the pair's threshold arena, and, when `bits` is given (rows = query frames, the
 // column thresholds are there already), the binarised row into the recurrence bitmap: bit = slot (bit b of
@@ -1018,9 +1020,6 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
     bool done = false;
     const int end_valid = MB + cshift;                                  // slots [cshift, end_valid) are cells
     const bool lane_has_data = lane * NV < end_valid;                   // first slot of the lane is a cell or a low pad
-    // pads inside the lanes that take part in the histogram: the low ones of lane 0 and the tail of the
-    // last lane with cells; they sit in bin 0 and rank below every cell
-    const int npadc = cshift + (((end_valid + NV - 1) / NV) * NV - end_valid);
     if (use_pivot) {
         const int g0 = (lane & ~(PGRP - 1)) * NV;                       // first slot of the lane's group
         const bool group_full = g0 >= cshift && g0 + PGRP * NV <= end_valid;
@@ -1029,14 +1028,11 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
         if (!done) zero_hist(FBINS);
     }
     if (!done)
-        done = wave_select_fast<NV, FBINS, FCOPIES, true>(xr, k + npadc, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, lane_has_data);
+        done = wave_select_fast<NV, FBINS, FCOPIES>(xr, k, interp && ihi != ilo, hist_addr, myrow, lane, slo, shi, lane_has_data);
     if (!done) {
         unsigned *ghist = reinterpret_cast<unsigned *>(myrow) + 64;
         unsigned *counter = reinterpret_cast<unsigned *>(myrow) + 64 + SelGeom<GBINS>::SLOTS;
-        float xi[NV];                                   // the generic selection wants its pads at +inf
-#pragma unroll
-        for (int t = 0; t < NV; ++t) xi[t] = xr[t] < 0.0f ? INF : xr[t];
-        const SelectResult sr = wave_select_regs<NV, GBINS>(xi, k, ghist, myrow, counter, lane, interp);
+        const SelectResult sr = wave_select_regs<NV, GBINS>(xr, k, ghist, myrow, counter, lane, interp);
         slo = sr.value;
         shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
     }
@@ -1132,14 +1128,14 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     const int rota = (rows_are_ref == (oti_target == 0)) ? P.oti : 0;
     const int rotb = (rows_are_ref == (oti_target == 0)) ? 0 : P.oti;
     // embedded norms of the row / column track in this pair's rotation (normtab_kernel)
-    const float *nrow = normtab + noff[role ? P.r : P.q] + (int64_t)rota * MA;
-    const float *ncol = normtab + noff[role ? P.q : P.r] + (int64_t)rotb * MB;
+    const float *nrow = normtab + noff[role ? P.r : P.q] + (int64_t)rota * (MA + NGUARD);
+    const float *ncol = normtab + noff[role ? P.q : P.r] + (int64_t)rotb * (MB + NGUARD);
     const float INF = __builtin_inff();
-    // Cells outside the matrix travel through the exchange as -inf: distances are >= +0, so a negative
-    // pad is the largest UNSIGNED and the smallest SIGNED bit pattern -- the selection's integer min /
-    // max skip it for free (a +inf pad needed a bias add per value for the max) -- and -inf stays -inf
-    // through the binning fma of the pivot-filtered pass, whatever the scale
-    const float PADV = -INF;
+    // Cells outside the matrix are +inf, and they get there by themselves: the norm of a nonexistent column
+    // (the table's guard entries) or row (below) is +inf, so d2 = (xx - 2 xy) + yy is.  The bit pattern of
+    // +inf is above every finite distance: the selection's unsigned minimum never picks it and the
+    // pivot-filtered histogram leaves it out.
+    const float PADV = INF;
 
     // ---- MFMA operands come straight from the rotated frame pool (frot, see rotpool_kernel):
     // frame f holds, for each rotation r = 0..2 and residue class cls = 0..3, the three bins
@@ -1166,7 +1162,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     }
     float xrow[BAND];
 #pragma unroll
-    for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : 0.0f;
+    for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : INF;       // rows past the matrix: +inf cells
     float *Sw = smem + wave * (G::AROWS * G::SP);               // this wave's Gram tile, [row frame][column frame]
 #ifdef ACX_TIMING
     StampT tstamp_{__builtin_readcyclecounter(), 0};
@@ -1179,45 +1175,28 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     // column-frame operands of a tile (frames 64 tile - 7 ... + BW)
     // (tb0: first 16-frame block wanted -- a wave's second and later tiles inherit their first HB
     // blocks from the tile before, see the sweep)
+    // (edge tiles read frames before / behind the track -- a neighbouring track of the pool or the zeroed slack at
+    // its ends, acx.hip POOL_SLACK: finite values, and the cells they feed get a norm of +inf)
     auto load_operands = [&](int tile, BvT &bv, auto tb0_tag) {
         constexpr int tb0 = decltype(tb0_tag)::value;
         const int base = 64 * tile - (BAND - 1);
-        if (base >= 0 && base + G::BW <= TB) {                  // wave-uniform: all frames exist
-            const float *p = frb + (ptrdiff_t)(base + lr) * FROT;
+        const float *p = frb + (ptrdiff_t)(base + lr) * FROT;
 #pragma unroll
-            for (int tb = tb0; tb < G::NCT; ++tb) {
-                const f32x3 v = *reinterpret_cast<const f32x3_u *>(p + 16 * FROT * tb);
-                bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
-            }
-        } else {                                                // clamp: those cells are masked anyway
-#pragma unroll
-            for (int tb = tb0; tb < G::NCT; ++tb) {
-                int f = base + 16 * tb + lr;
-                f = f < 0 ? 0 : (f > TB - 1 ? TB - 1 : f);
-                const f32x3 v = *reinterpret_cast<const f32x3_u *>(frb + (ptrdiff_t)f * FROT);
-                bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
-            }
+        for (int tb = tb0; tb < G::NCT; ++tb) {
+            const f32x3 v = *reinterpret_cast<const f32x3_u *>(p + 16 * FROT * tb);
+            bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
         }
     };
-    // embedded column norms of the lane's 8 cells
+    // embedded column norms of the lane's 8 cells: 8 consecutive norms as two (4-byte aligned) 16-byte loads
+    // (columns outside the matrix: the +inf guard entries of the table)
     auto load_norms = [&](int tile, float (&yv)[BAND]) {
         const int base = 64 * tile - (BAND - 1);
-        if (base >= 0 && base + 64 + BAND - 1 <= MB) {
-            // the lane's 8 consecutive norms as two (4-byte aligned) 16-byte loads
-            typedef float f32x4n __attribute__((ext_vector_type(4), aligned(4)));
-            const f32x4n *p = reinterpret_cast<const f32x4n *>(ncol + base + lane);
-            const f32x4n v0 = p[0], v1 = p[1];
-            yv[0] = v0.x; yv[1] = v0.y; yv[2] = v0.z; yv[3] = v0.w;
-            yv[4] = v1.x; yv[5] = v1.y; yv[6] = v1.z; yv[7] = v1.w;
-            static_assert(BAND == 8, "two 16-byte loads cover the band's 8 norms");
-        } else {
-#pragma unroll
-            for (int a = 0; a < BAND; ++a) {
-                int j = base + lane + a;
-                j = j < 0 ? 0 : (j > MB - 1 ? MB - 1 : j);
-                yv[a] = ncol[j];
-            }
-        }
+        typedef float f32x4n __attribute__((ext_vector_type(4), aligned(4)));
+        const f32x4n *p = reinterpret_cast<const f32x4n *>(ncol + base + lane);
+        const f32x4n v0 = p[0], v1 = p[1];
+        yv[0] = v0.x; yv[1] = v0.y; yv[2] = v0.z; yv[3] = v0.w;
+        yv[4] = v1.x; yv[5] = v1.y; yv[6] = v1.z; yv[7] = v1.w;
+        static_assert(BAND == 8, "two 16-byte loads cover the band's 8 norms");
     };
     // frame Gram on the matrix cores.  The COLUMN frames are the MFMA's row operand, so a lane ends
     // up with four consecutive column frames of one row frame: one 16-byte LDS store per 16x16 tile
@@ -1264,26 +1243,14 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
 
     auto keep = [&](auto st_tag, int tile, const float (&dv)[BAND]) {     // cells -> xv (+ debug D2)
         constexpr int st = decltype(st_tag)::value;
-        const int base = 64 * tile - (BAND - 1);
-        const int j0 = base + lane;                       // column of the lane's first cell
-        const bool interior = base >= 0 && base + 64 + BAND - 1 <= MB && i0 + BAND <= MA;   // wave-uniform
-        if (interior) {
 #pragma unroll
-            for (int a = 0; a < BAND; ++a) xv[a][st] = dv[a];
-            if (write_d2) {
-                float *Dl = D + j0;
-#pragma unroll
-                for (int a = 0; a < BAND; ++a) Dl[a * pitchD + a] = dv[a];
-            }
-        } else {
+        for (int a = 0; a < BAND; ++a) xv[a][st] = dv[a];   // (cells outside the matrix are +inf already)
+        if (write_d2) {
+            const int j0 = 64 * tile - (BAND - 1) + lane;   // column of the lane's first cell
 #pragma unroll
             for (int a = 0; a < BAND; ++a) {
                 const int j = j0 + a;
-                const bool rowok = (i0 + a) < MA;
-                const bool ok = rowok && j >= 0 && j < MB;
-                const float v = ok ? dv[a] : INF;
-                xv[a][st] = ok ? dv[a] : PADV;
-                if (write_d2 && rowok && j >= 0 && j < pitchD) D[a * pitchD + j] = v;
+                if (i0 + a < MA && j >= 0 && j < pitchD) D[a * pitchD + j] = dv[a];
             }
         }
     };
