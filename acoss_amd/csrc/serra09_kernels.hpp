@@ -1534,10 +1534,12 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
 // the columns k (low half) and k + CPL/2 (high half), so that the (i-1, j-1), (i-2, j-1), (i-1, j-2)
 // predecessors of register k are simply registers k-1 / k-2 of the previous rows (the first two are
 // stitched from the neighbour lane with one funnel shift each).  A cell is max(mx + t, 0) with
-// t = +2 (match) / -1 (gap) half-units = 3 bit - 1, the bits of both halves spread by one shift + and.
+// t = +2 (match) / -1 (gap) half-units = 3 bit - 1, the bits of both halves spread by one shift + and;
+// the clamp at 0 is the saturation of an unsigned subtract (v_pk_mad + v_pk_sub_u16 clamp).
 // Exactly the arithmetic of qmax_bits_kernel<true, false, CPL>: integers instead of exact floats.
 // ------------------------------------------------------------------------------------
 typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ i16x2 as_i16x2(unsigned v) { return __builtin_bit_cast(i16x2, v); }
 __device__ __forceinline__ unsigned as_u32(i16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
@@ -1574,7 +1576,8 @@ __global__ __launch_bounds__(64) void qmax_bits_h16_kernel(const PairDesc *__res
             if (has1) d1 = r[dw0 + 1];
         }
     };
-    const i16x2 three = {3, 3}, minus1 = {-1, -1}, zero = {0, 0};
+    const i16x2 three = {3, 3};
+    const u16x2 one_u = {1, 1};
     // One DP row: QA = row i-1, QB = row i-2 (overwritten with row i)
     auto dp_row = [&](int i, unsigned d0, unsigned d1, unsigned (&QA)[NR], unsigned (&QB)[NR]) {
         const int sh = (BAND - 1) - (i & (BAND - 1));
@@ -1596,8 +1599,9 @@ __global__ __launch_bounds__(64) void qmax_bits_h16_kernel(const PairDesc *__res
             unsigned sp;                                     // recurrence bit of column k -> low half, of column k + NR -> high half
             if constexpr (NR == 16) sp = (w >> k) & 0x00010001u;
             else sp = ((w >> k) & 1u) | (((w >> (k + NR)) & 1u) << 16);
-            const i16x2 t = as_i16x2(sp) * three + minus1;
-            const i16x2 q = __builtin_elementwise_max(mx + t, zero);
+            // max(mx + 3 bit - 1, 0): multiply-add, then an unsigned saturating subtract (all values are >= 0)
+            const u16x2 up = __builtin_bit_cast(u16x2, as_i16x2(sp) * three + mx);
+            const i16x2 q = __builtin_bit_cast(i16x2, __builtin_elementwise_sub_sat(up, one_u));
             QB[k] = as_u32(q);
             best = __builtin_elementwise_max(best, q);
         }
