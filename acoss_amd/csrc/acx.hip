@@ -91,6 +91,8 @@ struct acx_ctx {
     double *d_out64 = nullptr;  size_t out64_cap = 0;
     // EarlyFusion pool
     float *d_ef[3] = {nullptr, nullptr, nullptr};
+    unsigned short *d_efs[2] = {nullptr, nullptr};   // mfcc / ssm block features as three-term bf16 splits (ef_gemm_bf16x3_kernel)
+    int ef_kp[2] = {0, 0};                            // their row length (K rounded up to 32)
     float *d_efn[2] = {nullptr, nullptr};
     double *d_efmed = nullptr;
     int64_t *d_efoff = nullptr;
@@ -675,9 +677,13 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             {
                 const int tiles_x = (maxN + acx::EF_TILE - 1) / acx::EF_TILE, tiles_y = (maxM + acx::EF_TILE - 1) / acx::EF_TILE;
                 ProfScope ps(c, KS_EFGEMM, cells);
-                hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 3), dim3(256), 0, c->stream,
+                // mfcc, ssm: bf16 matrix pipe on the three-term splits; chroma (cosine, rolled by the pair's OTI): f32 MFMA
+                hipLaunchKernelGGL(acx::ef_gemm_bf16x3_kernel, dim3(tiles_x * tiles_y, B, 2), dim3(acx::EFB_THREADS), 0, c->stream,
+                                   c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
+                                   c->d_scratch, c->ef_kp[0], c->ef_kp[1], tiles_x);
+                hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 1), dim3(256), 0, c->stream,
                                    c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
-                                   c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x);
+                                   c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x, 2);
             }
         }
         const int nfeat = ext_matrix ? 1 : 3;
@@ -1271,6 +1277,7 @@ static void ef_free_pool(acx_ctx *c)
 {
     for (int k = 0; k < 3; ++k) if (c->d_ef[k]) { (void)hipFree(c->d_ef[k]); c->d_ef[k] = nullptr; }
     for (int k = 0; k < 2; ++k) if (c->d_efn[k]) { (void)hipFree(c->d_efn[k]); c->d_efn[k] = nullptr; }
+    for (int k = 0; k < 2; ++k) if (c->d_efs[k]) { (void)hipFree(c->d_efs[k]); c->d_efs[k] = nullptr; }
     if (c->d_efmed) { (void)hipFree(c->d_efmed); c->d_efmed = nullptr; }
     if (c->d_efoff) { (void)hipFree(c->d_efoff); c->d_efoff = nullptr; }
     c->ef_ntracks = 0;
@@ -1295,6 +1302,18 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
         for (int k = 0; k < 2; ++k)
             hipLaunchKernelGGL(acx::ef_rownorm_kernel, dim3(g), dim3(256), 0, c->stream, c->d_ef[k], nb, dims[k], 0, c->d_efn[k]);
         ACX_HIP(c, hipGetLastError());
+    }
+    // three-term bf16 splits of the two Euclidean features (the operands of ef_gemm_bf16x3_kernel)
+    for (int k = 0; k < 2; ++k) {
+        c->ef_kp[k] = (dims[k] + acx::EFB_BK - 1) / acx::EFB_BK * acx::EFB_BK;
+        const int64_t nel = std::max<int64_t>(1, nb) * 3 * c->ef_kp[k];
+        ACX_HIP(c, hipMalloc((void **)&c->d_efs[k], sizeof(unsigned short) * nel));
+        if (nb > 0) {
+            const int64_t nthr = nb * c->ef_kp[k];
+            hipLaunchKernelGGL(acx::ef_split_bf16_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream,
+                               c->d_ef[k], c->d_efs[k], nb, dims[k], c->ef_kp[k]);
+            ACX_HIP(c, hipGetLastError());
+        }
     }
     ACX_HIP(c, hipStreamSynchronize(c->stream));
     return ACX_OK;

@@ -6,7 +6,8 @@
 //                       get_csm (cross_recurrence.py:30-48: sqrt(max(0, |x|^2+|y|^2-2xy))) or
 //                       get_csm_cosine after the blocked OTI roll (:53-73, :105-134: rows are
 //                       pre-normalised at upload, the roll is a permutation of the k index);
-//                       writes C and C^T
+//                       writes C and C^T; the chroma matrix takes this kernel, the two Euclidean ones
+//   E1b ef_gemm_bf16x3_kernel  the same products from three-term bf16 splits on the bf16 matrix pipe
 //   E2 ef_rowstat_kernel one wave per row: the k-th smallest value of the row (threshold of
 //                       csm_to_binary, :136-161) and the mean of the K smallest
 //                       (getWCSM, similarity_fusion.py:46-50); on C^T rows = column stats
@@ -78,6 +79,49 @@ __global__ void ef_oti_kernel(EfPair *pd, int B, const double *__restrict__ med)
     pd[p].oti = best;
 }
 
+// epilogue + stores of a wave's 64 x 64 block of accumulators (acc[a][b][reg] = dot of row ib + 16 a + 4 lk + reg
+// and column jb + 16 b + lr): get_csm / get_csm_cosine, C row-major (16 lanes in a row write 64 contiguous
+// bytes) and C^T (a lane's four accumulator rows are four consecutive columns of C^T: one 16-byte store)
+template <int NA>
+__device__ __forceinline__ void ef_gemm_epilogue(const f32x4 (&acc)[NA][4], const EfPair &P, int s, int ib0, int jb0, int na, int nb,
+                                                 int lr, int lk, const float *__restrict__ nrm, const int64_t *__restrict__ boff,
+                                                 float *__restrict__ scratch)
+{
+    float *C = scratch + ef_c_off(P, s);
+    float *CT = scratch + ef_ct_off(P, s);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (!(a < na && b < nb)) continue;
+            const int ib = ib0 + 16 * a + 4 * lk;
+            const int j = jb0 + 16 * b + lr;
+            float v[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = ib + reg;
+                const float dot = acc[a][b][reg];
+                if (s == 2) {
+                    v[reg] = 1.0f - dot;
+                } else {
+                    const float nx = (i < P.M) ? nrm[boff[P.q] + i] : 0.0f, ny = (j < P.N) ? nrm[boff[P.r] + j] : 0.0f;
+                    float t = (nx + ny) - 2.0f * dot;
+                    if (t < 0.0f) t = 0.0f;
+                    v[reg] = __builtin_sqrtf(t);
+                }
+                if (i < P.M && j < P.N) C[(size_t)i * P.pitchC + j] = v[reg];
+            }
+            if (j < P.N) {
+                float *ct = CT + (size_t)j * P.pitchT + ib;
+                if (ib + 3 < P.M) *reinterpret_cast<float4 *>(ct) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        if (ib + reg < P.M) ct[reg] = v[reg];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------
 // E1: C[i][j] = epilogue( sum_k A[i][perm(k)] * B[j][k] ), 128 x 128 tile per workgroup,
 // 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles (16 accumulator tiles: every operand
@@ -99,12 +143,12 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
                                                       const float *__restrict__ nrm0, const float *__restrict__ nrm1,
                                                       const int64_t *__restrict__ boff,
                                                       const EfPair *__restrict__ pd, float *__restrict__ scratch,
-                                                      int K0, int K1, int K2, int tiles_x)
+                                                      int K0, int K1, int K2, int tiles_x, int s0)
 {
     __shared__ float As[EF_BK * EF_LP];
     __shared__ float Bs[EF_BK * EF_LP];
     const EfPair P = pd[blockIdx.y];
-    const int s = blockIdx.z;
+    const int s = s0 + blockIdx.z;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int i0 = ty * EF_TILE, j0 = tx * EF_TILE;
     if (i0 >= P.M || j0 >= P.N) return;
@@ -198,42 +242,142 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
         }
         __syncthreads();
     }
-    // epilogue + stores: C row-major (a lane's 16 lanes-in-a-row write 64 contiguous bytes) and C^T
-    // (a lane's four accumulator rows are four consecutive columns of C^T: one 16-byte store)
-    const float *nrm = s == 0 ? nrm0 : nrm1;
-    float *C = scratch + ef_c_off(P, s);
-    float *CT = scratch + ef_ct_off(P, s);
+    ef_gemm_epilogue<4>(acc, P, s, i0 + 64 * wr, j0 + 64 * wc, na, nb, lr, lk, s == 0 ? nrm0 : nrm1, boff, scratch);
+}
+
+// ------------------------------------------------------------------------------------
+// E1b: the two Euclidean cross-similarity matrices (mfcc, ssm: 80 % of the chain's flops) on the bf16 matrix
+// pipe, at f32 accuracy.  Every f32 feature value is split ONCE per pool into three bf16 terms
+// x = x1 + x2 + x3 (round-to-nearest each, remainders exact: 3 x 8 significant bits), and
+//   x . y  ~=  x1 y1 + (x1 y2 + x2 y1) + (x2 y2 + x1 y3 + x3 y1)
+// (the dropped terms are below 2^-24 |x| |y|, the size of one f32 rounding) with f32 accumulation in the
+// MFMA, smallest terms first.  Six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block cost 6 x 16 cycles where
+// eight v_mfma_f32_16x16x4_f32 cost 8 x 32 -- and unlike the f32 MFMA the bf16 MFMA leaves VALU / LDS issue
+// of the other waves alone (scripts/ubench/mfma_valu_overlap.hip).  Same tiling as ef_gemm_kernel
+// (128 x 128 per workgroup) but 8 waves of 32 x 64 cells, k in blocks of 32: a lane's MFMA operand is 8
+// consecutive k of one row = one 16-byte LDS read (row pitch 80 bytes: conflict free), 18 operand reads feed 48 MFMAs.
+// Layout of the split pool: [block][term 0..2][Kp] bf16, Kp = K rounded up to 32, zeros behind K.
+// ------------------------------------------------------------------------------------
+constexpr int EFB_BK = 32;
+constexpr int EFB_LP = 40;     // LDS row pitch in bf16 elements (80 bytes)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned ef_bf16_rne(float x)
+{
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+__global__ __launch_bounds__(256) void ef_split_bf16_kernel(const float *__restrict__ f, unsigned short *__restrict__ out,
+                                                            int64_t nblocks, int K, int Kp)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nblocks * Kp) return;
+    const int64_t row = idx / Kp;
+    const int k = (int)(idx - row * Kp);
+    const float x = k < K ? f[row * K + k] : 0.0f;
+    const unsigned h1 = ef_bf16_rne(x);
+    const float r1 = x - __uint_as_float(h1 << 16);            // exact
+    const unsigned h2 = ef_bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(h2 << 16);           // exact
+    const unsigned h3 = ef_bf16_rne(r2);
+    unsigned short *o = out + row * 3 * Kp + k;
+    o[0] = (unsigned short)h1; o[Kp] = (unsigned short)h2; o[2 * (int64_t)Kp] = (unsigned short)h3;
+}
+
+constexpr int EFB_THREADS = 512;    // 8 waves as 4 x 2: 32 x 64 cells per wave (two workgroups per CU = 4 waves per SIMD)
+
+__global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ef_gemm_bf16x3_kernel(const unsigned short *__restrict__ split0,
+                                                                        const unsigned short *__restrict__ split1,
+                                                                        const float *__restrict__ nrm0, const float *__restrict__ nrm1,
+                                                                        const int64_t *__restrict__ boff,
+                                                                        const EfPair *__restrict__ pd, float *__restrict__ scratch,
+                                                                        int Kp0, int Kp1, int tiles_x)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * EF_TILE * EFB_LP];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * EF_TILE * EFB_LP];
+    const EfPair P = pd[blockIdx.y];
+    const int s = blockIdx.z;                        // 0 mfcc, 1 ssm
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int i0 = ty * EF_TILE, j0 = tx * EF_TILE;
+    if (i0 >= P.M || j0 >= P.N) return;
+    const int Kp = s == 0 ? Kp0 : Kp1;
+    const unsigned short *S = s == 0 ? split0 : split1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    constexpr int NA = 2;                            // 16-row sub-tiles per wave
+    int na = (P.M - (i0 + 32 * wr) + 15) / 16, nb = (P.N - (j0 + 64 * wc) + 15) / 16;
+    na = na < 0 ? 0 : (na > NA ? NA : na);
+    nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
+
+    f32x4 acc[NA][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (!(a < na && b < nb)) continue;
-            const int ib = i0 + 64 * wr + 16 * a + 4 * lk;
-            const int j = j0 + 64 * wc + 16 * b + lr;
-            float v[4];
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: thread -> (row = tid / 4, 8 consecutive k = 8 * (tid % 4) ...) of every term: one 16-byte piece each
+    const int srow = tid >> 2, sk = (tid & 3) * 8;
+    const bool rowa = i0 + srow < P.M, rowb = j0 + srow < P.N;
+    const unsigned short *ap = S + (boff[P.q] + (rowa ? i0 + srow : 0)) * 3 * Kp + sk;    // (rows past the matrix read row 0; never stored)
+    const unsigned short *bp = S + (boff[P.r] + (rowb ? j0 + srow : 0)) * 3 * Kp + sk;
+    u32x4 ra[3], rb[3];
+    auto gload = [&]() {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int i = ib + reg;
-                const float dot = acc[a][b][reg];
-                if (s == 2) {
-                    v[reg] = 1.0f - dot;
-                } else {
-                    const float nx = (i < P.M) ? nrm[boff[P.q] + i] : 0.0f, ny = (j < P.N) ? nrm[boff[P.r] + j] : 0.0f;
-                    float t = (nx + ny) - 2.0f * dot;
-                    if (t < 0.0f) t = 0.0f;
-                    v[reg] = __builtin_sqrtf(t);
-                }
-                if (i < P.M && j < P.N) C[(size_t)i * P.pitchC + j] = v[reg];
-            }
-            if (j < P.N) {
-                float *ct = CT + (size_t)j * P.pitchT + ib;
-                if (ib + 3 < P.M) *reinterpret_cast<float4 *>(ct) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        if (ib + reg < P.M) ct[reg] = v[reg];
-            }
+        for (int t = 0; t < 3; ++t) {
+            ra[t] = *reinterpret_cast<const u32x4 *>(ap + (size_t)t * Kp);
+            rb[t] = *reinterpret_cast<const u32x4 *>(bp + (size_t)t * Kp);
         }
+        ap += EFB_BK;
+        bp += EFB_BK;
+    };
+    unsigned short *as0 = As + srow * EFB_LP + sk, *bs0 = Bs + srow * EFB_LP + sk;
+    auto lstore = [&]() {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            *reinterpret_cast<u32x4 *>(as0 + t * EF_TILE * EFB_LP) = ra[t];
+            *reinterpret_cast<u32x4 *>(bs0 + t * EF_TILE * EFB_LP) = rb[t];
+        }
+    };
+    const unsigned short *aop = As + (32 * wr + lr) * EFB_LP + 8 * lk;
+    const unsigned short *bop = Bs + (64 * wc + lr) * EFB_LP + 8 * lk;
+    gload();
+    for (int k0 = 0; k0 < Kp; k0 += EFB_BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + EFB_BK < Kp) gload();                     // in flight during the MFMAs below
+        bf16x8 av[NA][3];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                av[a][t] = *reinterpret_cast<const bf16x8 *>(aop + (t * EF_TILE + 16 * a) * EFB_LP);
+        // term-major, so that consecutive MFMAs go to different accumulators; a wave whose block lies inside the
+        // matrix runs the unguarded sequence
+        auto mma = [&](auto full_tag) {
+            constexpr bool full = decltype(full_tag)::value;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (full || b < nb) {
+                    bf16x8 bv[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bv[t] = *reinterpret_cast<const bf16x8 *>(bop + (t * EF_TILE + 16 * b) * EFB_LP);
+#define ACX_EFB_TERM(TA_, TB_)                                                                                         \
+    _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                                     \
+        if (full || a < na) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[a][TA_], bv[TB_], acc[a][b], 0, 0, 0);
+                    ACX_EFB_TERM(0, 2) ACX_EFB_TERM(2, 0) ACX_EFB_TERM(1, 1) ACX_EFB_TERM(0, 1) ACX_EFB_TERM(1, 0) ACX_EFB_TERM(0, 0)
+#undef ACX_EFB_TERM
+                }
+            }
+        };
+        if (na == NA && nb == 4) mma(std::true_type());
+        else mma(std::false_type());
+        __syncthreads();
+    }
+    ef_gemm_epilogue<NA>(acc, P, s, i0 + 32 * wr, j0 + 64 * wc, na, nb, lr, lk, s == 0 ? nrm0 : nrm1, boff, scratch);
 }
 
 // ------------------------------------------------------------------------------------
