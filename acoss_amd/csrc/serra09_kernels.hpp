@@ -1149,7 +1149,13 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     const int offA = (c0a >> 2) * NBIN + (c0a & 3) * 3;
     const int offB = (c0b >> 2) * NBIN + (c0b & 3) * 3;
     const float *fra = frot + toff[role ? P.r : P.q] * FROT + offA;
-    const float *frb = frot + toff[role ? P.q : P.r] * FROT + offB;
+    // column-frame operands go through a buffer descriptor: scalar base + scalar offset (the tile) + one 32-bit
+    // lane offset -- no 64-bit VALU address arithmetic in the tile loop.  The descriptor starts 8 frames before
+    // the track (a tile reaches back 7 frames: pool slack / the neighbouring track), no range check.
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(frot + (toff[role ? P.q : P.r] - 8) * FROT), 0, -1, 0x00020000);
+    const unsigned voffB = (unsigned)(offB + lr * FROT) * 4u;     // this lane's byte offset inside a 16-frame block
+    const float *frb = frot + toff[role ? P.q : P.r] * FROT + offB;   // (short-row classes: per-lane pointer, plain global loads)
     typedef float f32x3 __attribute__((ext_vector_type(3)));
     typedef f32x3 f32x3_u __attribute__((aligned(4)));
     float areg[G::NRT][3];
@@ -1180,11 +1186,23 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     auto load_operands = [&](int tile, BvT &bv, auto tb0_tag) {
         constexpr int tb0 = decltype(tb0_tag)::value;
         const int base = 64 * tile - (BAND - 1);
-        const float *p = frb + (ptrdiff_t)(base + lr) * FROT;
+        if constexpr (V4 >= 8) {
+            // wide rows (four tiles per wave): buffer loads, scalar tile offset + 32-bit lane offset (-1.7 % at T = 2000)
+            const unsigned so = (unsigned)((base + 8) * FROT) * 4u;             // wave-uniform byte offset of the tile
+            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 #pragma unroll
-        for (int tb = tb0; tb < G::NCT; ++tb) {
-            const f32x3 v = *reinterpret_cast<const f32x3_u *>(p + 16 * FROT * tb);
-            bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
+            for (int tb = tb0; tb < G::NCT; ++tb) {
+                const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rsB, voffB, so + 16u * FROT * 4u * tb, 0);
+                bv[tb][0] = __uint_as_float(v.x); bv[tb][1] = __uint_as_float(v.y); bv[tb][2] = __uint_as_float(v.z);
+            }
+        } else {
+            // short rows (one or two tiles per wave): plain global loads measure 4 % faster on the covers80-shaped set
+            const float *p = frb + (ptrdiff_t)(base + lr) * FROT;
+#pragma unroll
+            for (int tb = tb0; tb < G::NCT; ++tb) {
+                const f32x3 v = *reinterpret_cast<const f32x3_u *>(p + 16 * FROT * tb);
+                bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
+            }
         }
     };
     // embedded column norms of the lane's 8 cells: 8 consecutive norms as two (4-byte aligned) 16-byte loads
