@@ -1093,7 +1093,10 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
 
 // (short-row variants: 6 waves / SIMD = 3 workgroups per CU; m >= 10 needs two MFMA row tiles and is LDS-limited anyway)
 constexpr int band_waves_per_simd(int m, int v4) { return (v4 <= 4 && m <= 9) ? 6 : 4; }
-template <int M, int V4, int ROLE>
+// WD2: the debug entry point's variant, which also writes the band's distances to HBM (D2, query-major) -- a
+// template parameter, not a flag: as a run-time flag hipcc folds it into the per-cell store predicates and every
+// tile of the production kernel pays 24 VALU + 40 SALU instructions for stores that never happen.
+template <int M, int V4, int ROLE, bool WD2 = false>
 __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band_kernel(const float *__restrict__ frot,
                                                             const int64_t *__restrict__ toff,
                                                             const float *__restrict__ normtab,
@@ -1103,8 +1106,9 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
                                                             float *__restrict__ thr,
                                                             unsigned long long *__restrict__ bits,
                                                             float kappa, int pct_mode, int inclusive, int oti_target,
-                                                            int write_d2)
+                                                            int /*unused*/)
 {
+    constexpr bool write_d2 = WD2;
     using G = BandGeom<M>;
     constexpr int role = ROLE;           // 1: rows = reference frames (column thresholds); 0: rows = query frames
     constexpr int NV = 4 * V4;           // values per lane of a complete row
@@ -1263,7 +1267,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
         constexpr int st = decltype(st_tag)::value;
 #pragma unroll
         for (int a = 0; a < BAND; ++a) xv[a][st] = dv[a];   // (cells outside the matrix are +inf already)
-        if (write_d2) {
+        if constexpr (write_d2) {
             const int j0 = 64 * tile - (BAND - 1) + lane;   // column of the lane's first cell
 #pragma unroll
             for (int a = 0; a < BAND; ++a) {
@@ -1325,7 +1329,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
         }
     });
     // debug / v1 consumers: +inf into the pad columns [MB, pitchD) of the band's rows
-    if (write_d2) {
+    if constexpr (write_d2) {
         const int npad = pitchD - MB;
         for (int idx = tid; idx < BAND * npad; idx += BAND_THREADS) {
             const int a = idx / npad, j = MB + idx - a * npad;
