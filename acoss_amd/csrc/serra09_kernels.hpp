@@ -961,6 +961,29 @@ struct RowGeom {
     }
 };
 
+// Position of the kappa-percentile in a row of n cells (oracle percentile_f32): the same for every row of a
+// pair, so the kernels work it out once per workgroup, before the sweep, and keep it in scalar registers.
+struct PctPos { float kf, fl, ce; int ilo, ihi, k; };
+__device__ __forceinline__ PctPos pct_position(int n, float kappa, int pct_mode)
+{
+    PctPos p;
+    p.kf = (n > 1) ? __fmul_rn((float)(n - 1), kappa) : __fmul_rn((float)n, kappa);
+    p.fl = floorf(p.kf); p.ce = ceilf(p.kf);
+    int ilo = (int)p.fl, ihi = (int)p.ce;
+    ilo = ilo < 0 ? 0 : (ilo > n - 1 ? n - 1 : ilo);
+    ihi = ihi < 0 ? 0 : (ihi > n - 1 ? n - 1 : ihi);
+    int k = ilo;
+    if (pct_mode == 3) {
+        k = (int)floorf(__fadd_rn(p.kf, 0.5f));
+        k = k > n - 1 ? n - 1 : k;
+    }
+    p.ilo = __builtin_amdgcn_readfirstlane(ilo); p.ihi = __builtin_amdgcn_readfirstlane(ihi); p.k = __builtin_amdgcn_readfirstlane(k);
+    p.kf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(p.kf)));
+    p.fl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(p.fl)));
+    p.ce = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(p.ce)));
+    return p;
+}
+
 // ------------------------------------------------------------------------------------
 // The part of the band pipeline that follows the exchange: wave `wave` holds one complete row of the
 // pair's matrix in registers (xr[t] = slot NV lane + t; slot s <-> column s - cshift; slots without a
@@ -980,7 +1003,7 @@ struct RowGeom {
 template <int NV, int ROLE>
 __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int wave, int lane, int row, int MA, int MB,
                                               int cshift, const PairDesc &P, float *__restrict__ thr,
-                                              unsigned long long *__restrict__ bits, float kappa, int pct_mode,
+                                              unsigned long long *__restrict__ bits, const PctPos &pp, int pct_mode,
                                               int inclusive ACX_STAMP_PARM)
 {
     using RG = RowGeom<NV>;
@@ -993,16 +1016,8 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
     const int hist_off = RG::hist_off(wave);
     if (row >= MA) return;
     const int n = MB;
-    const float kf = (n > 1) ? __fmul_rn((float)(n - 1), kappa) : __fmul_rn((float)n, kappa);
-    const float fl = floorf(kf), ce = ceilf(kf);
-    int ilo = (int)fl, ihi = (int)ce;
-    ilo = ilo < 0 ? 0 : (ilo > n - 1 ? n - 1 : ilo);
-    ihi = ihi < 0 ? 0 : (ihi > n - 1 ? n - 1 : ihi);
-    int k = ilo;
-    if (pct_mode == 3) {
-        k = (int)floorf(__fadd_rn(kf, 0.5f));
-        k = k > n - 1 ? n - 1 : k;
-    }
+    const float kf = pp.kf, fl = pp.fl, ce = pp.ce;
+    const int ilo = pp.ilo, ihi = pp.ihi, k = pp.k;
     const bool interp = (pct_mode == 0 || pct_mode == 1);
     float *myrow = smem + wave * ROWP;
     float slo, shi;
@@ -1174,6 +1189,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
 #pragma unroll
     for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : INF;       // rows past the matrix: +inf cells
     float *Sw = smem + wave * (G::AROWS * G::SP);               // this wave's Gram tile, [row frame][column frame]
+    const PctPos pp = pct_position(MB, kappa, pct_mode);        // (before the sweep: off the tail's critical path)
 #ifdef ACX_TIMING
     StampT tstamp_{__builtin_readcyclecounter(), 0};
     if (lane == 0) atomicAdd(&g_band_clk[15], 1ull);
@@ -1385,7 +1401,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row has left LDS
     ACX_STAMP(4);        // row read
     band_row_tail<NV, ROLE>(xr, smem, wave, lane, i0 + wave, MA, MB, (BAND - 1) - wave, P, thr, role == 0 ? bits : nullptr,
-                            kappa, pct_mode, inclusive ACX_STAMP_ARG);
+                            pp, pct_mode, inclusive ACX_STAMP_ARG);
 }
 
 // One DP row for the CPL columns of a lane (descending column order, in place): QA = row i-1,
