@@ -16,7 +16,7 @@ void launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows,
     const int ndata = (maxCols + BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
 #define ACX_BAND_K(V4_, R_, W_) hipLaunchKernelGGL((band_kernel<M, V4_, R_, W_>), grid, dim3(BAND_THREADS), 0, L.stream, \
                                                   L.frot, L.toff, L.normtab, L.noff, dpd, L.scratch, L.thr, L.bits, L.kappa, \
-                                                  L.pct_mode, L.inclusive, L.oti_target, 0)
+                                                  L.pct_mode, L.inclusive, L.oti_target)
     // (the variant that also writes D2 exists for the row pass only: the debug entry point)
 #define ACX_BAND(V4_) do { if (role) ACX_BAND_K(V4_, 1, false); else if (write_d2) ACX_BAND_K(V4_, 0, true); else ACX_BAND_K(V4_, 0, false); } while (0)
     if (ndata <= 8) ACX_BAND(2);

@@ -1120,8 +1120,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
                                                             float *__restrict__ scratch,
                                                             float *__restrict__ thr,
                                                             unsigned long long *__restrict__ bits,
-                                                            float kappa, int pct_mode, int inclusive, int oti_target,
-                                                            int /*unused*/)
+                                                            float kappa, int pct_mode, int inclusive, int oti_target)
 {
     constexpr bool write_d2 = WD2;
     using G = BandGeom<M>;
