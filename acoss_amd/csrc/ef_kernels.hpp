@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
 {
     constexpr int NX = 4 * NQ;                        // values per lane
     __shared__ __attribute__((aligned(4096))) unsigned fhist[4][256];      // one-pass selection (wave_select_fast)
-    __shared__ __attribute__((aligned(16))) unsigned hist[4][SEL_SLOTS];   // generic fallback
+    constexpr int GB = 512;                           // bins of the generic fallback (small: LDS per workgroup decides how many rows a CU works on)
+    __shared__ __attribute__((aligned(16))) unsigned hist[4][SelGeom<GB>::SLOTS];   // generic fallback
     __shared__ __attribute__((aligned(16))) float cand[4][64];
     __shared__ unsigned counter[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         wave_lds_fence();
         float lo, hi;
         if (wave_select_fast<NX, 256>(xx, k, false, fh_addr, cand[wave], lane, lo, hi)) return lo;
-        return wave_select_regs<NX>(xx, k, hist[wave], cand[wave], &counter[wave], lane, false).value;
+        return wave_select_regs<NX, GB>(xx, k, hist[wave], cand[wave], &counter[wave], lane, false).value;
     };
     const EfPair P = pd[blockIdx.y];
     const int s = blockIdx.z;                         // feature (mode 2: always 0)
