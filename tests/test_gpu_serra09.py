@@ -115,6 +115,35 @@ def test_ties_and_degenerate_rows(ctx):
             _compare_pair(ctx, d, i, j, _lib.serra09_params(**kw), oracle.serra09_params(**kw), "ties(%d,%d) %s" % (i, j, kw))
 
 
+def test_pivot_filter_gives_up_on_periodic_rows(ctx):
+    """Rows on which the pivot-filtered histogram must give up: tracks that repeat a 32-frame (16-frame, 8-frame)
+    pattern put ONE near-zero distance into every owner lane's run of consecutive positions, so the largest
+    lane minimum -- the pivot -- sits far below the kappa-percentile and fewer than k + 2 cells pass the
+    filter.  The unfiltered pass takes over; thresholds, recurrence plot and score stay the oracle's bit for bit
+    (debug entry point) and the production kernels return the same score."""
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    rng = np.random.default_rng(2024)
+    def periodic(T, period, noise):
+        base = synth._frame_max_normalise(rng.random((period, 12)))
+        x = np.tile(base, (T // period + 1, 1))[:T] + noise * rng.random((T, 12))
+        return x.astype(np.float32)
+    tracks = [periodic(2000, 32, 0.02), periodic(1900, 32, 0.02), periodic(900, 16, 0.02), periodic(880, 32, 0.03),
+              periodic(450, 8, 0.02), periodic(400, 16, 0.02)]
+    # two tracks built on the SAME pattern, so that the near-zero cells exist between them
+    tracks[1] = (tracks[0][:1900] + 0.01 * rng.random((1900, 12))).astype(np.float32)
+    tracks[3] = (tracks[2][:880] + 0.01 * rng.random((880, 12))).astype(np.float32)
+    tracks[5] = (tracks[4][:400] + 0.01 * rng.random((400, 12))).astype(np.float32)
+    frames, offsets = synth.pack(tracks)
+    d = dict(frames=frames, offsets=offsets)
+    ctx.upload_pool(frames, offsets)
+    pairs = [(0, 1), (1, 0), (2, 3), (3, 2), (4, 5), (5, 4), (0, 2)]
+    scores = ctx.serra09_pairs(np.array(pairs, np.int32), _lib.serra09_params())
+    for (i, j), sc in zip(pairs, scores):
+        g, it = _compare_pair(ctx, d, i, j, _lib.serra09_params(), oracle.serra09_params(), "periodic(%d,%d)" % (i, j))
+        assert sc == g["score"]
+
+
 def test_full_size_pair_2000(ctx):
     from acoss_amd import synth, _lib
     oracle = _oracle()
