@@ -942,10 +942,7 @@ struct RowGeom {
     static constexpr bool HIST_IN_ROW = ROWP >= 64 + 2 * FBINS;        // room for an FBINS-aligned block behind the 64 candidate slots
     // Pivot-filtered pass (wave_select_pivot): bins, lanes per pivot group and the pivot's push-up, per row
     // width -- groups of 32 cells put the pivot near the 0.13 ... 0.2 quantile of an i.i.d. row
-#ifndef ACX_PBINS
-#define ACX_PBINS 512
-#endif
-    static constexpr int PBINS = NV >= 32 ? ACX_PBINS : 256;
+    static constexpr int PBINS = NV >= 32 ? 512 : 256;                  // (256 / 512 / 1024 measure the same at NV = 32)
     static constexpr int PGRP = NV >= 32 ? 1 : 2;
     static constexpr float PDELTA = NV >= 32 ? 0.04f : (NV >= 16 ? 0.15f : 0.0f);
     static constexpr int GBINS = 32 * NV;                              // bins of the generic (narrowing) selection
