@@ -1049,6 +1049,20 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
         shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
     }
     ACX_STAMP(5);        // selection
+    // (row pass: the column thresholds of the row, lane-interleaved, requested here -- behind the selection, whose
+    // registers they would otherwise compete for, and ahead of the eps / threshold arithmetic that covers their
+    // latency; see the bitmap step)
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr bool TC_VIA_LDS = NV >= 32;       // (the narrower classes measure 2 % faster with direct loads)
+    f32x4_u tcg[CH];
+    if constexpr (TC_VIA_LDS) {
+        if (role == 0 && bits) {
+            asm volatile("" ::: "memory");
+            const float *tc = thr + P.offX + P.pitchT - cshift + 4 * lane;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) tcg[q] = *reinterpret_cast<const f32x4_u *>(tc + 256 * q);
+        }
+    }
     const float eps = percentile_eps2(slo, shi, pct_mode, ilo, ihi, kf, fl, ce);
     const float thr_row = d2_threshold(eps, inclusive);
     ACX_STAMP(6);        // eps + threshold
@@ -1063,15 +1077,32 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
     // A lane owns NV consecutive slots, i.e. NV consecutive bits: R = [d2 <= min(thr_row, thr_col)] is
     // shifted into the lane's own word bit by bit (compare -> carry -> add-with-carry), no cross-lane traffic.
     if (role == 0 && bits) {
-        // column thresholds (d2 domain): NV consecutive floats per lane, no bounds check (columns
-        // -7 .. 64 ntiles + 63 of the threshold arena are always inside the pair's arena)
-        const float *tc = X + P.pitchT + (lane * NV - cshift);
-        typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+        // column thresholds (d2 domain) of the lane's NV slots.  In the wide class, read straight from memory, they
+        // are 128 contiguous bytes per lane -- every load instruction would touch 64 different lines, and those eight
+        // loads measured 4.5 of the band kernels' 47.8 ms.  So the wave reads the row's thresholds
+        // lane-interleaved (granule 64 q + lane: 1 KB of contiguous memory per instruction, issued right after
+        // the selection, see above) and turns them round through its own exchange row, which the selection no
+        // longer needs: 16-byte stores at the granule's padded place, 16-byte loads of the lane's own slots.
+        // (no bounds check: columns -7 .. 64 ntiles + 63 of the threshold arena are inside the pair's arena)
         float tcv[NV];
+        if constexpr (TC_VIA_LDS) {
+            float *tr = myrow + 4 * lane + 4 * ((4 * lane) / NV);
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const f32x4_u v = *reinterpret_cast<const f32x4_u *>(tc + 4 * j);
-            tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
+            for (int q = 0; q < CH; ++q) *reinterpret_cast<float4 *>(tr + q * (256 + 4 * (256 / NV))) = make_float4(tcg[q].x, tcg[q].y, tcg[q].z, tcg[q].w);
+            wave_lds_fence();
+            const float *mine = myrow + lane * RG::LNP;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float4 v = *reinterpret_cast<const float4 *>(mine + 4 * j);
+                tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
+            }
+        } else {
+            const float *tc = X + P.pitchT + (lane * NV - cshift);      // (the compiler hoists these loads above the selection)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const f32x4_u v = *reinterpret_cast<const f32x4_u *>(tc + 4 * j);
+                tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
+            }
         }
         // slots of this lane whose column exists: t in [lo, hi)
         int lo = cshift - lane * NV, hi = MB + cshift - lane * NV;
