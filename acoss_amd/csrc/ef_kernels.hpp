@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
 // of the other waves alone (scripts/ubench/mfma_valu_overlap.hip).  Same tiling as ef_gemm_kernel
 // (128 x 128 per workgroup) but 8 waves of 32 x 64 cells, k in blocks of 32: a lane's MFMA operand is 8
 // consecutive k of one row = one 16-byte LDS read (row pitch 80 bytes: conflict free), 18 operand reads feed 48 MFMAs.
-// Layout of the split pool: [block][term 0..2][Kp] bf16, Kp = K rounded up to 32, zeros behind K.
+// Layout of the split pool: [block][k / 32][term 0..2][k % 32] bf16, Kp = K rounded up to 32, zeros behind K.
 // ------------------------------------------------------------------------------------
 constexpr int EFB_BK = 32;
 constexpr int EFB_LP = 40;     // LDS row pitch in bf16 elements (80 bytes)
@@ -282,8 +282,10 @@ __global__ __launch_bounds__(256) void ef_split_bf16_kernel(const float *__restr
     const unsigned h2 = ef_bf16_rne(r1);
     const float r2 = r1 - __uint_as_float(h2 << 16);           // exact
     const unsigned h3 = ef_bf16_rne(r2);
-    unsigned short *o = out + row * 3 * Kp + k;
-    o[0] = (unsigned short)h1; o[Kp] = (unsigned short)h2; o[2 * (int64_t)Kp] = (unsigned short)h3;
+    // [block][k / 32][term][k % 32]: the three terms of a 32-k chunk are 192 contiguous bytes, so the GEMM's three
+    // 64-byte reads per row and chunk share their 128-byte lines
+    unsigned short *o = out + row * 3 * Kp + (int64_t)(k / EFB_BK) * (3 * EFB_BK) + (k % EFB_BK);
+    o[0] = (unsigned short)h1; o[EFB_BK] = (unsigned short)h2; o[2 * EFB_BK] = (unsigned short)h3;
 }
 
 constexpr int EFB_THREADS = 512;    // 8 waves as 4 x 2: 32 x 64 cells per wave (two workgroups per CU = 4 waves per SIMD)
@@ -328,11 +330,11 @@ __global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     auto gload = [&]() {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            ra[t] = *reinterpret_cast<const u32x4 *>(ap + (size_t)t * Kp);
-            rb[t] = *reinterpret_cast<const u32x4 *>(bp + (size_t)t * Kp);
+            ra[t] = *reinterpret_cast<const u32x4 *>(ap + t * EFB_BK);
+            rb[t] = *reinterpret_cast<const u32x4 *>(bp + t * EFB_BK);
         }
-        ap += EFB_BK;
-        bp += EFB_BK;
+        ap += 3 * EFB_BK;
+        bp += 3 * EFB_BK;
     };
     unsigned short *as0 = As + srow * EFB_LP + sk, *bs0 = Bs + srow * EFB_LP + sk;
     auto lstore = [&]() {
