@@ -16,8 +16,9 @@
 //   * <a, b> slides down the diagonal exactly as the reference's STOMP update does
 //     (simple_silva.py:107-110): dot[a][b] = dot[a-1][b-1] - <A[a-1], B'[b-1]> + <A[a+L-1], B'[b+L-1]>;
 //     dot[a-1][b-1] is the neighbour lane's value of the previous step (one 64-bit lane shift),
-//     for lane 0 the value the previous row group's lane 63 left in LDS; row 0 (and column 0) are
-//     evaluated in full (120 products) up front;
+//     for the first row of a group the value the previous row group's last lane left in LDS; the leaving
+//     product is the entering product of the lane L below, L steps ago (register ring + lane permute: one
+//     12-term product per cell instead of two); row 0 (and column 0) are evaluated in full up front;
 //   * the row minimum is a running v_min_f64 in the lane's own register -- no atomics, no reduction;
 //   * the median of the profile is an exact binary search on order-preserving 64-bit keys, counted
 //     with ballots.
@@ -151,17 +152,34 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *_
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    const int ngroups = (ma + 63) / 64;
+    // Row groups of 64 lanes: L FEEDER lanes + (64 - L) rows.  The product that leaves the window of row a at
+    // step b, <A[a - 1], B'[b - 1]>, is the product that ENTERED the window of row a - L at step b - L: lane l - L
+    // computed it L steps ago.  So a lane computes ONE 12-term product per step (the entering one), hands it L
+    // lanes up (one 64-bit lane permute, consumed L steps later: its latency is free) and keeps the L it has
+    // received in a register ring; the leaving frame of B is never loaded again.  The first L lanes of a group
+    // have nobody below them: they only feed -- they repeat the last L rows of the previous group (group 0: the
+    // rows -L .. -1 that do not exist; row 0 never uses the recurrence).
+    constexpr int STRIDE = 64 - L;
+    static_assert(L >= 1 && L <= 16, "feeder lanes");
+    const int ngroups = (ma + STRIDE - 1) / STRIDE;
+    const int up_src = ((lane - L) & 63) << 2;                     // ds_bpermute address of the lane L below
+    auto shift_up_L = [&](double v) {
+        const long long bits = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_ds_bpermute(up_src, (int)(bits & 0xffffffffll));
+        const int hi = __builtin_amdgcn_ds_bpermute(up_src, (int)(bits >> 32));
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
     for (int g = 0; g < ngroups; ++g) {
-        const int a = 64 * g + lane;
-        const bool valid = a < ma;
-        const int ac = valid ? a : ma - 1;                      // clamp: results of the idle lanes are dropped
+        const int a = STRIDE * g + lane - L;                    // this lane's row (feeders: a row of the group before, or < 0)
+        const bool valid = lane >= L && a < ma;
+        const int ac = a < 0 ? 0 : (a > ma - 1 ? ma - 1 : a);   // clamp: results of feeder / idle lanes are dropped
+        int fa = a + L - 1;                                     // frame entering the window of row a
+        fa = fa < 0 ? 0 : (fa > na - 1 ? na - 1 : fa);
         const double *ein = (g & 1) ? edge0 : edge1;            // written by group g - 1 (group 0: the row-0 values)
         double *eout = (g & 1) ? edge1 : edge0;
         const bool more = g + 1 < ngroups;
-        double An[12], Ao[12];
-        load_a(ac + L - 1, An);                                 // frame entering the window of row a
-        load_a(ac > 0 ? ac - 1 : 0, Ao);                        // frame that left it (row a - 1's first)
+        double An[12];
+        load_a(fa, An);
         const double a2 = wa[ac];
         // column 0 in full: dot[a][0] = sum_k <A[a + k], B'[k]>
         double dot = 0.0;
@@ -173,46 +191,53 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *_
                 dot += dot12(ak, gb + (size_t)k * 12);
             }
         }
-        if (g == 0 && lane == 0) dot = ein[0];
+        if (g == 0 && lane == L) dot = ein[0];
         double mn = (a2 + wb[0]) - 2.0 * dot;
         if (more && lane == 63) eout[0] = dot;
-        // The column's frames of B are wave-uniform: scalar loads.  The frame that ENTERS the window
-        // (bn, first touched here: a scalar-cache miss) is requested half a step ahead, right after
-        // its registers became free; the frame that LEAVES (bo, touched L steps ago: a hit) at the top
-        // of its step, behind the first dozen v_fma_f64.
-        double bn[12];
-        if (mb > 1) {
-            const double *pn = gb + (size_t)L * 12;
+        // ring[b % L] = the product leaving at step b.  Steps 1 .. L need the products that "entered" at steps
+        // 1 - L .. 0, i.e. with the frames B'[0 .. L - 1]: computed here, before the sweep.
+        double ring[L];
 #pragma unroll
-            for (int c = 0; c < 12; ++c) bn[c] = pn[c];
-        }
-        for (int b = 1; b < mb; ++b) {
-            const double *po = gb + (size_t)(b - 1) * 12;
-            double bo[12];
+        for (int j = 0; j < L; ++j) ring[(1 + j) % L] = shift_up_L(dot12(An, gb + (size_t)j * 12));
+        // The column's entering frame of B is wave-uniform: scalar loads into two register sets, requested TWO steps
+        // ahead (the step that has just used a set refills it): a miss of the scalar cache has a step and a half to land.
+        double bn[2][12];
 #pragma unroll
-            for (int c = 0; c < 12; ++c) bo[c] = po[c];
-            const double w = wb[b];
-            double prev = __shfl_up(dot, 1, 64);                // dot[a - 1][b - 1] of the neighbour lane
-            const double e = ein[b - 1 + (g == 0 ? 1 : 0)];     // group 0: row 0's own value top[b]; else dot[a - 1][b - 1] of the last lane
-            double gnew = 0.0;
+        for (int q = 0; q < 2; ++q)
+            if (1 + q < mb) {
+                const double *pn = gb + (size_t)(L + q) * 12;       // step b = 1 + q multiplies frame b + L - 1
 #pragma unroll
-            for (int c = 0; c < 12; ++c) gnew = __builtin_fma(An[c], bn[c], gnew);
-            asm volatile("" : "+v"(gnew));                      // bn is dead from here: its registers take the next frame
-            if (b + 1 < mb) {
-                const double *pn = gb + (size_t)(b + L) * 12;
-#pragma unroll
-                for (int c = 0; c < 12; ++c) bn[c] = pn[c];
+                for (int c = 0; c < 12; ++c) bn[(1 + q) & 1][c] = pn[c];
             }
-            double gold = 0.0;
+        constexpr int UN = (L % 2 == 0) ? L : 2 * L;            // steps per unrolled round: ring slot and register set are static
+        for (int b0 = 1; b0 < mb; b0 += UN) {
 #pragma unroll
-            for (int c = 0; c < 12; ++c) gold = __builtin_fma(Ao[c], bo[c], gold);
-            if (lane == 0) prev = e;
-            double nd = (prev - gold) + gnew;
-            if (g == 0 && lane == 0) nd = e;
-            dot = nd;
-            const double dist = (a2 + w) - 2.0 * dot;
-            mn = dist < mn ? dist : mn;
-            if (more && lane == 63) eout[b] = dot;
+            for (int j = 0; j < UN; ++j) {
+                const int b = b0 + j;                               // b % L == (1 + j) % L, b % 2 == (1 + j) % 2
+                if (b < mb) {                                       // wave-uniform
+                    const double w = wb[b];
+                    double prev = __shfl_up(dot, 1, 64);            // dot[a - 1][b - 1] of the neighbour lane
+                    const double e = ein[b - 1 + (g == 0 ? 1 : 0)]; // group 0: row 0's own value top[b]; else dot[a - 1][b - 1] of the last lane
+                    double gnew = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) gnew = __builtin_fma(An[c], bn[(1 + j) & 1][c], gnew);
+                    asm volatile("" : "+v"(gnew));                  // this register set is dead from here: it takes the frame of step b + 2
+                    if (b + 2 < mb) {
+                        const double *pn = gb + (size_t)(b + 1 + L) * 12;
+#pragma unroll
+                        for (int c = 0; c < 12; ++c) bn[(1 + j) & 1][c] = pn[c];
+                    }
+                    const double gold = ring[(1 + j) % L];          // entered the window of row a - L at step b - L
+                    ring[(1 + j) % L] = shift_up_L(gnew);           // leaves the window of this row at step b + L
+                    if (lane == L) prev = e;
+                    double nd = (prev - gold) + gnew;
+                    if (g == 0 && lane == L) nd = e;
+                    dot = nd;
+                    const double dist = (a2 + w) - 2.0 * dot;
+                    mn = dist < mn ? dist : mn;
+                    if (more && lane == 63) eout[b] = dot;
+                }
+            }
         }
         if (valid) mp[a] = f64_key(mn);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
