@@ -418,6 +418,8 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             d.pitchD = round_up(d.Mr, 64);
             d.pitchT = round_up(d.Mq, 64);
             d.nw = (d.Mr + acx::BAND - 1 + 63) / 64;
+            d.pos_q = acx::pct_position(d.Mq, p.kappa, p.pct_mode);
+            d.pos_r = acx::pct_position(d.Mr, p.kappa, p.pct_mode);
             const bool is_long = !band_ok || (std::max(d.Mq, d.Mr) + acx::BAND - 1 + 63) / 64 > 32;
             const int64_t needD = (dbg != nullptr || is_long) ? (int64_t)d.Mq * d.pitchD : 0;     // the band pipeline keeps D2 out of HBM
             const int64_t needL = is_long ? (int64_t)d.Mr * d.pitchT + 8 * (int64_t)d.Mq : 0;      // D2^T + the DP's strip records

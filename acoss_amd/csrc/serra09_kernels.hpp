@@ -31,6 +31,27 @@ constexpr int SEL_BINS = 2048; // histogram bins of the generic percentile selec
 constexpr int MAX_M = 16;      // largest stack size of the band kernel (larger m: long-track kernels)
 constexpr int NGUARD = 80;     // +inf entries behind every row of the embedded-norm table (normtab_kernel)
 
+// Position of the kappa-percentile in a row of n cells (oracle percentile_f32): the same for every row of a
+// pair, so the host works it out once per pair (both row lengths) and the kernels read it from the PairDesc
+// with scalar loads.
+struct PctPos { float kf, fl, ce; int32_t ilo, ihi, k; };
+__host__ __device__ inline PctPos pct_position(int n, float kappa, int pct_mode)
+{
+    PctPos p;
+    p.kf = (n > 1) ? (float)(n - 1) * kappa : (float)n * kappa;        // (one f32 multiplication: nothing to contract)
+    p.fl = floorf(p.kf); p.ce = ceilf(p.kf);
+    int ilo = (int)p.fl, ihi = (int)p.ce;
+    ilo = ilo < 0 ? 0 : (ilo > n - 1 ? n - 1 : ilo);
+    ihi = ihi < 0 ? 0 : (ihi > n - 1 ? n - 1 : ihi);
+    int k = ilo;
+    if (pct_mode == 3) {
+        k = (int)floorf(p.kf + 0.5f);
+        k = k > n - 1 ? n - 1 : k;
+    }
+    p.ilo = ilo; p.ihi = ihi; p.k = k;
+    return p;
+}
+
 struct PairDesc {
     int32_t q, r;          // track indices (query, reference)
     int32_t Tq, Tr;        // pooled lengths
@@ -45,6 +66,7 @@ struct PairDesc {
                            //   [thr rows: pitchT][thr cols: pitchD][eps rows: pitchT][eps cols: pitchD]
     int64_t offL;          // long tracks: float offset of D2^T (Mr rows x pitchT) in the scratch arena,
                            // followed by the DP's strip-boundary records (2 x 4 floats per row)
+    PctPos pos_q, pos_r;   // percentile position in a row of Mq cells (column pass) / of Mr cells (row pass)
 };
 
 __device__ __forceinline__ float wave_shfl(float v, int src)
@@ -958,29 +980,6 @@ struct RowGeom {
     }
 };
 
-// Position of the kappa-percentile in a row of n cells (oracle percentile_f32): the same for every row of a
-// pair, so the kernels work it out once per workgroup, before the sweep, and keep it in scalar registers.
-struct PctPos { float kf, fl, ce; int ilo, ihi, k; };
-__device__ __forceinline__ PctPos pct_position(int n, float kappa, int pct_mode)
-{
-    PctPos p;
-    p.kf = (n > 1) ? __fmul_rn((float)(n - 1), kappa) : __fmul_rn((float)n, kappa);
-    p.fl = floorf(p.kf); p.ce = ceilf(p.kf);
-    int ilo = (int)p.fl, ihi = (int)p.ce;
-    ilo = ilo < 0 ? 0 : (ilo > n - 1 ? n - 1 : ilo);
-    ihi = ihi < 0 ? 0 : (ihi > n - 1 ? n - 1 : ihi);
-    int k = ilo;
-    if (pct_mode == 3) {
-        k = (int)floorf(__fadd_rn(p.kf, 0.5f));
-        k = k > n - 1 ? n - 1 : k;
-    }
-    p.ilo = __builtin_amdgcn_readfirstlane(ilo); p.ihi = __builtin_amdgcn_readfirstlane(ihi); p.k = __builtin_amdgcn_readfirstlane(k);
-    p.kf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(p.kf)));
-    p.fl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(p.fl)));
-    p.ce = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(p.ce)));
-    return p;
-}
-
 // ------------------------------------------------------------------------------------
 // The part of the band pipeline that follows the exchange: wave `wave` holds one complete row of the
 // pair's matrix in registers (xr[t] = slot NV lane + t; slot s <-> column s - cshift; slots without a
@@ -1216,7 +1215,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
 #pragma unroll
     for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : INF;       // rows past the matrix: +inf cells
     float *Sw = smem + wave * (G::AROWS * G::SP);               // this wave's Gram tile, [row frame][column frame]
-    const PctPos pp = pct_position(MB, kappa, pct_mode);        // (before the sweep: off the tail's critical path)
+    const PctPos pp = role ? P.pos_q : P.pos_r;                 // rows of MB cells (worked out on the host)
 #ifdef ACX_TIMING
     StampT tstamp_{__builtin_readcyclecounter(), 0};
     if (lane == 0) atomicAdd(&g_band_clk[15], 1ull);
