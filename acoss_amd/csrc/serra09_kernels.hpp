@@ -10,7 +10,7 @@
 //   K1' band_kernel       role 1 then role 0: frame Gram on the matrix cores
 //                         (v_mfma_f32_16x16x4_f32, K = 12 = 3 k-steps, exact f32 == fmaf chain),
 //                         diagonal doubling-tree window sums, exact kappa-percentile thresholds
-//                         per row (one histogram pass), recurrence bitmap; D2 never reaches HBM
+//                         per row (one pivot-filtered histogram pass), recurrence bitmap; D2 never reaches HBM
 //   K3b qmax_bits_kernel  Qmax / Dmax row sweep over the recurrence bitmap, one wave per pair
 // Tracks whose embedded matrix has rows of more than 2041 cells (or a stack size m > 16) take the
 // streaming kernels of serra09_long_kernels.hpp (materialised D2 + D2^T) and rejoin this pipeline at
@@ -847,21 +847,26 @@ __global__ __launch_bounds__(256) void normtab_kernel(const float *__restrict__ 
 
 // ------------------------------------------------------------------------------------
 // K1': fused band kernel.  One workgroup (8 waves) owns a band of 8 rows of the embedded
-// distance matrix; the band is cut into tiles of 64 columns and WAVE w sweeps tiles
-// w, w+8, w+16, ... on its own -- no workgroup barrier and no LDS staging of inputs in the sweep:
-//   * MFMA operands are plain global loads from the rotated frame pool (rotpool_kernel): one
-//     12-byte load per lane per 16-frame tile, already in the rotated chain order of the
-//     arithmetic spec; the next tile's operands are in flight while the current one is worked on;
+// distance matrix; the band is cut into tiles of 64 columns and WAVE w sweeps ceil(ntiles / 8)
+// CONSECUTIVE tiles on its own -- no workgroup barrier and no LDS staging of inputs in the sweep:
+//   * MFMA operands are plain loads from the rotated frame pool (rotpool_kernel): one 12-byte load
+//     per lane per 16-frame block, already in the rotated chain order of the arithmetic spec (wide
+//     class: buffer loads, scalar tile offset + one lane offset); the next tile's operands are in
+//     flight while the current one is worked on; frames and norms OUTSIDE the matrix are read like
+//     all others (pool slack, +inf guard norms): every tile runs the same code and the cells
+//     outside the matrix come out as +inf, the pad value of the exchange;
 //   * the (8+m-1) x (64+7+m-1) frame Gram is built on the matrix cores
 //     (v_mfma_f32_16x16x4_f32, K = 12 in 3 k-steps; row-frame operands stay in registers for
-//     the whole band) and parked in the wave's private LDS slab (one 16-byte store per block);
+//     the whole band; a tile inherits the 16-frame block it shares with its left neighbour) and
+//     parked in the wave's private LDS slab (one 16-byte store per block);
 //   * lane c walks the 8 cells (a, c + a), a = 0..7, down one diagonal: m+7 LDS reads give
 //     all 8 window sums (doubling-tree subterms are shared between the cells); tile t
 //     therefore covers, for band row a, the 64 columns 64 t - 7 + a ...;
-//   * distances stay in registers (debug: also to the row-major D2 matrix in HBM).
+//   * distances stay in registers (debug variant WD2: also to the row-major D2 matrix in HBM).
 // After the sweep the 8 waves exchange their pieces through LDS so that wave w holds band
-// row w completely (32 values per lane) and runs the exact percentile selection on it
-// (wave_select_fast, one histogram pass; wave_select_regs as the generic fallback).
+// row w completely (32 values per lane) and finishes it on its own (band_row_tail): exact
+// percentile selection (wave_select_pivot: one pivot-filtered histogram pass; wave_select_fast /
+// wave_select_regs behind it), eps, d2-domain threshold and, in the row pass, the bitmap.
 // role 1 (launched first): rows = reference frames, columns = query frames (the transposed
 //         problem, same bits) -> the column thresholds.
 // role 0: rows = query frames -> the row thresholds and, with both thresholds known while the
