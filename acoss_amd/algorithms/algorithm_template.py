@@ -79,6 +79,12 @@ class CoverAlgorithm(object):
             self._dmat_paths[s] = "%s_%s_dmat%s" % (self.get_cacheprefix(), s, "" if rank == 0 else ".rank%d" % rank)
         return self._dmat_paths[s]
 
+    def owns_result(self):
+        """True on the rank that holds the filled matrices (rank 0, or the only process).  The N x N
+        post-processing steps (normalize_by_length, do_late_fusion) return at once everywhere else:
+        the other ranks' matrices stay empty by design."""
+        return _dist.world()[0] == 0
+
     def _register_label(self, i, label):
         self.cliques.setdefault(label, set()).add(int(i))
 
@@ -89,24 +95,34 @@ class CoverAlgorithm(object):
         return feats
 
     def get_all_clique_ids(self, verbose=False):
-        """Clique membership of every track, cached in <prefix>_clique_info.txt ("i,label")."""
+        """Clique membership of every track, cached in <prefix>_clique_info.txt ("i,label").
+        Under torch.distributed this is a COLLECTIVE (every rank must call it): rank 0 reads the cache
+        file -- or builds it from the feature files -- and broadcasts the table; the other ranks touch
+        neither the feature files nor the cache (no shared file system is assumed)."""
         path = "%s_clique_info.txt" % self.get_cacheprefix()
         rank, ws = _dist.world()
-        if rank == 0 and not os.path.exists(path):
-            # written to a temporary name and renamed: nobody ever sees half a file
-            tmp = "%s.tmp%d" % (path, os.getpid())
-            with open(tmp, "w") as fout:
-                for i in range(len(self.filepaths)):
-                    feats = CoverAlgorithm.load_features(self, i)
-                    if verbose:
-                        print(i)
-                    fout.write("%i,%s\n" % (i, feats["label"]))
-            os.replace(tmp, path)
-        _dist.barrier()
-        with open(path) as fin:
-            for line in fin:
-                i, label = line.split(",", 1)
-                self._register_label(int(i), label.strip())
+        table = None
+        if rank == 0:
+            table = []
+            if os.path.exists(path):
+                with open(path) as fin:
+                    for line in fin:
+                        i, label = line.split(",", 1)
+                        table.append((int(i), label.strip()))
+            else:
+                # written to a temporary name and renamed: nobody ever sees half a file
+                tmp = "%s.tmp%d" % (path, os.getpid())
+                with open(tmp, "w") as fout:
+                    for i in range(len(self.filepaths)):
+                        feats = CoverAlgorithm.load_features(self, i)
+                        if verbose:
+                            print(i)
+                        fout.write("%i,%s\n" % (i, feats["label"]))
+                        table.append((i, str(feats["label"]).strip()))
+                os.replace(tmp, path)
+        table = _dist.broadcast_object(table)
+        for i, label in table:
+            self._register_label(int(i), label)
 
     # ------------------------------------------------------------------ pairwise
     def similarity(self, idxs):
@@ -132,7 +148,10 @@ class CoverAlgorithm(object):
         npz = "%s_Ds.npz" % self.get_cacheprefix()
         h5 = "%s_Ds.h5" % self.get_cacheprefix()          # the reference's cache file (algorithm_template.py:163-166,192)
         if precomputed:
-            if os.path.exists(npz):
+            loaded = {}
+            if not self.owns_result():
+                pass                                           # the cache belongs to rank 0, like the result
+            elif os.path.exists(npz):
                 with np.load(npz) as z:
                     loaded = {s: z[s] for s in z.files}
             else:
@@ -164,7 +183,8 @@ class CoverAlgorithm(object):
             if symmetric and rank == 0:
                 for s in self.Ds:
                     self.Ds[s] += self.Ds[s].T
-        if not self.cliques:
+        # (a collective decision: a rank whose labels were injected must not skip the broadcast the others wait in)
+        if _dist.any_rank(not self.cliques):
             self.get_all_clique_ids()
         if rank == 0:
             np.savez(npz, **{s: np.asarray(self.Ds[s]) for s in self.Ds})
@@ -181,6 +201,9 @@ class CoverAlgorithm(object):
             ctx.pair_grid(algo, symmetric, params, planes, mirror=symmetric)
             return
         import torch
+        # torch's collectives (and its allocator) must work on the GPU libacx works on: one process, one GPU
+        if ctx.torch_device().type == "cuda":
+            _dist.bind_device(ctx.device)
         lengths = ctx.pool_lengths(algo)
         plan = _lib.grid_plan(lengths, algo, symmetric, world=ws)
         stride = int(max(1, plan["floats_per_rank"].max()))
@@ -207,7 +230,10 @@ class CoverAlgorithm(object):
     def getEvalStatistics(self, similarity_type, topsidx=[1, 10, 100, 1000]):
         """MR, MRR, MDR, MAP and Top-k of one similarity matrix; appends a row to
         results_<shortname>_<name>.csv.  Same definitions as the reference (:205-290),
-        including MRR's division by ALL N songs and the %.3g CSV format."""
+        including MRR's division by ALL N songs and the %.3g CSV format.
+        Under torch.distributed this is a COLLECTIVE: rank 0 (the owner of the matrices) evaluates and
+        writes the CSV, the tuple is broadcast and returned on every rank -- so every rank must call it
+        (`if rank == 0: algo.getEvalStatistics(...)` would leave rank 0 waiting in the broadcast)."""
         rank, ws = _dist.world()
         res = None
         if rank == 0:

@@ -124,7 +124,12 @@ class EarlyFusion(CoverAlgorithm):
 
     def do_late_fusion(self):
         """SNF of 1/(1+D) over the three / four score matrices (earlyfusion_traile.py:200-206), on the
-        GPU (acx_snf_fuse_dists; no device -> the call fails)."""
+        GPU (acx_snf_fuse_dists; no device -> the call fails) of the rank that owns the matrices."""
+        if not self.owns_result():
+            for key in ("late", "early+late"):                  # same keys on every rank (getEvalStatistics is collective)
+                self.Ds[key] = np.zeros((0, 0), np.float64)
+            return
+
         def inv(s):
             return 1.0 / (1.0 + np.array(self.Ds[s], dtype=np.float64))
         ctx = self._fusion_context()

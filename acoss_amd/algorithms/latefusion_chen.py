@@ -48,6 +48,8 @@ class ChenFusion(Serra09):
     def normalize_by_length(self):
         """D[i, j] = sqrt(T_j) / D[i, j] (latefusion_chen.py:75-85): a DISTANCE, smaller =
         closer; unfilled cells (the diagonal) become +inf exactly as in the reference."""
+        if not self.owns_result():
+            return
         norm = np.sqrt(self._pooled_lengths().astype(np.float64))
         for key in self.Ds.keys():
             D = self.Ds[key]
@@ -59,7 +61,11 @@ class ChenFusion(Serra09):
     def do_late_fusion(self):
         """SNF of the two distance matrices (latefusion_chen.py:87-91): Ds["Late"] = fused
         similarity; the two inputs are negated so that larger = closer everywhere.  Runs on the GPU
-        (acx_snf_fuse_dists)."""
+        (acx_snf_fuse_dists) of the rank that owns the matrices; the other ranks return at once (their
+        matrices are empty: 20 N x N sweeps over inf / NaN for nothing)."""
+        if not self.owns_result():
+            self.Ds["Late"] = np.zeros((0, 0), np.float64)     # same keys on every rank (getEvalStatistics is collective)
+            return
         if self._ctx is None:
             import os
             self._ctx = _lib.Context(self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0")))

@@ -118,6 +118,8 @@ class Serra09(CoverAlgorithm):
     def normalize_by_length(self):
         """Non-symmetric normalisation: D[i, j] /= sqrt(T_j), T_j the pooled length
         (rqa_serra09.py:71-83; the reciprocal of the paper's distance, so larger = closer)."""
+        if not self.owns_result():
+            return
         norm = np.sqrt(self._pooled_lengths().astype(np.float64))
         for key in self.Ds.keys():
             D = self.Ds[key]

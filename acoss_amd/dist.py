@@ -8,7 +8,15 @@ RCCL, no host staging.  Rank 0 then scatters the tiles into the N x N matrices.
 """
 import numpy as np
 
-__all__ = ["world", "barrier", "broadcast_object", "shard_bounds", "gather_scores", "gather_tiles"]
+__all__ = ["world", "bind_device", "barrier", "broadcast_object", "any_rank", "shard_bounds", "gather_scores",
+           "gather_tiles"]
+
+# The GPU this process works on (set by bind_device).  Under "nccl" EVERY collective needs a device:
+# torch picks torch.cuda.current_device() for dist.barrier() and for the tensors behind
+# broadcast_object_list(), which is cuda:0 on every rank unless somebody called set_device -- RCCL then
+# reports "Duplicate GPU detected" or hangs.  libacx picks its GPU from LOCAL_RANK on its own and never
+# touches torch's current device, so the package binds it here, once, when a context joins a process group.
+_BOUND = None
 
 
 def world():
@@ -22,29 +30,79 @@ def world():
     return 0, 1
 
 
+def _is_nccl():
+    import torch.distributed as dist
+    return dist.get_backend() == "nccl"
+
+
+def bind_device(index):
+    """Make GPU `index` this process's device for torch's collectives (torch.cuda.set_device) -- called by
+    the device-backed classes with the device of their libacx context before the first collective.  One
+    process, one GPU: binding a second, different device is an error."""
+    global _BOUND
+    index = int(index)
+    if _BOUND is not None and _BOUND != index:
+        raise RuntimeError("acoss_amd.dist: this process is bound to GPU %d, cannot also use GPU %d "
+                           "(one process per GPU)" % (_BOUND, index))
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.set_device(index)
+    _BOUND = index
+
+
+def _collective_device():
+    """torch.device the nccl collectives of this rank run on: the bound GPU, else LOCAL_RANK's."""
+    import os
+    import torch
+    if _BOUND is None:
+        bind_device(int(os.environ.get("LOCAL_RANK", "0")))
+    return torch.device("cuda", _BOUND)
+
+
 def barrier():
     rank, ws = world()
     if ws > 1:
         import torch.distributed as dist
-        dist.barrier()
+        if _is_nccl():
+            dist.barrier(device_ids=[_collective_device().index])
+        else:
+            dist.barrier()
 
 
 def broadcast_object(obj, src=0):
-    """Small picklable object from rank `src` to every rank."""
+    """Small picklable object from rank `src` to every rank (a collective: every rank must call it)."""
     rank, ws = world()
     if ws == 1:
         return obj
     import torch.distributed as dist
     box = [obj if rank == src else None]
-    dist.broadcast_object_list(box, src=src)
+    if _is_nccl():
+        dist.broadcast_object_list(box, src=src, device=_collective_device())
+    else:
+        dist.broadcast_object_list(box, src=src)
     return box[0]
+
+
+def any_rank(flag):
+    """True on every rank iff `flag` is true on at least one (a collective: every rank must call it).
+    Decisions that lead into another collective are taken with this, never from rank-local state."""
+    rank, ws = world()
+    if ws == 1:
+        return bool(flag)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_collective_device() if _is_nccl() else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
 
 
 def gather_tiles(local, stride):
     """All-gather of the per-rank tile-score buffers: `local` is a torch tensor of `stride` float32
-    (on the rank's GPU under nccl).  Returns the gathered (world * stride,) float32 numpy array.
-    Under nccl the collective runs on the device buffers themselves (one D2H copy of the result);
-    under gloo (CPU tests, ranks sharing one GPU) the buffer is moved to the host first."""
+    (on the rank's GPU under nccl).  Rank 0 -- the owner of the result -- gets the gathered
+    (world * stride,) float32 numpy array, every other rank None (no device-to-host copy there: at
+    N = 15 000 that would be 450 MB per rank for nothing).  Under nccl the collective runs on the
+    device buffers themselves; under gloo (CPU tests, ranks sharing one GPU) the buffer is moved to
+    the host first."""
     import torch
     import torch.distributed as dist
     rank, ws = world()
@@ -54,11 +112,11 @@ def gather_tiles(local, stride):
     if dist.get_backend() == "nccl":
         out = torch.empty(ws * stride, dtype=torch.float32, device=local.device)
         dist.all_gather_into_tensor(out, local)
-        return out.cpu().numpy()
+        return out.cpu().numpy() if rank == 0 else None
     loc = local.cpu()
     outs = [torch.empty_like(loc) for _ in range(ws)]
     dist.all_gather(outs, loc)
-    return torch.cat(outs).numpy()
+    return torch.cat(outs).numpy() if rank == 0 else None
 
 
 # ---- pair-LIST sharding: the CPU loop of user subclasses that implement similarity() themselves
@@ -86,7 +144,7 @@ def gather_scores(local, n_items, device=None):
     buf[:len(local)] = local
     t = torch.from_numpy(buf)
     if dist.get_backend() == "nccl":
-        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        t = t.to(device if device is not None else _collective_device())
     outs = [torch.empty_like(t) for _ in range(ws)]
     dist.all_gather(outs, t)
     parts = []

@@ -130,6 +130,23 @@ def cpu_baseline(frames, offsets, pairs, budget_s=20.0):
         "value_1core": round(1.0 / t_pair, 3), "cpu_model": model, "host_cpus": cores}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- torch.distributed.run as a
+    CHILD process, before this process has made any GPU call (it never does), one rank per GPU on
+    127.0.0.1 -- relay what the ranks print (rank 0's ONE JSON line included) and return the child's exit
+    code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,15 +154,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tracks", type=int, default=N_TRACKS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="rendezvous, deal the tiles, print the plan as one JSON line and stop: no GPU work "
+                         "(checks a multi-rank launch on any box; ACX_BENCH_BACKEND=gloo without GPUs)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d: start exactly one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...)"
+                         % (args.gpus, world, args.gpus, args.gpus))
 
     from acoss_amd import _lib
-    frames, offsets = make_pool(args.tracks, T_FRAMES)
-    lengths = np.diff(offsets)
+    lengths = np.full(args.tracks, T_FRAMES, np.int64)
     plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=world, tile=TILE, want_tiles=True)
     spec = plan["spec"]
     mine = [t for t in plan["tiles"] if t.rank == rank]
@@ -164,6 +191,32 @@ def main():
             out.append(np.stack([i[keep], j[keep]], 1))
         return np.concatenate(out).astype(np.int32)
 
+    if args.plan_only:
+        import torch
+        import torch.distributed as dist
+        seen = 1
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(os.environ.get("ACX_BENCH_BACKEND", "gloo"))
+            t = torch.tensor([len(mine)], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                torch.cuda.set_device(local_rank)
+                t = t.cuda()
+            outs = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            seen = dist.get_world_size()
+            per_rank = [int(o.item()) for o in outs]
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            per_rank = [len(mine)]
+        if rank == 0:
+            print(json.dumps({"plan_only": True, "n_gpus": world, "ranks_seen": seen, "tiles_per_rank": per_rank,
+                              "tiles": int(plan["n_tiles"]), "tile": TILE, "pool_tracks": args.tracks,
+                              "cost_per_rank": [float(c) for c in plan["cost_per_rank"]]}))
+        return
+
+    frames, offsets = make_pool(args.tracks, T_FRAMES)
     # ---- CPU baseline first: worker processes are forked before any GPU state exists
     cpu = cpu_sample = cpu_scores = None
     if world == 1 and rank == 0 and not args.no_cpu:
@@ -206,7 +259,10 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
@@ -230,6 +286,7 @@ def main():
         total_pairs = float(pp.item())
     else:
         total_pairs = my_pairs
+    ranks_seen = dist.get_world_size() if world > 1 else 1        # what the collective actually spanned
     prof = ctx.profile()
 
     if rank == 0:
@@ -276,7 +333,7 @@ def main():
                 raise SystemExit("bench: GPU scores differ from the CPU oracle on the sampled pairs")
         line = {
             "metric": "track-pairs/sec on N x N Serra09 Qmax (HPCP, T=2000)",
-            "value": round(value, 1), "unit": "track-pairs/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "track-pairs/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -293,7 +350,7 @@ def main():
         print(json.dumps(line))
     ctx.close()
     if world > 1:
-        dist.barrier()
+        fence()
         dist.destroy_process_group()
 
 

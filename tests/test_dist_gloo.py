@@ -32,7 +32,7 @@ def _worker(rank, ws, port, workdir, sym, out, kind):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=ws)
     try:
-        D, stats = (_run_grid if kind == "grid" else _run_toy)(workdir, sym)
+        D, stats = {"grid": _run_grid, "toy": _run_toy, "labels": _run_labels}[kind](workdir, sym)
         np.save(os.path.join(out, "D_rank%d.npy" % rank), D)
         np.save(os.path.join(out, "S_rank%d.npy" % rank), np.array(stats[:4]))
     finally:
@@ -55,6 +55,38 @@ def _run_toy(workdir, sym):
     toy.all_pairwise(symmetric=sym)
     stats = toy.getEvalStatistics("main", topsidx=[1, 10])
     return np.stack([np.array(toy.Ds["main"]), np.array(toy.Ds["aux"])]), stats
+
+
+def _run_labels(workdir, sym):
+    """Rank-local state must not decide whether a collective runs: rank 1 has its labels injected (its
+    `cliques` is not empty), rank 0 has not -- all_pairwise has to take every rank through the clique
+    broadcast anyway -- and the owner-only post-processing steps return at once on the other ranks."""
+    import torch.distributed as dist
+    from acoss_amd.algorithms.algorithm_template import CoverAlgorithm
+    n = 11
+    S = np.random.default_rng(5).random((n, n)).astype(np.float32)
+
+    class Toy(CoverAlgorithm):
+        def similarity(self, idxs):
+            i, j = idxs[:, 0], idxs[:, 1]
+            self.Ds["main"][i, j] = S[i, j] + (S[j, i] if sym else 0)
+
+        def normalize(self):
+            if not self.owns_result():
+                return "skipped"
+            self.Ds["main"][:] = self.Ds["main"] * 2
+            return "done"
+
+    toy = Toy(os.path.join(workdir, "toy.csv"), name="Toy", datapath=workdir + "/", shortname="l")
+    if dist.is_initialized() and dist.get_rank() == 1:
+        for i in range(n):
+            toy._register_label(i, "w%d" % (i % 4))
+    toy.all_pairwise(symmetric=sym)
+    assert len(toy.cliques) == 4 and sum(len(c) for c in toy.cliques.values()) == n
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    assert toy.normalize() == ("done" if rank == 0 else "skipped")
+    stats = toy.getEvalStatistics("main", topsidx=[1, 10])
+    return np.array(toy.Ds["main"])[None], stats
 
 
 class _FakeContext(object):
@@ -148,7 +180,8 @@ def _dataset(wd, name, n, nworks):
             save_track(os.path.join(wd, "w%d/t%d.h5" % (k % nworks, k)), {"label": "w%d" % (k % nworks), "track_id": "t%d" % k})
 
 
-@pytest.mark.parametrize("kind,sym", [("toy", True), ("toy", False), ("grid", True), ("grid", False)])
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("kind,sym", [("toy", True), ("toy", False), ("grid", True), ("grid", False), ("labels", True)])
 def test_two_ranks_equal_one(tmp_path, kind, sym):
     import torch.multiprocessing as mp
     wd = str(tmp_path)
@@ -157,14 +190,14 @@ def test_two_ranks_equal_one(tmp_path, kind, sym):
     cwd = os.getcwd()
     os.chdir(wd)
     try:
-        single, sstats = (_run_grid if kind == "grid" else _run_toy)(wd, sym)
+        single, sstats = {"grid": _run_grid, "toy": _run_toy, "labels": _run_labels}[kind](wd, sym)
     finally:
         os.chdir(cwd)
     if kind == "grid":
         assert np.array_equal(single, _expected_grid(75, sym))
     out = str(tmp_path / "out")
     os.makedirs(out)
-    for stale in ("results_t_Toy.csv", "results_g_Dev.csv"):
+    for stale in ("results_t_Toy.csv", "results_g_Dev.csv", "results_l_Toy.csv"):
         if os.path.exists(os.path.join(wd, stale)):
             os.remove(os.path.join(wd, stale))
     mp.spawn(_worker, args=(2, _free_port(), wd, sym, out, kind), nprocs=2, join=True)
@@ -175,6 +208,35 @@ def test_two_ranks_equal_one(tmp_path, kind, sym):
     # rank 0 alone wrote the results file: one header, one row
     res = [f for f in os.listdir(wd) if f.startswith("results_")]
     assert len(res) == 1 and len(open(os.path.join(wd, res[0])).read().strip().split("\n")) == 2
+
+
+@pytest.mark.timeout(600)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (a child
+    torch.distributed.run, before any GPU call) and the line says n_gpus = ranks_seen = 2; a rank count that
+    contradicts --gpus is refused.  --plan-only stops after the rendezvous and the deal: no GPU needed."""
+    import json
+    import subprocess
+    env = dict(os.environ, ACX_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--plan-only", "--tracks", "640"], env=env, capture_output=True,
+                       text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["tiles_per_rank"]) == 2
+    assert sum(line["tiles_per_rank"]) == line["tiles"] == 55          # 10 x 10 tile blocks, upper triangle
+    c = line["cost_per_rank"]
+    assert max(c) / (sum(c) / 2) <= 1.02
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--plan-only"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
+    one = subprocess.run([sys.executable, bench, "--plan-only", "--tracks", "640"], env=env, capture_output=True, text=True,
+                         timeout=120)
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
 
 
 def test_grid_plan_is_cost_balanced_on_ragged_lengths():
