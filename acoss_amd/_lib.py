@@ -28,6 +28,7 @@ EXPORTS = [
     "acx_chenfusion_pairs", "acx_csm_binary_sw", "acx_upload_raw_pool", "acx_download_pool",
     "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse", "acx_qmax_binary",
     "acx_ef_block_features", "acx_ef_upload_raw_pool", "acx_snf_fuse_dists", "acx_grid_plan", "acx_pool_lengths", "acx_grid_run", "acx_grid_scatter", "acx_pair_grid",
+    "acx_set_nonfinite_policy", "acx_nonfinite_zeroed",
 ]
 
 ALGO_SERRA09, ALGO_CHENFUSION, ALGO_SIMPLE, ALGO_EARLYFUSION = 0, 1, 2, 3
@@ -109,6 +110,9 @@ def load():
     L.acx_last_error.restype = ctypes.c_char_p
     L.acx_last_error.argtypes = [vp]
     L.acx_set_scratch_limit.argtypes = [vp, ctypes.c_int64]
+    L.acx_set_nonfinite_policy.argtypes = [vp, ctypes.c_int32]
+    L.acx_nonfinite_zeroed.restype = ctypes.c_int64
+    L.acx_nonfinite_zeroed.argtypes = [vp]
     L.acx_upload_pool.argtypes = [vp, fp, lp, ctypes.c_int32, ctypes.c_int32]
     L.acx_upload_raw_pool.argtypes = [vp, fp, lp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, lp]
     L.acx_download_pool.argtypes = [vp, fp, ctypes.c_int64]
@@ -216,7 +220,7 @@ def grid_scatter(lengths, spec, gathered, rank_stride, planes, mirror, first=0, 
 class Context(object):
     """One libacx context = one GPU.  Single-owner (one host thread)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, nonfinite="raise"):
         self._L = load()
         err = ctypes.c_int(0)
         self._h = self._L.acx_create(int(device), ctypes.byref(err))
@@ -227,6 +231,8 @@ class Context(object):
         self.device = int(device)
         self.n_tracks = 0
         self.lengths = None
+        if nonfinite != "raise":
+            self.set_nonfinite_policy(nonfinite)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -252,6 +258,15 @@ class Context(object):
             raise MemoryError(msg)
         # ACX_ERR_SHORT mirrors essentia's exception for inputs shorter than the stack
         raise AcxError(msg)
+
+    def set_nonfinite_policy(self, policy):
+        """'raise' (default): an upload with NaN / Inf features fails (ValueError naming the track);
+        'zero': they are replaced by 0 on the device (nonfinite_zeroed() counts them)."""
+        code = {"raise": 0, "reject": 0, "zero": 1}.get(policy, policy)
+        self._check(self._L.acx_set_nonfinite_policy(self._h, int(code)))
+
+    def nonfinite_zeroed(self):
+        return int(self._L.acx_nonfinite_zeroed(self._h))
 
     def set_scratch_limit(self, nbytes):
         self._check(self._L.acx_set_scratch_limit(self._h, int(nbytes)))

@@ -34,7 +34,7 @@ class EarlyFusion(CoverAlgorithm):
 
     def __init__(self, dataset_csv, datapath, chroma_type='hpcp', shortname='Covers80', blocksize=20,
                  mfccs_per_block=50, ssm_res=50, chromas_per_block=40, kappa=0.1, K=10, niters=5,
-                 log_times=False, device=None):
+                 log_times=False, device=None, nonfinite="raise"):
         self.chroma_type = chroma_type
         self.blocksize = blocksize
         self.mfccs_per_block = mfccs_per_block
@@ -47,6 +47,7 @@ class EarlyFusion(CoverAlgorithm):
         if log_times:
             self.times = {'features': [], 'raw': []}
         self._device = device
+        self._nonfinite = nonfinite
         self._ctx = None
         self._pool_ready = False
         CoverAlgorithm.__init__(self, dataset_csv=dataset_csv, name="EarlyFusionTraile", datapath=datapath,
@@ -89,7 +90,7 @@ class EarlyFusion(CoverAlgorithm):
     def _context(self):
         if self._ctx is None:
             dev = self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0"))
-            self._ctx = _lib.Context(dev)
+            self._ctx = _lib.Context(dev, nonfinite=getattr(self, "_nonfinite", "raise"))
         if not self._pool_ready:
             feats = None
             if not self.all_block_feats:
@@ -119,7 +120,7 @@ class EarlyFusion(CoverAlgorithm):
         """The GPU context of the pair grid, or a fresh one (scores loaded with precomputed=True)."""
         if getattr(self, "_ctx", None) is None:
             dev = getattr(self, "_device", None)
-            self._ctx = _lib.Context(dev if dev is not None else int(os.environ.get("LOCAL_RANK", "0")))
+            self._ctx = _lib.Context(dev if dev is not None else int(os.environ.get("LOCAL_RANK", "0")), nonfinite=getattr(self, "_nonfinite", "raise"))
         return self._ctx
 
     def do_late_fusion(self):

@@ -18,7 +18,7 @@ __all__ = ["ChenFusion"]
 
 class ChenFusion(Serra09):
     def __init__(self, dataset_csv, datapath, chroma_type='hpcp', shortname='benchmark',
-                 oti=True, kappa=0.095, tau=1, m=9, downsample_fac=40, device=None, engine=None):
+                 oti=True, kappa=0.095, tau=1, m=9, downsample_fac=40, device=None, engine=None, nonfinite="raise"):
         self.oti = oti
         self.kappa = kappa
         self.tau = tau
@@ -27,6 +27,7 @@ class ChenFusion(Serra09):
         self.downsample_fac = downsample_fac
         self.all_feats = {}
         self._device = device
+        self._nonfinite = nonfinite
         self._engine = dict(engine or {})
         self._ctx = None
         self._pool_ready = False
@@ -68,7 +69,7 @@ class ChenFusion(Serra09):
             return
         if self._ctx is None:
             import os
-            self._ctx = _lib.Context(self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0")))
+            self._ctx = _lib.Context(self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0")), nonfinite=getattr(self, "_nonfinite", "raise"))
         DLate = doSimilarityFusion([self.Ds[s] for s in self.Ds], K=20, niters=20, reg_diag=1, ctx=self._ctx,
                                    want_ws=False)[1]
         for key in self.Ds:

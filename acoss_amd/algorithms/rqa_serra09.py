@@ -37,7 +37,7 @@ class Serra09(CoverAlgorithm):
     n_chunks = 1      # the whole pair list goes to the GPU in one similarity() call
 
     def __init__(self, dataset_csv, datapath, chroma_type='hpcp', shortname='benchmark',
-                 oti=True, kappa=0.095, tau=1, m=9, downsample_fac=40, device=None, engine=None):
+                 oti=True, kappa=0.095, tau=1, m=9, downsample_fac=40, device=None, engine=None, nonfinite="raise"):
         self.oti = oti
         self.kappa = kappa
         self.tau = tau
@@ -46,6 +46,7 @@ class Serra09(CoverAlgorithm):
         self.downsample_fac = downsample_fac
         self.all_feats = {}
         self._device = device
+        self._nonfinite = nonfinite
         self._engine = dict(engine or {})
         self._ctx = None
         self._pool_ready = False
@@ -80,7 +81,7 @@ class Serra09(CoverAlgorithm):
             dev = self._device
             if dev is None:
                 dev = int(os.environ.get("LOCAL_RANK", "0"))
-            self._ctx = _lib.Context(dev)
+            self._ctx = _lib.Context(dev, nonfinite=getattr(self, "_nonfinite", "raise"))
         if not self._pool_ready:
             if len(self.all_feats) == self.N or self.downsample_fac > 64:
                 # pooled features injected (set_pooled_features) or already prepared by load_features

@@ -29,13 +29,14 @@ class Simple(CoverAlgorithm):
     n_chunks = 1
 
     def __init__(self, dataset_csv, datapath, chroma_type='hpcp', shortname='Covers80',
-                 SSLEN=10, WIN=200, SKIP=100, device=None):
+                 SSLEN=10, WIN=200, SKIP=100, device=None, nonfinite="raise"):
         self.SSLEN = SSLEN
         self.WIN = WIN
         self.SKIP = SKIP
         self.chroma_type = chroma_type
         self.all_feats = {}
         self._device = device
+        self._nonfinite = nonfinite
         self._ctx = None
         self._pool_ready = False
         CoverAlgorithm.__init__(self, dataset_csv=dataset_csv, name="SiMPle", datapath=datapath,
@@ -89,7 +90,7 @@ class Simple(CoverAlgorithm):
         if self._ctx is None:
             import os
             dev = self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0"))
-            self._ctx = _lib.Context(dev)
+            self._ctx = _lib.Context(dev, nonfinite=getattr(self, "_nonfinite", "raise"))
         if not self._pool_ready:
             if len(self.all_feats) == self.N:
                 # features injected (set_features) or already prepared by load_features
@@ -106,16 +107,18 @@ class Simple(CoverAlgorithm):
         return self._ctx
 
     def simple_sim(self, seq_a, seq_b):
-        """median_i min_j ||A[:, i:i+L] - B[:, j:j+L]||^2 of two (12, n) sequences (no OTI)."""
+        """median_i min_j ||A[:, i:i+L] - B[:, j:j+L]||^2 of two (12, n) sequences (no OTI).  The two
+        sequences become a two-track pool of a side context that lives as long as this object (the
+        collection's pool in the main context stays where it is)."""
         import os
-        ctx = _lib.Context(self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0")))
-        try:
-            a = np.ascontiguousarray(np.asarray(seq_a, dtype=np.float64).T)
-            b = np.ascontiguousarray(np.asarray(seq_b, dtype=np.float64).T)
-            ctx.upload_pool_f64(np.concatenate([a, b]), np.array([0, len(a), len(a) + len(b)], np.int64))
-            return float(-ctx.simple_pairs(np.array([[0, 1]], np.int32), self.SSLEN, oti=False)[0])
-        finally:
-            ctx.close()
+        if getattr(self, "_aux_ctx", None) is None:
+            self._aux_ctx = _lib.Context(self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0")),
+                                         nonfinite=getattr(self, "_nonfinite", "raise"))
+        ctx = self._aux_ctx
+        a = np.ascontiguousarray(np.asarray(seq_a, dtype=np.float64).T)
+        b = np.ascontiguousarray(np.asarray(seq_b, dtype=np.float64).T)
+        ctx.upload_pool_f64(np.concatenate([a, b]), np.array([0, len(a), len(a) + len(b)], np.int64))
+        return float(-ctx.simple_pairs(np.array([[0, 1]], np.int32), self.SSLEN, oti=False)[0])
 
     def _grid(self):
         return self._context(), _lib.ALGO_SIMPLE, _lib.SimpleParams(int(self.SSLEN), 1), ["main"]

@@ -98,6 +98,7 @@ struct acx_ctx {
     int64_t *d_efoff = nullptr;
     std::vector<int64_t> h_efoff;
     int32_t ef_ntracks = 0;
+    int32_t ef_open = 0;                              // > 0: a pool of that many tracks is being filled (acx_ef_pool_begin .. _end)
     int32_t ef_dims[3] = {0, 0, 0};
     acx::EfPair *d_efpd = nullptr; size_t efpd_cap = 0;
     // scratch (grow-only)
@@ -108,6 +109,16 @@ struct acx_ctx {
     unsigned long long *d_bits = nullptr; size_t bits_cap = 0;   // recurrence bitmaps (u64 words)
     int64_t scratch_limit = 0;                            // bytes
     size_t total_mem = 0;
+    // the pair grid: last plan (a pure function of lengths and spec; sorting 10^4 tiles per call is what the cache saves)
+    std::vector<int64_t> plan_len;
+    acx_grid_spec plan_spec = {-1, 0, 0, 0};
+    std::vector<acx_grid_tile> plan_tiles;
+    int64_t *d_idx = nullptr;   size_t idx_cap = 0;       // score destinations of a chunk of pairs (grid runs)
+    int64_t *h_idx = nullptr;   size_t hidx_cap = 0;      // pinned staging of the same
+    void *d_tiles = nullptr;    size_t tiles_cap = 0;     // tile descriptors of a chunk (device-side pair enumeration), bytes
+    int nonfinite_policy = ACX_NONFINITE_REJECT;          // what an upload does with NaN / Inf features
+    int *d_nf = nullptr;                                  // {first offending track, values zeroed} of the upload scan
+    int64_t nf_zeroed = 0;                                // values zeroed by the last upload
     // profiling
     bool prof = false;
     KStat stats[KS_COUNT] = {{"oti_kernel", 0, 0, 0}, {"norms_kernel", 0, 0, 0}, {"band_kernel", 0, 0, 0},
@@ -184,6 +195,34 @@ void drain_profile(acx_ctx *c)
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Upload scan for non-finite features (prep_kernels.hpp P0) over `n` values of a packed (rows, dim) device
+// array whose first row is row `row_base` of the pool; d_off = the pool's track offsets (device).  Policy
+// REJECT: ACX_ERR_INVALID naming the first offending track; ZERO: the values are replaced by 0 in place
+// and counted in c->nf_zeroed.  nan_zero_always: NaN is zeroed whatever the policy (MFCCs, as the
+// reference does at earlyfusion_traile.py:105).
+template <typename T>
+int scan_nonfinite(acx_ctx *c, const char *who, const char *what, T *d_x, int64_t n, int dim, int64_t row_base,
+                   const int64_t *d_off, int n_tracks, bool nan_zero_always = false, int track_base = 0)
+{
+    if (n <= 0) return ACX_OK;
+    if (!c->d_nf) ACX_HIP(c, hipMalloc((void **)&c->d_nf, 2 * sizeof(int)));
+    const int init[2] = {0x7fffffff, 0};
+    ACX_HIP(c, hipMemcpyAsync(c->d_nf, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    const bool zero = c->nonfinite_policy == ACX_NONFINITE_ZERO;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+    hipLaunchKernelGGL((acx::nonfinite_kernel<T>), dim3(grid), dim3(256), 0, c->stream, d_x, n, dim, row_base, d_off, n_tracks,
+                       (zero || nan_zero_always) ? 1 : 0, zero ? 1 : 0, c->d_nf);
+    ACX_HIP(c, hipGetLastError());
+    int res[2];
+    ACX_HIP(c, hipMemcpyAsync(res, c->d_nf, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    c->nf_zeroed += res[1];
+    if (res[0] != 0x7fffffff)
+        return fail(c, ACX_ERR_INVALID, std::string(who) + ": track " + std::to_string(track_base + res[0]) + " holds a non-finite value (NaN / Inf) in its " +
+                    what + "; clean the features or select acx_set_nonfinite_policy(ctx, ACX_NONFINITE_ZERO)");
+    return ACX_OK;
+}
 
 // Number of embedded frames of a track of T pooled frames (oracle embed_len): the stack at base
 // frame i = 0, tau, 2 tau, ... holds frames i, i + tau, ..., i + (m - 1) tau.
@@ -372,6 +411,53 @@ static __global__ void scatter_scores_kernel(const float *__restrict__ src, cons
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= B) return;
     for (int e = 0; e < w; ++e) dst[idx[k] + e] = src[(size_t)k * w + e];
+}
+
+static __global__ void scatter_f64_kernel(const double *__restrict__ src, const int64_t *__restrict__ idx, float *__restrict__ dst, int n)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[idx[k]] = (float)src[k];          // the f32 store of Ds['main'][i, j] = sim (simple_silva.py:125-126)
+}
+
+// The pairs of a chunk of grid tiles, enumerated ON THE DEVICE (no host pair list, no sort, no upload):
+// tile t's pairs land at [pair_base, pair_base + P) in COLUMN-major order -- second track slowest, which is
+// the order simple_kernel wants its pairs in (neighbouring waves walk the same track B).  A diagonal tile of
+// a symmetric grid holds i < j only (column b has b pairs), of an ordered grid i != j (n - 1 per column).
+struct TileDev {
+    int32_t row0, col0, rows, cols;
+    int32_t diagonal, pad;
+    int64_t offset;        // float offset of the tile in the rank's score buffer
+    int64_t pair_base;     // first pair of the tile in the chunk
+};
+
+static __host__ __device__ inline int64_t tile_pair_count(int rows, int cols, int diagonal, int symmetric)
+{
+    if (!diagonal) return (int64_t)rows * cols;
+    return symmetric ? (int64_t)rows * (rows - 1) / 2 : (int64_t)rows * (rows - 1);
+}
+
+static __global__ void grid_pairs_kernel(const TileDev *__restrict__ tiles, int symmetric, int w, int32_t *__restrict__ pairs,
+                                         int64_t *__restrict__ idx)
+{
+    const TileDev t = tiles[blockIdx.y];
+    const int64_t P = tile_pair_count(t.rows, t.cols, t.diagonal, symmetric);
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < P; k += (int64_t)gridDim.x * blockDim.x) {
+        int a, b;
+        if (!t.diagonal) {
+            b = (int)(k / t.rows); a = (int)(k - (int64_t)b * t.rows);
+        } else if (symmetric) {
+            b = (int)((1.0 + __builtin_sqrt(1.0 + 8.0 * (double)k)) * 0.5);
+            while ((int64_t)b * (b - 1) / 2 > k) --b;
+            while ((int64_t)(b + 1) * b / 2 <= k) ++b;
+            a = (int)(k - (int64_t)b * (b - 1) / 2);
+        } else {
+            b = (int)(k / (t.rows - 1)); a = (int)(k - (int64_t)b * (t.rows - 1));
+            a += (a >= b) ? 1 : 0;
+        }
+        pairs[2 * (t.pair_base + k)] = t.row0 + a;
+        pairs[2 * (t.pair_base + k) + 1] = t.col0 + b;
+        idx[t.pair_base + k] = t.offset + ((int64_t)a * t.cols + b) * w;
+    }
 }
 
 // Runs the chain over `K` pairs in scratch-sized batches.
@@ -608,11 +694,28 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
 // ---------------------------------------------------------------------------------------
 struct EfDebug { float *csm, *fused; int32_t *oti; };
 
+// pinned host staging + device copy of `n` score destinations idx[0 .. n)
+static int stage_idx(acx_ctx *c, const int64_t *idx, int64_t n)
+{
+    int rc;
+    if ((size_t)n > c->hidx_cap) {
+        if (c->h_idx) ACX_HIP(c, hipHostFree(c->h_idx));
+        c->h_idx = nullptr; c->hidx_cap = 0;
+        ACX_HIP(c, hipHostMalloc((void **)&c->h_idx, sizeof(int64_t) * (size_t)n, hipHostMallocDefault));
+        c->hidx_cap = (size_t)n;
+    }
+    if ((rc = ensure(c, c->d_idx, c->idx_cap, (size_t)n)) != ACX_OK) return rc;
+    memcpy(c->h_idx, idx, sizeof(int64_t) * (size_t)n);
+    ACX_HIP(c, hipMemcpyAsync(c->d_idx, c->h_idx, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    return ACX_OK;
+}
+
+// `dd` (grid runs): the four scores of pair k go to dd->base[dd->idx[k] .. + 4) on the DEVICE instead of out[4 k ..].
 int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, float *out, const EfDebug *dbg,
-           const float *ext_matrix, int extM, int extN)
+           const float *ext_matrix, int extM, int extN, const DevDst *dd = nullptr)
 {
     using acx::EfPair;
-    if (!ext_matrix && !c->d_ef[0]) return fail(c, ACX_ERR_STATE, "earlyfusion: block-feature pool not uploaded (acx_ef_upload_pool)");
+    if (!ext_matrix && (!c->d_ef[0] || c->ef_open)) return fail(c, ACX_ERR_STATE, "earlyfusion: block-feature pool not uploaded (acx_ef_upload_pool)");
     if (!(p.kappa >= 0.0)) return fail(c, ACX_ERR_INVALID, "earlyfusion: kappa must be >= 0");
     if (p.K < 1) return fail(c, ACX_ERR_INVALID, "earlyfusion: K must be >= 1");
     ACX_HIP(c, hipSetDevice(c->device));
@@ -723,7 +826,13 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             }
         }
         ACX_HIP(c, hipGetLastError());
-        ACX_HIP(c, hipMemcpyAsync(out + 4 * k0, c->d_out, sizeof(float) * 4 * B, hipMemcpyDeviceToHost, c->stream));
+        if (dd) {
+            if ((rc = stage_idx(c, dd->idx + k0, B)) != ACX_OK) return rc;
+            hipLaunchKernelGGL(scatter_scores_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream, c->d_out, c->d_idx, dd->base, B, 4);
+            ACX_HIP(c, hipGetLastError());
+        } else {
+            ACX_HIP(c, hipMemcpyAsync(out + 4 * k0, c->d_out, sizeof(float) * 4 * B, hipMemcpyDeviceToHost, c->stream));
+        }
         ACX_HIP(c, hipStreamSynchronize(c->stream));
         drain_profile(c);
         if (dbg && B >= 1) {
@@ -851,6 +960,10 @@ void acx_destroy(acx_ctx *c)
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_nf) (void)hipFree(c->d_nf);
+    if (c->d_idx) (void)hipFree(c->d_idx);
+    if (c->h_idx) (void)hipHostFree(c->h_idx);
+    if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_bits) (void)hipFree(c->d_bits);
     if (c->d_frames64) (void)hipFree(c->d_frames64);
     if (c->d_toff64) (void)hipFree(c->d_toff64);
@@ -873,9 +986,28 @@ int acx_set_scratch_limit(acx_ctx *c, int64_t bytes)
     return ACX_OK;
 }
 
+int acx_set_nonfinite_policy(acx_ctx *c, int32_t policy)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (policy != ACX_NONFINITE_REJECT && policy != ACX_NONFINITE_ZERO) return fail(c, ACX_ERR_INVALID, "set_nonfinite_policy: unknown policy");
+    c->nonfinite_policy = policy;
+    return ACX_OK;
+}
+
+int64_t acx_nonfinite_zeroed(const acx_ctx *c) { return c ? c->nf_zeroed : 0; }
+
+static int upload_pool_impl(acx_ctx *c, const float *frames, const int64_t *offsets, int32_t n_tracks, int32_t dim);
+static int upload_pool_f64_impl(acx_ctx *c, const double *frames, const int64_t *offsets, int32_t n_tracks, int32_t dim);
+
 int acx_upload_pool(acx_ctx *c, const float *frames, const int64_t *offsets, int32_t n_tracks, int32_t dim)
 {
     if (!c) return ACX_ERR_INVALID;
+    c->nf_zeroed = 0;
+    return upload_pool_impl(c, frames, offsets, n_tracks, dim);
+}
+
+static int upload_pool_impl(acx_ctx *c, const float *frames, const int64_t *offsets, int32_t n_tracks, int32_t dim)
+{
     if (!frames || !offsets || n_tracks <= 0 || dim <= 0) return fail(c, ACX_ERR_INVALID, "upload_pool: bad argument");
     if (offsets[0] != 0) return fail(c, ACX_ERR_INVALID, "upload_pool: offsets[0] must be 0");
     for (int i = 0; i < n_tracks; ++i)
@@ -890,6 +1022,16 @@ int acx_upload_pool(acx_ctx *c, const float *frames, const int64_t *offsets, int
     ACX_HIP(c, hipMalloc((void **)&c->d_toff0, sizeof(int64_t) * (n_tracks + 1)));
     ACX_HIP(c, hipMemcpy(c->d_frames0, frames, sizeof(float) * total * dim, hipMemcpyHostToDevice));
     ACX_HIP(c, hipMemcpy(c->d_toff0, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    {
+        const int rc = scan_nonfinite(c, "upload_pool", "frames", c->d_frames0, total * dim, dim, 0, c->d_toff0, n_tracks);
+        if (rc != ACX_OK) { free_pool(c); c->n_tracks = 0; return rc; }
+    }
+    std::vector<float> cleaned;                     // policy ZERO and something was zeroed: the host-side sums below see what the device holds
+    if (c->nf_zeroed > 0 && dim == acx::NBIN) {
+        cleaned.resize((size_t)total * dim);
+        ACX_HIP(c, hipMemcpy(cleaned.data(), c->d_frames0, sizeof(float) * total * dim, hipMemcpyDeviceToHost));
+        frames = cleaned.data();
+    }
     if (dim == acx::NBIN) {
         // the active pool (rotated copy included) for the default stack stride
         const int rc = ensure_tau(c, 1);
@@ -936,6 +1078,7 @@ int acx_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_offsets
     if (fac < 1) return fail(c, ACX_ERR_INVALID, "upload_raw_pool: downsample factor must be >= 1");
     if (fac > acx::POOL_MAXFAC) return fail(c, ACX_ERR_UNSUPPORTED, "upload_raw_pool: downsample factors above 64 are not supported on the device");
     ACX_HIP(c, hipSetDevice(c->device));
+    c->nf_zeroed = 0;
     std::vector<int64_t> poff((size_t)n_tracks + 1, 0);
     for (int t = 0; t < n_tracks; ++t) {
         const int64_t T0 = raw_offsets[t + 1] - raw_offsets[t];
@@ -975,6 +1118,10 @@ int acx_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_offsets
                 ACX_HIPC(hipMalloc((void **)&d_pooled, sizeof(float) * cap_pooled));
             }
             ACX_HIPC(hipMemcpyAsync(d_raw, raw + raw_offsets[t0] * 12, sizeof(float) * nraw * 12, hipMemcpyHostToDevice, c->stream));
+            if ((rc = scan_nonfinite(c, "upload_raw_pool", "raw chroma", d_raw, nraw * 12, 12, raw_offsets[t0], d_roff, n_tracks)) != ACX_OK) {
+                cleanup();
+                return rc;
+            }
             const int64_t blocks = (npool + acx::POOL_FPB - 1) / acx::POOL_FPB;
             hipLaunchKernelGGL(acx::pool_median_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream,
                                d_raw, raw_offsets[t0], d_roff, d_poff, n_tracks, poff[t0], poff[t1], fac, d_pooled);
@@ -987,7 +1134,7 @@ int acx_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_offsets
 #undef ACX_HIPC
     cleanup();
     if (pooled_offsets_out) memcpy(pooled_offsets_out, poff.data(), sizeof(int64_t) * (n_tracks + 1));
-    return acx_upload_pool(c, pooled.data(), poff.data(), n_tracks, dim);
+    return upload_pool_impl(c, pooled.data(), poff.data(), n_tracks, dim);
 }
 
 int acx_download_pool(acx_ctx *c, float *frames, int64_t capacity)
@@ -1102,6 +1249,12 @@ int acx_qmax_binary(acx_ctx *c, const uint8_t *R, int32_t M, int32_t N, const ac
 int acx_upload_pool_f64(acx_ctx *c, const double *frames, const int64_t *offsets, int32_t n_tracks, int32_t dim)
 {
     if (!c) return ACX_ERR_INVALID;
+    c->nf_zeroed = 0;
+    return upload_pool_f64_impl(c, frames, offsets, n_tracks, dim);
+}
+
+static int upload_pool_f64_impl(acx_ctx *c, const double *frames, const int64_t *offsets, int32_t n_tracks, int32_t dim)
+{
     if (!frames || !offsets || n_tracks <= 0 || dim != 12) return fail(c, ACX_ERR_INVALID, "upload_pool_f64: bad argument (dim must be 12)");
     if (offsets[0] != 0) return fail(c, ACX_ERR_INVALID, "upload_pool_f64: offsets[0] must be 0");
     for (int i = 0; i < n_tracks; ++i)
@@ -1113,18 +1266,34 @@ int acx_upload_pool_f64(acx_ctx *c, const double *frames, const int64_t *offsets
     if (c->d_wn64) { (void)hipFree(c->d_wn64); c->d_wn64 = nullptr; }
     c->wn64_L = 0;
     const int64_t total = offsets[n_tracks];
+    std::vector<double> cleaned;
     c->h_off64.assign(offsets, offsets + n_tracks + 1);
     c->n_tracks64 = n_tracks;
+    ACX_HIP(c, hipMalloc((void **)&c->d_frames64, sizeof(double) * std::max<int64_t>(1, total) * 12));
+    ACX_HIP(c, hipMalloc((void **)&c->d_toff64, sizeof(int64_t) * (n_tracks + 1)));
+    ACX_HIP(c, hipMemcpy(c->d_frames64, frames, sizeof(double) * total * 12, hipMemcpyHostToDevice));
+    ACX_HIP(c, hipMemcpy(c->d_toff64, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    {
+        const int64_t before = c->nf_zeroed;
+        const int rc = scan_nonfinite(c, "upload_pool_f64", "frames", c->d_frames64, total * 12, 12, 0, c->d_toff64, n_tracks);
+        if (rc != ACX_OK) {
+            (void)hipFree(c->d_frames64); c->d_frames64 = nullptr;
+            (void)hipFree(c->d_toff64); c->d_toff64 = nullptr;
+            c->n_tracks64 = 0;
+            return rc;
+        }
+        if (c->nf_zeroed > before) {      // policy ZERO: the profile below sums what the device holds
+            cleaned.resize((size_t)total * 12);
+            ACX_HIP(c, hipMemcpy(cleaned.data(), c->d_frames64, sizeof(double) * total * 12, hipMemcpyDeviceToHost));
+            frames = cleaned.data();
+        }
+    }
     // per-track chroma profile: sum over time (np.sum(seq, 1), simple_silva.py:46-47)
     std::vector<double> prof((size_t)n_tracks * 12, 0.0);
     for (int t = 0; t < n_tracks; ++t)
         for (int64_t f = offsets[t]; f < offsets[t + 1]; ++f)
             for (int b = 0; b < 12; ++b) prof[(size_t)t * 12 + b] += frames[f * 12 + b];
-    ACX_HIP(c, hipMalloc((void **)&c->d_frames64, sizeof(double) * std::max<int64_t>(1, total) * 12));
-    ACX_HIP(c, hipMalloc((void **)&c->d_toff64, sizeof(int64_t) * (n_tracks + 1)));
     ACX_HIP(c, hipMalloc((void **)&c->d_prof64, sizeof(double) * prof.size()));
-    ACX_HIP(c, hipMemcpy(c->d_frames64, frames, sizeof(double) * total * 12, hipMemcpyHostToDevice));
-    ACX_HIP(c, hipMemcpy(c->d_toff64, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
     ACX_HIP(c, hipMemcpy(c->d_prof64, prof.data(), sizeof(double) * prof.size(), hipMemcpyHostToDevice));
     return ACX_OK;
 }
@@ -1138,6 +1307,7 @@ int acx_simple_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_
     if (win < 1 || skip < 1 || win_len_smooth < 0) return fail(c, ACX_ERR_INVALID, "simple_upload_raw_pool: WIN, SKIP must be >= 1 and the smoothing length >= 0");
     if (win_len_smooth + 2 > acx::SIMPLE_PREP_MAXW) return fail(c, ACX_ERR_UNSUPPORTED, "simple_upload_raw_pool: smoothing windows above 14 are not supported on the device");
     ACX_HIP(c, hipSetDevice(c->device));
+    c->nf_zeroed = 0;
     std::vector<int64_t> poff((size_t)n_tracks + 1, 0);
     for (int t = 0; t < n_tracks; ++t) {
         const int64_t n = (raw_offsets[t + 1] - raw_offsets[t]) / skip;          // int(T0 / SKIP), simple_silva.py:37
@@ -1189,6 +1359,10 @@ int acx_simple_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_
                 ACX_HIPC(hipMalloc((void **)&d_feats, sizeof(double) * cap_feats));
             }
             ACX_HIPC(hipMemcpyAsync(d_raw, raw + raw_offsets[t0] * 12, sizeof(float) * nraw * 12, hipMemcpyHostToDevice, c->stream));
+            if ((rc = scan_nonfinite(c, "simple_upload_raw_pool", "raw chroma", d_raw, nraw * 12, 12, raw_offsets[t0], d_roff, n_tracks)) != ACX_OK) {
+                cleanup();
+                return rc;
+            }
             hipLaunchKernelGGL(acx::simple_prep_kernel, dim3((unsigned)(t1 - t0)), dim3(256), 0, c->stream,
                                d_raw, raw_offsets[t0], d_roff, d_poff, t0, win, skip, sw, d_feats, poff[t0]);
             ACX_HIPC(hipGetLastError());
@@ -1200,7 +1374,7 @@ int acx_simple_upload_raw_pool(acx_ctx *c, const float *raw, const int64_t *raw_
 #undef ACX_HIPC
     cleanup();
     if (pooled_offsets_out) memcpy(pooled_offsets_out, poff.data(), sizeof(int64_t) * (n_tracks + 1));
-    return acx_upload_pool_f64(c, feats.data(), poff.data(), n_tracks, 12);
+    return upload_pool_f64_impl(c, feats.data(), poff.data(), n_tracks, 12);
 }
 
 int acx_download_pool_f64(acx_ctx *c, double *frames, int64_t capacity)
@@ -1283,6 +1457,7 @@ static void ef_free_pool(acx_ctx *c)
     if (c->d_efmed) { (void)hipFree(c->d_efmed); c->d_efmed = nullptr; }
     if (c->d_efoff) { (void)hipFree(c->d_efoff); c->d_efoff = nullptr; }
     c->ef_ntracks = 0;
+    c->ef_open = 0;
 }
 
 // The block features are on the device (d_ef[0..2], d_efmed): unit-norm chroma rows in place
@@ -1296,6 +1471,13 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
     for (int k = 0; k < 3; ++k) c->ef_dims[k] = dims[k];
     ACX_HIP(c, hipMalloc((void **)&c->d_efoff, sizeof(int64_t) * (n_tracks + 1)));
     ACX_HIP(c, hipMemcpy(c->d_efoff, offsets, sizeof(int64_t) * (n_tracks + 1), hipMemcpyHostToDevice));
+    {
+        static const char *what[3] = {"mfcc blocks", "ssm blocks", "chroma blocks"};
+        for (int k = 0; k < 3; ++k) {
+            const int rc = scan_nonfinite(c, "ef pool", what[k], c->d_ef[k], nb * dims[k], dims[k], 0, c->d_efoff, n_tracks);
+            if (rc != ACX_OK) { ef_free_pool(c); return rc; }
+        }
+    }
     for (int k = 0; k < 2; ++k)
         ACX_HIP(c, hipMalloc((void **)&c->d_efn[k], sizeof(float) * std::max<int64_t>(1, nb)));
     if (nb > 0) {
@@ -1321,28 +1503,80 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
     return ACX_OK;
 }
 
+// The pool in slices of whole tracks (a DA-TACOS-sized collection is 56 GB of block features: the host need
+// not hold it in one piece).  begin: sizes and allocation; tracks: one slice, from HOST or DEVICE memory
+// (hipMemcpyDefault: features that are already on the device, e.g. in a torch tensor, stay there); end: the
+// non-finite scan, norms and bf16 splits -- the pool cannot be used before.
+int acx_ef_pool_begin(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, const int32_t *dims)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!offsets || !dims || n_tracks <= 0) return fail(c, ACX_ERR_INVALID, "ef_pool_begin: bad argument");
+    if (dims[0] < 1 || dims[1] < 1 || dims[2] < 12 || dims[2] % 12 != 0)
+        return fail(c, ACX_ERR_INVALID, "ef_pool_begin: dims must be positive and dims[2] a multiple of 12");
+    if (offsets[0] != 0) return fail(c, ACX_ERR_INVALID, "ef_pool_begin: offsets[0] must be 0");
+    for (int i = 0; i < n_tracks; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(c, ACX_ERR_INVALID, "ef_pool_begin: offsets must be non-decreasing");
+    ACX_HIP(c, hipSetDevice(c->device));
+    ef_free_pool(c);
+    c->nf_zeroed = 0;
+    const int64_t nb = offsets[n_tracks];
+    for (int k = 0; k < 3; ++k) {
+        const hipError_t e = hipMalloc((void **)&c->d_ef[k], sizeof(float) * std::max<int64_t>(1, nb) * dims[k]);
+        if (e != hipSuccess) { ef_free_pool(c); return fail(c, ACX_ERR_NOMEM, std::string("ef_pool_begin: the block features do not fit the device: ") + hipGetErrorString(e)); }
+    }
+    ACX_HIP(c, hipMalloc((void **)&c->d_efmed, sizeof(double) * 12 * n_tracks));
+    c->h_efoff.assign(offsets, offsets + n_tracks + 1);
+    for (int k = 0; k < 3; ++k) c->ef_dims[k] = dims[k];
+    c->ef_open = n_tracks;
+    return ACX_OK;
+}
+
+int acx_ef_pool_tracks(acx_ctx *c, int32_t first_track, int32_t count, const float *mfccs, const float *ssms, const float *chromas,
+                       const double *chroma_med)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (c->ef_open <= 0) return fail(c, ACX_ERR_STATE, "ef_pool_tracks: no pool is being filled (acx_ef_pool_begin)");
+    if (first_track < 0 || count < 0 || (int64_t)first_track + count > c->ef_open || !chroma_med)
+        return fail(c, ACX_ERR_INVALID, "ef_pool_tracks: bad argument");
+    if (count == 0) return ACX_OK;
+    const int64_t b0 = c->h_efoff[first_track], nb = c->h_efoff[first_track + count] - b0;
+    const float *src[3] = {mfccs, ssms, chromas};
+    ACX_HIP(c, hipSetDevice(c->device));
+    for (int k = 0; k < 3 && nb > 0; ++k) {
+        if (!src[k]) return fail(c, ACX_ERR_INVALID, "ef_pool_tracks: bad argument");
+        ACX_HIP(c, hipMemcpy(c->d_ef[k] + b0 * c->ef_dims[k], src[k], sizeof(float) * nb * c->ef_dims[k], hipMemcpyDefault));
+    }
+    ACX_HIP(c, hipMemcpy(c->d_efmed + (size_t)12 * first_track, chroma_med, sizeof(double) * 12 * count, hipMemcpyDefault));
+    return ACX_OK;
+}
+
+int acx_ef_pool_end(acx_ctx *c)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (c->ef_open <= 0) return fail(c, ACX_ERR_STATE, "ef_pool_end: no pool is being filled (acx_ef_pool_begin)");
+    const int n_tracks = c->ef_open;
+    c->ef_open = 0;
+    ACX_HIP(c, hipSetDevice(c->device));
+    {   // the chroma medians: one row of 12 per track
+        const int rc = scan_nonfinite<double>(c, "ef pool", "chroma median", c->d_efmed, (int64_t)12 * n_tracks, 12, 0, nullptr, n_tracks);
+        if (rc != ACX_OK) { ef_free_pool(c); return rc; }
+    }
+    const std::vector<int64_t> off = c->h_efoff;
+    const int32_t dims[3] = {c->ef_dims[0], c->ef_dims[1], c->ef_dims[2]};
+    return ef_finish_pool(c, off.data(), n_tracks, dims);
+}
+
 int acx_ef_upload_pool(acx_ctx *c, const float *mfccs, const float *ssms, const float *chromas,
                        const double *chroma_med, const int64_t *offsets, int32_t n_tracks, const int32_t *dims)
 {
     if (!c) return ACX_ERR_INVALID;
     if (!mfccs || !ssms || !chromas || !chroma_med || !offsets || !dims || n_tracks <= 0)
         return fail(c, ACX_ERR_INVALID, "ef_upload_pool: bad argument");
-    if (dims[0] < 1 || dims[1] < 1 || dims[2] < 12 || dims[2] % 12 != 0)
-        return fail(c, ACX_ERR_INVALID, "ef_upload_pool: dims must be positive and dims[2] a multiple of 12");
-    if (offsets[0] != 0) return fail(c, ACX_ERR_INVALID, "ef_upload_pool: offsets[0] must be 0");
-    for (int i = 0; i < n_tracks; ++i)
-        if (offsets[i + 1] < offsets[i]) return fail(c, ACX_ERR_INVALID, "ef_upload_pool: offsets must be non-decreasing");
-    ACX_HIP(c, hipSetDevice(c->device));
-    ef_free_pool(c);
-    const int64_t nb = offsets[n_tracks];
-    const float *src[3] = {mfccs, ssms, chromas};
-    for (int k = 0; k < 3; ++k) {
-        ACX_HIP(c, hipMalloc((void **)&c->d_ef[k], sizeof(float) * std::max<int64_t>(1, nb) * dims[k]));
-        ACX_HIP(c, hipMemcpy(c->d_ef[k], src[k], sizeof(float) * nb * dims[k], hipMemcpyHostToDevice));
-    }
-    ACX_HIP(c, hipMalloc((void **)&c->d_efmed, sizeof(double) * 12 * n_tracks));
-    ACX_HIP(c, hipMemcpy(c->d_efmed, chroma_med, sizeof(double) * 12 * n_tracks, hipMemcpyHostToDevice));
-    return ef_finish_pool(c, offsets, n_tracks, dims);
+    int rc = acx_ef_pool_begin(c, offsets, n_tracks, dims);
+    if (rc == ACX_OK) rc = acx_ef_pool_tracks(c, 0, n_tracks, mfccs, ssms, chromas, chroma_med);
+    if (rc == ACX_OK) rc = acx_ef_pool_end(c);
+    else { ef_free_pool(c); c->ef_open = 0; }
+    return rc;
 }
 
 // Block features of tracks [0, n_tracks) into fresh device arrays (caller frees / adopts them).
@@ -1411,6 +1645,11 @@ static int ef_build_blocks(acx_ctx *c, const float *chroma, const int64_t *coff,
         ACX_HIPC(hipMemcpyAsync(d_moff, lm.data(), sizeof(int64_t) * (nt + 1), hipMemcpyHostToDevice, c->stream));
         ACX_HIPC(hipMemcpyAsync(d_ooff, lo.data(), sizeof(int64_t) * (nt + 1), hipMemcpyHostToDevice, c->stream));
         ACX_HIPC(hipMemcpyAsync(d_boff, lb.data(), sizeof(int64_t) * (nt + 1), hipMemcpyHostToDevice, c->stream));
+        {   // NaN MFCCs count as 0 like in the reference (earlyfusion_traile.py:105); anything else non-finite follows the policy
+            int rcs = scan_nonfinite(c, "ef block features", "raw chroma", d_ch, nch * 12, 12, 0, d_coff, nt, false, t0);
+            if (rcs == ACX_OK) rcs = scan_nonfinite(c, "ef block features", "MFCCs", d_mf, nmf * ncoef, ncoef, 0, d_moff, nt, true, t0);
+            if (rcs != ACX_OK) { cleanup_all(); return rcs; }
+        }
         if (nbs > 0) {
             acx::EfPrepParams kp{pp.blocksize, pp.mfccs_per_block, pp.chromas_per_block, ncoef};
             hipLaunchKernelGGL(acx::ef_blocks_kernel, dim3((unsigned)nbs), dim3(256), 0, c->stream,
@@ -1443,6 +1682,7 @@ int acx_ef_block_features(acx_ctx *c, const float *chroma, int64_t n_chroma, con
     if (rc != ACX_OK) return rc;
     if (n_chroma < 0 || n_mfcc < 0 || n_beats < 0) return fail(c, ACX_ERR_INVALID, "ef_block_features: bad argument");
     ACX_HIP(c, hipSetDevice(c->device));
+    c->nf_zeroed = 0;
     const int64_t coff[2] = {0, n_chroma}, moff[2] = {0, n_mfcc}, ooff[2] = {0, n_beats};
     std::vector<int64_t> boff;
     float *d_out[3];
@@ -1471,6 +1711,7 @@ int acx_ef_upload_raw_pool(acx_ctx *c, const float *chroma, const int64_t *chrom
     if (!chroma_offsets || !mfcc_offsets || !onset_offsets || n_tracks <= 0) return fail(c, ACX_ERR_INVALID, "ef_upload_raw_pool: bad argument");
     ACX_HIP(c, hipSetDevice(c->device));
     ef_free_pool(c);
+    c->nf_zeroed = 0;
     std::vector<int64_t> boff;
     float *d_out[3];
     double *d_med;
@@ -1718,7 +1959,7 @@ static int pool_lengths(acx_ctx *c, int algo, std::vector<int64_t> &len)
         if (!c->d_frames64) return fail(c, ACX_ERR_STATE, "grid: f64 feature pool not uploaded (acx_upload_pool_f64)");
         off = &c->h_off64; n = c->n_tracks64; break;
     case ACX_ALGO_EARLYFUSION:
-        if (!c->d_ef[0]) return fail(c, ACX_ERR_STATE, "grid: block-feature pool not uploaded (acx_ef_upload_pool)");
+        if (!c->d_ef[0] || c->ef_open) return fail(c, ACX_ERR_STATE, "grid: block-feature pool not uploaded (acx_ef_upload_pool)");
         off = &c->h_efoff; n = c->ef_ntracks; break;
     default: return fail(c, ACX_ERR_INVALID, "grid: unknown algorithm");
     }
@@ -1761,6 +2002,92 @@ int acx_pool_lengths(acx_ctx *c, int32_t algo, int64_t *lengths, int32_t capacit
     return ACX_OK;
 }
 
+// The plan of (pool lengths, spec), cached in the context: acx_grid_run is called once per slice of tiles
+// (bench.py: once per step) and the plan is the same every time.
+static const std::vector<acx_grid_tile> &cached_plan(acx_ctx *c, const std::vector<int64_t> &len, const acx_grid_spec &spec)
+{
+    const acx_grid_spec &q = c->plan_spec;
+    if (q.algo != spec.algo || q.symmetric != spec.symmetric || q.tile != spec.tile || q.world != spec.world || c->plan_len != len) {
+        std::vector<int64_t> fl;
+        std::vector<double> co;
+        acx::grid_plan(len.data(), (int)len.size(), spec, c->plan_tiles, fl, co);
+        c->plan_len = len;
+        c->plan_spec = spec;
+    }
+    return c->plan_tiles;
+}
+
+// SiMPle over a slice of tiles, everything on the device: pairs enumerated by grid_pairs_kernel (column-major
+// inside a tile = sorted by the second track), simple_kernel, then the f64 -> f32 scatter into the score buffer.
+// Nothing comes back to the host and the host waits for nothing between chunks.
+static int run_simple_tiles(acx_ctx *c, const std::vector<acx_grid_tile> &mine, int symmetric, const acx_simple_params &sp, float *d_scores)
+{
+    const int sslen = sp.sslen;
+    if (sslen < 1 || sslen > acx::SIMPLE_MAXL) return fail(c, ACX_ERR_UNSUPPORTED, "simple: SSLEN must be in 1..16 on the device");
+    int maxn = 0;
+    for (const acx_grid_tile &t : mine) {
+        for (int side = 0; side < 2; ++side) {
+            const int a0 = side ? t.col0 : t.row0, a1 = a0 + (side ? t.cols : t.rows);
+            for (int tr = a0; tr < a1; ++tr) {
+                const int n = (int)(c->h_off64[tr + 1] - c->h_off64[tr]);
+                if (n < sslen) return fail(c, ACX_ERR_SHORT, "simple: track " + std::to_string(tr) + " is shorter than SSLEN");
+                if (n > acx::SIMPLE_MAXN) return fail(c, ACX_ERR_UNSUPPORTED, "simple: tracks with more than 6000 pooled frames are not supported on the device");
+                maxn = std::max(maxn, n);
+            }
+        }
+    }
+    const size_t smem = 64 + sizeof(double) * 3 * (size_t)maxn;
+    int rc = ensure_winnorm(c, sslen);
+    if (rc != ACX_OK) return rc;
+    const int64_t CHUNK = (int64_t)1 << 22;
+    std::vector<TileDev> td;
+    size_t t0 = 0;
+    while (t0 < mine.size()) {
+        td.clear();
+        int64_t n = 0, maxP = 0;
+        size_t t1 = t0;
+        while (t1 < mine.size()) {
+            const acx_grid_tile &t = mine[t1];
+            const int64_t P = tile_pair_count(t.rows, t.cols, t.diagonal, symmetric);
+            if (t1 > t0 && n + P > CHUNK) break;
+            if (P > 0) { td.push_back(TileDev{t.row0, t.col0, t.rows, t.cols, t.diagonal, 0, t.offset, n}); maxP = std::max(maxP, P); }
+            n += P;
+            ++t1;
+        }
+        if (n > 0) {
+            if (n > 0x7fffffff) return fail(c, ACX_ERR_UNSUPPORTED, "simple: a single tile holds more than 2^31 pairs");
+            if ((rc = ensure(c, c->d_pairs, c->pairs_cap, (size_t)2 * n)) != ACX_OK) return rc;
+            if ((rc = ensure(c, c->d_out64, c->out64_cap, (size_t)n)) != ACX_OK) return rc;
+            if ((rc = ensure(c, c->d_idx, c->idx_cap, (size_t)n)) != ACX_OK) return rc;
+            const size_t tbytes = sizeof(TileDev) * td.size();
+            if (tbytes > c->tiles_cap) {
+                if (c->d_tiles) ACX_HIP(c, hipFree(c->d_tiles));
+                c->d_tiles = nullptr; c->tiles_cap = 0;
+                ACX_HIP(c, hipMalloc(&c->d_tiles, tbytes));
+                c->tiles_cap = tbytes;
+            }
+            // (pageable source: the copy is staged before the call returns, `td` may be reused at once)
+            ACX_HIP(c, hipMemcpyAsync(c->d_tiles, td.data(), tbytes, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(grid_pairs_kernel, dim3((unsigned)std::min<int64_t>((maxP + 255) / 256, 256), (unsigned)td.size()), dim3(256), 0,
+                               c->stream, static_cast<const TileDev *>(c->d_tiles), symmetric, 1, c->d_pairs, c->d_idx);
+            {
+                ProfScope ps(c, KS_SIMPLE, n);
+                switch (sslen) {
+#define ACX_L(L_) case L_: rc = launch_simple<L_>(c, (int)n, smem, sp.oti); break;
+                    ACX_L(1) ACX_L(2) ACX_L(3) ACX_L(4) ACX_L(5) ACX_L(6) ACX_L(7) ACX_L(8)
+                    ACX_L(9) ACX_L(10) ACX_L(11) ACX_L(12) ACX_L(13) ACX_L(14) ACX_L(15) ACX_L(16)
+#undef ACX_L
+                }
+                if (rc != ACX_OK) return rc;
+            }
+            hipLaunchKernelGGL(scatter_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_out64, c->d_idx, d_scores, (int)n);
+            ACX_HIP(c, hipGetLastError());
+        }
+        t0 = t1;
+    }
+    return ACX_OK;
+}
+
 int acx_grid_run(acx_ctx *c, const acx_grid_spec *spec, const void *params, int32_t rank, int64_t first, int64_t count,
                  float *d_scores)
 {
@@ -1771,11 +2098,7 @@ int acx_grid_run(acx_ctx *c, const acx_grid_spec *spec, const void *params, int3
     int rc = pool_lengths(c, spec->algo, len);
     if (rc != ACX_OK) return rc;
     ACX_HIP(c, hipSetDevice(c->device));
-    std::vector<acx_grid_tile> tiles;
-    std::vector<int64_t> fl;
-    std::vector<double> co;
-    acx::grid_plan(len.data(), (int)len.size(), *spec, tiles, fl, co);
-    const std::vector<acx_grid_tile> mine = acx::grid_slice(tiles, rank, first, count);
+    const std::vector<acx_grid_tile> mine = acx::grid_slice(cached_plan(c, len, *spec), rank, first, count);
     if (mine.empty()) return ACX_OK;
     const int w = acx::grid_planes(spec->algo);
     {   // blocks of one rank are contiguous in deal order: zero the slice (diagonal blocks keep zeros)
@@ -1783,11 +2106,19 @@ int acx_grid_run(acx_ctx *c, const acx_grid_spec *spec, const void *params, int3
         const int64_t hi = mine.back().offset + (int64_t)mine.back().rows * mine.back().cols * w;
         ACX_HIP(c, hipMemsetAsync(d_scores + lo, 0, sizeof(float) * (size_t)(hi - lo), c->stream));
     }
+    if (spec->algo == ACX_ALGO_SIMPLE) {
+        if (!c->d_frames64) return fail(c, ACX_ERR_STATE, "grid_run: f64 feature pool not uploaded (acx_upload_pool_f64)");
+        rc = run_simple_tiles(c, mine, spec->symmetric, *static_cast<const acx_simple_params *>(params), d_scores);
+        if (rc != ACX_OK) return rc;
+        ACX_HIP(c, hipStreamSynchronize(c->stream));
+        drain_profile(c);
+        return ACX_OK;
+    }
+    // Serra09 / ChenFusion / EarlyFusion: per-pair descriptors are built by the host (pairs of a few tiles at a
+    // time); the scores go from the kernels' output straight into d_scores (scatter_scores_kernel)
     const int64_t CHUNK_PAIRS = (int64_t)1 << 20;
     std::vector<int32_t> pairs;
     std::vector<int64_t> idx;
-    std::vector<float> host;          // SiMPle / EarlyFusion: scores come back through the host
-    std::vector<double> host64;
     size_t t0 = 0;
     while (t0 < mine.size()) {
         pairs.clear(); idx.clear();
@@ -1798,31 +2129,13 @@ int acx_grid_run(acx_ctx *c, const acx_grid_spec *spec, const void *params, int3
         }
         const int64_t K = (int64_t)idx.size();
         if (K > 0) {
-            if (spec->algo == ACX_ALGO_SERRA09 || spec->algo == ACX_ALGO_CHENFUSION) {
-                DevDst dd{d_scores, idx.data()};
+            DevDst dd{d_scores, idx.data()};
+            if (spec->algo == ACX_ALGO_EARLYFUSION)
+                rc = run_ef(c, pairs.data(), K, *static_cast<const acx_ef_params *>(params), nullptr, nullptr, nullptr, 0, 0, &dd);
+            else
                 rc = run_serra09(c, pairs.data(), K, *static_cast<const acx_serra09_params *>(params), nullptr, nullptr,
                                  spec->algo == ACX_ALGO_CHENFUSION, &dd);
-                if (rc != ACX_OK) return rc;
-            } else {
-                // list-based drivers deliver host scores; they go back up block by block
-                host.assign((size_t)K * w, 0.0f);
-                if (spec->algo == ACX_ALGO_SIMPLE) {
-                    const acx_simple_params *sp = static_cast<const acx_simple_params *>(params);
-                    host64.resize((size_t)K);
-                    rc = acx_simple_pairs(c, pairs.data(), K, sp->sslen, sp->oti, host64.data());
-                    if (rc != ACX_OK) return rc;
-                    for (int64_t k = 0; k < K; ++k) host[(size_t)k] = (float)host64[(size_t)k];
-                } else {
-                    rc = acx_earlyfusion_pairs(c, pairs.data(), K, static_cast<const acx_ef_params *>(params), host.data());
-                    if (rc != ACX_OK) return rc;
-                }
-                const int64_t lo = mine[t0].offset;
-                const int64_t hi = mine[t1 - 1].offset + (int64_t)mine[t1 - 1].rows * mine[t1 - 1].cols * w;
-                std::vector<float> stage((size_t)(hi - lo), 0.0f);
-                for (int64_t k = 0; k < K; ++k)
-                    for (int e = 0; e < w; ++e) stage[(size_t)(idx[(size_t)k] - lo) + e] = host[(size_t)k * w + e];
-                ACX_HIP(c, hipMemcpy(d_scores + lo, stage.data(), sizeof(float) * stage.size(), hipMemcpyHostToDevice));
-            }
+            if (rc != ACX_OK) return rc;
         }
         t0 = t1;
     }
@@ -1848,27 +2161,51 @@ int acx_pair_grid(acx_ctx *c, const acx_grid_spec *spec, const void *params, flo
 {
     if (!c) return ACX_ERR_INVALID;
     if (!acx::grid_spec_ok(spec) || spec->world != 1 || !params || !D) return fail(c, ACX_ERR_INVALID, "pair_grid: bad argument (world must be 1)");
+    for (int e = 0; e < acx::grid_planes(spec->algo); ++e) if (!D[e]) return fail(c, ACX_ERR_INVALID, "pair_grid: null plane");
     std::vector<int64_t> len;
     int rc = pool_lengths(c, spec->algo, len);
     if (rc != ACX_OK) return rc;
     if (ld < (int64_t)len.size()) return fail(c, ACX_ERR_INVALID, "pair_grid: leading dimension smaller than the number of tracks");
-    int64_t fl = 0, nt = 0;
-    if ((rc = acx_grid_plan(len.data(), (int32_t)len.size(), spec, nullptr, 0, &nt, &fl, nullptr)) != ACX_OK) return rc;
     ACX_HIP(c, hipSetDevice(c->device));
-    float *d = nullptr;
-    ACX_HIP(c, hipMalloc((void **)&d, sizeof(float) * (size_t)std::max<int64_t>(1, fl)));
-    rc = acx_grid_run(c, spec, params, 0, 0, -1, d);
-    std::vector<float> host;
-    if (rc == ACX_OK) {
-        host.resize((size_t)fl);
-        const hipError_t e = hipMemcpy(host.data(), d, sizeof(float) * (size_t)fl, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(c, ACX_ERR_HIP, std::string("pair_grid: ") + hipGetErrorString(e));
+    // slices of consecutive tiles (deal order) of at most SLICE floats: run on the device, one D2H copy of the
+    // slice into pinned memory, scattered into the caller's planes -- the host never holds more than a slice
+    const std::vector<acx_grid_tile> tiles = cached_plan(c, len, *spec);       // (a copy: grid_run re-reads the cache)
+    const int w = acx::grid_planes(spec->algo);
+    const int64_t SLICE = (int64_t)1 << 26;                                    // 256 MB of scores
+    int64_t cap = 0;
+    for (size_t a = 0; a < tiles.size();) {
+        int64_t fl = 0;
+        size_t b = a;
+        while (b < tiles.size() && (b == a || fl + (int64_t)tiles[b].rows * tiles[b].cols * w <= SLICE)) { fl += (int64_t)tiles[b].rows * tiles[b].cols * w; ++b; }
+        cap = std::max(cap, fl);
+        a = b;
+    }
+    float *d = nullptr, *h = nullptr;
+    ACX_HIP(c, hipMalloc((void **)&d, sizeof(float) * (size_t)std::max<int64_t>(1, cap)));
+    if (hipHostMalloc((void **)&h, sizeof(float) * (size_t)std::max<int64_t>(1, cap), hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(c, ACX_ERR_NOMEM, "pair_grid: cannot allocate the pinned staging slice");
+    }
+    for (size_t a = 0; a < tiles.size() && rc == ACX_OK;) {
+        int64_t fl = 0;
+        size_t b = a;
+        while (b < tiles.size() && (b == a || fl + (int64_t)tiles[b].rows * tiles[b].cols * w <= SLICE)) { fl += (int64_t)tiles[b].rows * tiles[b].cols * w; ++b; }
+        // grid_run writes tile t at d_scores + t.offset: rebase so that the slice starts at d[0]
+        rc = acx_grid_run(c, spec, params, 0, (int64_t)a, (int64_t)(b - a), d - tiles[a].offset);
+        if (rc == ACX_OK) {
+            const hipError_t e = hipMemcpy(h, d, sizeof(float) * (size_t)fl, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail(c, ACX_ERR_HIP, std::string("pair_grid: ") + hipGetErrorString(e));
+        }
+        if (rc == ACX_OK) {
+            std::vector<acx_grid_tile> part(tiles.begin() + a, tiles.begin() + b);
+            for (acx_grid_tile &t : part) t.offset -= tiles[a].offset;
+            acx::grid_scatter(part, *spec, h, 0, 0, -1, D, ld, mirror);
+        }
+        a = b;
     }
     (void)hipFree(d);
-    if (rc != ACX_OK) return rc;
-    rc = acx_grid_scatter(len.data(), (int32_t)len.size(), spec, host.data(), fl, 0, -1, D, ld, mirror);
-    if (rc != ACX_OK) return fail(c, rc, "pair_grid: scatter failed");
-    return ACX_OK;
+    (void)hipHostFree(h);
+    return rc;
 }
 
 int acx_profile_enable(acx_ctx *c, int on)

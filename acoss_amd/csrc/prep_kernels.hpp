@@ -23,6 +23,34 @@ __device__ __forceinline__ int track_of(const int64_t *__restrict__ poff, int n_
 }
 
 // ------------------------------------------------------------------------------------
+// P0: non-finite values.  One NaN / Inf frame poisons more than its own track: the band kernel's edge
+// tiles read a neighbouring track's frames unclamped (the cells they feed lie outside the matrix and
+// are +inf by construction -- unless the neighbour turns the sum into NaN, which the clamp at 0 makes a
+// spurious smallest element).  So every pool is scanned once on its way in.  `x` holds `n` values of
+// the rows [row_base, ...) of a packed (rows, dim) array whose track t owns rows off[t] .. off[t + 1].
+// A NaN is replaced by 0 when zero_nan, an Inf when zero_inf (the reference itself zeroes NaN MFCCs,
+// earlyfusion_traile.py:105); anything else non-finite is reported: res[0] = smallest offending track
+// (atomicMin; initialised to INT_MAX), res[1] += values zeroed.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nonfinite_kernel(T *__restrict__ x, int64_t n, int dim, int64_t row_base,
+                                                        const int64_t *__restrict__ off, int n_tracks, int zero_nan,
+                                                        int zero_inf, int *__restrict__ res)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int zeroed = 0;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+        const T v = x[k];
+        const bool is_nan = !(v == v);
+        const bool is_inf = !is_nan && !(v - v == (T)0);
+        if (!is_nan && !is_inf) continue;
+        if ((is_nan && zero_nan) || (is_inf && zero_inf)) { x[k] = (T)0; ++zeroed; continue; }
+        atomicMin(&res[0], off ? track_of(off, n_tracks, row_base + k / dim) : (int)(row_base + k / dim));     // no offsets: one row per track
+    }
+    if (zeroed) atomicAdd(&res[1], zeroed);
+}
+
+// ------------------------------------------------------------------------------------
 // P1: block medians.  Workgroup = 16 pooled frames; the raw block of a pooled frame (<= 64
 // frames x 12 bins, contiguous) is staged in LDS; thread (frame, bin) finds the two middle order
 // statistics by rank counting (ties ranked by position) and writes their f32 mean -- np.median

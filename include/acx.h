@@ -55,6 +55,22 @@ int acx_set_scratch_limit(acx_ctx *ctx, int64_t bytes);
 /* ---- feature pool ------------------------------------------------------- */
 
 /*
+ * What an upload does with non-finite feature values.  Real feature files carry them -- the reference
+ * zeroes NaN MFCCs itself (earlyfusion_traile.py:105) and hands everything else to essentia / numpy
+ * unchecked, where one NaN frame spoils the scores of its own track.  Here it would spoil more: the
+ * band kernel reads a neighbouring track's frames for the cells beyond a matrix's edge.  So every
+ * acx_*upload* call scans what it receives, on the device:
+ *   ACX_NONFINITE_REJECT (default)  the upload fails with ACX_ERR_INVALID, the message names the first
+ *                                   offending track; no pool is left behind
+ *   ACX_NONFINITE_ZERO              NaN / Inf values are replaced by 0 (what the reference does for MFCCs);
+ *                                   acx_nonfinite_zeroed() tells how many the last upload replaced
+ * NaN MFCC samples (acx_ef_block_features / acx_ef_upload_raw_pool) are zeroed under either policy.
+ */
+enum { ACX_NONFINITE_REJECT = 0, ACX_NONFINITE_ZERO = 1 };
+int acx_set_nonfinite_policy(acx_ctx *ctx, int32_t policy);
+int64_t acx_nonfinite_zeroed(const acx_ctx *ctx);
+
+/*
  * Upload the packed feature pool: `frames` is row-major (sum_i T_i, dim) f32,
  * track i occupies rows offsets[i] .. offsets[i+1].  Replaces the per-track
  * feature cache of the reference (Serra09.load_features -> self.all_feats,
@@ -202,6 +218,22 @@ int acx_simple_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, int32_t ssle
 int acx_ef_upload_pool(acx_ctx *ctx, const float *mfccs, const float *ssms, const float *chromas,
                        const double *chroma_med, const int64_t *offsets, int32_t n_tracks,
                        const int32_t *dims);
+
+/*
+ * The same pool in slices of whole tracks, for collections whose block features the host cannot (or need
+ * not) hold in one piece -- the reference keeps every track's blocks in a Python dict
+ * (self.all_block_feats, earlyfusion_traile.py:100-154: 56 GB at DA-TACOS size).
+ *   acx_ef_pool_begin   offsets (n_tracks + 1) and dims as in acx_ef_upload_pool; allocates
+ *   acx_ef_pool_tracks  tracks [first_track, first_track + count): their rows of the three feature arrays
+ *                       and their chroma medians, packed as in acx_ef_upload_pool.  The pointers may be
+ *                       HOST or DEVICE memory (features that already live on the GPU, e.g. in a torch
+ *                       tensor, are copied device to device)
+ *   acx_ef_pool_end     non-finite scan, row norms, bf16 splits; the pool is usable from here on
+ */
+int acx_ef_pool_begin(acx_ctx *ctx, const int64_t *offsets, int32_t n_tracks, const int32_t *dims);
+int acx_ef_pool_tracks(acx_ctx *ctx, int32_t first_track, int32_t count, const float *mfccs, const float *ssms,
+                       const float *chromas, const double *chroma_med);
+int acx_ef_pool_end(acx_ctx *ctx);
 
 /* Block-feature parameters of EarlyFusion.load_features (ctor arguments blocksize,
  * mfccs_per_block, chromas_per_block; earlyfusion_traile.py:44-45): defaults 20, 50, 40. */

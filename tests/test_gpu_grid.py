@@ -96,9 +96,17 @@ def test_pair_grid_simple_and_earlyfusion(ctx):
     n = len(feats)
     pairs = oracle.all_pairs(n, False).astype(np.int32)
     want = _from_pairs(n, pairs, ctx.simple_pairs(pairs, 10).astype(np.float32), False)
-    D = np.zeros((n, n), np.float32)
-    ctx.pair_grid(_lib.ALGO_SIMPLE, False, _lib.SimpleParams(10, 1), [D], mirror=False, tile=4)
-    assert np.array_equal(D, want)
+    for tile in (4, 0, 3):                  # device-side pair enumeration: full, ordered-diagonal and ragged edge tiles
+        D = np.zeros((n, n), np.float32)
+        ctx.pair_grid(_lib.ALGO_SIMPLE, False, _lib.SimpleParams(10, 1), [D], mirror=False, tile=tile)
+        assert np.array_equal(D, want)
+    # all_pairwise(symmetric=True) on SiMPle: i < j only (triangular diagonal tiles), mirrored
+    up = oracle.all_pairs(n, True).astype(np.int32)
+    want_sym = _from_pairs(n, up, ctx.simple_pairs(up, 10).astype(np.float32), True)
+    for tile in (4, 0):
+        D = np.zeros((n, n), np.float32)
+        ctx.pair_grid(_lib.ALGO_SIMPLE, True, _lib.SimpleParams(10, 1), [D], mirror=True, tile=tile)
+        assert np.array_equal(D, want_sym)
     tracks = synth.earlyfusion_set(6, seed=3, nb_range=(40, 90))
     ctx.ef_upload_pool(tracks)
     pairs = oracle.all_pairs(6, True).astype(np.int32)
