@@ -28,7 +28,8 @@ EXPORTS = [
     "acx_chenfusion_pairs", "acx_csm_binary_sw", "acx_upload_raw_pool", "acx_download_pool",
     "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse", "acx_qmax_binary",
     "acx_ef_block_features", "acx_ef_upload_raw_pool", "acx_snf_fuse_dists", "acx_grid_plan", "acx_pool_lengths", "acx_grid_run", "acx_grid_scatter", "acx_pair_grid",
-    "acx_set_nonfinite_policy", "acx_nonfinite_zeroed",
+    "acx_set_nonfinite_policy", "acx_nonfinite_zeroed", "acx_ef_pool_begin", "acx_ef_pool_tracks", "acx_ef_pool_end",
+    "acx_set_ef_gemm",
 ]
 
 ALGO_SERRA09, ALGO_CHENFUSION, ALGO_SIMPLE, ALGO_EARLYFUSION = 0, 1, 2, 3
@@ -137,6 +138,10 @@ def load():
     L.acx_simple_pairs.argtypes = [vp, ip, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, dp]
     ep = ctypes.POINTER(EfParams)
     L.acx_ef_upload_pool.argtypes = [vp, fp, fp, fp, dp, lp, ctypes.c_int32, ip]
+    L.acx_ef_pool_begin.argtypes = [vp, lp, ctypes.c_int32, ip]
+    L.acx_ef_pool_tracks.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp]
+    L.acx_ef_pool_end.argtypes = [vp]
+    L.acx_set_ef_gemm.argtypes = [vp, ctypes.c_int32]
     L.acx_earlyfusion_pairs.argtypes = [vp, ip, ctypes.c_int64, ep, fp]
     L.acx_ef_debug_pair.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ep, fp, fp, fp, ip]
     L.acx_sw_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, fp]
@@ -332,19 +337,55 @@ class Context(object):
                                              out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return out
 
-    def ef_upload_pool(self, tracks):
+    def ef_upload_pool(self, tracks, slice_bytes=1 << 30):
         """tracks: list of dicts with mfccs (nb,650), ssms (nb,1225), chromas (nb,480) f32 and
-        chroma_med (12,) -- the block features of EarlyFusion.load_features."""
+        chroma_med (12,) -- the block features of EarlyFusion.load_features.  Goes up in slices of
+        whole tracks of about `slice_bytes` (acx_ef_pool_begin / _tracks / _end): the host never holds a
+        second copy of the collection."""
         nb = np.array([t["mfccs"].shape[0] for t in tracks], dtype=np.int64)
+        dims = [int(tracks[0][k].shape[1]) for k in ("mfccs", "ssms", "chromas")] if len(tracks) else [650, 1225, 480]
+        self.ef_pool_begin(nb, dims)
+        row_bytes = 4 * sum(dims)
+        t0 = 0
+        while t0 < len(tracks):
+            t1, acc = t0, 0
+            while t1 < len(tracks) and (t1 == t0 or acc + int(nb[t1]) * row_bytes <= slice_bytes):
+                acc += int(nb[t1]) * row_bytes
+                t1 += 1
+            part = tracks[t0:t1]
+            mats = [np.ascontiguousarray(np.concatenate([t[k] for t in part], axis=0), dtype=np.float32)
+                    for k in ("mfccs", "ssms", "chromas")]
+            med = np.ascontiguousarray(np.stack([np.asarray(t["chroma_med"], dtype=np.float64) for t in part]))
+            self.ef_pool_tracks(t0, t1 - t0, mats[0], mats[1], mats[2], med)
+            t0 = t1
+        self.ef_pool_end()
+
+    def ef_pool_begin(self, blocks_per_track, dims=(650, 1225, 480)):
+        """Start a block-feature pool of len(blocks_per_track) tracks (acx_ef_pool_begin)."""
+        nb = np.ascontiguousarray(blocks_per_track, dtype=np.int64)
         offs = np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
-        mats = [np.ascontiguousarray(np.concatenate([t[k] for t in tracks], axis=0), dtype=np.float32)
-                for k in ("mfccs", "ssms", "chromas")]
-        med = np.ascontiguousarray(np.stack([np.asarray(t["chroma_med"], dtype=np.float64) for t in tracks]))
-        dims = (ctypes.c_int32 * 3)(*[m.shape[1] for m in mats])
-        self._check(self._L.acx_ef_upload_pool(self._h, _fptr(mats[0]), _fptr(mats[1]), _fptr(mats[2]),
-                                               med.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                               offs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(tracks), dims))
+        d = (ctypes.c_int32 * 3)(*[int(x) for x in dims])
+        self._check(self._L.acx_ef_pool_begin(self._h, _lptr(offs), len(nb), d))
         self.ef_blocks = nb
+        self._ef_dims = tuple(int(x) for x in dims)
+
+    def ef_pool_tracks(self, first, count, mfccs, ssms, chromas, chroma_med):
+        """Rows of tracks [first, first + count).  Every argument is a C-contiguous numpy array (f32 / f64 for
+        the medians) OR anything with data_ptr() -- a torch tensor on this GPU is copied device to device."""
+        def ptr(a, dtype):
+            if hasattr(a, "data_ptr"):
+                return ctypes.c_void_p(int(a.data_ptr())), a
+            a = np.ascontiguousarray(a, dtype=dtype)
+            return ctypes.c_void_p(a.ctypes.data), a
+        keep = [ptr(mfccs, np.float32), ptr(ssms, np.float32), ptr(chromas, np.float32), ptr(chroma_med, np.float64)]
+        self._check(self._L.acx_ef_pool_tracks(self._h, int(first), int(count), *[k[0] for k in keep]))
+
+    def set_ef_gemm(self, mode):
+        """'bf16x3' (default) or 'f32': arithmetic of EarlyFusion's two Euclidean GEMMs (acx_set_ef_gemm)."""
+        self._check(self._L.acx_set_ef_gemm(self._h, {"bf16x3": 0, "f32": 1}.get(mode, mode)))
+
+    def ef_pool_end(self):
+        self._check(self._L.acx_ef_pool_end(self._h))
 
     def ef_block_features(self, chroma, mfcc, onsets, blocksize=20, mfccs_per_block=50, chromas_per_block=40):
         """EarlyFusion.load_features for one track on the device (acx_ef_block_features): chroma (T, 12),

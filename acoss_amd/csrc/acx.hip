@@ -98,6 +98,7 @@ struct acx_ctx {
     int64_t *d_efoff = nullptr;
     std::vector<int64_t> h_efoff;
     int32_t ef_ntracks = 0;
+    int32_t ef_gemm = ACX_EF_GEMM_BF16X3;             // arithmetic of the two Euclidean cross-similarity GEMMs
     int32_t ef_open = 0;                              // > 0: a pool of that many tracks is being filled (acx_ef_pool_begin .. _end)
     int32_t ef_dims[3] = {0, 0, 0};
     acx::EfPair *d_efpd = nullptr; size_t efpd_cap = 0;
@@ -783,12 +784,18 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                 const int tiles_x = (maxN + acx::EF_TILE - 1) / acx::EF_TILE, tiles_y = (maxM + acx::EF_TILE - 1) / acx::EF_TILE;
                 ProfScope ps(c, KS_EFGEMM, cells);
                 // mfcc, ssm: bf16 matrix pipe on the three-term splits; chroma (cosine, rolled by the pair's OTI): f32 MFMA
-                hipLaunchKernelGGL(acx::ef_gemm_bf16x3_kernel, dim3(tiles_x * tiles_y, B, 2), dim3(acx::EFB_THREADS), 0, c->stream,
-                                   c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
-                                   c->d_scratch, c->ef_kp[0], c->ef_kp[1], tiles_x);
-                hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 1), dim3(256), 0, c->stream,
-                                   c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
-                                   c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x, 2);
+                if (c->ef_gemm == ACX_EF_GEMM_F32) {
+                    hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 3), dim3(256), 0, c->stream,
+                                       c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
+                                       c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x, 0);
+                } else {
+                    hipLaunchKernelGGL(acx::ef_gemm_bf16x3_kernel, dim3(tiles_x * tiles_y, B, 2), dim3(acx::EFB_THREADS), 0, c->stream,
+                                       c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
+                                       c->d_scratch, c->ef_kp[0], c->ef_kp[1], tiles_x);
+                    hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 1), dim3(256), 0, c->stream,
+                                       c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
+                                       c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x, 2);
+                }
             }
         }
         const int nfeat = ext_matrix ? 1 : 3;
@@ -1507,6 +1514,14 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
 // not hold it in one piece).  begin: sizes and allocation; tracks: one slice, from HOST or DEVICE memory
 // (hipMemcpyDefault: features that are already on the device, e.g. in a torch tensor, stay there); end: the
 // non-finite scan, norms and bf16 splits -- the pool cannot be used before.
+int acx_set_ef_gemm(acx_ctx *c, int32_t mode)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (mode != ACX_EF_GEMM_BF16X3 && mode != ACX_EF_GEMM_F32) return fail(c, ACX_ERR_INVALID, "set_ef_gemm: unknown mode");
+    c->ef_gemm = mode;
+    return ACX_OK;
+}
+
 int acx_ef_pool_begin(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, const int32_t *dims)
 {
     if (!c) return ACX_ERR_INVALID;

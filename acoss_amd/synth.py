@@ -112,3 +112,45 @@ def earlyfusion_set(n_tracks, seed=4321, nb_range=(300, 500)):
                         chromas=rng.random((nb, 480)).astype(np.float32),
                         chroma_med=rng.random(12)))
     return out
+
+
+def earlyfusion_cover_set(n_works=30, versions=5, seed=4321, nb_range=(60, 100), noise=0.6, clique_sizes=None):
+    """Cover-structured block features (the structure of cover_set carried into EarlyFusion's block space):
+    a work is a piecewise-constant sequence of "states" (segments of 3-8 blocks), every state one random
+    point per feature (mfcc block (650,), ssm (1225,), chroma block (40 x 12)); a version re-times the
+    work (factor U[0.8, 1.25], nearest block), transposes the chroma (circular shift of the 12 bins of
+    every frame and of chroma_med) and adds fresh noise of relative amplitude `noise`.  Cliques are
+    recoverable but not trivially (MAP < 1 at the default noise).  Returns (tracks, labels)."""
+    rng = np.random.default_rng(seed)
+    if clique_sizes is None:
+        clique_sizes = [versions] * n_works
+    tracks, labels = [], []
+    for w, nv in enumerate(clique_sizes):
+        nb = int(rng.integers(nb_range[0], nb_range[1] + 1))
+        nstates = int(rng.integers(6, 12))
+        S = dict(mfccs=rng.standard_normal((nstates, 650)), ssms=2 * rng.random((nstates, 1225)),
+                 chromas=rng.random((nstates, 40, 12)) ** 3)
+        seq = []
+        st = int(rng.integers(0, nstates))
+        while len(seq) < nb:
+            seq += [st] * int(rng.integers(3, 9))
+            st = (st + int(rng.integers(1, nstates))) % nstates
+        seq = np.array(seq[:nb])
+        # slow drift inside a segment so that consecutive blocks of one state are close but not identical
+        drift = np.cumsum(rng.standard_normal(nb)) * 0.05
+        for _ in range(nv):
+            fac = float(rng.uniform(0.8, 1.25))
+            nbv = max(24, int(round(nb * fac)))
+            pos = np.clip(np.round(np.linspace(0, nb - 1, nbv)).astype(int), 0, nb - 1)
+            sv, dv = seq[pos], drift[pos]
+            shift = int(rng.integers(0, 12))
+            mf = S["mfccs"][sv] * (1.0 + dv[:, None]) + noise * rng.standard_normal((nbv, 650))
+            mf /= np.linalg.norm(mf, axis=1, keepdims=True)
+            ss = S["ssms"][sv] * (1.0 + dv[:, None]) + noise * 2 * rng.random((nbv, 1225))
+            ch = S["chromas"][sv] + noise * 0.5 * rng.random((nbv, 40, 12))
+            ch = np.roll(ch, shift, axis=2)
+            tracks.append(dict(mfccs=mf.astype(np.float32), ssms=ss.astype(np.float32),
+                               chromas=ch.reshape(nbv, 480).astype(np.float32),
+                               chroma_med=np.median(ch.reshape(-1, 12), axis=0)))
+            labels.append("w%d" % w)
+    return tracks, labels

@@ -83,19 +83,47 @@ def _cpu_init():
     oracle.lib()
 
 
-def cpu_baseline(frames, offsets, pairs, budget_s=20.0):
-    """Oracle on all host cores, process fan-out (fork: no GPU state exists yet).  Bounded: a pilot round of
-    one pair per worker measures the rate under full load (the oracle streams ~100 MB per pair: with
-    every core busy it is memory-bound and far slower per core than alone), the timed round is sized
-    from it to about `budget_s` seconds -- or is the pilot itself when that already took longer."""
+def _cpu_triad(_):
+    """STREAM triad a = b + s c on 3 x 32 MB f64 per worker for ~1 s: bytes moved per second by this worker."""
+    n = 4 << 20
+    b, c = np.ones(n), np.full(n, 2.0)
+    a = np.empty(n)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 1.0:
+        np.multiply(c, 3.0, out=a)
+        np.add(a, b, out=a)
+        reps += 1
+    return reps * 5 * 8 * n / (time.perf_counter() - t0)      # multiply: read c, write a; add: read a, b, write a
+
+
+def cpu_baseline(frames, offsets, pairs, n_tracks, budget_s=15.0):
+    """SURVEY 8d's two CPU figures, both from the oracle (a C port of the chain, gcc -O3) and both timed BEFORE
+    the GPU is initialised (the workers are forks):
+      (1) one process, one thread, on randomly chosen pairs of the same synthetic pool (seeded; 64 of them -- 8d
+          names 256, which at ~0.2 s per pair would be a minute of the bench's budget) -> value_1core;
+      (2) every host core through a process fan-out over max(45, cores) chunks (the reference's joblib scheme,
+          algorithm_template.py:172-177, has 45) -> value.  Bounded: a pilot round of one pair per worker measures
+          the rate under full load, the timed round is sized from it to about `budget_s` seconds.
+    If (2) is less than half of cores x (1), a one-second STREAM triad on the same workers is reported beside it
+    (the oracle streams a 16 MB distance matrix per pair three times; hundreds of copies of it share the memory
+    controllers)."""
     import multiprocessing as mp
     import oracle
     oracle.lib()
     _CPU["frames"], _CPU["offsets"] = frames, offsets
     cores = os.cpu_count() or 1
+    rng = np.random.default_rng(8)
+    rnd = rng.integers(0, n_tracks, (2 * 64, 2))
+    rnd = np.ascontiguousarray(rnd[rnd[:, 0] != rnd[:, 1]][:64].astype(np.int32))
     t0 = time.perf_counter()
-    one = oracle.serra09_pairs(frames, offsets, pairs[:2])
-    t_pair = (time.perf_counter() - t0) / 2
+    rnd_scores = oracle.serra09_pairs(frames, offsets, rnd[:4])
+    t4 = time.perf_counter() - t0
+    n1 = int(min(64, max(4, 4 * round(0.25 * budget_s / max(t4, 1e-3)))))     # ~budget_s of single-core work
+    t0 = time.perf_counter()
+    rnd_scores = oracle.serra09_pairs(frames, offsets, rnd[:n1])
+    t_1core = time.perf_counter() - t0
+    stream = None
     with mp.get_context("fork").Pool(cores, initializer=_cpu_init) as pool:
         nchunks = max(45, cores)                                  # the reference's joblib scheme has 45 chunks
         pilot = np.ascontiguousarray(pairs[:nchunks])
@@ -113,8 +141,10 @@ def cpu_baseline(frames, offsets, pairs, budget_s=20.0):
             parts = pool.map(_cpu_chunk, chunks, chunksize=1)
             dt = time.perf_counter() - t0
             scores = np.concatenate(parts)
-    n = len(sample)
-    assert np.array_equal(scores[:2], one)
+        n = len(sample)
+        v1, vall = n1 / t_1core, n / dt
+        if vall < 0.5 * cores * v1:
+            stream = round(sum(pool.map(_cpu_triad, range(cores), chunksize=1)) / 1e9, 1)
     model = ""
     try:
         for line in subprocess.run(["lscpu"], capture_output=True, text=True).stdout.splitlines():
@@ -122,12 +152,15 @@ def cpu_baseline(frames, offsets, pairs, budget_s=20.0):
                 model = line.split(":", 1)[1].strip()
     except OSError:
         pass
-    return sample, scores, {
-        "value": round(n / dt, 3), "unit": "track-pairs/s", "cores": cores, "kind": "port",
-        "sample": "first %d pairs of step 0's tiles of the same workload (T=%d), C oracle -O2, %d worker "
-                  "processes over %d chunks (reference scheme: 45 joblib chunks), %.1f s; scores bit-identical to the GPU's"
-                  % (n, T_FRAMES, cores, max(45, cores), dt),
-        "value_1core": round(1.0 / t_pair, 3), "cpu_model": model, "host_cpus": cores}
+    check = np.concatenate([sample, rnd[:n1]]), np.concatenate([scores, rnd_scores])
+    return check[0], check[1], {
+        "value": round(vall, 3), "unit": "track-pairs/s", "cores": cores, "kind": "port",
+        "sample": "first %d pairs of step 0's tiles of the same workload (T=%d), C oracle (gcc -O3), %d worker "
+                  "processes over %d chunks (reference scheme: 45 joblib chunks), %.1f s; value_1core: %d randomly chosen "
+                  "pairs of the pool (seed 8) in one process, %.1f s; all scores bit-identical to the GPU's"
+                  % (n, T_FRAMES, cores, max(45, cores), dt, n1, t_1core),
+        "value_1core": round(v1, 3), "parallel_efficiency": round(vall / (cores * v1), 3),
+        "stream_triad_gbs_all_workers": stream, "cpu_model": model, "host_cpus": cores}
 
 
 def launch_ranks(n, argv):
@@ -154,6 +187,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tracks", type=int, default=N_TRACKS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-other", action="store_true", help="skip the SiMPle / EarlyFusion legs (the `other` object)")
     ap.add_argument("--plan-only", action="store_true",
                     help="rendezvous, deal the tiles, print the plan as one JSON line and stop: no GPU work "
                          "(checks a multi-rank launch on any box; ACX_BENCH_BACKEND=gloo without GPUs)")
@@ -220,7 +254,7 @@ def main():
     # ---- CPU baseline first: worker processes are forked before any GPU state exists
     cpu = cpu_sample = cpu_scores = None
     if world == 1 and rank == 0 and not args.no_cpu:
-        cpu_sample, cpu_scores, cpu = cpu_baseline(frames, offsets, pairs_of(slice_of(args.warmup)[1]))
+        cpu_sample, cpu_scores, cpu = cpu_baseline(frames, offsets, pairs_of(slice_of(args.warmup)[1]), args.tracks)
 
     import torch
     import torch.distributed as dist
@@ -318,7 +352,8 @@ def main():
             except Exception:
                 real_bound = None
         bpp = chain_bytes_per_pair(T_FRAMES, T_FRAMES)
-        roofline = {"bound": "simd-issue (valu + f32 mfma)", "model": "hbm byte model of SURVEY 8d (throughput proxy, not a memory bound)",
+        roofline = {"bound": "hbm", "model": "hbm byte model of SURVEY 8d: a throughput proxy -- the pipeline keeps the distance matrix out of "
+                                              "HBM, what the SIMDs wait for is in real_bound (valu + f32 mfma issue)",
                     "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": traffic_source, "real_bound": real_bound,
@@ -347,6 +382,12 @@ def main():
                        "pool_tracks": args.tracks, "parallelism": "pair-grid tiles over %d GPU(s)" % world},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if world == 1 and not args.no_other:
+            # the other two algorithms of the path, outside the timed region above: 2 steps each at their
+            # BASELINE configs[3] / [4] per-track shapes (bench_other.py), each with its own roofline and CPU baseline
+            import bench_other
+            line["other"] = {"simple": bench_other.simple_leg(ctx, steps=2, warmup=1),
+                             "earlyfusion": bench_other.earlyfusion_leg(ctx, steps=2, warmup=1)}
         print(json.dumps(line))
     ctx.close()
     if world > 1:

@@ -283,6 +283,18 @@ typedef struct {
 int acx_earlyfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const acx_ef_params *params,
                           float *out);
 
+/*
+ * Arithmetic of the two Euclidean cross-similarity products (mfccs, ssms; get_csm, cross_recurrence.py:30-48 --
+ * the reference's is one BLAS sgemm in f32):
+ *   ACX_EF_GEMM_BF16X3 (default)  three-term bf16 splits on the bf16 matrix pipe, f32 accumulation: the dropped
+ *                                 terms are below one f32 rounding of the product, 1.35 x faster
+ *   ACX_EF_GEMM_F32               f32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation)
+ * Both meet the same bound against the f64 truth (tests/test_gpu_earlyfusion.py); scores that differ between
+ * them sit on a row-kappa threshold tie (profiles/r03_parity_ef.json holds the measured histogram).
+ */
+enum { ACX_EF_GEMM_BF16X3 = 0, ACX_EF_GEMM_F32 = 1 };
+int acx_set_ef_gemm(acx_ctx *ctx, int32_t mode);
+
 /* One pair with intermediates (tests): csm (3, M, N), fused (M, N), scores (4); any may be NULL. */
 int acx_ef_debug_pair(acx_ctx *ctx, int32_t i, int32_t j, const acx_ef_params *params,
                       float *csm, float *fused, float *scores, int32_t *oti);

@@ -21,7 +21,7 @@
  *     is pinned by golden vectors generated from the reference itself
  *     (tests/golden/make_goldens.py).
  *
- * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off; no fast-math: the f32
+ * Build: oracle/Makefile  (gcc -O3 -ffp-contract=off; no fast-math: the f32
  * operation order below IS the specification the HIP kernels are checked
  * against bit-for-bit).
  */
@@ -31,9 +31,10 @@
 #include <string.h>
 #include <malloc.h>
 
-/* Every pair allocates (and frees) a handful of T x T matrices.  Keep them on the heap instead of
+/* Every pair allocates (and frees) one T x T f32 distance matrix and its byte-sized recurrence plot (the
+ * frame Gram is a ring of m rows, the alignment three rolling rows).  Keep them on the heap instead of
  * mmap / munmap per call: with one worker per host core the page faults of fresh mappings otherwise
- * dominate (measured on the 256-core bench host: 21 pairs/s for 256 workers vs 2 pairs/s for one). */
+ * dominate. */
 __attribute__((constructor)) static void acx_o_init(void)
 {
     mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024);      /* glibc's maximum: the 16 MB matrices of a T = 2000 pair stay below it */
@@ -107,11 +108,14 @@ int32_t acx_o_oti(const float *ga, const float *gb)
  * high to low. */
 static float tree_w(const float *s, size_t stride, int w)
 {
-    if (w == 1) return s[0];
-    int h = w / 2;
-    float a = tree_w(s, stride, h);
-    float b = tree_w(s + (size_t)h * stride, stride, h);
-    return a + b;
+    /* pairwise reduction, bottom-up: the same association as the recursive definition
+     * tree_w(first half) + tree_w(second half) */
+    float v[64];
+    v[0] = s[0];
+    for (int t = 1; t < w; ++t) v[t] = s[(size_t)t * stride];
+    for (int step = 1; step < w; step *= 2)
+        for (int t = 0; t + step < w; t += 2 * step) v[t] = v[t] + v[t + step];
+    return v[0];
 }
 static float tree_sum(const float *s, size_t stride, int m)
 {
@@ -128,10 +132,27 @@ static float tree_sum(const float *s, size_t stride, int m)
     return acc;
 }
 
-static int cmp_float(const void *a, const void *b)
+/* k-th smallest (0-based) of w[0..n) by quickselect (Hoare partition, median-of-three pivot); on return
+ * w[k] is that value, everything left of it is <= and everything right of it >= .  Order statistics do
+ * not depend on how they are found: same values as sorting the row. */
+static float select_kth(float *w, int n, int k)
 {
-    float x = *(const float *)a, y = *(const float *)b;
-    return (x > y) - (x < y);
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = lo + (hi - lo) / 2;
+        float a = w[lo], b = w[mid], c = w[hi];
+        float pv = (a < b) ? ((b < c) ? b : (a < c ? c : a)) : ((a < c) ? a : (b < c ? c : b));
+        int i = lo, j = hi;
+        while (i <= j) {
+            while (w[i] < pv) ++i;
+            while (w[j] > pv) --j;
+            if (i <= j) { float t = w[i]; w[i] = w[j]; w[j] = t; ++i; --j; }
+        }
+        if (k <= j) hi = j;
+        else if (k >= i) lo = i;
+        else break;
+    }
+    return w[k];
 }
 
 /* percentile of v[0..n) at fraction q.  f32 arithmetic
@@ -139,7 +160,6 @@ static int cmp_float(const void *a, const void *b)
 static float percentile_f32(const float *v, int n, float q, int mode, float *work)
 {
     memcpy(work, v, (size_t)n * sizeof(float));
-    qsort(work, (size_t)n, sizeof(float), cmp_float);
     float k = (n > 1) ? (float)(n - 1) * q : (float)n * q;
     float fl = floorf(k), ce = ceilf(k);
     int ilo = (int)fl, ihi = (int)ce;
@@ -147,19 +167,30 @@ static float percentile_f32(const float *v, int n, float q, int mode, float *wor
     if (ihi < 0) ihi = 0;
     if (ilo > n - 1) ilo = n - 1;
     if (ihi > n - 1) ihi = n - 1;
+    if (mode == 3) {
+        int r = (int)floorf(k + 0.5f);
+        if (r > n - 1) r = n - 1;
+        if (r < 0) r = 0;
+        return select_kth(work, n, r);
+    }
+    /* sorted[ilo], and sorted[ihi] = the smallest element to its right when ihi == ilo + 1 */
+    float vlo = select_kth(work, n, ilo), vhi = vlo;
+    if (ihi > ilo) {
+        vhi = work[ilo + 1];
+        for (int t = ilo + 2; t < n; ++t) if (work[t] < vhi) vhi = work[t];
+    }
     switch (mode) {
-    case 2: return work[ilo];
-    case 3: { int r = (int)floorf(k + 0.5f); if (r > n - 1) r = n - 1; return work[r]; }
+    case 2: return vlo;
     case 1: {
-        float d0 = work[ilo] * (ce - k);
-        float d1 = work[ihi] * (k - fl);
+        float d0 = vlo * (ce - k);
+        float d1 = vhi * (k - fl);
         return d0 + d1;
     }
     default:
-        if (ihi == ilo) return work[ilo];
+        if (ihi == ilo) return vlo;
         {
-            float d0 = work[ilo] * (ce - k);
-            float d1 = work[ihi] * (k - fl);
+            float d0 = vlo * (ce - k);
+            float d1 = vhi * (k - fl);
             return d0 + d1;
         }
     }
@@ -221,8 +252,12 @@ float acx_o_serra09_pair(const float *Q, int32_t Tq, const float *Rf, int32_t Tr
     /* 2+3. distances */
     float *d = (float *)malloc((size_t)Mq * Mr * sizeof(float));
     if (p->arith == 0) {
-        /* frame-level Gram (fmaf chain over the 12 bins), frame norms */
-        float *G = (float *)malloc((size_t)Tq * Tr * sizeof(float));
+        /* frame-level Gram (fmaf chain over the 12 bins), frame norms.  Row i of d needs the Gram rows
+         * i tau .. (i + m - 1) tau only: they live in a ring of `span` rows instead of a Tq x Tr matrix. */
+        const int span = (m - 1) * tau + 1;
+        float *G = (float *)malloc((size_t)span * Tr * sizeof(float));
+        const float **grow = (const float **)malloc((size_t)m * sizeof(float *));
+        float *gd = (float *)malloc((size_t)m * sizeof(float));
         float *nq = (float *)malloc((size_t)Tq * sizeof(float));
         float *nr = (float *)malloc((size_t)Tr * sizeof(float));
         for (int a = 0; a < Tq; ++a) {
@@ -235,26 +270,34 @@ float acx_o_serra09_pair(const float *Q, int32_t Tq, const float *Rf, int32_t Tr
             for (int c = 0; c < NB; ++c) acc = fmaf(B[(size_t)b * NB + c], B[(size_t)b * NB + c], acc);
             nr[b] = acc;
         }
-        for (int a = 0; a < Tq; ++a)
-            for (int b = 0; b < Tr; ++b) {
-                float acc = 0.0f;
-                for (int c = 0; c < NB; ++c) acc = fmaf(A[(size_t)a * NB + c], B[(size_t)b * NB + c], acc);
-                G[(size_t)a * Tr + b] = acc;
-            }
         float *xx = (float *)malloc((size_t)Mq * sizeof(float));
         float *yy = (float *)malloc((size_t)Mr * sizeof(float));
         for (int i = 0; i < Mq; ++i) xx[i] = tree_sum(nq + (size_t)i * tau, (size_t)tau, m);
         for (int j = 0; j < Mr; ++j) yy[j] = tree_sum(nr + (size_t)j * tau, (size_t)tau, m);
-        for (int i = 0; i < Mq; ++i)
+        int have = 0;                      /* Gram rows [0, have) have been computed (row a sits in ring slot a % span) */
+        for (int i = 0; i < Mq; ++i) {
+            const int last = i * tau + (m - 1) * tau;
+            for (; have <= last; ++have) {
+                float *g = G + (size_t)(have % span) * Tr;
+                const float *xa = A + (size_t)have * NB;
+                for (int b = 0; b < Tr; ++b) {
+                    float acc = 0.0f;
+                    for (int c = 0; c < NB; ++c) acc = fmaf(xa[c], B[(size_t)b * NB + c], acc);
+                    g[b] = acc;
+                }
+            }
+            for (int k = 0; k < m; ++k) grow[k] = G + (size_t)((i * tau + k * tau) % span) * Tr;
             for (int j = 0; j < Mr; ++j) {
-                float xy = tree_sum(G + (size_t)(i * tau) * Tr + (size_t)j * tau,
-                                    (size_t)tau * ((size_t)Tr + 1), m);
+                for (int k = 0; k < m; ++k) gd[k] = grow[k][(size_t)j * tau + (size_t)k * tau];   /* the diagonal G[i tau + k tau][j tau + k tau] */
+                float xy = tree_sum(gd, 1, m);
                 float t1 = 2.0f * xy;
                 float t2 = xx[i] - t1;
                 float t3 = t2 + yy[j];
                 if (!(t3 > 0.0f)) t3 = 0.0f;
                 d[(size_t)i * Mr + j] = sqrtf(t3);
             }
+        }
+        free((void *)grow); free(gd);
         free(G); free(nq); free(nr); free(xx); free(yy);
     } else {
         /* sequential 108-dim inner products (mul then add, f32) */
@@ -300,12 +343,16 @@ float acx_o_serra09_pair(const float *Q, int32_t Tq, const float *Rf, int32_t Tr
     {
         int nmax = Mq > Mr ? Mq : Mr;
         float *work = (float *)malloc((size_t)nmax * sizeof(float));
-        float *col = (float *)malloc((size_t)Mq * sizeof(float));
+        enum { CB = 16 };                /* columns gathered per pass over d: one cache line of a row feeds 16 columns */
+        float *col = (float *)malloc((size_t)CB * Mq * sizeof(float));
         for (int i = 0; i < Mq; ++i)
             epsq[i] = percentile_f32(d + (size_t)i * Mr, Mr, p->kappa, p->pct_mode, work);
-        for (int j = 0; j < Mr; ++j) {
-            for (int i = 0; i < Mq; ++i) col[i] = d[(size_t)i * Mr + j];
-            epsr[j] = percentile_f32(col, Mq, p->kappa, p->pct_mode, work);
+        for (int j0 = 0; j0 < Mr; j0 += CB) {
+            const int nc = (Mr - j0 < CB) ? Mr - j0 : CB;
+            for (int i = 0; i < Mq; ++i)
+                for (int jj = 0; jj < nc; ++jj) col[(size_t)jj * Mq + i] = d[(size_t)i * Mr + j0 + jj];
+            for (int jj = 0; jj < nc; ++jj)
+                epsr[j0 + jj] = percentile_f32(col + (size_t)jj * Mq, Mq, p->kappa, p->pct_mode, work);
         }
         free(work); free(col);
     }
@@ -320,21 +367,24 @@ float acx_o_serra09_pair(const float *Q, int32_t Tq, const float *Rf, int32_t Tr
             R[(size_t)i * Mr + j] = (uint8_t)(a && b);
         }
 
-    /* 6. Qmax / Dmax, f32, two rolling rows are not used here on purpose:
-     * the oracle keeps the full matrix for clarity. */
+    /* 6. Qmax / Dmax in f32.  Cell (i, j) reads rows i - 1 and i - 2 of the score matrix only: three
+     * rolling rows (rows and columns below dp_start stay 0). */
     float best = 0.0f;
     {
-        float *C = (float *)calloc((size_t)Mq * Mr, sizeof(float));
+        float *rows = (float *)calloc((size_t)3 * Mr, sizeof(float));
         const int st = p->dp_start;
         const int o = (st == 3) ? 1 : 0; /* R index offset */
         const float go = p->gamma_o, ge = p->gamma_e;
 #define RR(i, j) R[(size_t)(i) * Mr + (j)]
-#define CC(i, j) C[(size_t)(i) * Mr + (j)]
 #define GAM(v) ((v) ? go : ge)
-        for (int i = st; i < Mq; ++i)
+        for (int i = st; i < Mq; ++i) {
+            float *cur = rows + (size_t)(i % 3) * Mr;
+            const float *p1 = rows + (size_t)((i + 2) % 3) * Mr;     /* row i - 1 */
+            const float *p2 = rows + (size_t)((i + 1) % 3) * Mr;     /* row i - 2 */
+            for (int j = 0; j < st && j < Mr; ++j) cur[j] = 0.0f;
             for (int j = st; j < Mr; ++j) {
                 int ri = i - o, rj = j - o;
-                float c2 = CC(i - 1, j - 1), c3 = CC(i - 2, j - 1), c4 = CC(i - 1, j - 2);
+                float c2 = p1[j - 1], c3 = p2[j - 1], c4 = p1[j - 2];
                 if (p->dmax) {
                     c3 = c3 + (float)RR(ri - 1, rj);
                     c4 = c4 + (float)RR(ri, rj - 1);
@@ -350,13 +400,13 @@ float acx_o_serra09_pair(const float *Q, int32_t Tq, const float *Rf, int32_t Tr
                     float mx = 0.0f; if (a2 > mx) mx = a2; if (a3 > mx) mx = a3; if (a4 > mx) mx = a4;
                     v = mx;
                 }
-                CC(i, j) = v;
+                cur[j] = v;
                 if (v > best) best = v;
             }
+        }
 #undef RR
-#undef CC
 #undef GAM
-        free(C);
+        free(rows);
     }
 
     if (d_out) memcpy(d_out, d, (size_t)Mq * Mr * sizeof(float));

@@ -1,0 +1,323 @@
+"""
+GPU parity tests on cover-structured sets and at dataset scale for SiMPle and EarlyFusion (-m gpu).
+
+What BASELINE.json's metric asks of every algorithm is "MAP parity vs CPU": the evaluation statistics
+(algorithm_template.py:205-290) of the HIP distance matrix against those of the CPU oracle's on a set
+where cliques exist and MAP is not trivially 1.
+
+  * EarlyFusion, 150 tracks / 30 works in block space (synth.earlyfusion_cover_set): all 11 175 pairs
+    through acx_pair_grid, four score planes; the oracle (numpy f32 + C Smith-Waterman, golden-pinned
+    to the reference's own outputs) on a process pool.  MR / MRR / MDR / MAP / Top-k identical per plane;
+    per-pair |dscore| <= EF_TOL (the measured maximum; the histograms HIP vs oracle, exact-f32 GEMM vs
+    oracle and bf16x3 vs f32 go to gpurun_out/parity_ef.json -> profiles/).
+  * EarlyFusion at BASELINE configs[4] scale: a 15 000-track pool (300-500 blocks per track: 56 GB of
+    block features + 69 GB of bf16 splits in HBM) generated on the device and uploaded in slices
+    (acx_ef_pool_begin / _tracks / _end), 100 000 random pairs + one full 128 x 128 tile through
+    acx_grid_run; sampled pairs against the oracle.
+  * SiMPle, 150 tracks / 30 works: all 22 350 ordered pairs, 2e-7 relative (the f32 store of an f64
+    result), identical statistics; and one exhaustive off-diagonal + one diagonal 128 x 128 tile of the
+    15 000-track grid (32 640 ordered pairs) against the oracle.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# per-pair tolerance of the EarlyFusion scores against the oracle, in score units (Smith-Waterman
+# scores are multiples of 0.1).  Two f32 evaluations of a 650- / 1225-term product differ in the last
+# bits; where the k-th and (k+1)-th smallest of a row are that close the binary matrix gains / loses a
+# cell and an alignment path may shift.  Measured maximum on the sets below: see profiles/r03_parity_ef.json.
+EF_TOL = 2.0
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from acoss_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _record(name, key, value):
+    path = os.path.join(ROOT, "gpurun_out", name)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = value
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _hist(delta, edges=(0, 0.05, 0.15, 0.55, 1.05, 2.05, 5.05, 1e9)):
+    delta = np.abs(np.asarray(delta, dtype=np.float64)).ravel()
+    names = ["0", "0.1", "0.2-0.5", "0.6-1.0", "1.1-2.0", "2.1-5.0", ">5"]
+    h = {"0": int(np.sum(delta < 0.05))}
+    for k in range(1, len(edges) - 1):
+        h[names[k]] = int(np.sum((delta >= edges[k]) & (delta < edges[k + 1])))
+    h["max"] = float(delta.max()) if len(delta) else 0.0
+    h["n"] = int(len(delta))
+    return h
+
+
+def _cliques(labels):
+    cl = {}
+    for i, l in enumerate(labels):
+        cl.setdefault(l, []).append(i)
+    return list(cl.values())
+
+
+# ---- oracle on a process pool (spawn: the parent holds a GPU context) -----------------------------
+_POOL_STATE = {}
+
+
+def _pool_init(root, tracks):
+    sys.path.insert(0, root)
+    import oracle
+    oracle.lib()
+    _POOL_STATE["tracks"] = tracks
+    _POOL_STATE["oracle"] = oracle
+
+
+def _ef_chunk(pairs):
+    o, tr = _POOL_STATE["oracle"], _POOL_STATE["tracks"]
+    out = np.zeros((len(pairs), 4), np.float64)
+    for k, (i, j) in enumerate(pairs):
+        sc = o.earlyfusion_pair(tr[i], tr[j], kappa=0.1, K=10)[0]
+        out[k] = [sc[s] for s in ("mfccs", "ssms", "chromas", "early")]
+    return out
+
+
+def _simple_chunk(pairs):
+    o, tr = _POOL_STATE["oracle"], _POOL_STATE["tracks"]
+    return np.array([o.simple_pair(tr[i], tr[j]) for i, j in pairs], np.float64)
+
+
+def _oracle_pool(fn, tracks, pairs, workers=None):
+    import multiprocessing as mp
+    workers = workers or max(1, min(32, (os.cpu_count() or 2) // 2))
+    chunks = [c for c in np.array_split(np.asarray(pairs), workers * 4) if len(c)]
+    with mp.get_context("spawn").Pool(workers, initializer=_pool_init, initargs=(ROOT, tracks)) as pool:
+        parts = pool.map(fn, chunks, chunksize=1)
+    return np.concatenate(parts, axis=0)
+
+
+# ---- EarlyFusion ------------------------------------------------------------------------------------
+
+def test_earlyfusion_cover_set_map(ctx):
+    import oracle
+    from acoss_amd import synth, _lib
+    tracks, labels = synth.earlyfusion_cover_set(n_works=30, versions=5, seed=2024, nb_range=(60, 100), noise=4.0)
+    n = len(tracks)
+    assert n == 150
+    pairs = oracle.all_pairs(n, True).astype(np.int32)
+    ref = _oracle_pool(_ef_chunk, tracks, pairs)
+    ctx.ef_upload_pool(tracks)
+    names = ("mfccs", "ssms", "chromas", "early")
+    cl = _cliques(labels)
+
+    def grid(mode):
+        ctx.set_ef_gemm(mode)
+        planes = [np.zeros((n, n), np.float32) for _ in range(4)]
+        ctx.pair_grid(_lib.ALGO_EARLYFUSION, True, _lib.EfParams(0.1, 10), planes, mirror=True)
+        return planes
+    try:
+        P = grid("bf16x3")
+        P32 = grid("f32")
+    finally:
+        ctx.set_ef_gemm("bf16x3")
+    rec = {"tracks": n, "works": 30, "pairs": int(len(pairs)), "noise": 4.0}
+    for e, s in enumerate(names):
+        Dref = np.zeros((n, n), np.float32)
+        Dref[pairs[:, 0], pairs[:, 1]] = ref[:, e]
+        Dref += Dref.T
+        st_ref = oracle.eval_statistics(Dref, cl, topsidx=(1, 10, 100))
+        st_hip = oracle.eval_statistics(P[e], cl, topsidx=(1, 10, 100))
+        st_f32 = oracle.eval_statistics(P32[e], cl, topsidx=(1, 10, 100))
+        got = P[e][pairs[:, 0], pairs[:, 1]].astype(np.float64)
+        got32 = P32[e][pairs[:, 0], pairs[:, 1]].astype(np.float64)
+        rec[s] = {"hip_vs_oracle": _hist(got - ref[:, e]), "f32gemm_vs_oracle": _hist(got32 - ref[:, e]),
+                  "bf16x3_vs_f32gemm": _hist(got - got32),
+                  "MAP_oracle": st_ref[3], "MAP_hip": st_hip[3], "MAP_hip_f32gemm": st_f32[3],
+                  "MR_oracle": st_ref[0], "MR_hip": st_hip[0], "MRR_oracle": st_ref[1], "MRR_hip": st_hip[1],
+                  "top1_oracle": float(st_ref[4][0]), "top1_hip": float(st_hip[4][0])}
+    _record("parity_ef.json", "earlyfusion_cover150", rec)
+    for e, s in enumerate(names):
+        r = rec[s]
+        assert 0.3 < r["MAP_oracle"] < 0.999, (s, r["MAP_oracle"])            # the set is neither trivial nor noise
+        assert abs(r["MAP_hip"] - r["MAP_oracle"]) <= 1e-4, (s, r)
+        assert abs(r["MAP_hip_f32gemm"] - r["MAP_oracle"]) <= 1e-4, (s, r)
+        assert abs(r["MR_hip"] - r["MR_oracle"]) <= 1e-2 and r["top1_hip"] == r["top1_oracle"], (s, r)
+        assert r["hip_vs_oracle"]["max"] <= EF_TOL + 1e-6, (s, r["hip_vs_oracle"])
+        # the chroma plane is the f32 kernel in both modes: identical
+        if s == "chromas":
+            assert r["bf16x3_vs_f32gemm"]["max"] == 0.0
+
+
+def test_earlyfusion_scale_15000(ctx):
+    """BASELINE configs[4] at DA-TACOS scale: the pool is generated on the device slice by slice (torch)
+    and handed over device to device; nothing of it ever exists on the host except the tracks of the
+    pairs checked against the oracle."""
+    import time
+    import torch
+    import oracle
+    from acoss_amd import _lib
+    N = 15000
+    rng = np.random.default_rng(15)
+    nb = rng.integers(300, 501, N).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(nb)])
+    check = [(17, 9000), (14999, 3), (7000, 7001), (5, 5000), (12345, 678), (2500, 14000)]
+    keep = {t: None for p in check for t in p}
+    ctx.set_scratch_limit(32 << 30)
+    ctx.ef_pool_begin(nb, (650, 1225, 480))
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    SL = 250                                                    # tracks per slice: <= 1.2 GB of features
+    t0 = time.time()
+    for a in range(0, N, SL):
+        b = min(N, a + SL)
+        rows = int(off[b] - off[a])
+        gen.manual_seed(1000 + a)
+        mf = torch.randn((rows, 650), generator=gen, device=dev, dtype=torch.float32)
+        mf /= torch.linalg.vector_norm(mf, dim=1, keepdim=True)
+        ss = 2 * torch.rand((rows, 1225), generator=gen, device=dev, dtype=torch.float32)
+        ch = torch.rand((rows, 480), generator=gen, device=dev, dtype=torch.float32)
+        med = torch.rand((b - a, 12), generator=gen, device=dev, dtype=torch.float64)
+        torch.cuda.synchronize()
+        ctx.ef_pool_tracks(a, b - a, mf, ss, ch, med)
+        for t in keep:
+            if a <= t < b:
+                r0, r1 = int(off[t] - off[a]), int(off[t + 1] - off[a])
+                keep[t] = dict(mfccs=mf[r0:r1].cpu().numpy(), ssms=ss[r0:r1].cpu().numpy(), chromas=ch[r0:r1].cpu().numpy(),
+                               chroma_med=med[t - a].cpu().numpy())
+        del mf, ss, ch, med
+    torch.cuda.empty_cache()
+    ctx.ef_pool_end()
+    t_pool = time.time() - t0
+    assert np.array_equal(ctx.pool_lengths(_lib.ALGO_EARLYFUSION), nb)
+    # 100 000 random pairs through the pair-list entry
+    pairs = rng.integers(0, N, (100400, 2)).astype(np.int32)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]][:100000]
+    t0 = time.time()
+    sc = ctx.earlyfusion_pairs(pairs)
+    t_pairs = time.time() - t0
+    assert sc.shape == (len(pairs), 4) and np.all(np.isfinite(sc)) and np.all(sc >= 0.0)
+    assert np.all(np.abs(sc * 10 - np.round(sc * 10)) < 1e-3)             # Smith-Waterman scores are tenths
+    again = ctx.earlyfusion_pairs(pairs[:700][::-1].copy())
+    assert np.array_equal(again, sc[:700][::-1])
+    # sampled pairs against the oracle (incl. the first / last track: offsets beyond 2^31 elements)
+    cp = np.array(check, np.int32)
+    got = ctx.earlyfusion_pairs(cp)
+    worst = 0.0
+    for k, (i, j) in enumerate(check):
+        o = oracle.earlyfusion_pair(keep[i], keep[j], kappa=0.1, K=10)[0]
+        want = np.array([o[s] for s in ("mfccs", "ssms", "chromas", "early")])
+        worst = max(worst, float(np.max(np.abs(got[k] - want))))
+        assert np.all(np.abs(got[k] - want) <= EF_TOL + 1e-6), (i, j, got[k], want)
+    # one full 128 x 128 tile of the 15 000 x 15 000 grid through acx_grid_run == the pair-list scores
+    plan = _lib.grid_plan(nb, _lib.ALGO_EARLYFUSION, True, world=8, want_tiles=True)
+    tile_k, tile = next((k, t) for k, t in enumerate([t for t in plan["tiles"] if t.rank == 3]) if not t.diagonal and t.rows == 128 and t.cols == 128)
+    buf = torch.full((128 * 128 * 4,), -1.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ctx.grid_run(plan["spec"], _lib.EfParams(0.1, 10), 3, buf.data_ptr() - 4 * tile.offset, first=tile_k, count=1)
+    t_tile = time.time() - t0
+    T = buf.cpu().numpy().reshape(128, 128, 4)
+    ii, jj = np.meshgrid(np.arange(tile.row0, tile.row0 + 128), np.arange(tile.col0, tile.col0 + 128), indexing="ij")
+    tp = np.stack([ii.ravel(), jj.ravel()], 1).astype(np.int32)
+    assert np.array_equal(T.reshape(-1, 4), ctx.earlyfusion_pairs(tp))
+    ctx.set_scratch_limit(0)
+    _record("parity_ef.json", "earlyfusion_15000", {
+        "tracks": N, "blocks": int(off[-1]), "feature_bytes": int(off[-1]) * 2355 * 4, "seconds_pool_device_generated": round(t_pool, 1),
+        "pairs_run": int(len(pairs)), "pairs_per_s_incl_host": round(len(pairs) / t_pairs), "tile_pairs": 128 * 128,
+        "tile_pairs_per_s": round(128 * 128 / t_tile), "oracle_checked": len(check), "max_abs_dscore_vs_oracle": worst})
+
+
+# ---- SiMPle -----------------------------------------------------------------------------------------
+
+def test_simple_cover_set_map(ctx):
+    import oracle
+    from acoss_amd import synth, _lib
+    d = synth.cover_set(n_works=30, versions=5, seed=77, t_range=(15000, 25000), noise=1.0, segment_keep=0.6)
+    n = len(d["offsets"]) - 1
+    assert n == 150
+    raw = [d["frames"][d["offsets"][i]:d["offsets"][i + 1]] for i in range(n)]
+    feats = [oracle.simple_features(r) for r in raw]                       # (12, n_i) f64, simple_silva.py:34-43
+    pairs = oracle.all_pairs(n, False).astype(np.int32)
+    ref = _oracle_pool(_simple_chunk, feats, pairs)
+    Dref = np.zeros((n, n), np.float32)
+    Dref[pairs[:, 0], pairs[:, 1]] = ref
+    cl = _cliques(d["labels"])
+    st_ref = oracle.eval_statistics(Dref, cl, topsidx=(1, 10, 100))
+    assert 0.3 < st_ref[3] < 0.999
+    # (a) the oracle's features, device kernel: the f32 store of the same f64 number
+    tm = [np.ascontiguousarray(f.T) for f in feats]
+    offs = np.concatenate([[0], np.cumsum([len(t) for t in tm])]).astype(np.int64)
+    ctx.upload_pool_f64(np.concatenate(tm), offs)
+    D = np.zeros((n, n), np.float32)
+    ctx.pair_grid(_lib.ALGO_SIMPLE, False, _lib.SimpleParams(10, 1), [D], mirror=False)
+    got = D[pairs[:, 0], pairs[:, 1]].astype(np.float64)
+    rel = np.abs(got - ref) / np.abs(ref)
+    assert rel.max() <= 2e-7, rel.max()
+    st = oracle.eval_statistics(D, cl, topsidx=(1, 10, 100))
+    assert st[:4] == st_ref[:4] and np.array_equal(st[4], st_ref[4])
+    # (b) the whole device path: raw chroma -> features on the device -> grid
+    ro = np.concatenate([[0], np.cumsum([len(r) for r in raw])]).astype(np.int64)
+    ctx.simple_upload_raw_pool(np.concatenate(raw), ro, 200, 100, 4)
+    D2 = np.zeros((n, n), np.float32)
+    ctx.pair_grid(_lib.ALGO_SIMPLE, False, _lib.SimpleParams(10, 1), [D2], mirror=False)
+    got2 = D2[pairs[:, 0], pairs[:, 1]].astype(np.float64)
+    rel2 = np.abs(got2 - ref) / np.abs(ref)
+    st2 = oracle.eval_statistics(D2, cl, topsidx=(1, 10, 100))
+    assert rel2.max() <= 1e-5, rel2.max()                               # f32 window means summed in another order
+    assert abs(st2[3] - st_ref[3]) <= 1e-4 and abs(st2[0] - st_ref[0]) <= 1e-2
+    _record("parity_ef.json", "simple_cover150", {"tracks": n, "ordered_pairs": int(len(pairs)), "MAP_oracle": st_ref[3], "MAP_hip": st[3],
+                                                 "MAP_hip_device_features": st2[3], "MR_oracle": st_ref[0], "MR_hip": st[0],
+                                                 "max_rel_err": float(rel.max()), "max_rel_err_device_features": float(rel2.max())})
+
+
+def test_simple_exhaustive_tiles_of_15000(ctx):
+    """Two whole 128 x 128 tiles of the 15 000-track grid -- one off the diagonal (16 384 ordered pairs),
+    one on it (16 256) -- every cell against the oracle.  The kernel hands its sliding dot products from
+    lane to lane and walks the pairs sorted by their second track: position-dependent machinery that a
+    sample of cells cannot vouch for."""
+    import torch
+    import oracle
+    from acoss_amd import _lib
+    N = 15000
+    rng = np.random.default_rng(15000)
+    lens = rng.integers(150, 251, N)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    frames = rng.random((int(offs[-1]), 12))
+    frames /= np.linalg.norm(frames, axis=1, keepdims=True)
+    ctx.upload_pool_f64(frames, offs)
+    plan = _lib.grid_plan(lens, _lib.ALGO_SIMPLE, False, world=8, want_tiles=True)
+    feats = {}
+    total = 0
+    for want_diag in (0, 1):
+        r = 5
+        mine = [t for t in plan["tiles"] if t.rank == r]
+        k, t = next((k, t) for k, t in enumerate(mine) if t.diagonal == want_diag and t.rows == 128 and t.cols == 128)
+        buf = torch.full((128 * 128,), 7.0, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.grid_run(plan["spec"], _lib.SimpleParams(10, 1), r, buf.data_ptr() - 4 * t.offset, first=k, count=1)
+        T = buf.cpu().numpy().reshape(128, 128)
+        ii, jj = np.meshgrid(np.arange(t.row0, t.row0 + 128), np.arange(t.col0, t.col0 + 128), indexing="ij")
+        pr = np.stack([ii.ravel(), jj.ravel()], 1)
+        pr = pr[pr[:, 0] != pr[:, 1]]
+        for tr in np.unique(pr):
+            feats[int(tr)] = np.ascontiguousarray(frames[offs[tr]:offs[tr + 1]].T)
+        ref = _oracle_pool(_simple_chunk, feats, pr)
+        got = T[pr[:, 0] - t.row0, pr[:, 1] - t.col0].astype(np.float64)
+        rel = np.abs(got - ref) / np.abs(ref)
+        assert rel.max() <= 2e-7, (want_diag, rel.max())
+        if want_diag:
+            assert np.all(np.diag(T) == 0.0)
+        total += len(pr)
+    _record("parity_ef.json", "simple_15000_exhaustive_tiles", {"pairs_checked": int(total), "tolerance_rel": 2e-7})
