@@ -83,6 +83,35 @@ def _cpu_init():
     oracle.lib()
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (a container on a
+    256-thread host is often allowed a dozen of them; os.cpu_count() still says 256)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n
+
+
 def _cpu_triad(_):
     """STREAM triad a = b + s c on 3 x 32 MB f64 per worker for ~1 s: bytes moved per second by this worker."""
     n = 4 << 20
@@ -112,7 +141,7 @@ def cpu_baseline(frames, offsets, pairs, n_tracks, budget_s=15.0):
     import oracle
     oracle.lib()
     _CPU["frames"], _CPU["offsets"] = frames, offsets
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     rng = np.random.default_rng(8)
     rnd = rng.integers(0, n_tracks, (2 * 64, 2))
     rnd = np.ascontiguousarray(rnd[rnd[:, 0] != rnd[:, 1]][:64].astype(np.int32))
@@ -160,7 +189,8 @@ def cpu_baseline(frames, offsets, pairs, n_tracks, budget_s=15.0):
                   "pairs of the pool (seed 8) in one process, %.1f s; all scores bit-identical to the GPU's"
                   % (n, T_FRAMES, cores, max(45, cores), dt, n1, t_1core),
         "value_1core": round(v1, 3), "parallel_efficiency": round(vall / (cores * v1), 3),
-        "stream_triad_gbs_all_workers": stream, "cpu_model": model, "host_cpus": cores}
+        "stream_triad_gbs_all_workers": stream, "cpu_model": model, "host_cpus": os.cpu_count(),
+        "cores_note": "cores = CPUs this process may use (affinity mask and cgroup CPU quota), one worker process each"}
 
 
 def launch_ranks(n, argv):

@@ -284,17 +284,28 @@ def get_wcsm(C, k1, k2, mu=0.5):
     return np.exp(-C ** 2 / (2 * (mu * eps) ** 2))
 
 
-def earlyfusion_pair(f1, f2, kappa=0.1, K=10):
+def earlyfusion_pair(f1, f2, kappa=0.1, K=10, csm_f64=False):
     """earlyfusion_traile.py:157-198 (the arithmetic only).  f1/f2: dicts with
     mfccs (nb,650) f32, ssms (nb,1225) f32, chromas (nb,480) f32, chroma_med (12,).
-    Returns dict(mfccs, ssms, chromas, early) of SW scores + the intermediates."""
+    Returns dict(mfccs, ssms, chromas, early) of SW scores + the intermediates.
+    csm_f64 (a yardstick, not the reference's arithmetic): the three cross-similarity matrices are
+    evaluated in f64 and rounded to f32 once -- what ANY f32 evaluation (numpy's sgemm, an MFMA) approximates.
+    Scores that differ between two f32 evaluations sit on row-kappa ties of those matrices; how many pairs
+    the reference's own f32 arithmetic moves against this yardstick is the natural size of that effect."""
     csms = {}
     scores = {}
-    csms["mfccs"] = get_csm(f1["mfccs"], f2["mfccs"])
+    if csm_f64:
+        g1 = {s: np.asarray(f1[s], dtype=np.float64) for s in ("mfccs", "ssms", "chromas")}
+        g2 = {s: np.asarray(f2[s], dtype=np.float64) for s in ("mfccs", "ssms", "chromas")}
+        cast = lambda C: C.astype(np.float32)
+    else:
+        g1, g2 = f1, f2
+        cast = lambda C: C
+    csms["mfccs"] = cast(get_csm(g1["mfccs"], g2["mfccs"]))
     scores["mfccs"] = sw_constrained(csm_to_binary(csms["mfccs"], kappa))
-    csms["ssms"] = get_csm(f1["ssms"], f2["ssms"])
+    csms["ssms"] = cast(get_csm(g1["ssms"], g2["ssms"]))
     scores["ssms"] = sw_constrained(csm_to_binary(csms["ssms"], kappa))
-    csms["chromas"] = get_csm_blocked_oti(f1["chromas"], f2["chromas"], f1["chroma_med"], f2["chroma_med"])
+    csms["chromas"] = cast(get_csm_blocked_oti(g1["chromas"], g2["chromas"], f1["chroma_med"], f2["chroma_med"]))
     scores["chromas"] = sw_constrained(csm_to_binary(csms["chromas"], kappa))
     wsum = np.zeros_like(csms["mfccs"])
     for s in ("mfccs", "ssms", "chromas"):

@@ -245,7 +245,7 @@ def test_earlyfusion_scale_1200(ctx):
         i, j = pairs[k]
         o = oracle.earlyfusion_pair(tracks[i], tracks[j], kappa=0.1, K=10)[0]
         want = np.array([o[s] for s in ("mfccs", "ssms", "chromas", "early")])
-        assert np.all(np.abs(sc[k] - want) <= 2.0), (sc[k], want)
+        assert np.all(np.abs(sc[k] - want) <= 3.0), (sc[k], want)       # (tests/test_gpu_parity_sets.py: what the cap means)
     again = ctx.earlyfusion_pairs(pairs[:500][::-1].copy())
     assert np.array_equal(again, sc[:500][::-1])
     _record("earlyfusion_1200", {"tracks": 1200, "pairs_run": int(len(pairs)), "oracle_checked": 6})
