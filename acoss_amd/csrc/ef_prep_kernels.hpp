@@ -11,11 +11,14 @@
 //     chromas[b] frames [o_b, o_{b+blocksize}) of the chroma resized to chromas_per_block rows
 //   chroma_med   per-bin median over ALL frames of the track
 //
-// The resize is skimage.transform.resize(x, (rows, d), anti_aliasing=True, mode='constant') restated
-// from its published algorithm (skimage is not part of the reference's pinned dependencies and is
-// absent here: PARITY UNPINNED for this step): a Gaussian filter along time with
-// sigma = max(0, (n / rows - 1) / 2), truncated at 4 sigma, zeros outside the block, followed by
-// linear interpolation on the pixel-centre grid in = (out + 0.5) n / rows - 0.5 with zeros outside.
+// The resize is skimage.transform.resize(x, (rows, d), anti_aliasing=True, mode='constant'): a Gaussian
+// filter along time with sigma = max(0, (n / rows - 1) / 2), truncated at 4 sigma, zeros outside the
+// block; linear interpolation on the pixel-centre grid in = (out + 0.5) n / rows - 0.5 with zeros
+// outside; and skimage's output clip (clip=True): every value is clipped to [min, max] of the INPUT
+// block -- over all its columns --, except that values equal to the fill value 0 stay 0 when 0 lies
+// outside that range (it matters for all-positive chroma blocks, whose first / last rows blend with the
+// zeros outside).  Pinned by tests/golden/efprep_skimage.npz: the reference's own load_features /
+// resize_block run with scikit-image 0.18.3 (tests/golden/make_efprep_goldens.py).
 // All arithmetic in f64 (the reference converts the block to float64), results stored as f32.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -49,10 +52,34 @@ __device__ __forceinline__ double efp_filtered(const float *__restrict__ x, int 
 
 // resize of frames [i1, i2) of X (rows x dim, f32) to `rows` rows into out[rows][dim] (LDS, f64)
 __device__ __forceinline__ void efp_resize(const float *__restrict__ X, int64_t i1, int64_t i2, int dim, int rows,
-                                           double *out, double *w, int tid, int nthreads)
+                                           double *out, double *w, double *red, int tid, int nthreads)
 {
     const int n = (int)(i2 - i1);
     const float *x = X + i1 * dim;
+    // range of the input block (skimage's clip); NaN samples count as 0 like everywhere else
+    {
+        double mn = __builtin_inf(), mx = -__builtin_inf();
+        for (int e = tid; e < n * dim; e += nthreads) {
+            const float v0 = x[e];
+            const double v = v0 == v0 ? (double)v0 : 0.0;
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        __syncthreads();                                  // (red may still be read by the previous call's tail)
+        if ((tid & 63) == 0) { red[2 * (tid >> 6)] = mn; red[2 * (tid >> 6) + 1] = mx; }
+        __syncthreads();
+    }
+    double bmin = red[0], bmax = red[1];
+    for (int k = 1; k < (nthreads >> 6); ++k) {
+        bmin = red[2 * k] < bmin ? red[2 * k] : bmin;
+        bmax = red[2 * k + 1] > bmax ? red[2 * k + 1] : bmax;
+    }
+    const bool keep_fill = !(bmin <= 0.0 && 0.0 <= bmax);  // the fill value 0 lies outside the block's range
     const double factor = (double)n / (double)rows;
     const double sigma = factor > 1.0 ? (factor - 1.0) * 0.5 : 0.0;
     int r = sigma > 0.0 ? (int)(4.0 * sigma + 0.5) : 0;
@@ -80,6 +107,7 @@ __device__ __forceinline__ void efp_resize(const float *__restrict__ X, int64_t 
             const double a = efp_filtered(x, n, dim, d, t0, w, r);
             const double b = efp_filtered(x, n, dim, d, t0 + 1, w, r);
             v = (1.0 - f) * a + f * b;
+            if (!(keep_fill && v == 0.0)) { v = v < bmin ? bmin : v; v = v > bmax ? bmax : v; }     // skimage: clip to the input's range
             if (!(v == v) || v == __builtin_inf() || v == -__builtin_inf()) v = 0.0;   // ret[isinf] = ret[isnan] = 0
         }
         out[e] = v;
@@ -100,6 +128,7 @@ __global__ __launch_bounds__(256) void ef_blocks_kernel(const float *__restrict_
     __shared__ double colmean[EFP_MAXDIM];
     __shared__ double rownorm[EFP_MAXROWS];
     __shared__ double rowsq[EFP_MAXROWS];
+    __shared__ double red[8];
     const int tid = threadIdx.x;
     const int64_t gb = blockIdx.x;
     int lo = 0, hi = n_tracks - 1;                     // track with boff[t] <= gb < boff[t + 1]
@@ -117,7 +146,7 @@ __global__ __launch_bounds__(256) void ef_blocks_kernel(const float *__restrict_
     const int R = P.mfcc_rows, C = P.ncoef;
     {
         const int64_t i1 = clampi(on[b], Tm), i2 = clampi(on[b + P.blocksize - 1], Tm);     // numpy slicing clips
-        efp_resize(mfcc + moff[track] * C, i1, i2 < i1 ? i1 : i2, C, R, xs, w, tid, 256);
+        efp_resize(mfcc + moff[track] * C, i1, i2 < i1 ? i1 : i2, C, R, xs, w, red, tid, 256);
     }
     if (tid < C) {
         double s = 0.0;
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(256) void ef_blocks_kernel(const float *__restrict_
     {
         const int Rc = P.chroma_rows;
         const int64_t i1 = clampi(on[b], Tc), i2 = clampi(on[b + P.blocksize], Tc);
-        efp_resize(chroma + coff[track] * 12, i1, i2 < i1 ? i1 : i2, 12, Rc, xs, w, tid, 256);
+        efp_resize(chroma + coff[track] * 12, i1, i2 < i1 ? i1 : i2, 12, Rc, xs, w, red, tid, 256);
         for (int e = tid; e < Rc * 12; e += 256) out_chromas[(size_t)gb * (Rc * 12) + e] = (float)xs[e];
     }
 }

@@ -517,10 +517,12 @@ def snf_fuse(Scores, K=5, niters=5, reg_diag=1):
 
 def ef_resize(x, rows):
     """skimage.transform.resize(x, (rows, d), anti_aliasing=True, mode='constant') along the first
-    axis, restated from the primitives skimage calls (scipy.ndimage.gaussian_filter with
-    sigma = max(0, (n / rows - 1) / 2) truncated at 4 sigma, then an order-1 scipy.ndimage.zoom on the
-    pixel-centre grid, zeros outside) -- tests/test_oracle_golden.py checks it against those scipy
-    calls.  UNPINNED against skimage itself (absent).  NaN / inf results -> 0 (:245-246)."""
+    axis (resize_block, earlyfusion_traile.py:241-244): scipy.ndimage.gaussian_filter with
+    sigma = max(0, (n / rows - 1) / 2) truncated at 4 sigma, zeros outside; linear interpolation on the
+    pixel-centre grid, zeros outside; skimage's clip=True: the result is clipped to [min, max] of the
+    input block, values equal to the fill value 0 stay 0 when 0 lies outside that range.  PINNED by
+    tests/golden/efprep_skimage.npz (the reference run with scikit-image 0.18.3,
+    tests/golden/make_efprep_goldens.py).  NaN / inf results -> 0 (:245-246)."""
     x = np.asarray(x, dtype=np.float64)
     n, d = x.shape
     if n == 0:
@@ -542,6 +544,12 @@ def ef_resize(x, rows):
     a = ext[np.clip(t0, -2, n + 1) + 2]
     b = ext[np.clip(t0 + 1, -2, n + 1) + 2]
     out = (1.0 - f) * a + f * b
+    mn, mx = x.min(), x.max()                                # skimage warp(..., clip=True): _clip_warp_output
+    keep_fill = not (mn <= 0.0 <= mx)
+    fill = out == 0.0
+    out = np.minimum(np.maximum(out, mn), mx)
+    if keep_fill:
+        out[fill] = 0.0
     out[~np.isfinite(out)] = 0
     return out
 

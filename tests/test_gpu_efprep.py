@@ -62,6 +62,29 @@ def test_block_features_against_oracle(ctx):
         ctx.ef_block_features(t["chroma"], t["mfcc"], t["onsets"], mfccs_per_block=65)
 
 
+def test_block_features_against_reference_with_skimage(ctx, golden):
+    """The device against the reference itself run with the real scikit-image (tests/golden/efprep_skimage.npz,
+    made by tests/golden/make_efprep_goldens.py): f64 on both sides, f32 results, 2e-6 / 1e-5 like the oracle test."""
+    g = golden("efprep_skimage")
+    for k in (0, 1, 2, 9):
+        args = dict(blocksize=20, mfccs_per_block=50, chromas_per_block=40) if k != 9 else dict(blocksize=12, mfccs_per_block=32, chromas_per_block=24)
+        got = ctx.ef_block_features(g["lf%d_hpcp" % k], np.ascontiguousarray(g["lf%d_mfcc_htk" % k].T), g["lf%d_onsets" % k], **args)
+        want = {key: g["lf%d_%s" % (k, key)] for key in ("mfccs", "ssms", "chromas", "chroma_med")}
+        np.testing.assert_allclose(got["mfccs"], want["mfccs"], atol=2e-6)
+        np.testing.assert_allclose(got["ssms"], want["ssms"], atol=1e-5)
+        np.testing.assert_allclose(got["chromas"], want["chromas"], atol=2e-6)
+        np.testing.assert_array_equal(got["chroma_med"].astype(np.float32), want["chroma_med"])
+    # resize_block alone through a one-block track: chroma rows i1 .. i2 -> 40 rows, incl. the case skimage's clip decides
+    C = g["rb_C"]
+    for k, (which, i1, i2, rows) in enumerate(g["rb_cases"]):
+        if which != 1 or rows != 40:
+            continue
+        on = np.concatenate([[i1], np.full(19, i1, np.int64), [i2]]).astype(np.int64)      # 21 beats -> one block [i1, i2)
+        mf = np.zeros((len(C), 13), np.float32)
+        got = ctx.ef_block_features(C, mf, on)
+        np.testing.assert_allclose(got["chromas"][0].reshape(40, 12), g["rb_out_%d" % k], atol=2e-6, err_msg="case %d" % k)
+
+
 def test_raw_pool_equals_uploaded_block_features(ctx):
     """The collection-level entry point keeps the features on the device: the pair scores equal those
     of a pool uploaded from the per-track results (same kernels, same bits), and the oracle's

@@ -242,10 +242,10 @@ def test_earlyfusion_class_surface(tmp_path, monkeypatch):
 
 def test_earlyfusion_block_feature_oracle():
     """The checker of the device's block-feature kernels (oracle.ef_resize / ef_block_features;
-    earlyfusion_traile.py:100-140, 214-247).  skimage is neither pinned by the reference nor
-    installed, so the resize is held (1) to the scipy.ndimage primitives skimage.transform.resize
-    calls, and (2) to the properties of the algorithm: identity at scale 1, constants and linear
-    ramps preserved away from the zero border, no blur when upsampling."""
+    earlyfusion_traile.py:100-140, 214-247).  Pinned to the reference run with the real scikit-image by
+    tests/test_oracle_golden.py::test_efprep_against_reference_with_skimage; here the resize is held
+    (1) to the scipy.ndimage primitives + the output clip skimage applies, and (2) to the properties of
+    the algorithm: identity at scale 1, constants and linear ramps preserved, no blur when upsampling."""
     import scipy.ndimage as ndi
     rng = np.random.default_rng(11)
     X = rng.random((400, 5))
@@ -255,10 +255,13 @@ def test_earlyfusion_block_feature_oracle():
         sigma = max(0.0, (n / rows - 1) / 2)
         filt = ndi.gaussian_filter(x, (sigma, 0.0), cval=0.0, mode="constant") if sigma > 0 else x
         want = ndi.zoom(filt, (rows / n, 1.0), order=1, mode="grid-constant", cval=0.0, grid_mode=True)
+        want = np.where(want == 0.0, 0.0, np.clip(want, x.min(), x.max()))        # skimage warp(clip=True); 0 < min here
         np.testing.assert_allclose(oracle.ef_resize(x, rows), want, atol=1e-12)
     np.testing.assert_allclose(oracle.ef_resize(X[30:80], 50), X[30:80], atol=1e-12)          # scale 1: identity
     r = oracle.ef_resize(np.full((240, 2), 3.0), 40)
-    assert r.shape == (40, 2) and np.allclose(r[6:-6], 3.0) and r.max() <= 3.0 + 1e-12 and r[0, 0] < 3.0   # zero border leaks in
+    assert r.shape == (40, 2) and np.allclose(r, 3.0)          # the zero border leaks into the first rows, the clip to [3, 3] undoes it
+    r = oracle.ef_resize(np.concatenate([np.full((120, 2), -1.0), np.full((120, 2), 3.0)]), 40)
+    assert r[0, 0] > -1.0 and r[-1, 0] < 3.0                    # 0 inside the range: the border does leak in
     ramp = np.arange(600, dtype=np.float64)[:, None] * np.ones((1, 2))
     r = oracle.ef_resize(ramp[100:500], 50)                                                # 8 : 1
     np.testing.assert_allclose(r[8:-8, 0], (100 + (np.arange(50) + 0.5) * 8 - 0.5)[8:-8], atol=1e-6)

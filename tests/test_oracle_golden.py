@@ -139,3 +139,29 @@ def test_snf_matches_reference(golden):
     Ws, F = oracle.snf_fuse(list(g["Ds"]), K=5, niters=4, reg_diag=1)
     np.testing.assert_allclose(np.stack(Ws), g["Ws"], rtol=1e-12)
     np.testing.assert_allclose(F, g["F"], rtol=1e-10, atol=1e-12)
+
+
+def test_efprep_against_reference_with_skimage(golden):
+    """EarlyFusion's block features against THE REFERENCE run with the real scikit-image (0.18.3):
+    tests/golden/efprep_skimage.npz holds the outputs of the reference's own resize_block and
+    EarlyFusion.load_features (earlyfusion_traile.py:67-154, 214-247; generator:
+    tests/golden/make_efprep_goldens.py under the image's /opt/conda/bin/python3.9).  The oracle's
+    restatement agrees to 1e-12 on the f64 resize and BIT FOR BIT on the float32 block features."""
+    g = golden("efprep_skimage")
+    X, C = g["rb_X"], g["rb_C"]
+    for k, (which, i1, i2, rows) in enumerate(g["rb_cases"]):
+        src = X if which == 0 else C
+        got = oracle.ef_resize(src[i1:i2].astype(np.float64), int(rows))
+        np.testing.assert_allclose(got, g["rb_out_%d" % k], rtol=0, atol=1e-12, err_msg="resize_block case %d" % k)
+    # case 9 is the one skimage's clip decides: 13 all-positive frames -> 40 rows, the first rows blend with the
+    # zeros outside and are lifted back to the block's minimum
+    k9 = g["rb_out_9"]
+    assert k9[0].min() >= C[700:713].min() and k9[0].min() > 0
+    for k in (0, 1, 2, 9):
+        args = dict(blocksize=20, mfccs_per_block=50, chromas_per_block=40) if k != 9 else dict(blocksize=12, mfccs_per_block=32, chromas_per_block=24)
+        bf = oracle.ef_block_features(g["lf%d_hpcp" % k], g["lf%d_mfcc_htk" % k].T, g["lf%d_onsets" % k], **args)
+        for key in ("mfccs", "ssms", "chromas"):
+            want = g["lf%d_%s" % (k, key)]
+            assert bf[key].dtype == want.dtype == np.float32 and bf[key].shape == want.shape
+            np.testing.assert_array_equal(bf[key], want, err_msg="track %d %s" % (k, key))
+        np.testing.assert_array_equal(np.asarray(bf["chroma_med"], np.float32), g["lf%d_chroma_med" % k])
