@@ -1,9 +1,11 @@
 """
-Per-track feature files.  The reference stores one deepdish HDF5 per track at
-feature_dir/work_id/track_id.h5 (README.md:116-150, algorithm_template.py:90).  Neither
-h5py nor deepdish exists in the build environment, so the native format here is one
-`.npz` per track at the same place (same keys: hpcp / crema (T,12), mfcc_htk, label,
-track_id, madmom_features_onsets ...).  `.h5` files are read when h5py is importable.
+Per-track feature files and the distance-matrix cache.  The reference stores one deepdish HDF5 per track
+at feature_dir/work_id/track_id.h5 (README.md:116-150, algorithm_template.py:90) and the matrices in
+<prefix>_Ds.h5 (:163-166, :192).  Both are read and written here through h5py when it is importable, else
+through the HDF5 C library itself (acoss_amd.hdf5: libhdf5 via ctypes -- the image has the library but no
+Python binding for the system interpreter); without either, HDF5 files raise IOError.  A `.npz` next to a
+track's `.h5` with the same stem takes precedence (same keys: hpcp / crema (T,12), mfcc_htk, label,
+track_id, madmom_features_onsets ...): the format of the synthetic sets and of scripts/h5_to_npz.py.
 """
 import os
 
@@ -12,12 +14,30 @@ import numpy as np
 __all__ = ["load_track", "save_track", "save_matrices_h5", "load_matrices_h5"]
 
 
-def _load_h5(path):
+def hdf5_backend():
+    """'h5py', 'libhdf5' (ctypes) or None."""
     try:
-        import h5py
+        import h5py  # noqa: F401
+        return "h5py"
     except ImportError:
-        raise IOError("%s is an HDF5 file but h5py is not installed; convert the features to .npz "
-                      "(acoss_amd.featurestore.save_track)" % path)
+        pass
+    from . import hdf5
+    return "libhdf5" if hdf5.available() else None
+
+
+def _load_h5(path):
+    backend = hdf5_backend()
+    if backend is None:
+        raise IOError("%s is an HDF5 file but neither h5py nor the HDF5 C library is available; convert the "
+                      "features to .npz (acoss_amd.featurestore.save_track)" % path)
+    if backend == "libhdf5":
+        from . import hdf5
+        d = hdf5.read_tree(path)
+        for k in ("label", "track_id"):
+            if isinstance(d.get(k), bytes):
+                d[k] = d[k].decode()
+        return d
+    import h5py
 
     def rec(g):
         out = {}
@@ -53,10 +73,18 @@ def load_track(path):
     raise IOError("feature file not found: %s (or %s)" % (path, npz))
 
 
-def save_track(path, feats):
-    """Write a feature dict as .npz next to `path` (any extension)."""
+def save_track(path, feats, fmt="npz"):
+    """Write a feature dict next to `path` (any extension): fmt="npz" (default) or "h5" -- the reference's own
+    per-track layout (deepdish: arrays as datasets, sub-dictionaries as groups, strings / scalars as
+    attributes), through the HDF5 C library."""
     stem, _ = os.path.splitext(path)
     os.makedirs(os.path.dirname(stem) or ".", exist_ok=True)
+    if fmt == "h5":
+        from . import hdf5
+        hdf5.write_tree(stem + ".h5", feats)
+        return
+    if fmt != "npz":
+        raise ValueError("save_track: fmt must be 'npz' or 'h5'")
     flat = {}
     for k, v in feats.items():
         if isinstance(v, dict):
@@ -70,12 +98,16 @@ def save_track(path, feats):
 def save_matrices_h5(path, Ds):
     """{name: (N, N) array} -> one HDF5 file with a dataset per name -- what the reference's
     dd.io.save("<prefix>_Ds.h5", self.Ds) leaves on disk (algorithm_template.py:192; deepdish stores
-    plain ndarrays as plain datasets).  Returns False when h5py is not installed (the .npz cache is
-    always written)."""
-    try:
-        import h5py
-    except ImportError:
+    arrays of more than 300 elements as chunked, shuffled, zlib-compressed CArrays).  Returns False when no
+    HDF5 backend exists (the .npz cache is always written)."""
+    backend = hdf5_backend()
+    if backend is None:
         return False
+    if backend == "libhdf5":
+        from . import hdf5
+        hdf5.write_tree(path, {k: np.asarray(v) for k, v in Ds.items()}, compress=1)
+        return True
+    import h5py
     with h5py.File(path, "w") as f:
         for k, v in Ds.items():
             f.create_dataset(k, data=np.asarray(v))
