@@ -29,7 +29,7 @@ EXPORTS = [
     "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse", "acx_qmax_binary",
     "acx_ef_block_features", "acx_ef_upload_raw_pool", "acx_snf_fuse_dists", "acx_grid_plan", "acx_pool_lengths", "acx_grid_run", "acx_grid_scatter", "acx_pair_grid",
     "acx_set_nonfinite_policy", "acx_nonfinite_zeroed", "acx_ef_pool_begin", "acx_ef_pool_tracks", "acx_ef_pool_end",
-    "acx_set_ef_gemm",
+    "acx_set_ef_gemm", "acx_hip_versions",
 ]
 
 ALGO_SERRA09, ALGO_CHENFUSION, ALGO_SIMPLE, ALGO_EARLYFUSION = 0, 1, 2, 3
@@ -79,6 +79,58 @@ class Serra09Params(ctypes.Structure):
 
 
 _lib = None
+HIP_RUNTIME = None        # where the HIP runtime of this process came from (see _preload_hip_runtime)
+HIP_VERSIONS = None       # {"build", "runtime", "runtime_from"} once the library is loaded
+
+
+def _preload_hip_runtime():
+    """PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  When torch and libacx live in one
+    process -- the multi-GPU path hands torch device buffers to libacx -- that copy has to be the ONE runtime of
+    the process whatever the import order: loaded first, libacx binds to it by soname, and a later `import torch`
+    finds it already there (the other order leaves torch without a device: "No HIP GPUs are available").
+    So the library itself is loaded here, by path, without importing torch (1.5 s, and single-GPU users may
+    never need it).  No torch installed: the system runtime (/opt/rocm) is what libacx finds on its own."""
+    global HIP_RUNTIME
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        HIP_RUNTIME = "torch (imported before libacx)"
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            try:
+                ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+                HIP_RUNTIME = p
+                return
+            except OSError:
+                pass
+    HIP_RUNTIME = "system"
+
+
+def _check_hip_version(L):
+    """libacx was compiled against one HIP release and runs on whatever runtime the process loaded (torch's
+    bundled one, see above).  HIP_VERSIONS records both; a different MAJOR release (no ABI promise) warns instead
+    of failing in some obscure way later.  (This image: built against 7.2, PyTorch ships the 7.0 runtime.)"""
+    global HIP_VERSIONS
+    import warnings
+    build, run = ctypes.c_int(0), ctypes.c_int(0)
+    try:
+        L.acx_hip_versions.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        if L.acx_hip_versions(ctypes.byref(build), ctypes.byref(run)) != 0:
+            return
+    except AttributeError:
+        return
+    # HIP_VERSION = major * 10^7 + minor * 10^5 + patch
+    HIP_VERSIONS = {"build": "%d.%d" % (build.value // 10000000, build.value // 100000 % 100),
+                    "runtime": "%d.%d" % (run.value // 10000000, run.value // 100000 % 100), "runtime_from": HIP_RUNTIME}
+    if run.value > 0 and build.value // 10000000 != run.value // 10000000:
+        warnings.warn("libacx.so was built against HIP %d.%d but runs on HIP runtime %d.%d (%s)" % (
+            build.value // 10000000, build.value // 100000 % 100, run.value // 10000000, run.value // 100000 % 100, HIP_RUNTIME))
 
 
 def load():
@@ -90,13 +142,7 @@ def load():
         raise ImportError(
             "libacx.so is not built (%s). Build it with `make -C acoss_amd/csrc` or "
             "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
-    # PyTorch-ROCm bundles its own HIP runtime: when both live in one process (the multi-GPU path hands
-    # torch device buffers to libacx) torch's copy has to be the one that is loaded -- libacx then binds
-    # to it by soname.  The other order leaves torch without a device ("No HIP GPUs are available").
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    _preload_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     fp = ctypes.POINTER(ctypes.c_float)
     ip = ctypes.POINTER(ctypes.c_int32)
@@ -164,6 +210,7 @@ def load():
     L.acx_grid_scatter.argtypes = [lp, ctypes.c_int32, gp, fp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                    ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int32]
     L.acx_pair_grid.argtypes = [vp, gp, vp, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int32]
+    _check_hip_version(L)
     _lib = L
     return L
 

@@ -921,6 +921,14 @@ extern "C" {
 
 int acx_abi_version(void) { return ACX_ABI_VERSION; }
 
+int acx_hip_versions(int *build, int *runtime)
+{
+    if (build) *build = HIP_VERSION;
+    int v = 0;
+    if (runtime) *runtime = hipRuntimeGetVersion(&v) == hipSuccess ? v : 0;
+    return 0;
+}
+
 acx_ctx *acx_create(int device, int *err)
 {
     auto bad = [&](int code, const std::string &msg) -> acx_ctx * {

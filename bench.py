@@ -23,7 +23,7 @@ Also in the line:
                 8 TB/s HBM peak -- a THROUGHPUT PROXY: the production pipeline keeps the distance
                 matrix out of HBM, so the kernel is bound by SIMD issue (VALU + f32 MFMA share the
                 issue port), which `bound` / `real_bound` say (utilisations from the committed
-                rocprofv3 counter run, profiles/r02_real_bound.json); `traffic` = HBM bytes per
+                rocprofv3 counter run, profiles/real_bound.json); `traffic` = HBM bytes per
                 launch from the committed PMC run (profiles/pmc_traffic.json), scaled by cells.
   cpu_baseline  the CPU oracle (a C port of the same chain) on ALL host cores through a process
                 fan-out over max(45, cores) chunks (the reference's joblib scheme,
@@ -58,6 +58,16 @@ ALGO_BYTES_PER_CELL = {"band_kernel": 4.0, "csm_long_kernel": 4.0, "rowsel_long_
                        "oti_kernel": 0.0, "norms_kernel": 0.0}
 
 _CPU = {}
+
+
+def kernel_source_sha16():
+    """Hash of the Serra09 kernel sources (scripts/summarise_profile.py stamps the committed counter records with it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("serra09_kernels.hpp", "acx_band.hip", "Makefile"):
+        with open(os.path.join(ROOT, "acoss_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def chain_bytes_per_pair(Tq, Tr, m=M_STACK):
@@ -364,21 +374,30 @@ def main():
         if kname in ("csm_long_kernel", "band_kernel"):
             algo_bytes += 48.0 * 2 * T_FRAMES * (cells_per_launch / float((T_FRAMES - M_STACK) ** 2))
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM traffic and pipe utilisations come from rocprofv3 --pmc passes of a SEPARATE run (counters and this run's
+        # timing cannot be collected together); the records carry the hash of the kernel sources they were taken
+        # on and are reported only when it is the hash of THIS build -- a kernel change without a re-profile
+        # yields null, not stale numbers.
         traffic, traffic_source, real_bound = None, None, None
+        sha = kernel_source_sha16()
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if kname in tj and tj[kname].get("cells_per_launch"):
+                if tj.get("kernel_source_sha16") != sha:
+                    traffic_source = "profiles/pmc_traffic.json was taken on other kernel sources (%s, this build %s): not reported" % (
+                        tj.get("kernel_source_sha16"), sha)
+                elif kname in tj and tj[kname].get("cells_per_launch"):
                     traffic = tj[kname]["hbm_bytes_per_launch"] * cells_per_launch / tj[kname]["cells_per_launch"]
                     traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in a separate run "
-                                      "(%s), scaled by cells per launch; not measured in this run" % tj.get("source", "round 1"))
+                                      "(%s, same kernel sources %s), scaled by cells per launch" % (tj.get("source"), sha))
             except Exception:
                 traffic = None
-        rpath = os.path.join(ROOT, "profiles", "r02_real_bound.json")
+        rpath = os.path.join(ROOT, "profiles", "real_bound.json")
         if os.path.exists(rpath):
             try:
-                real_bound = json.load(open(rpath)).get(kname)
+                rj = json.load(open(rpath))
+                real_bound = rj.get(kname) if rj.get("kernel_source_sha16") == sha else None
             except Exception:
                 real_bound = None
         bpp = chain_bytes_per_pair(T_FRAMES, T_FRAMES)

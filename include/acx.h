@@ -48,6 +48,10 @@ void acx_destroy(acx_ctx *ctx);
 /* Last error message of this context (ctx == NULL: of the last failed acx_create). */
 const char *acx_last_error(const acx_ctx *ctx);
 int acx_abi_version(void);
+/* HIP_VERSION the library was compiled against and the version of the HIP runtime it is running on (0: unknown);
+ * the ctypes shim warns when their major.minor differ (a process that also holds PyTorch-ROCm runs on the
+ * runtime torch bundles). */
+int acx_hip_versions(int *build, int *runtime);
 /* Upper bound (bytes) for the per-batch device scratch; 0 restores the default
  * (env ACX_SCRATCH_GB, else 40 % of device memory). */
 int acx_set_scratch_limit(acx_ctx *ctx, int64_t bytes);

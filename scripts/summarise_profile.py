@@ -7,10 +7,24 @@ HBM bytes: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  Per MI355X_MICROAR
 streaming reads, i.e. HALF the bytes: the read side is doubled here and both raw and
 corrected values are listed.  WRITE_SIZE is taken as is (uncalibrated per that section)."""
 import csv
+import hashlib
 import json
 import os
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def kernel_source_sha16():
+    """Hash of the Serra09 kernel sources: bench.py reports the committed counters only for the build they were
+    taken on (same function in bench.py)."""
+    h = hashlib.sha256()
+    for f in ("serra09_kernels.hpp", "acx_band.hip", "Makefile"):
+        with open(os.path.join(ROOT, "acoss_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = sys.argv[2] if len(sys.argv) > 2 else os.path.join("gpurun_out", "prof_" + tag)
@@ -116,9 +130,12 @@ for v in real.values():
                    "i.e. it over-counts by up to a third" % tag)
 os.makedirs("profiles", exist_ok=True)
 open(os.path.join("profiles", tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
-json.dump(real, open(os.path.join("profiles", "r02_real_bound.json"), "w"), indent=1)
+real["kernel_source_sha16"] = kernel_source_sha16()
+real["source_tag"] = tag
+json.dump(real, open(os.path.join("profiles", "real_bound.json"), "w"), indent=1)
 for t in traffic.values():
     t.pop("_calls", None)
 traffic["source"] = tag
+traffic["kernel_source_sha16"] = kernel_source_sha16()
 json.dump(traffic, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))

@@ -154,3 +154,34 @@ def test_two_ranks_share_one_gpu(tmp_path):
         if k.endswith("_stats"):
             assert np.array_equal(one[k], two1[k], equal_nan=True), k
     assert float(one["serra09_main"].max()) > 10.0
+
+
+def test_libacx_before_torch_in_one_process():
+    """Import order must not matter: a process that creates its libacx context FIRST and imports torch later still
+    gets a working torch.cuda (acoss_amd._lib preloads the HIP runtime PyTorch bundles, so both end up on the same
+    one), and libacx writes into a torch tensor allocated afterwards."""
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+assert "torch" not in sys.modules
+from acoss_amd import _lib, synth
+ctx = _lib.Context(0)
+assert "torch" not in sys.modules, "creating a context must not import torch"
+d = synth.cover_set(clique_sizes=[2] * 5, seed=3, t_range=(60, 200))
+n = len(d["offsets"]) - 1
+ctx.upload_pool(d["frames"], d["offsets"])
+want = np.zeros((n, n), np.float32)
+ctx.pair_grid(_lib.ALGO_SERRA09, True, _lib.serra09_params(), [want], mirror=False)
+import torch
+assert torch.cuda.is_available() and torch.cuda.device_count() >= 1
+plan = _lib.grid_plan(np.diff(d["offsets"]), _lib.ALGO_SERRA09, True, world=1, tile=n, want_tiles=True)
+buf = torch.full((n * n,), -3.0, dtype=torch.float32, device="cuda:0")
+torch.cuda.synchronize()
+ctx.grid_run(plan["spec"], _lib.serra09_params(), 0, buf.data_ptr())
+got = buf.cpu().numpy().reshape(n, n)
+assert np.array_equal(np.triu(got, 1), np.triu(want, 1)), "scores through the torch buffer differ"
+print("ok", _lib.HIP_VERSIONS)
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
