@@ -328,7 +328,7 @@ int ensure_tau(acx_ctx *c, int tau)
     ACX_HIP(c, hipMemsetAsync(c->d_frot + (POOL_SLACK + total) * acx::FROT, 0, sizeof(float) * POOL_SLACK * acx::FROT, c->stream));
     if (total > 0) {
         const int64_t nout = total * acx::FROT;
-        hipLaunchKernelGGL(acx::rotpool_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(acx::rotpool_kernel, dim3((unsigned)std::min<int64_t>((nout + 255) / 256, 1 << 22)), dim3(256), 0, c->stream,
                            c->d_frames, c->d_frot + POOL_SLACK * acx::FROT, total);
         ACX_HIP(c, hipGetLastError());
     }
@@ -1509,7 +1509,7 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
         ACX_HIP(c, hipMalloc((void **)&c->d_efs[k], sizeof(unsigned short) * nel));
         if (nb > 0) {
             const int64_t nthr = nb * c->ef_kp[k];
-            hipLaunchKernelGGL(acx::ef_split_bf16_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(acx::ef_split_bf16_kernel, dim3((unsigned)std::min<int64_t>((nthr + 255) / 256, 1 << 22)), dim3(256), 0, c->stream,
                                c->d_ef[k], c->d_efs[k], nb, dims[k], c->ef_kp[k]);
             ACX_HIP(c, hipGetLastError());
         }
@@ -1841,6 +1841,7 @@ struct SnfRun {
 static int snf_alloc(acx_ctx *c, SnfRun &R, int m, int n, int K)
 {
     const size_t nn = (size_t)n * n;
+    if (n > 65535) return fail(c, ACX_ERR_UNSUPPORTED, "snf_fuse: more than 65535 tracks are not supported on the device (one work-item per matrix cell)");
     const size_t need = ((size_t)2 * m + 2) * nn * sizeof(double) + (size_t)m * n * K * (sizeof(double) + sizeof(int32_t));
     if (need > (size_t)(0.8 * (double)c->total_mem)) return fail(c, ACX_ERR_NOMEM, "snf_fuse: matrices do not fit the device");
     R.m = m; R.n = n; R.K = K;

@@ -269,23 +269,26 @@ __device__ __forceinline__ unsigned ef_bf16_rne(float x)
     return u >> 16;
 }
 
+// (grid-stride: a launch carries at most 2^32 - 1 work-items per dimension, and a DA-TACOS-sized pool has 7.5e9
+// split values per feature -- a one-thread-per-value grid wraps silently and leaves the tail of the pool unwritten)
 __global__ __launch_bounds__(256) void ef_split_bf16_kernel(const float *__restrict__ f, unsigned short *__restrict__ out,
                                                             int64_t nblocks, int K, int Kp)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nblocks * Kp) return;
-    const int64_t row = idx / Kp;
-    const int k = (int)(idx - row * Kp);
-    const float x = k < K ? f[row * K + k] : 0.0f;
-    const unsigned h1 = ef_bf16_rne(x);
-    const float r1 = x - __uint_as_float(h1 << 16);            // exact
-    const unsigned h2 = ef_bf16_rne(r1);
-    const float r2 = r1 - __uint_as_float(h2 << 16);           // exact
-    const unsigned h3 = ef_bf16_rne(r2);
-    // [block][k / 32][term][k % 32]: the three terms of a 32-k chunk are 192 contiguous bytes, so the GEMM's three
-    // 64-byte reads per row and chunk share their 128-byte lines
-    unsigned short *o = out + row * 3 * Kp + (int64_t)(k / EFB_BK) * (3 * EFB_BK) + (k % EFB_BK);
-    o[0] = (unsigned short)h1; o[EFB_BK] = (unsigned short)h2; o[2 * EFB_BK] = (unsigned short)h3;
+    const int64_t total = nblocks * Kp, stride = (int64_t)gridDim.x * 256;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const int64_t row = idx / Kp;
+        const int k = (int)(idx - row * Kp);
+        const float x = k < K ? f[row * K + k] : 0.0f;
+        const unsigned h1 = ef_bf16_rne(x);
+        const float r1 = x - __uint_as_float(h1 << 16);            // exact
+        const unsigned h2 = ef_bf16_rne(r1);
+        const float r2 = r1 - __uint_as_float(h2 << 16);           // exact
+        const unsigned h3 = ef_bf16_rne(r2);
+        // [block][k / 32][term][k % 32]: the three terms of a 32-k chunk are 192 contiguous bytes, so the GEMM's three
+        // 64-byte reads per row and chunk share their 128-byte lines
+        unsigned short *o = out + row * 3 * Kp + (int64_t)(k / EFB_BK) * (3 * EFB_BK) + (k % EFB_BK);
+        o[0] = (unsigned short)h1; o[EFB_BK] = (unsigned short)h2; o[2 * EFB_BK] = (unsigned short)h3;
+    }
 }
 
 constexpr int EFB_THREADS = 512;    // 8 waves as 4 x 2: 32 x 64 cells per wave (two workgroups per CU = 4 waves per SIMD)

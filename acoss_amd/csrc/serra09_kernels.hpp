@@ -881,12 +881,14 @@ constexpr int FROT = 3 * NBIN;      // floats per frame of the rotated frame poo
 // frot[f][r][cls][kb] = frame[f][cls + 4 ((r + kb) mod 3)], r = 0..2, cls = 0..3, kb = 0..2.
 static __global__ void rotpool_kernel(const float *__restrict__ pool, float *__restrict__ frot, int64_t nframes)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one output float each
-    if (idx >= nframes * FROT) return;
-    const int64_t f = idx / FROT;
-    const int e = (int)(idx - f * FROT);
-    const int r = e / NBIN, rem = e - r * NBIN, cls = rem / 3, kb = rem - 3 * cls;
-    frot[idx] = pool[f * NBIN + cls + 4 * ((r + kb) % 3)];
+    // (grid-stride: a launch carries at most 2^32 - 1 work-items per dimension; pools beyond 119 M frames exceed that)
+    const int64_t total = nframes * FROT, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {     // one output float each
+        const int64_t f = idx / FROT;
+        const int e = (int)(idx - f * FROT);
+        const int r = e / NBIN, rem = e - r * NBIN, cls = rem / 3, kb = rem - 3 * cls;
+        frot[idx] = pool[f * NBIN + cls + 4 * ((r + kb) % 3)];
+    }
 }
 
 // Pool decimated by the stack stride tau: frame t of the output track = frame t tau of the input
