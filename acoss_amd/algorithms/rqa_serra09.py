@@ -31,8 +31,22 @@ def pool_median(chroma, fac):
 class Serra09(CoverAlgorithm):
     """
     Attributes (as in the reference): chroma_type, downsample_fac, all_feats, oti, kappa,
-    tau, m.  Extra keyword `device` selects the GPU (default: LOCAL_RANK or 0); `engine`
-    holds further switches of the essentia-recalled details (acx_serra09_params).
+    tau, m.  Extra keywords (all optional, behind the reference's):
+      device     the GPU (default: LOCAL_RANK or 0)
+      nonfinite  "raise" (default): NaN / Inf features fail the upload naming the track; "zero": replaced by 0
+      engine     dict of the details of essentia's arithmetic that are only RECALLED, not pinned (essentia is not
+                 installable here; include/acx.h acx_serra09_params, oracle/acx_oracle.c):
+                   pct_mode    0 (default) linear-interpolated percentile, an exact-integer position k returns d_(k);
+                               1 essentia's formula as recalled, d_(floor k) (ceil k - k) + d_(ceil k) (k - floor k),
+                                 which is 0 at an exact-integer k (rows of 201, 401, ... cells at kappa = 0.095:
+                                 the row binarises to nothing) -- pass engine={"pct_mode": 1} to reproduce that;
+                               2 lower, 3 nearest
+                   embed_full  0 (default) M = T - m tau frames, 1: T - (m - 1) tau
+                   oti_target  0 (default) the reference track is transposed, 1: the query
+                   dp_start    2 (default) or 3: first row / column of the alignment recursion
+                   inclusive   1 (default) d <= eps, 0: d <
+                   gamma_o, gamma_e  gap penalties (essentia's defaults 0.5 / 0.5)
+                 tests/test_essentia_pin.py finds the combination that reproduces essentia wherever it is installed.
     """
     n_chunks = 1      # the whole pair list goes to the GPU in one similarity() call
 

@@ -326,6 +326,8 @@ def main():
         if world > 1:                               # the one collective of the path, device to device
             if backend == "nccl":
                 dist.all_gather_into_tensor(gathered, local)
+                # the next step's kernels (libacx's own stream) overwrite `local`: the host waits for the collective
+                torch.cuda.current_stream().synchronize()
             else:
                 outs = [torch.empty(slice_floats) for _ in range(world)]
                 dist.all_gather(outs, local.cpu())

@@ -29,17 +29,22 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#include <malloc.h>
 
-/* Every pair allocates (and frees) one T x T f32 distance matrix and its byte-sized recurrence plot (the
- * frame Gram is a ring of m rows, the alignment three rolling rows).  Keep them on the heap instead of
- * mmap / munmap per call: with one worker per host core the page faults of fresh mappings otherwise
- * dominate. */
-__attribute__((constructor)) static void acx_o_init(void)
+/* The two big per-pair arrays -- the T x T f32 distance matrix and its byte-sized recurrence plot -- live in
+ * per-thread buffers that grow on demand and are reused from pair to pair (the frame Gram is a ring of m rows,
+ * the alignment three rolling rows): a fresh 16 MB malloc per pair is an mmap / munmap and a page fault per
+ * 4 KB, which with one worker per host core dominates everything else.  (Round 2 retuned glibc's malloc
+ * process-wide from a library constructor instead; that also changed the process that loaded the oracle.) */
+static __thread float *tl_d = NULL;
+static __thread size_t tl_d_cap = 0;
+static __thread uint8_t *tl_r = NULL;
+static __thread size_t tl_r_cap = 0;
+static void *tl_grow(void *p, size_t *cap, size_t need)
 {
-    mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024);      /* glibc's maximum: the 16 MB matrices of a T = 2000 pair stay below it */
-    mallopt(M_TRIM_THRESHOLD, 1 << 30);
-    mallopt(M_TOP_PAD, 64 << 20);
+    if (need <= *cap) return p;
+    free(p);
+    *cap = need + need / 8;
+    return malloc(*cap);
 }
 
 
@@ -250,7 +255,7 @@ float acx_o_serra09_pair(const float *Q, int32_t Tq, const float *Rf, int32_t Tr
     if (oti_out) *oti_out = s;
 
     /* 2+3. distances */
-    float *d = (float *)malloc((size_t)Mq * Mr * sizeof(float));
+    float *d = tl_d = (float *)tl_grow(tl_d, &tl_d_cap, (size_t)Mq * Mr * sizeof(float));
     if (p->arith == 0) {
         /* frame-level Gram (fmaf chain over the 12 bins), frame norms.  Row i of d needs the Gram rows
          * i tau .. (i + m - 1) tau only: they live in a ring of `span` rows instead of a Tq x Tr matrix. */
@@ -358,7 +363,7 @@ float acx_o_serra09_pair(const float *Q, int32_t Tq, const float *Rf, int32_t Tr
     }
 
     /* 5. cross recurrence plot */
-    uint8_t *R = (uint8_t *)malloc((size_t)Mq * Mr);
+    uint8_t *R = tl_r = (uint8_t *)tl_grow(tl_r, &tl_r_cap, (size_t)Mq * Mr);
     for (int i = 0; i < Mq; ++i)
         for (int j = 0; j < Mr; ++j) {
             float v = d[(size_t)i * Mr + j];
@@ -413,7 +418,7 @@ float acx_o_serra09_pair(const float *Q, int32_t Tq, const float *Rf, int32_t Tr
     if (epsq_out) memcpy(epsq_out, epsq, (size_t)Mq * sizeof(float));
     if (epsr_out) memcpy(epsr_out, epsr, (size_t)Mr * sizeof(float));
     if (bin_out) memcpy(bin_out, R, (size_t)Mq * Mr);
-    free(d); free(epsq); free(epsr); free(R);
+    free(epsq); free(epsr);           /* (d and R stay with the thread) */
     return best;
 }
 
