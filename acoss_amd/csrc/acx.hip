@@ -102,6 +102,12 @@ struct acx_ctx {
     int32_t ef_open = 0;                              // > 0: a pool of that many tracks is being filled (acx_ef_pool_begin .. _end)
     int32_t ef_dims[3] = {0, 0, 0};
     acx::EfPair *d_efpd = nullptr; size_t efpd_cap = 0;
+    // rectangles of the segment GEMM (ef_gemm_seg_bf16x3_kernel): row / column groups, rectangles, pair tables
+    acx::EfSegGroup *d_segr = nullptr; size_t segr_cap = 0;
+    acx::EfSegGroup *d_segc = nullptr; size_t segc_cap = 0;
+    acx::EfSegRect *d_rects = nullptr; size_t rects_cap = 0;
+    int32_t *d_ptab = nullptr;         size_t ptab_cap = 0;
+    acx::EfSegWg *d_segw = nullptr;    size_t segw_cap = 0;
     // scratch (grow-only)
     float *d_scratch = nullptr; size_t scratch_cap = 0;   // floats
     float *d_thr = nullptr;     size_t thr_cap = 0;
@@ -711,6 +717,93 @@ static int stage_idx(acx_ctx *c, const int64_t *idx, int64_t n)
     return ACX_OK;
 }
 
+// Rectangles for the segment GEMM: consecutive pairs of the batch are collected while they involve at most
+// SEG_TRACKS distinct query and SEG_TRACKS distinct reference tracks (and no (query, reference) combination
+// twice); the blocks of those tracks, each padded to a multiple of 16, become the rows / columns of one dense
+// matrix.  A grid tile of 128 x 128 tracks is exactly one rectangle; an arbitrary pair list degrades to
+// rectangles whose pair table is mostly -1 (their empty workgroup tiles return at once).
+namespace {
+constexpr int SEG_TRACKS = 128;
+struct SegBatch {
+    std::vector<acx::EfSegGroup> rowg, colg;
+    std::vector<acx::EfSegRect> rects;
+    std::vector<int32_t> ptab;
+    std::vector<acx::EfSegWg> wgs;
+};
+void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_t> &efoff, int n_tracks, SegBatch &sb,
+                    std::vector<int32_t> &qslot, std::vector<int32_t> &rslot)
+{
+    sb.rowg.clear(); sb.colg.clear(); sb.rects.clear(); sb.ptab.clear(); sb.wgs.clear();
+    std::vector<uint8_t> mark;
+    std::vector<int32_t> gfirst_q, gfirst_r;      // first group of every slot (+ one past the last)
+    qslot.assign((size_t)n_tracks, -1);
+    rslot.assign((size_t)n_tracks, -1);
+    std::vector<int32_t> qs, rs;                 // tracks of the open rectangle, in slot order
+    std::vector<std::pair<int32_t, int32_t>> members;     // (pair index, qslot * SEG_TRACKS + rslot)
+    std::vector<uint8_t> seen((size_t)SEG_TRACKS * SEG_TRACKS, 0);
+    auto close = [&]() {
+        if (members.empty()) return;
+        acx::EfSegRect R;
+        R.g0 = (int32_t)sb.rowg.size(); R.h0 = (int32_t)sb.colg.size();
+        auto lay = [&](const std::vector<int32_t> &tracks, std::vector<acx::EfSegGroup> &out, std::vector<int32_t> &gfirst) {
+            const size_t start = out.size();
+            gfirst.clear();
+            for (size_t sl = 0; sl < tracks.size(); ++sl) {
+                gfirst.push_back((int32_t)(out.size() - start));
+                const int64_t base = efoff[tracks[sl]];
+                const int n = (int)(efoff[tracks[sl] + 1] - base);
+                for (int l0 = 0; l0 < n; l0 += 16)
+                    out.push_back(acx::EfSegGroup{base + l0, std::min(16, n - l0), (int32_t)sl, l0, 0});
+            }
+            gfirst.push_back((int32_t)(out.size() - start));
+        };
+        lay(qs, sb.rowg, gfirst_q);
+        lay(rs, sb.colg, gfirst_r);
+        R.ng = (int32_t)sb.rowg.size() - R.g0; R.nh = (int32_t)sb.colg.size() - R.h0;
+        R.ncols = (int32_t)rs.size();
+        R.ptab0 = (int32_t)sb.ptab.size();
+        sb.ptab.resize(sb.ptab.size() + qs.size() * rs.size(), -1);
+        // workgroup tiles (8 x 8 groups) that hold at least one pair, row-major: neighbours share their row operand
+        const int tiles_y = (R.ng + 7) / 8, tiles_x = (R.nh + 7) / 8;
+        mark.assign((size_t)tiles_y * tiles_x, 0);
+        for (const auto &m : members) {
+            const int a = m.second / SEG_TRACKS, b = m.second % SEG_TRACKS;
+            sb.ptab[(size_t)R.ptab0 + (size_t)a * R.ncols + b] = m.first;
+            seen[(size_t)m.second] = 0;
+            if (gfirst_q[a + 1] == gfirst_q[a] || gfirst_r[b + 1] == gfirst_r[b]) continue;     // (a track without blocks)
+            for (int ty = gfirst_q[a] / 8; ty <= (gfirst_q[a + 1] - 1) / 8; ++ty)
+                for (int tx = gfirst_r[b] / 8; tx <= (gfirst_r[b + 1] - 1) / 8; ++tx) mark[(size_t)ty * tiles_x + tx] = 1;
+        }
+        const int32_t rid = (int32_t)sb.rects.size();
+        for (int ty = 0; ty < tiles_y; ++ty)
+            for (int tx = 0; tx < tiles_x; ++tx)
+                if (mark[(size_t)ty * tiles_x + tx]) sb.wgs.push_back(acx::EfSegWg{rid, ty, tx, 0});
+        sb.rects.push_back(R);
+        for (int32_t t : qs) qslot[(size_t)t] = -1;
+        for (int32_t t : rs) rslot[(size_t)t] = -1;
+        qs.clear(); rs.clear(); members.clear();
+    };
+    for (size_t k = 0; k < pd.size(); ++k) {
+        const int q = pd[k].q, r = pd[k].r;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool newq = qslot[(size_t)q] < 0, newr = rslot[(size_t)r] < 0;
+            const bool fits = (!newq || (int)qs.size() < SEG_TRACKS) && (!newr || (int)rs.size() < SEG_TRACKS);
+            const bool dup = !newq && !newr && seen[(size_t)qslot[(size_t)q] * SEG_TRACKS + rslot[(size_t)r]];
+            if (fits && !dup) {
+                if (newq) { qslot[(size_t)q] = (int32_t)qs.size(); qs.push_back(q); }
+                if (newr) { rslot[(size_t)r] = (int32_t)rs.size(); rs.push_back(r); }
+                const int code = qslot[(size_t)q] * SEG_TRACKS + rslot[(size_t)r];
+                seen[(size_t)code] = 1;
+                members.push_back({(int32_t)k, code});
+                break;
+            }
+            close();                              // (the second attempt always fits an empty rectangle)
+        }
+    }
+    close();
+}
+}  // namespace
+
 // `dd` (grid runs): the four scores of pair k go to dd->base[dd->idx[k] .. + 4) on the DEVICE instead of out[4 k ..].
 int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, float *out, const EfDebug *dbg,
            const float *ext_matrix, int extM, int extN, const DevDst *dd = nullptr)
@@ -728,6 +821,8 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
     }
     const int64_t limit_floats = limit / 4;
     std::vector<EfPair> pd;
+    SegBatch seg;
+    std::vector<int32_t> qslot, rslot;
     int rc;
     int64_t k0 = 0;
     while (k0 < K) {
@@ -789,9 +884,30 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                                        c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
                                        c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x, 0);
                 } else {
-                    hipLaunchKernelGGL(acx::ef_gemm_bf16x3_kernel, dim3(tiles_x * tiles_y, B, 2), dim3(acx::EFB_THREADS), 0, c->stream,
-                                       c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
-                                       c->d_scratch, c->ef_kp[0], c->ef_kp[1], tiles_x);
+                    if (c->ef_gemm == ACX_EF_GEMM_BF16X3_PAIRWISE) {
+                        hipLaunchKernelGGL(acx::ef_gemm_bf16x3_kernel, dim3(tiles_x * tiles_y, B, 2), dim3(acx::EFB_THREADS), 0, c->stream,
+                                           c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
+                                           c->d_scratch, c->ef_kp[0], c->ef_kp[1], tiles_x);
+                    } else {
+                        // mfcc, ssm: the pairs of the batch laid out as dense rectangles (ef_gemm_seg_bf16x3_kernel)
+                        ef_build_rects(pd, c->h_efoff, c->ef_ntracks, seg, qslot, rslot);
+                        if ((rc = ensure(c, c->d_segr, c->segr_cap, seg.rowg.size())) != ACX_OK) return rc;
+                        if ((rc = ensure(c, c->d_segc, c->segc_cap, seg.colg.size())) != ACX_OK) return rc;
+                        if ((rc = ensure(c, c->d_rects, c->rects_cap, seg.rects.size())) != ACX_OK) return rc;
+                        if ((rc = ensure(c, c->d_ptab, c->ptab_cap, seg.ptab.size())) != ACX_OK) return rc;
+                        ACX_HIP(c, hipMemcpyAsync(c->d_segr, seg.rowg.data(), sizeof(acx::EfSegGroup) * seg.rowg.size(), hipMemcpyHostToDevice, c->stream));
+                        ACX_HIP(c, hipMemcpyAsync(c->d_segc, seg.colg.data(), sizeof(acx::EfSegGroup) * seg.colg.size(), hipMemcpyHostToDevice, c->stream));
+                        ACX_HIP(c, hipMemcpyAsync(c->d_rects, seg.rects.data(), sizeof(acx::EfSegRect) * seg.rects.size(), hipMemcpyHostToDevice, c->stream));
+                        ACX_HIP(c, hipMemcpyAsync(c->d_ptab, seg.ptab.data(), sizeof(int32_t) * seg.ptab.size(), hipMemcpyHostToDevice, c->stream));
+                        if ((rc = ensure(c, c->d_segw, c->segw_cap, seg.wgs.size())) != ACX_OK) return rc;
+                        ACX_HIP(c, hipMemcpyAsync(c->d_segw, seg.wgs.data(), sizeof(acx::EfSegWg) * seg.wgs.size(), hipMemcpyHostToDevice, c->stream));
+                        // (the copies above are staged before they return: `seg` may be rebuilt for the next batch)
+                        if (seg.wgs.size() > 0x7fffffffu) return fail(c, ACX_ERR_UNSUPPORTED, "earlyfusion: batch too large for one launch");
+                        if (!seg.wgs.empty())
+                            hipLaunchKernelGGL(acx::ef_gemm_seg_bf16x3_kernel, dim3((unsigned)seg.wgs.size(), 1, 2), dim3(acx::EFB_THREADS), 0, c->stream,
+                                               c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd, c->d_rects, c->d_segw,
+                                               c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1]);
+                    }
                     hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 1), dim3(256), 0, c->stream,
                                        c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
                                        c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x, 2);
@@ -988,6 +1104,11 @@ void acx_destroy(acx_ctx *c)
     if (c->d_out64) (void)hipFree(c->d_out64);
     ef_free_pool(c);
     if (c->d_efpd) (void)hipFree(c->d_efpd);
+    if (c->d_segr) (void)hipFree(c->d_segr);
+    if (c->d_segc) (void)hipFree(c->d_segc);
+    if (c->d_rects) (void)hipFree(c->d_rects);
+    if (c->d_ptab) (void)hipFree(c->d_ptab);
+    if (c->d_segw) (void)hipFree(c->d_segw);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1525,7 +1646,8 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
 int acx_set_ef_gemm(acx_ctx *c, int32_t mode)
 {
     if (!c) return ACX_ERR_INVALID;
-    if (mode != ACX_EF_GEMM_BF16X3 && mode != ACX_EF_GEMM_F32) return fail(c, ACX_ERR_INVALID, "set_ef_gemm: unknown mode");
+    if (mode != ACX_EF_GEMM_BF16X3 && mode != ACX_EF_GEMM_F32 && mode != ACX_EF_GEMM_BF16X3_PAIRWISE)
+        return fail(c, ACX_ERR_INVALID, "set_ef_gemm: unknown mode");
     c->ef_gemm = mode;
     return ACX_OK;
 }

@@ -386,6 +386,185 @@ __global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 // ------------------------------------------------------------------------------------
+// E1c: the same two Euclidean products for a whole RECTANGLE of pairs at once (round 3).  The per-pair kernel
+// above tiles every (M x N) matrix on its own: a 400 x 400 matrix needs 16 workgroup tiles of 128 x 128 where 9.8
+// would hold its cells (measured: 92 TFLOP/s f32-equivalent at 400 blocks per track against 131 - 138 at 384 / 512),
+// and every pair re-reads its two tracks.  Here the blocks of up to 128 query tracks are laid end to end as the
+// rows of ONE matrix and the blocks of up to 128 reference tracks as its columns (every track padded to a multiple
+// of 16 rows, so that a 16 x 16 MFMA sub-tile never straddles two pairs): a dense GEMM whose tiles are full, whose
+// operands are shared by all the pairs of a query / reference track, and whose epilogue drops every 16 x 16
+// sub-tile into the matrix of the pair it belongs to (pairtab: -1 = that (query, reference) combination is not
+// asked for -- the lower triangle of a diagonal grid tile, or an arbitrary pair list).  The arithmetic of a cell
+// is untouched -- the same k chunks in the same order through the same six MFMAs --, so the matrices are
+// bit-identical to the per-pair kernel's.
+// ------------------------------------------------------------------------------------
+struct EfSegGroup {        // 16 consecutive rows (or columns) of the laid-out matrix
+    int64_t poolrow;       // first block (pool row) of the group
+    int32_t valid;         // rows of the group that exist (1 .. 16; 0: padding group)
+    int32_t slot;          // index of its track among the rectangle's query (reference) tracks
+    int32_t local0;        // row (column) of the group's first block inside the pair's own matrix
+    int32_t pad;
+};
+struct EfSegRect {
+    int32_t g0, ng;        // row groups [g0, g0 + ng) of the batch's row-group array
+    int32_t h0, nh;        // column groups
+    int32_t ncols;         // reference tracks of the rectangle (row length of its pair table)
+    int32_t ptab0;         // offset of its pair table (nrows x ncols ints: index into the batch's EfPair array or -1)
+};
+struct EfSegWg { int32_t rect, ty, tx, pad; };      // one workgroup tile (8 x 8 groups) that holds at least one pair
+
+__global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ef_gemm_seg_bf16x3_kernel(
+    const unsigned short *__restrict__ split0, const unsigned short *__restrict__ split1, const float *__restrict__ nrm0,
+    const float *__restrict__ nrm1, const EfPair *__restrict__ pd, const EfSegRect *__restrict__ rects,
+    const EfSegWg *__restrict__ wgs, const EfSegGroup *__restrict__ rowg, const EfSegGroup *__restrict__ colg, const int32_t *__restrict__ pairtab,
+    float *__restrict__ scratch, int Kp0, int Kp1)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * EF_TILE * EFB_LP];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * EF_TILE * EFB_LP];
+    const EfSegWg W = wgs[blockIdx.x];               // (the host lists only tiles that hold at least one pair)
+    const EfSegRect R = rects[W.rect];
+    const int ty = W.ty, tx = W.tx;
+    const int s = blockIdx.z;                        // 0 mfcc, 1 ssm
+    const int Kp = s == 0 ? Kp0 : Kp1;
+    const unsigned short *S = s == 0 ? split0 : split1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    constexpr int NA = 2;                            // 16-row sub-tiles per wave
+    const int gr0 = 8 * ty + 2 * wr, gc0 = 8 * tx + 4 * wc;      // this wave's first row / column group inside the rectangle
+    // pair of every sub-tile of the wave (-1: nothing to compute) -- wave-uniform
+    int pidx[NA][4];
+    bool any = false, full = true;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int p = -1;
+            if (gr0 + a < R.ng && gc0 + b < R.nh) {
+                const EfSegGroup ga = rowg[R.g0 + gr0 + a], gb = colg[R.h0 + gc0 + b];
+                if (ga.valid > 0 && gb.valid > 0) p = pairtab[R.ptab0 + ga.slot * R.ncols + gb.slot];
+            }
+            pidx[a][b] = __builtin_amdgcn_readfirstlane(p);
+            any = any || p >= 0;
+            full = full && p >= 0;
+        }
+    f32x4 acc[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: thread -> (row = tid / 4, 8 consecutive k = 8 * (tid % 4) ...) of every term: one 16-byte piece each
+    const int srow = tid >> 2, sk = (tid & 3) * 8;
+    const int sg = srow >> 4, sr = srow & 15;
+    bool rowa = false, rowb = false;
+    const unsigned short *ap = S, *bp = S;
+    if (8 * ty + sg < R.ng) {
+        const EfSegGroup g = rowg[R.g0 + 8 * ty + sg];
+        rowa = sr < g.valid;
+        if (rowa) ap = S + (g.poolrow + sr) * 3 * Kp + sk;
+    }
+    if (8 * tx + sg < R.nh) {
+        const EfSegGroup g = colg[R.h0 + 8 * tx + sg];
+        rowb = sr < g.valid;
+        if (rowb) bp = S + (g.poolrow + sr) * 3 * Kp + sk;
+    }
+    u32x4 ra[3], rb[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { ra[q] = u32x4{0u, 0u, 0u, 0u}; rb[q] = u32x4{0u, 0u, 0u, 0u}; }
+    auto gload = [&]() {
+        if (rowa) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ra[q] = *reinterpret_cast<const u32x4 *>(ap + q * EFB_BK);
+            ap += 3 * EFB_BK;
+        }
+        if (rowb) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rb[q] = *reinterpret_cast<const u32x4 *>(bp + q * EFB_BK);
+            bp += 3 * EFB_BK;
+        }
+    };
+    unsigned short *as0 = As + srow * EFB_LP + sk, *bs0 = Bs + srow * EFB_LP + sk;
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            *reinterpret_cast<u32x4 *>(as0 + q * EF_TILE * EFB_LP) = ra[q];        // (rows that do not exist: zeros)
+            *reinterpret_cast<u32x4 *>(bs0 + q * EF_TILE * EFB_LP) = rb[q];
+        }
+    };
+    const unsigned short *aop = As + (32 * wr + lr) * EFB_LP + 8 * lk;
+    const unsigned short *bop = Bs + (64 * wc + lr) * EFB_LP + 8 * lk;
+    gload();
+    for (int k0 = 0; k0 < Kp; k0 += EFB_BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + EFB_BK < Kp) gload();                     // in flight during the MFMAs below
+        if (any) {
+            bf16x8 av[NA][3];
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    av[a][q] = *reinterpret_cast<const bf16x8 *>(aop + (q * EF_TILE + 16 * a) * EFB_LP);
+            auto mma = [&](auto full_tag) {
+                constexpr bool fullc = decltype(full_tag)::value;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (fullc || pidx[0][b] >= 0 || pidx[1][b] >= 0) {
+                        bf16x8 bv[3];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) bv[q] = *reinterpret_cast<const bf16x8 *>(bop + (q * EF_TILE + 16 * b) * EFB_LP);
+#define ACX_EFB_TERM(TA_, TB_)                                                                                         \
+    _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                                     \
+        if (fullc || pidx[a][b] >= 0) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[a][TA_], bv[TB_], acc[a][b], 0, 0, 0);
+                        ACX_EFB_TERM(0, 2) ACX_EFB_TERM(2, 0) ACX_EFB_TERM(1, 1) ACX_EFB_TERM(0, 1) ACX_EFB_TERM(1, 0) ACX_EFB_TERM(0, 0)
+#undef ACX_EFB_TERM
+                    }
+                }
+            };
+            if (full) mma(std::true_type());
+            else mma(std::false_type());
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: every sub-tile into the matrices of its own pair (get_csm: sqrt(max(0, |x|^2 + |y|^2 - 2 x.y)))
+    const float *nrm = s == 0 ? nrm0 : nrm1;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (pidx[a][b] < 0) continue;                                  // wave-uniform
+            const EfPair P = pd[pidx[a][b]];
+            const EfSegGroup ga = rowg[R.g0 + gr0 + a], gb = colg[R.h0 + gc0 + b];
+            float *C = scratch + ef_c_off(P, s);
+            float *CT = scratch + ef_ct_off(P, s);
+            const int il = 4 * lk, jl = lr;                                // position inside the 16 x 16 sub-tile
+            const int ib = ga.local0 + il, j = gb.local0 + jl;
+            const bool jok = jl < gb.valid;
+            const float ny = jok ? nrm[gb.poolrow + jl] : 0.0f;
+            float v[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const bool iok = il + reg < ga.valid;
+                const float nx = iok ? nrm[ga.poolrow + il + reg] : 0.0f;
+                float tq = (nx + ny) - 2.0f * acc[a][b][reg];
+                if (tq < 0.0f) tq = 0.0f;
+                v[reg] = __builtin_sqrtf(tq);
+                if (iok && jok) C[(size_t)(ib + reg) * P.pitchC + j] = v[reg];
+            }
+            if (jok) {
+                float *ct = CT + (size_t)j * P.pitchT + ib;
+                if (il + 3 < ga.valid) *reinterpret_cast<float4 *>(ct) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        if (il + reg < ga.valid) ct[reg] = v[reg];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------
 // E2: per-row statistics of a matrix with rows <= 256 NQ long (NQ = 2: 512, NQ = 4: 1024).  mode 0 (C rows): threshold
 // t_i = the kb-th smallest (k = round(kappa n), kappa < 1; kappa >= 1: k = kappa; k = 0 or
 // kappa == 0 handled by the host) and r_i = mean of the kw smallest; mode 1 (C^T rows):

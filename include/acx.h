@@ -291,12 +291,16 @@ int acx_earlyfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const a
  * Arithmetic of the two Euclidean cross-similarity products (mfccs, ssms; get_csm, cross_recurrence.py:30-48 --
  * the reference's is one BLAS sgemm in f32):
  *   ACX_EF_GEMM_BF16X3 (default)  three-term bf16 splits on the bf16 matrix pipe, f32 accumulation: the dropped
- *                                 terms are below one f32 rounding of the product, 1.35 x faster
+ *                                 terms are below one f32 rounding of the product; the pairs of a batch are laid
+ *                                 out as dense rectangles (query tracks' blocks x reference tracks' blocks), so
+ *                                 the 128 x 128 tiles of the GEMM are full and tracks are read once per rectangle
  *   ACX_EF_GEMM_F32               f32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation)
  * Both meet the same bound against the f64 truth (tests/test_gpu_earlyfusion.py); scores that differ between
  * them sit on a row-kappa threshold tie (profiles/r03_parity_ef.json holds the measured histogram).
  */
-enum { ACX_EF_GEMM_BF16X3 = 0, ACX_EF_GEMM_F32 = 1 };
+enum { ACX_EF_GEMM_BF16X3 = 0, ACX_EF_GEMM_F32 = 1,
+       ACX_EF_GEMM_BF16X3_PAIRWISE = 2 /* the same arithmetic, one matrix at a time (round 2's kernel; bit-identical
+                                          results -- kept as the cross-check of the rectangle kernel) */ };
 int acx_set_ef_gemm(acx_ctx *ctx, int32_t mode);
 
 /* One pair with intermediates (tests): csm (3, M, N), fused (M, N), scores (4); any may be NULL. */

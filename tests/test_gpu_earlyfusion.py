@@ -222,3 +222,65 @@ def test_benchmark_end_to_end(tmp_path, monkeypatch):
     assert res["early"][0] == 1.0 and res["early"][3] == 1.0           # MR, MAP
     Ds = np.load("cache/EarlyFusionTraile_toy_hpcp_Ds.npz")
     assert np.array_equal(Ds["early"], Ds["early"].T) and Ds["early"][0, 1] > 10
+
+
+def test_rectangle_gemm_equals_pairwise_gemm(ctx):
+    """The dense-rectangle GEMM (ef_gemm_seg_bf16x3_kernel, the default) against the one-matrix-at-a-time kernel of
+    round 2: the arithmetic of a cell is the same sequence of MFMAs, so the cross-similarity matrices -- and with
+    them all four scores -- must be BIT-identical, whatever the shape of the pair list: full grid tiles, a
+    triangular (diagonal) tile, repeated pairs, self pairs, pairs in both orders, tracks of 1 / 15 / 16 / 17 blocks,
+    more than 128 distinct tracks on either side (several rectangles), a track of more than 1024 blocks."""
+    from acoss_amd import _lib
+    rng = np.random.default_rng(44)
+    nbs = [1, 15, 16, 17, 33, 128, 129, 300, 47, 250] + [int(v) for v in rng.integers(20, 90, 150)]
+
+    def track(nb):
+        mf = rng.standard_normal((nb, 650)).astype(np.float32)
+        mf /= np.linalg.norm(mf, axis=1, keepdims=True)
+        return dict(mfccs=mf, ssms=(2 * rng.random((nb, 1225))).astype(np.float32), chromas=rng.random((nb, 480)).astype(np.float32),
+                    chroma_med=rng.random(12))
+    tracks = [track(nb) for nb in nbs]
+    ctx.ef_upload_pool(tracks)
+    n = len(tracks)
+    lists = []
+    ii, jj = np.meshgrid(np.arange(0, 12), np.arange(5, 30), indexing="ij")
+    lists.append(np.stack([ii.ravel(), jj.ravel()], 1))                                  # a full rectangle (with i == j cells)
+    iu, ju = np.triu_indices(20, 1)
+    lists.append(np.stack([iu, ju], 1))                                                   # a diagonal tile
+    rnd = rng.integers(0, n, (700, 2))
+    lists.append(rnd)                                                                     # arbitrary, > 128 distinct tracks per side
+    lists.append(np.array([[3, 4], [3, 4], [4, 3], [7, 7], [3, 4], [0, 1], [1, 0], [0, 0]]))   # repeats, both orders, self pairs
+    try:
+        for pairs in lists:
+            pairs = np.ascontiguousarray(pairs, np.int32)
+            ctx.set_ef_gemm("bf16x3_pairwise")
+            want = ctx.earlyfusion_pairs(pairs)
+            ctx.set_ef_gemm("bf16x3")
+            got = ctx.earlyfusion_pairs(pairs)
+            assert np.array_equal(got, want), int(np.sum(np.any(got != want, axis=1)))
+        # the matrices themselves, through the debug entry (a one-pair rectangle)
+        for (i, j) in [(7, 128 % n), (5, 6), (0, 7), (3, 2)]:
+            ctx.set_ef_gemm("bf16x3_pairwise")
+            a = ctx.ef_debug_pair(i, j)
+            ctx.set_ef_gemm("bf16x3")
+            b = ctx.ef_debug_pair(i, j)
+            assert np.array_equal(a["csm"], b["csm"]) and np.array_equal(a["fused"], b["fused"])
+        # through the pair grid (tile = 128 tracks: rectangles of 128 x 128 track slots; and a small tile)
+        for tile in (0, 7):
+            planes = {}
+            for mode in ("bf16x3_pairwise", "bf16x3"):
+                ctx.set_ef_gemm(mode)
+                planes[mode] = [np.zeros((n, n), np.float32) for _ in range(4)]
+                ctx.pair_grid(_lib.ALGO_EARLYFUSION, True, _lib.EfParams(0.1, 10), planes[mode], mirror=True, tile=tile)
+            for e in range(4):
+                assert np.array_equal(planes["bf16x3"][e], planes["bf16x3_pairwise"][e])
+        # a track of more than 1024 blocks (streaming row statistics / Smith-Waterman behind the same GEMM)
+        big = [track(1100), track(40), track(520)]
+        ctx.ef_upload_pool(big)
+        pr = np.array([[0, 1], [1, 0], [0, 2], [2, 1]], np.int32)
+        ctx.set_ef_gemm("bf16x3_pairwise")
+        want = ctx.earlyfusion_pairs(pr)
+        ctx.set_ef_gemm("bf16x3")
+        assert np.array_equal(ctx.earlyfusion_pairs(pr), want)
+    finally:
+        ctx.set_ef_gemm("bf16x3")
