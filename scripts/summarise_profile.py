@@ -54,7 +54,7 @@ for sub in sorted(os.listdir(src)):
             pmc[k]["_lds"] = [float(row["LDS_Block_Size"])]
 
 lines = ["# rocprofv3 summary `%s`" % tag, "",
-         "Command: `python bench.py --no-cpu --steps 2 --warmup 1 --tracks 640` "
+         "Command: `python bench.py --no-cpu --no-other --steps 2 --warmup 1 --tracks 640` "
          "(8192 pairs of 1991 x 1991 cells per launch); one `--kernel-trace --stats` pass and separate "
          "`--pmc` passes (scripts/profile.sh).", "",
          "| kernel | calls | avg ms | % time | VGPR | LDS B | FETCH KiB | WRITE KiB | HBM GB (2 x fetch + write) | GB/s |",
