@@ -907,10 +907,16 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                             hipLaunchKernelGGL(acx::ef_gemm_seg_bf16x3_kernel, dim3((unsigned)seg.wgs.size(), 1, 2), dim3(acx::EFB_THREADS), 0, c->stream,
                                                c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd, c->d_rects, c->d_segw,
                                                c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1]);
+                        // chroma over the same rectangles (f32 MFMA; the pair's OTI roll applied when the operand is read)
+                        if (!seg.wgs.empty())
+                            hipLaunchKernelGGL(acx::ef_gemm_seg_f32_kernel, dim3((unsigned)seg.wgs.size()), dim3(256), 0, c->stream,
+                                               c->d_ef[2], c->d_efpd, c->d_rects, c->d_segw, c->d_segr, c->d_segc, c->d_ptab,
+                                               c->d_scratch, c->ef_dims[2]);
                     }
-                    hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 1), dim3(256), 0, c->stream,
-                                       c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
-                                       c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x, 2);
+                    if (c->ef_gemm == ACX_EF_GEMM_BF16X3_PAIRWISE)
+                        hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 1), dim3(256), 0, c->stream,
+                                           c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
+                                           c->d_scratch, c->ef_dims[0], c->ef_dims[1], c->ef_dims[2], tiles_x, 2);
                 }
             }
         }

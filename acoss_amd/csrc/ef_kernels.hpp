@@ -565,6 +565,188 @@ __global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 // ------------------------------------------------------------------------------------
+// E1d: the chroma (cosine) cross-similarity matrices over the same rectangles, f32 MFMA.  The blocked-OTI roll of
+// the first song's bins (get_csm_blocked_oti, cross_recurrence.py:105-134) depends on the PAIR, so it cannot be
+// applied while the operands are staged (a tile of a rectangle serves several pairs): the operands go to LDS
+// unrolled and every lane READS its A value from the rolled k-row instead -- A1[12 g + c] = A[12 g + (c - oti) mod 12]
+// -- with the roll of the wave's pair (one pair per wave in all but the few waves that straddle a track boundary;
+// those read A once per sub-tile).  Same k steps, same operand values per cell as ef_gemm_kernel: same bits.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ef_gemm_seg_f32_kernel(const float *__restrict__ feat, const EfPair *__restrict__ pd,
+                                                              const EfSegRect *__restrict__ rects, const EfSegWg *__restrict__ wgs,
+                                                              const EfSegGroup *__restrict__ rowg, const EfSegGroup *__restrict__ colg,
+                                                              const int32_t *__restrict__ pairtab, float *__restrict__ scratch, int K)
+{
+    __shared__ float As[EF_BK * EF_LP];
+    __shared__ float Bs[EF_BK * EF_LP];
+    const EfSegWg W = wgs[blockIdx.x];
+    const EfSegRect R = rects[W.rect];
+    const int ty = W.ty, tx = W.tx;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int gr0 = 8 * ty + 4 * wr, gc0 = 8 * tx + 4 * wc;
+    int pidx[4][4], rot[4][4];
+    bool any = false, uniform = true;
+    int rot0 = -1;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int p = -1, r = 0;
+            if (gr0 + a < R.ng && gc0 + b < R.nh) {
+                const EfSegGroup ga = rowg[R.g0 + gr0 + a], gb = colg[R.h0 + gc0 + b];
+                if (ga.valid > 0 && gb.valid > 0) p = pairtab[R.ptab0 + ga.slot * R.ncols + gb.slot];
+            }
+            if (p >= 0) r = pd[p].oti;
+            p = __builtin_amdgcn_readfirstlane(p);
+            r = __builtin_amdgcn_readfirstlane(r);
+            pidx[a][b] = p; rot[a][b] = r;
+            any = any || p >= 0;
+            if (p < 0) uniform = false;
+            else if (rot0 < 0) rot0 = r;
+            else if (r != rot0) uniform = false;
+        }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: thread -> (row = tid / 2, 12 consecutive k = 12 * (tid % 2) ...) as three float4 per operand
+    const int srow = tid >> 1, sk = (tid & 1) * 12;
+    const int sg = srow >> 4, sr = srow & 15;
+    bool rowa = false, rowb = false;
+    const float *ap = feat, *bp = feat;
+    if (8 * ty + sg < R.ng) {
+        const EfSegGroup g = rowg[R.g0 + 8 * ty + sg];
+        rowa = sr < g.valid;
+        if (rowa) ap = feat + (g.poolrow + sr) * K + sk;
+    }
+    if (8 * tx + sg < R.nh) {
+        const EfSegGroup g = colg[R.h0 + 8 * tx + sg];
+        rowb = sr < g.valid;
+        if (rowb) bp = feat + (g.poolrow + sr) * K + sk;
+    }
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    float ra[12], rb[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) { ra[e] = 0.f; rb[e] = 0.f; }
+    auto gload = [&](int k0) {
+        if (k0 + EF_BK <= K) {                       // workgroup-uniform
+            if (rowa) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const f32x4 va = *reinterpret_cast<const f32x4u *>(ap + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra[4 * q + e] = va[e];
+                }
+            }
+            if (rowb) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const f32x4 vb = *reinterpret_cast<const f32x4u *>(bp + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[4 * q + e] = vb[e];
+                }
+            }
+            ap += EF_BK;
+            bp += EF_BK;
+        } else {                                     // the block that crosses K: element-wise, zeros beyond K
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const bool ok = k0 + sk + e < K;
+                ra[e] = (ok && rowa) ? ap[e] : 0.f;
+                rb[e] = (ok && rowb) ? bp[e] : 0.f;
+            }
+        }
+    };
+    const int swrow = srow ^ (16 * (tid & 1));       // (the XOR of the second 12-group, as in ef_gemm_kernel)
+    float *as0 = As + sk * EF_LP + swrow, *bs0 = Bs + sk * EF_LP + swrow;
+    auto lstore = [&]() {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) { as0[e * EF_LP] = ra[e]; bs0[e * EF_LP] = rb[e]; }
+    };
+    // rolled k-row of A for k-step kb of the lane: c = (4 kb + lk) mod 12 = 4 (kb mod 3) + lk
+    auto arow = [&](int kb, int r) {
+        int idx = 4 * (kb % 3) + lk - r;
+        idx = idx < 0 ? idx + 12 : idx;
+        return 12 * (kb / 3) + idx;
+    };
+    int arow_u[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { int idx = 4 * q + lk - (rot0 < 0 ? 0 : rot0); arow_u[q] = idx < 0 ? idx + 12 : idx; }
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += EF_BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + EF_BK < K) gload(k0 + EF_BK);           // in flight during the MFMAs below
+        if (uniform) {
+#pragma unroll
+            for (int kb = 0; kb < EF_BK / 4; ++kb) {
+                const int sw = 16 * (kb / 3);
+                float av[4], bv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) av[a] = As[(12 * (kb / 3) + arow_u[kb % 3]) * EF_LP + ((64 * wr + 16 * a + lr) ^ sw)];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bv[b] = Bs[(4 * kb + lk) * EF_LP + ((64 * wc + 16 * b + lr) ^ sw)];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+        } else if (any) {
+#pragma unroll
+            for (int kb = 0; kb < EF_BK / 4; ++kb) {
+                const int sw = 16 * (kb / 3);
+                float bv[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bv[b] = Bs[(4 * kb + lk) * EF_LP + ((64 * wc + 16 * b + lr) ^ sw)];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (pidx[a][b] >= 0) {
+                            const float ava = As[arow(kb, rot[a][b]) * EF_LP + ((64 * wr + 16 * a + lr) ^ sw)];
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ava, bv[b], acc[a][b], 0, 0, 0);
+                        }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: get_csm_cosine (rows are unit vectors: 1 - dot), every sub-tile into its own pair's matrices
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (pidx[a][b] < 0) continue;
+            const EfPair P = pd[pidx[a][b]];
+            const EfSegGroup ga = rowg[R.g0 + gr0 + a], gb = colg[R.h0 + gc0 + b];
+            float *C = scratch + ef_c_off(P, 2);
+            float *CT = scratch + ef_ct_off(P, 2);
+            const int il = 4 * lk, jl = lr;
+            const int ib = ga.local0 + il, j = gb.local0 + jl;
+            const bool jok = jl < gb.valid;
+            float v[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                v[reg] = 1.0f - acc[a][b][reg];
+                if (il + reg < ga.valid && jok) C[(size_t)(ib + reg) * P.pitchC + j] = v[reg];
+            }
+            if (jok) {
+                float *ct = CT + (size_t)j * P.pitchT + ib;
+                if (il + 3 < ga.valid) *reinterpret_cast<float4 *>(ct) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        if (il + reg < ga.valid) ct[reg] = v[reg];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------
 // E2: per-row statistics of a matrix with rows <= 256 NQ long (NQ = 2: 512, NQ = 4: 1024).  mode 0 (C rows): threshold
 // t_i = the kb-th smallest (k = round(kappa n), kappa < 1; kappa >= 1: k = kappa; k = 0 or
 // kappa == 0 handled by the host) and r_i = mean of the kw smallest; mode 1 (C^T rows):
@@ -779,28 +961,67 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
 #pragma unroll
         for (int e = 0; e < CPL; ++e) U1[e] = b[e] ? 0 : -7;
         int best = 0;
-        for (int i = 2; i <= M - 2; ++i) {
-            load_b(i, b);
-            const int l1a = __shfl(U1[CPL - 1], prev, 64), l1b = __shfl(U1[CPL - 2], prev, 64), l2a = __shfl(U2[CPL - 1], prev, 64);
-            int Tn[CPL];
+        // The rows of the matrix arrive through a register ring, SW_PF rows ahead of the row the recursion works
+        // on: one wave walks one matrix, every row is a dependent trip to L2 / HBM otherwise (measured: 0.95 ms
+        // per 1984 matrices of 400 x 400, ~ 2 us per row, with only two waves per SIMD to hide it).
+        constexpr int SW_PF = 8;
+        float4 ring[SW_PF][CPL / 4];
+        float tring[SW_PF];
+        int jring[SW_PF];
+        auto issue = [&](int row, float4 (&dst)[CPL / 4], float &t, int &jc) {
+            const int r = row < M ? row : M - 1;            // (rows past the last one: a valid address, never used)
+            t = thr[r];
+            jc = jcut[r];
 #pragma unroll
-            for (int e = 0; e < CPL; ++e) {
-                const int c2 = (e >= 1) ? U1[e - 1] : l1a;                        // U[i-1][j-1]
-                const int c3 = (e >= 1) ? U2[e - 1] : l2a;                        // U[i-2][j-1]
-                const int c4 = (e >= 2) ? U1[e - 2] : (e == 1 ? l1a : l1b);       // U[i-1][j-2]
-                int mx = c2 > c3 ? c2 : c3;
-                mx = mx > c4 ? mx : c4;
-                int t = (b[e] ? 10 : -10) + mx;
-                t = t > 0 ? t : 0;
-                const int j = j0 + e;
-                if (j < 2) t = 0;                  // columns 0, 1 (lane 0 only; its shuffled inputs are unused)
-                Tn[e] = t;
-                if (j <= N - 2) best = best > t ? best : t;
+            for (int q = 0; q < CPL / 4; ++q) {
+                dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j0 + 4 * q < pitch) dst[q] = *reinterpret_cast<const float4 *>(C + (size_t)r * pitch + j0 + 4 * q);
             }
+        };
 #pragma unroll
-            for (int e = 0; e < CPL; ++e) {
-                U2[e] = U1[e];
-                U1[e] = Tn[e] + (b[e] ? 0 : -7);
+        for (int sl = 0; sl < SW_PF; ++sl) issue(2 + sl, ring[sl], tring[sl], jring[sl]);
+        for (int i0 = 2; i0 <= M - 2; i0 += SW_PF) {
+#pragma unroll
+            for (int sl = 0; sl < SW_PF; ++sl) {
+                const int i = i0 + sl;
+                if (i <= M - 2) {                            // wave-uniform
+                    {
+                        const float t = tring[sl];
+                        const int jc = jring[sl];
+#pragma unroll
+                        for (int q = 0; q < CPL / 4; ++q) {
+                            const float4 v = ring[sl][q];
+                            const float d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) {
+                                const int e = 4 * q + e4;
+                                b[e] = (j0 + e < N) && (d[e4] < t || (d[e4] == t && j0 + e <= jc));
+                            }
+                        }
+                    }
+                    issue(i + SW_PF, ring[sl], tring[sl], jring[sl]);
+                    const int l1a = __shfl(U1[CPL - 1], prev, 64), l1b = __shfl(U1[CPL - 2], prev, 64), l2a = __shfl(U2[CPL - 1], prev, 64);
+                    int Tn[CPL];
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        const int c2 = (e >= 1) ? U1[e - 1] : l1a;                        // U[i-1][j-1]
+                        const int c3 = (e >= 1) ? U2[e - 1] : l2a;                        // U[i-2][j-1]
+                        const int c4 = (e >= 2) ? U1[e - 2] : (e == 1 ? l1a : l1b);       // U[i-1][j-2]
+                        int mx = c2 > c3 ? c2 : c3;
+                        mx = mx > c4 ? mx : c4;
+                        int t = (b[e] ? 10 : -10) + mx;
+                        t = t > 0 ? t : 0;
+                        const int j = j0 + e;
+                        if (j < 2) t = 0;                  // columns 0, 1 (lane 0 only; its shuffled inputs are unused)
+                        Tn[e] = t;
+                        if (j <= N - 2) best = best > t ? best : t;
+                    }
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        U2[e] = U1[e];
+                        U1[e] = Tn[e] + (b[e] ? 0 : -7);
+                    }
+                }
             }
         }
 #pragma unroll
