@@ -37,3 +37,33 @@ def create_dataset_filepaths(dataset_csv, root_audio_dir, file_format=".mp3"):
                           "columns of key 'work_id', 'track_id'" % dataset_csv)
     return [root_audio_dir + str(w) + "/" + str(t) + file_format
             for w, t in zip(table["work_id"], table["track_id"])]
+
+
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (a container on a
+    256-thread host is often allowed a dozen of them; os.cpu_count() still says 256)."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n

@@ -86,6 +86,11 @@ _POOL_STATE = {}
 
 def _pool_init(root, tracks):
     sys.path.insert(0, root)
+    try:                                    # one BLAS thread per worker: the pool is the parallelism
+        from threadpoolctl import threadpool_limits
+        _POOL_STATE["blas"] = threadpool_limits(limits=1)
+    except ImportError:
+        pass
     import oracle
     oracle.lib()
     _POOL_STATE["tracks"] = tracks
@@ -110,7 +115,8 @@ def _simple_chunk(pairs):
 
 def _oracle_pool(fn, tracks, pairs, workers=None):
     import multiprocessing as mp
-    workers = workers or max(1, min(32, (os.cpu_count() or 2) // 2))
+    from acoss_amd.utils import effective_cpus
+    workers = workers or max(1, min(32, effective_cpus()))
     chunks = [c for c in np.array_split(np.asarray(pairs), workers * 4) if len(c)]
     with mp.get_context("spawn").Pool(workers, initializer=_pool_init, initargs=(ROOT, tracks)) as pool:
         parts = pool.map(fn, chunks, chunksize=1)
