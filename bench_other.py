@@ -147,7 +147,7 @@ def earlyfusion_leg(ctx, steps=3, warmup=1, n=48, cpu_pairs=4):
         "data": "synthetic",
         "config": {"workload": "configs[4] per-track shape: %d tracks of 300-500 blocks, all %d pairs per step through acx_grid_run "
                                "(scores scattered into a device buffer)" % (n, npairs)},
-        "roofline": {"bound": "mfma", "kernel": "ef_gemm_seg_bf16x3_kernel (mfcc / ssm: three-term bf16 splits over dense rectangles of pairs) + ef_gemm_kernel (chroma: f32 MFMA, per pair)",
+        "roofline": {"bound": "mfma", "kernel": "ef_gemm_seg_bf16x3_kernel (mfcc / ssm: three-term bf16 splits) + ef_gemm_seg_f32_kernel (chroma: f32 MFMA), both over dense rectangles of pairs",
                      "achieved": round(flops / (kms * 1e-3) / 1e12, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(flops / (kms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 4), "traffic": None,
                      "flops": "f32-equivalent: 2 (650 + 1225 + 480) nb1 nb2 per pair (SURVEY 8d) against the f32 matrix peak",
