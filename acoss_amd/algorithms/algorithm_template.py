@@ -173,7 +173,7 @@ class CoverAlgorithm(object):
             for chunk in np.array_split(mine, max(1, min(self.n_chunks, len(mine)))):
                 if len(chunk):
                     self.similarity(chunk)
-            if ws > 1:
+            if not _dist.single():
                 keys = list(self.Ds.keys())
                 local = np.stack([np.asarray(self.Ds[s][mine[:, 0], mine[:, 1]]) for s in keys], axis=1)
                 full = _dist.gather_scores(local, len(pairs))
@@ -197,7 +197,7 @@ class CoverAlgorithm(object):
         ctx, algo, params, keys = self._grid()
         planes = [self.Ds[k] for k in keys]
         rank, ws = _dist.world()
-        if ws == 1:
+        if _dist.single():
             ctx.pair_grid(algo, symmetric, params, planes, mirror=symmetric)
             return
         import torch

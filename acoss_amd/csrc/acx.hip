@@ -745,10 +745,15 @@ void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_
         if (members.empty()) return;
         acx::EfSegRect R;
         R.g0 = (int32_t)sb.rowg.size(); R.h0 = (int32_t)sb.colg.size();
+        // a sparse rectangle (an arbitrary pair list: few of its query x reference combinations are pairs) starts every
+        // track on a workgroup-tile boundary (8 groups), so that a tile never stages the rows of tracks it has no pair
+        // for; a dense one (a grid tile) packs the tracks tightly: its tiles are full anyway
+        const bool sparse = 2 * members.size() < qs.size() * rs.size();
         auto lay = [&](const std::vector<int32_t> &tracks, std::vector<acx::EfSegGroup> &out, std::vector<int32_t> &gfirst) {
             const size_t start = out.size();
             gfirst.clear();
             for (size_t sl = 0; sl < tracks.size(); ++sl) {
+                while (sparse && ((out.size() - start) & 7) != 0) out.push_back(acx::EfSegGroup{0, 0, (int32_t)sl, 0, 0});
                 gfirst.push_back((int32_t)(out.size() - start));
                 const int64_t base = efoff[tracks[sl]];
                 const int n = (int)(efoff[tracks[sl] + 1] - base);

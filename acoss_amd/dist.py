@@ -19,6 +19,26 @@ __all__ = ["world", "bind_device", "barrier", "broadcast_object", "any_rank", "s
 _BOUND = None
 
 
+def _forced():
+    """ACX_GRID_VIA_COLLECTIVE=1: take the multi-rank code path -- tile buffers, the all-gather, the broadcasts --
+    even when the process group has ONE rank.  A 1-GPU box cannot hold two RCCL ranks (one communicator rank per
+    device), so this is how the nccl branch of this module gets executed there at all
+    (tests/test_gpu_grid.py::test_nccl_world_of_one)."""
+    import os
+    return os.environ.get("ACX_GRID_VIA_COLLECTIVE", "") not in ("", "0")
+
+
+def single():
+    """True when no collective is needed: no process group, or one rank and not forced through the collectives."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size() == 1 and not _forced()
+    except ImportError:
+        pass
+    return True
+
+
 def world():
     """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
     try:
@@ -60,8 +80,7 @@ def _collective_device():
 
 
 def barrier():
-    rank, ws = world()
-    if ws > 1:
+    if not single():
         import torch.distributed as dist
         if _is_nccl():
             dist.barrier(device_ids=[_collective_device().index])
@@ -72,7 +91,7 @@ def barrier():
 def broadcast_object(obj, src=0):
     """Small picklable object from rank `src` to every rank (a collective: every rank must call it)."""
     rank, ws = world()
-    if ws == 1:
+    if single():
         return obj
     import torch.distributed as dist
     box = [obj if rank == src else None]
@@ -87,7 +106,7 @@ def any_rank(flag):
     """True on every rank iff `flag` is true on at least one (a collective: every rank must call it).
     Decisions that lead into another collective are taken with this, never from rank-local state."""
     rank, ws = world()
-    if ws == 1:
+    if single():
         return bool(flag)
     import torch
     import torch.distributed as dist
@@ -107,7 +126,7 @@ def gather_tiles(local, stride):
     import torch.distributed as dist
     rank, ws = world()
     assert local.dtype == torch.float32 and local.numel() == stride
-    if ws == 1:
+    if single():
         return local.cpu().numpy()
     if dist.get_backend() == "nccl":
         out = torch.empty(ws * stride, dtype=torch.float32, device=local.device)
@@ -137,7 +156,7 @@ def gather_scores(local, n_items, device=None):
     if local.ndim == 1:
         local = local[:, None]
     C = local.shape[1]
-    if ws == 1:
+    if single():
         return local
     longest = max(shard_bounds(n_items, r, ws)[1] - shard_bounds(n_items, r, ws)[0] for r in range(ws))
     buf = np.zeros((longest, C), np.float32)

@@ -185,3 +185,61 @@ print("ok", _lib.HIP_VERSIONS)
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_nccl_world_of_one(tmp_path):
+    """RCCL on the code path, as far as a 1-GPU box allows: a process group of ONE rank under the "nccl" backend,
+    and ACX_GRID_VIA_COLLECTIVE=1 so that the classes take the multi-rank route anyway -- device binding, tile
+    buffer on the GPU, all_gather_into_tensor over RCCL on that buffer, rank-0 scatter, the clique-table and
+    statistics broadcasts (broadcast_object_list with an explicit device), barrier(device_ids=...), any_rank's
+    all-reduce.  Matrices and statistics must equal the plain single-process run."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+os.chdir(%r)
+from acoss_amd import synth, dist as adist
+from acoss_amd.algorithms.rqa_serra09 import Serra09
+from acoss_amd.algorithms.latefusion_chen import ChenFusion
+d = synth.cover_set(clique_sizes=[2] * 6 + [3], seed=12, t_range=(60, 260))
+n = len(d["offsets"]) - 1
+with open("ds.csv", "w") as f:
+    f.write("work_id,track_id\n")
+    for i, l in enumerate(d["labels"]):
+        f.write("%%s,t%%d\n" %% (l, i))
+tracks = [d["frames"][d["offsets"][i]:d["offsets"][i + 1]] for i in range(n)]
+
+def run(cls, tag):
+    a = cls("ds.csv", "feat/", shortname=tag)
+    a.set_pooled_features(tracks, d["labels"])
+    a.all_pairwise(symmetric=True)
+    a.normalize_by_length()
+    if cls is ChenFusion:
+        a.do_late_fusion()
+    st = {k: a.getEvalStatistics(k, topsidx=[1, 10]) for k in list(a.Ds.keys())}
+    out = {k: np.array(a.Ds[k]) for k in a.Ds}
+    a.cleanup_memmap()
+    return out, st
+
+plain = {c.__name__: run(c, "plain" + c.__name__) for c in (Serra09, ChenFusion)}
+import torch
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", ACX_GRID_VIA_COLLECTIVE="1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dist.init_process_group("nccl")
+assert dist.get_backend() == "nccl" and not adist.single()
+adist.barrier()
+assert adist.any_rank(False) is False and adist.any_rank(True) is True
+assert adist.broadcast_object({"x": 3}) == {"x": 3}
+coll = {c.__name__: run(c, "coll" + c.__name__) for c in (Serra09, ChenFusion)}
+dist.barrier(device_ids=[0])
+dist.destroy_process_group()
+for name in plain:
+    for k in plain[name][0]:
+        assert np.array_equal(plain[name][0][k], coll[name][0][k], equal_nan=True), (name, k)
+        a, b = plain[name][1][k], coll[name][1][k]
+        assert a[:4] == b[:4] and np.array_equal(a[4], b[4]), (name, k)
+print("ok nccl world of one")
+""" % (ROOT, str(tmp_path), str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok nccl world of one" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
