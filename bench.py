@@ -413,8 +413,12 @@ def main():
             # the other two algorithms of the path, outside the timed region above: 2 steps each at their
             # BASELINE configs[3] / [4] per-track shapes (bench_other.py), each with its own roofline and CPU baseline
             import bench_other
-            line["other"] = {"simple": bench_other.simple_leg(ctx, steps=2, warmup=1),
-                             "earlyfusion": bench_other.earlyfusion_leg(ctx, steps=2, warmup=1)}
+            line["other"] = {}
+            for key, leg in (("simple", bench_other.simple_leg), ("earlyfusion", bench_other.earlyfusion_leg)):
+                try:
+                    line["other"][key] = leg(ctx, steps=2, warmup=1)
+                except Exception as e:            # a failing companion leg must not take the headline line with it
+                    line["other"][key] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line))
     ctx.close()
     if world > 1:
