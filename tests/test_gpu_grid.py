@@ -201,7 +201,7 @@ os.chdir(%r)
 from acoss_amd import synth, dist as adist
 from acoss_amd.algorithms.rqa_serra09 import Serra09
 from acoss_amd.algorithms.latefusion_chen import ChenFusion
-d = synth.cover_set(clique_sizes=[2] * 6 + [3], seed=12, t_range=(60, 260))
+d = synth.cover_set(clique_sizes=[2] * 11 + [3], seed=12, t_range=(60, 200))      # 25 tracks: SNF takes K = 20 neighbours
 n = len(d["offsets"]) - 1
 with open("ds.csv", "w") as f:
     f.write("work_id,track_id\n")
