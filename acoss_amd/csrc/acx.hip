@@ -1885,7 +1885,26 @@ int acx_earlyfusion_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, const acx
     if (!c) return ACX_ERR_INVALID;
     if (K < 0 || (K > 0 && (!pairs || !out)) || !params) return fail(c, ACX_ERR_INVALID, "earlyfusion_pairs: bad argument");
     if (K == 0) return ACX_OK;
-    return run_ef(c, pairs, K, *params, out, nullptr, nullptr, 0, 0);
+    // An arbitrary pair list is processed sorted by (first track, second track): pairs that share a track then fall
+    // into the same rectangle of the GEMMs (shared operands) and neighbouring pairs read neighbouring memory.  A list
+    // that is sorted already (a grid tile, np.triu_indices ...) goes through as it is.
+    bool sorted = true;
+    for (int64_t k = 1; k < K && sorted; ++k)
+        sorted = pairs[2 * k - 2] < pairs[2 * k] || (pairs[2 * k - 2] == pairs[2 * k] && pairs[2 * k - 1] <= pairs[2 * k + 1]);
+    if (sorted) return run_ef(c, pairs, K, *params, out, nullptr, nullptr, 0, 0);
+    std::vector<int64_t> order((size_t)K);
+    for (int64_t k = 0; k < K; ++k) order[(size_t)k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        return pairs[2 * a] != pairs[2 * b] ? pairs[2 * a] < pairs[2 * b] : pairs[2 * a + 1] < pairs[2 * b + 1];
+    });
+    std::vector<int32_t> sp((size_t)2 * K);
+    for (int64_t k = 0; k < K; ++k) { sp[(size_t)2 * k] = pairs[2 * order[(size_t)k]]; sp[(size_t)2 * k + 1] = pairs[2 * order[(size_t)k] + 1]; }
+    std::vector<float> so((size_t)4 * K);
+    const int rc = run_ef(c, sp.data(), K, *params, so.data(), nullptr, nullptr, 0, 0);
+    if (rc != ACX_OK) return rc;
+    for (int64_t k = 0; k < K; ++k)
+        for (int e = 0; e < 4; ++e) out[4 * order[(size_t)k] + e] = so[(size_t)4 * k + e];
+    return ACX_OK;
 }
 
 int acx_ef_debug_pair(acx_ctx *c, int32_t i, int32_t j, const acx_ef_params *params, float *csm, float *fused,
