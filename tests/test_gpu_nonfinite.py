@@ -137,3 +137,44 @@ def test_zero_policy_other_pools():
             ctx.ef_upload_pool(bad)
     finally:
         ctx.close()
+
+
+def test_raw_earlyfusion_features():
+    """EarlyFusion's raw per-track features: NaN MFCC samples are zeroed under EITHER policy, as the reference does
+    (earlyfusion_traile.py:105); an infinite MFCC sample or a NaN chroma frame follows the policy."""
+    import oracle
+    from acoss_amd import _lib
+    rng = np.random.default_rng(5)
+    T = 900
+    chroma = rng.random((T, 12)).astype(np.float32)
+    mfcc = rng.standard_normal((T, 13)).astype(np.float32)
+    on = np.sort(rng.choice(T - 10, 40, replace=False)).astype(np.int64)
+    ctx = _lib.Context(0)
+    try:
+        m_nan = mfcc.copy()
+        m_nan[300, 4] = np.nan
+        got = ctx.ef_block_features(chroma, m_nan, on)
+        want = oracle.ef_block_features(chroma, m_nan, on)               # (the oracle zeroes NaN like the reference)
+        np.testing.assert_allclose(got["mfccs"], want["mfccs"], atol=2e-6)
+        np.testing.assert_allclose(got["chromas"], want["chromas"], atol=2e-6)
+        m_inf = mfcc.copy()
+        m_inf[300, 4] = np.inf
+        with pytest.raises(ValueError, match=r"track 0 holds a non-finite value .* MFCCs"):
+            ctx.ef_block_features(chroma, m_inf, on)
+        c_nan = chroma.copy()
+        c_nan[17, 3] = np.nan
+        with pytest.raises(ValueError, match=r"track 0 holds a non-finite value .* raw chroma"):
+            ctx.ef_block_features(c_nan, mfcc, on)
+        tracks = [dict(chroma=chroma, mfcc=mfcc, onsets=on), dict(chroma=c_nan, mfcc=m_inf, onsets=on)]
+        with pytest.raises(ValueError, match=r"track 1 holds"):
+            ctx.ef_upload_raw_pool(tracks)
+        ctx.set_nonfinite_policy("zero")
+        ctx.ef_upload_raw_pool(tracks)
+        assert ctx.nonfinite_zeroed() == 2
+        z = dict(chroma=np.nan_to_num(c_nan, nan=0.0), mfcc=np.nan_to_num(m_inf, posinf=0.0), onsets=on)
+        a = ctx.earlyfusion_pairs(np.array([[0, 1]], np.int32))
+        ctx.set_nonfinite_policy("raise")
+        ctx.ef_upload_raw_pool([tracks[0], z])
+        assert np.array_equal(ctx.earlyfusion_pairs(np.array([[0, 1]], np.int32)), a)
+    finally:
+        ctx.close()
