@@ -243,3 +243,43 @@ print("ok nccl world of one")
 """ % (ROOT, str(tmp_path), str(_free_port()))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok nccl world of one" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_grid_run_ranks_simple_and_earlyfusion(ctx):
+    """The per-rank route (acx_grid_run into a device buffer, then acx_grid_scatter of the gathered buffers) for the
+    two algorithms whose grid scores stay on the device since round 3: SiMPle (pairs enumerated on the device, ordered
+    grid, diagonal tiles with i != j) and EarlyFusion (four planes, rectangles of pairs) on 3-rank plans, whole and
+    tile by tile, against the one-GPU grid."""
+    import torch
+    from acoss_amd import synth, _lib
+    rng = np.random.default_rng(9)
+    feats = [rng.random((int(rng.integers(30, 90)), 12)) for _ in range(23)]
+    feats = [f / np.linalg.norm(f, axis=1, keepdims=True) for f in feats]
+    offs = np.concatenate([[0], np.cumsum([len(f) for f in feats])]).astype(np.int64)
+    ctx.upload_pool_f64(np.concatenate(feats), offs)
+    tracks = synth.earlyfusion_set(11, seed=4, nb_range=(20, 70))
+    ctx.ef_upload_pool(tracks)
+    cases = [(_lib.ALGO_SIMPLE, False, _lib.SimpleParams(10, 1), 23, 1), (_lib.ALGO_SIMPLE, True, _lib.SimpleParams(10, 1), 23, 1),
+             (_lib.ALGO_EARLYFUSION, True, _lib.EfParams(0.1, 10), 11, 4)]
+    for algo, sym, params, n, w in cases:
+        want = [np.zeros((n, n), np.float32) for _ in range(w)]
+        ctx.pair_grid(algo, sym, params, want, mirror=sym)
+        lengths = ctx.pool_lengths(algo)
+        ws = 3
+        plan = _lib.grid_plan(lengths, algo, sym, world=ws, tile=4, want_tiles=True)
+        stride = int(plan["floats_per_rank"].max())
+        for sliced in (False, True):
+            bufs = []
+            for r in range(ws):
+                t = torch.full((stride,), -7.0, dtype=torch.float32, device="cuda:0")
+                torch.cuda.synchronize()
+                if sliced:
+                    for k in range(sum(1 for tl in plan["tiles"] if tl.rank == r)):
+                        ctx.grid_run(plan["spec"], params, r, t.data_ptr(), first=k, count=1)
+                else:
+                    ctx.grid_run(plan["spec"], params, r, t.data_ptr())
+                bufs.append(t.cpu().numpy())
+            D = [np.zeros((n, n), np.float32) for _ in range(w)]
+            _lib.grid_scatter(lengths, plan["spec"], np.concatenate(bufs), stride, D, mirror=sym)
+            for e in range(w):
+                assert np.array_equal(D[e], want[e]), (algo, sym, sliced, e)
