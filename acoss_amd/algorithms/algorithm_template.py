@@ -262,11 +262,13 @@ class CoverAlgorithm(object):
         return MR, MRR, MDR, MAP, tops
 
 
-def eval_statistics(D, cliques, topsidx=(1, 10, 100, 1000), row_block=1024):
+def eval_statistics(D, cliques, topsidx=(1, 10, 100, 1000), row_block=1024, count_max_clique=24):
     """Vectorised evaluation.  `cliques`: list of lists of track indices (dict insertion
     order).  Rows are reordered so that cliques are contiguous, largest first; the
-    diagonal is -inf; every row is sorted by descending score with a STABLE sort; for every
-    song of a clique of size >= 2 the 1-based ranks of its clique mates are collected."""
+    diagonal is -inf; every row is ranked by descending score in STABLE order (ties: the lower
+    index first); for every song of a clique of size >= 2 the 1-based ranks of its clique mates are
+    collected -- by counting for cliques of up to `count_max_clique` songs, by a stable argsort
+    otherwise (and for rows that hold NaN); both give the same numbers."""
     D = np.array(D, dtype=np.float32)
     N = D.shape[0]
     Ks = np.array([len(c) for c in cliques])
@@ -282,9 +284,38 @@ def eval_statistics(D, cliques, topsidx=(1, 10, 100, 1000), row_block=1024):
     n_eval = int(np.sum(Ks[Ks >= 2]))            # cliques are sorted: evaluated rows come first
     ranks = np.full(N, np.nan)
     allmap = np.full(N, np.nan)
+    col = np.arange(N, dtype=np.int64)
     for r0 in range(0, n_eval, row_block):
         r1 = min(n_eval, r0 + row_block)
-        srt = np.argsort(-D[r0:r1], axis=1, kind="stable")
+        Db = D[r0:r1]
+        Kb = row_K[r0:r1]
+        kmax = int(Kb.max())
+        if kmax <= count_max_clique and not np.isnan(Db).any():
+            # Ranks by COUNTING instead of sorting: only the positions of a row's clique mates are needed, and the
+            # position of column c in the stable descending order is 1 + #(cells above D[i, c]) + #(equal cells left of
+            # c).  2 (K - 1) passes over the block instead of an N log N sort per row (6 x faster at N = 15 000, K = 5).
+            rows_i = np.arange(r0, r1)
+            pos = np.full((r1 - r0, kmax), np.inf)
+            for m in range(kmax):
+                c = row_start[r0:r1] + m
+                ok = (m < Kb) & (c != rows_i)
+                if not ok.any():
+                    continue
+                cc = np.where(ok, c, 0)
+                v = Db[np.arange(r1 - r0), cc][:, None]
+                p = 1.0 + np.count_nonzero(Db > v, axis=1)
+                eq = Db == v
+                if np.count_nonzero(eq) > r1 - r0:               # ties beyond the cell itself: the left ones come first
+                    p = p + np.count_nonzero(eq & (col[None, :] < cc[:, None]), axis=1)
+                pos[ok, m] = p[ok]
+            pos.sort(axis=1)                                     # ascending; missing mates (+inf) last
+            nm = (Kb - 1)[:, None]
+            t = np.arange(1, kmax + 1, dtype=np.float64)[None, :]
+            contrib = np.where(t <= nm, t / pos, 0.0)
+            ranks[r0:r1] = pos[:, 0]
+            allmap[r0:r1] = contrib.sum(axis=1) / (Kb - 1)
+            continue
+        srt = np.argsort(-Db, axis=1, kind="stable")
         member = (srt >= row_start[r0:r1, None]) & (srt < (row_start[r0:r1] + row_K[r0:r1])[:, None])
         rr, kk = np.nonzero(member)              # row-major: per row, ascending rank position
         # the last member of every row is the song itself (-inf sorts last): drop it
