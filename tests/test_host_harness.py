@@ -372,3 +372,31 @@ def test_hdf5_feature_store_and_cache_branch(tmp_path, monkeypatch):
     monkeypatch.setitem(sys.modules, "h5py", None)
     with pytest.raises(IOError):
         featurestore.load_track(root + "a/t0.h5")
+
+
+def test_eval_statistics_counting_equals_sorting():
+    """getEvalStatistics ranks a row's clique mates by counting (cliques of up to 24 songs) or by a stable argsort
+    (larger cliques, rows with NaN): the same numbers, also under heavy ties -- Serra09 scores are multiples of 0.5."""
+    from acoss_amd.algorithms.algorithm_template import eval_statistics
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        n = int(rng.integers(20, 200))
+        sizes = []
+        while sum(sizes) < n:
+            sizes.append(int(rng.integers(1, 8)))
+        sizes[-1] -= sum(sizes) - n
+        perm = rng.permutation(n)
+        cl, p = [], 0
+        for k in [k for k in sizes if k > 0]:
+            cl.append([int(t) for t in perm[p:p + k]])
+            p += k
+        D = [rng.random((n, n)), rng.integers(0, 4, (n, n)), np.round(rng.random((n, n)) * 6) / 2][trial % 3].astype(np.float32)
+        a = eval_statistics(D, cl, (1, 10, 100))
+        b = eval_statistics(D, cl, (1, 10, 100), count_max_clique=0)
+        assert np.allclose(a[:4], b[:4], rtol=1e-13, atol=0) and np.array_equal(a[4], b[4]), (trial, a, b)
+    # against the oracle (golden-pinned to the reference's own evaluation) on a tie-free matrix
+    D = rng.random((60, 60)).astype(np.float32)
+    cl = [list(range(i, i + 4)) for i in range(0, 60, 4)]
+    a = eval_statistics(D, cl, (1, 10))
+    o = oracle.eval_statistics(D, cl, (1, 10))
+    assert np.allclose(a[:4], o[:4], rtol=1e-12) and np.array_equal(a[4], o[4])
