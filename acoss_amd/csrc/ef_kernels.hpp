@@ -788,10 +788,22 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
     typedef __attribute__((address_space(3))) void lds_void;
     const unsigned fh_addr = (unsigned)(uintptr_t)(lds_void *)(&fhist[wave][0]);
     // k-th smallest (0-based) of the row: one histogram pass, generic narrowing when that cannot decide
-    auto kth = [&](const float (&xx)[NX], int k) -> float {
+    // Small ranks (the row-kappa threshold sits at rank ~ 0.1 n, the neighbourhood mean at rank 9) first try the
+    // pivot-filtered pass of the band kernel (wave_select_pivot): only the cells below a pivot near the 0.2 quantile
+    // enter the histogram, under an exec mask.  The cross-similarity values of a row crowd into a few bins (counters of
+    // round 3: 69 % of this kernel's LDS cycles were bank / same-address conflicts of the unfiltered atomics); the
+    // filtered pass issues an eighth of them.  It gives up (too few cells below the pivot, ties, short rows) and the
+    // unfiltered pass takes over: all paths are exact.
+    bool lane_has_data = false, group_full = false;        // set once the row is loaded (below)
+    auto kth = [&](const float (&xx)[NX], int k, int n_) -> float {
         *reinterpret_cast<uint4 *>(&fhist[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_fence();
         float lo, hi;
+        if ((k + 2) * 6 <= n_) {
+            if (wave_select_pivot<NX, 256, 2>(xx, k, false, fh_addr, cand[wave], lane, lo, hi, lane_has_data, group_full, 0.15f)) return lo;
+            *reinterpret_cast<uint4 *>(&fhist[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+            wave_lds_fence();
+        }
         if (wave_select_fast<NX, 256>(xx, k, false, fh_addr, cand[wave], lane, lo, hi)) return lo;
         return wave_select_regs<NX, GB>(xx, k, hist[wave], cand[wave], &counter[wave], lane, false).value;
     };
@@ -816,6 +828,19 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         x[4 * q + 2] = (j + 2 < n) ? t.z : INF;
         x[4 * q + 3] = (j + 3 < n) ? t.w : INF;
     }
+    {   // which lanes / lane pairs hold cells: a pair of lanes (16 slots) takes part in the pivot estimate when at
+        // least three quarters of the slots it can have in a row of this length are cells (a pair with few cells has a large
+        // minimum: a pivot that filters nothing)
+        int cells = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int j = 256 * q + 4 * lane;
+            cells += j + 3 < n ? 4 : (j < n ? n - j : 0);
+        }
+        lane_has_data = cells > 0;
+        const int cap = 8 * ((n + 255) / 256);                 // slots of a lane pair that CAN be cells in a row of n (4 per lane and 256 columns)
+        group_full = cells + __shfl_xor(cells, 1, 64) >= cap - cap / 4;
+    }
     float *S = stat + P.offS + (mode == 2 ? 3 * ef_s_stride(P) : s * ef_s_stride(P));
     if (mode != 1) {
         const int kb = P.kbin;
@@ -824,7 +849,7 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         if (kb <= 0) t = -INF;                         // no neighbours: empty rows
         else if (kb >= n) t = INF;
         else {
-            t = kth(x, kb - 1);
+            t = kth(x, kb - 1, n);
             // cells equal to t: if there are more than the row may still take, find the column of
             // the last one taken (column of x[4 q + e] = 256 q + 4 lane + e)
             int lt = 0, eq[NQ];
@@ -873,7 +898,7 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
     }
     if (mode != 2) {
         const int kk = kw < n ? kw : n;
-        const float vk = kth(x, kk - 1);
+        const float vk = kth(x, kk - 1, n);
         const float m = mean_k_smallest(x, kk, vk, lane);
         if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
     }
