@@ -255,11 +255,14 @@ __global__ __launch_bounds__(256) void ef_gemm_kernel(const float *__restrict__ 
 // eight v_mfma_f32_16x16x4_f32 cost 8 x 32 -- and unlike the f32 MFMA the bf16 MFMA leaves VALU / LDS issue
 // of the other waves alone (scripts/ubench/mfma_valu_overlap.hip).  Same tiling as ef_gemm_kernel
 // (128 x 128 per workgroup) but 8 waves of 32 x 64 cells, k in blocks of 32: a lane's MFMA operand is 8
-// consecutive k of one row = one 16-byte LDS read (row pitch 80 bytes: conflict free), 18 operand reads feed 48 MFMAs.
+// consecutive k of one row = one 16-byte LDS read (XOR-swizzled 64-byte rows: conflict free), 18 operand reads feed 48 MFMAs.
 // Layout of the split pool: [block][k / 32][term 0..2][k % 32] bf16, Kp = K rounded up to 32, zeros behind K.
 // ------------------------------------------------------------------------------------
 constexpr int EFB_BK = 32;
-constexpr int EFB_LP = 40;     // LDS row pitch in bf16 elements (80 bytes)
+constexpr int EFB_LP = 32;     // LDS row pitch in bf16 elements (64 bytes, no padding): the four 16-byte pieces of a row are
+                               // stored XOR-swizzled, piece ^ ((row >> 2) & 3) -- the staging stores (4 rows x 4 pieces per 16 lanes)
+                               // and the operand reads (16 rows x 1 piece per 16 lanes) are then both bank-conflict free (round 3:
+                               // with a padded pitch of 80 bytes half of the kernel's LDS cycles were conflicts of the stores)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned ef_bf16_rne(float x)
@@ -339,7 +342,8 @@ __global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         ap += 3 * EFB_BK;
         bp += 3 * EFB_BK;
     };
-    unsigned short *as0 = As + srow * EFB_LP + sk, *bs0 = Bs + srow * EFB_LP + sk;
+    const int skl = ((tid & 3) ^ ((srow >> 2) & 3)) * 8;             // swizzled piece of the row in LDS
+    unsigned short *as0 = As + srow * EFB_LP + skl, *bs0 = Bs + srow * EFB_LP + skl;
     auto lstore = [&]() {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -347,8 +351,9 @@ __global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             *reinterpret_cast<u32x4 *>(bs0 + t * EF_TILE * EFB_LP) = rb[t];
         }
     };
-    const unsigned short *aop = As + (32 * wr + lr) * EFB_LP + 8 * lk;
-    const unsigned short *bop = Bs + (64 * wc + lr) * EFB_LP + 8 * lk;
+    const int lks = lk ^ ((lr >> 2) & 3);                             // (rows 16 a + lr: (row >> 2) & 3 == (lr >> 2) & 3)
+    const unsigned short *aop = As + (32 * wr + lr) * EFB_LP + 8 * lks;
+    const unsigned short *bop = Bs + (64 * wc + lr) * EFB_LP + 8 * lks;
     gload();
     for (int k0 = 0; k0 < Kp; k0 += EFB_BK) {
         lstore();
@@ -485,7 +490,8 @@ __global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             bp += 3 * EFB_BK;
         }
     };
-    unsigned short *as0 = As + srow * EFB_LP + sk, *bs0 = Bs + srow * EFB_LP + sk;
+    const int skl = ((tid & 3) ^ ((srow >> 2) & 3)) * 8;             // swizzled piece of the row in LDS
+    unsigned short *as0 = As + srow * EFB_LP + skl, *bs0 = Bs + srow * EFB_LP + skl;
     auto lstore = [&]() {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -493,8 +499,9 @@ __global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             *reinterpret_cast<u32x4 *>(bs0 + q * EF_TILE * EFB_LP) = rb[q];
         }
     };
-    const unsigned short *aop = As + (32 * wr + lr) * EFB_LP + 8 * lk;
-    const unsigned short *bop = Bs + (64 * wc + lr) * EFB_LP + 8 * lk;
+    const int lks = lk ^ ((lr >> 2) & 3);                             // (rows 16 a + lr: (row >> 2) & 3 == (lr >> 2) & 3)
+    const unsigned short *aop = As + (32 * wr + lr) * EFB_LP + 8 * lks;
+    const unsigned short *bop = Bs + (64 * wc + lr) * EFB_LP + 8 * lks;
     gload();
     for (int k0 = 0; k0 < Kp; k0 += EFB_BK) {
         lstore();
