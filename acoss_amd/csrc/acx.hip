@@ -1556,7 +1556,7 @@ int acx_simple_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, int32_t sslen,
             maxn = std::max(maxn, n);
         }
     }
-    const size_t smem = 64 + sizeof(double) * 3 * (size_t)maxn;        // per wave: two edge rows + the profile keys
+    const size_t smem = 64 + sizeof(double) * (2 * (size_t)maxn + (size_t)maxn / 48 + 4);   // per wave: the hand-over row + the profile keys
     int rcw = ensure_winnorm(c, sslen);
     if (rcw != ACX_OK) return rcw;
     const int64_t chunk = 1 << 22;
@@ -2214,7 +2214,7 @@ static int run_simple_tiles(acx_ctx *c, const std::vector<acx_grid_tile> &mine, 
             }
         }
     }
-    const size_t smem = 64 + sizeof(double) * 3 * (size_t)maxn;
+    const size_t smem = 64 + sizeof(double) * (2 * (size_t)maxn + (size_t)maxn / 48 + 4);
     int rc = ensure_winnorm(c, sslen);
     if (rc != ACX_OK) return rc;
     const int64_t CHUNK = (int64_t)1 << 22;

@@ -22,14 +22,14 @@
 //   * the row minimum is a running v_min_f64 in the lane's own register -- no atomics, no reduction;
 //   * the median of the profile is an exact binary search on order-preserving 64-bit keys, counted
 //     with ballots.
-// LDS per pair: 8 (2 nb + na) bytes -- tracks of thousands of pooled frames fit.
+// LDS per pair: 8 (nb + na + row groups) bytes -- tracks of thousands of pooled frames fit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace acx {
 
-constexpr int SIMPLE_MAXN = 6000;    // pooled frames per track (LDS: 8 (2 nb + na) + 64 bytes <= 160 KB)
+constexpr int SIMPLE_MAXN = 6000;    // pooled frames per track (LDS per wave: 8 (nb + na + row groups) + 64 bytes = 97 KB at 6000)
 constexpr int SIMPLE_MAXL = 16;      // subsequence length
 
 __device__ __forceinline__ unsigned long long f64_key(double v)
@@ -105,9 +105,15 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *_
     const int64_t oa = toff[ti], ob = toff[tj];
     const int na = (int)(toff[ti + 1] - oa), nb = (int)(toff[tj + 1] - ob);
     const int ma = na - L + 1, mb = nb - L + 1;      // profile length, columns
-    double *edge0 = reinterpret_cast<double *>(smem_raw);       // mb: dot of the last lane, even row groups (and row 0 before the sweep)
-    double *edge1 = edge0 + mb;                                  // mb: odd row groups
-    unsigned long long *mp = reinterpret_cast<unsigned long long *>(edge1 + mb);   // ma keys of the profile
+    // E: the dot products a row group hands to the next one (its last lane's value of every column; before group 0:
+    // row 0 in full).  ONE array serves all groups: group g reads column c of its predecessor at slot c + eoff and
+    // stores its own column c one slot lower, at c + eoff - 1 -- the slot it has just read (column c - 1's) --, and
+    // the next group reads with eoff - 1.  (Two alternating arrays cost a third more LDS per wave, and LDS is what
+    // limits this kernel to 6 waves per SIMD; with one array 8 fit.)
+    constexpr int STRIDE_ = 64 - L;
+    const int ngroups_ = (ma + STRIDE_ - 1) / STRIDE_;
+    double *E = reinterpret_cast<double *>(smem_raw);            // mb + ngroups + 1 slots
+    unsigned long long *mp = reinterpret_cast<unsigned long long *>(E + mb + ngroups_ + 1);   // ma keys of the profile
 
     // ---- OTI (simple_silva.py:45-54): v[s] = <pa, roll(pb, s)>; np.argsort(v)[-1]  (wave-uniform)
     int shift = 0;
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *_
         return acc;
     };
 
-    // ---- row 0 in full: top[b] = sum_k <A[k], B'[b + k]>  (lanes over b), kept in edge1 until group 0 is done
+    // ---- row 0 in full: top[b] = sum_k <A[k], B'[b + k]>  (lanes over b), kept in E (slots b + ngroups) for group 0
     for (int b = lane; b < mb; b += 64) {
         double acc = 0.0;
 #pragma unroll
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *_
             load_a(k, ak);                                   // wave-uniform address: scalar loads
             acc += dot12(ak, gb + (size_t)(b + k) * 12);
         }
-        edge1[b] = acc;
+        E[b + ngroups_] = acc;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -175,8 +181,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *_
         const int ac = a < 0 ? 0 : (a > ma - 1 ? ma - 1 : a);   // clamp: results of feeder / idle lanes are dropped
         int fa = a + L - 1;                                     // frame entering the window of row a
         fa = fa < 0 ? 0 : (fa > na - 1 ? na - 1 : fa);
-        const double *ein = (g & 1) ? edge0 : edge1;            // written by group g - 1 (group 0: the row-0 values)
-        double *eout = (g & 1) ? edge1 : edge0;
+        const int eoff = ngroups - g;                           // this group reads column c of its predecessor at E[c + eoff]
         const bool more = g + 1 < ngroups;
         double An[12];
         load_a(fa, An);
@@ -191,9 +196,9 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *_
                 dot += dot12(ak, gb + (size_t)k * 12);
             }
         }
-        if (g == 0 && lane == L) dot = ein[0];
+        if (g == 0 && lane == L) dot = E[eoff];
         double mn = (a2 + wb[0]) - 2.0 * dot;
-        if (more && lane == 63) eout[0] = dot;
+        if (more && lane == 63) E[eoff - 1] = dot;
         // ring[b % L] = the product leaving at step b.  Steps 1 .. L need the products that "entered" at steps
         // 1 - L .. 0, i.e. with the frames B'[0 .. L - 1]: computed here, before the sweep.
         double ring[L];
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *_
                 if (b < mb) {                                       // wave-uniform
                     const double w = wb[b];
                     double prev = __shfl_up(dot, 1, 64);            // dot[a - 1][b - 1] of the neighbour lane
-                    const double e = ein[b - 1 + (g == 0 ? 1 : 0)]; // group 0: row 0's own value top[b]; else dot[a - 1][b - 1] of the last lane
+                    const double e = E[b - 1 + (g == 0 ? 1 : 0) + eoff];   // group 0: row 0's own value top[b]; else dot[a - 1][b - 1] of the last lane
                     double gnew = 0.0;
 #pragma unroll
                     for (int c = 0; c < 12; ++c) gnew = __builtin_fma(An[c], bn[(1 + j) & 1][c], gnew);
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *_
                     dot = nd;
                     const double dist = (a2 + w) - 2.0 * dot;
                     mn = dist < mn ? dist : mn;
-                    if (more && lane == 63) eout[b] = dot;
+                    if (more && lane == 63) E[b + eoff - 1] = dot;        // (slot of column b - 1, read above)
                 }
             }
         }
