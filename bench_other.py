@@ -89,7 +89,7 @@ def simple_leg(ctx, steps=3, warmup=1, n=512, cpu_pairs=64):
         "data": "synthetic",
         "config": {"workload": "configs[3] per-track shape: %d tracks, all %d ordered pairs per step through acx_grid_run "
                                "(128 x 128 tiles, scores scattered into a device buffer)" % (n, npairs)},
-        "roofline": {"bound": "valu-f64 (the wave waits on scalar-cache misses of the streamed frames)", "kernel": "simple_kernel",
+        "roofline": {"bound": "valu-f64 issue (~ 0.6 - 0.7 busy) next to the LDS permutes of the sliding dot product (0.46 busy); not the scalar cache: one second track for every pair runs at the same rate (scripts/simple_probe2.py)", "kernel": "simple_kernel",
                      "achieved": round(executed / (kms * 1e-3) / 1e12, 2), "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(executed / (kms * 1e-3) / 1e12 / F64_VALU_PEAK_TF, 4), "traffic": None,
                      "kernel_ms_per_step": round(kms, 3), "executed_flop_per_cell": round(30.0 * 64.0 / 54.0, 2),
