@@ -196,6 +196,16 @@ def launch_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def json_only_stdout():
+    """Keep the process's stdout for the ONE JSON line: everything else that writes to fd 1 from here on -- RCCL's
+    version banner (printf from librccl at communicator creation), Python prints of imported modules -- goes to
+    stderr.  Returns the stream the JSON line is written to."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(keep, "w")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,6 +223,7 @@ def main():
         raise SystemExit("bench: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    out = json_only_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -263,7 +274,7 @@ def main():
         if rank == 0:
             print(json.dumps({"plan_only": True, "n_gpus": world, "ranks_seen": seen, "tiles_per_rank": per_rank,
                               "tiles": int(plan["n_tiles"]), "tile": TILE, "pool_tracks": args.tracks,
-                              "cost_per_rank": [float(c) for c in plan["cost_per_rank"]]}))
+                              "cost_per_rank": [float(c) for c in plan["cost_per_rank"]]}), file=out, flush=True)
         return
 
     frames, offsets = make_pool(args.tracks, T_FRAMES)
@@ -277,11 +288,17 @@ def main():
     # ACX_BENCH_BACKEND=gloo (development): functional run of the N > 1 path on a box with fewer
     # GPUs than ranks -- ranks share the devices and the gather goes through host memory
     backend = os.environ.get("ACX_BENCH_BACKEND", "nccl")
+    # ACX_BENCH_FORCE_COLLECTIVE=1: a world of ONE still forms its process group and runs every collective of the
+    # N > 1 step (RCCL all_gather_into_tensor, device barrier, all-reduce) -- the multi-GPU code path on a 1-GPU box
+    collective = world > 1 or os.environ.get("ACX_BENCH_FORCE_COLLECTIVE") == "1"
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
@@ -291,7 +308,7 @@ def main():
     params = _lib.serra09_params()
     slice_floats = max(sum(t.rows * t.cols for t in mine[k:k + TILES_PER_STEP]) for k in range(0, nslices * TILES_PER_STEP, TILES_PER_STEP))
     local = torch.zeros(slice_floats, dtype=torch.float32, device=dev)
-    gathered = torch.zeros(world * slice_floats, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.zeros(world * slice_floats, dtype=torch.float32, device=dev) if collective else None
     torch.cuda.synchronize()
     pairs_per_step = []
 
@@ -299,7 +316,7 @@ def main():
         k, tiles = slice_of(s)
         # acx_grid_run writes tile t at d_scores + t.offset: rebase so that the slice starts at local[0]
         ctx.grid_run(spec, params, rank, local.data_ptr() - 4 * tiles[0].offset, first=k, count=TILES_PER_STEP)
-        if world > 1:                               # the one collective of the path, device to device
+        if collective:                              # the one collective of the path, device to device
             if backend == "nccl":
                 dist.all_gather_into_tensor(gathered, local)
                 # the next step's kernels (libacx's own stream) overwrite `local`: the host waits for the collective
@@ -310,7 +327,7 @@ def main():
         return sum((t.rows * (t.rows - 1)) // 2 if t.diagonal else t.rows * t.cols for t in tiles)
 
     def fence():
-        if world > 1:
+        if collective:
             if backend == "nccl":
                 dist.barrier(device_ids=[local_rank])
             else:
@@ -328,7 +345,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     my_pairs = float(sum(pairs_per_step))
-    if world > 1:
+    if collective:
         cdev = dev if backend == "nccl" else torch.device("cpu")
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -338,7 +355,7 @@ def main():
         total_pairs = float(pp.item())
     else:
         total_pairs = my_pairs
-    ranks_seen = dist.get_world_size() if world > 1 else 1        # what the collective actually spanned
+    ranks_seen = dist.get_world_size() if collective else 1        # what the collective actually spanned
     prof = ctx.profile()
 
     if rank == 0:
@@ -395,7 +412,7 @@ def main():
                 raise SystemExit("bench: GPU scores differ from the CPU oracle on the sampled pairs")
         line = {
             "metric": "track-pairs/sec on N x N Serra09 Qmax (HPCP, T=2000)",
-            "value": round(value, 1), "unit": "track-pairs/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
+            "value": round(value, 1), "unit": "track-pairs/s", "n_gpus": world, "ranks_seen": ranks_seen, "collectives": (backend if collective else None), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -419,9 +436,9 @@ def main():
                     line["other"][key] = leg(ctx, steps=2, warmup=1)
                 except Exception as e:            # a failing companion leg must not take the headline line with it
                     line["other"][key] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(line))
+        print(json.dumps(line), file=out, flush=True)
     ctx.close()
-    if world > 1:
+    if collective:
         fence()
         dist.destroy_process_group()
 
