@@ -108,6 +108,8 @@ struct acx_ctx {
     acx::EfSegRect *d_rects = nullptr; size_t rects_cap = 0;
     int32_t *d_ptab = nullptr;         size_t ptab_cap = 0;
     acx::EfSegWg *d_segw = nullptr;    size_t segw_cap = 0;
+    acx::EfSegWg *d_segw2 = nullptr;   size_t segw2_cap = 0;
+    bool ef_rect_attr = false;
     // scratch (grow-only)
     float *d_scratch = nullptr; size_t scratch_cap = 0;   // floats
     float *d_thr = nullptr;     size_t thr_cap = 0;
@@ -728,13 +730,14 @@ struct SegBatch {
     std::vector<acx::EfSegGroup> rowg, colg;
     std::vector<acx::EfSegRect> rects;
     std::vector<int32_t> ptab;
-    std::vector<acx::EfSegWg> wgs;
+    std::vector<acx::EfSegWg> wgs;          // workgroup tiles of 8 x 8 groups (128 x 128 cells)
+    std::vector<acx::EfSegWg> wgs2;         // workgroup tiles of 16 x 8 groups (256 x 128 cells: ef_gemm_rect_bf16x3_kernel)
 };
 void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_t> &efoff, int n_tracks, SegBatch &sb,
                     std::vector<int32_t> &qslot, std::vector<int32_t> &rslot)
 {
-    sb.rowg.clear(); sb.colg.clear(); sb.rects.clear(); sb.ptab.clear(); sb.wgs.clear();
-    std::vector<uint8_t> mark;
+    sb.rowg.clear(); sb.colg.clear(); sb.rects.clear(); sb.ptab.clear(); sb.wgs.clear(); sb.wgs2.clear();
+    std::vector<uint8_t> mark, mark2;
     std::vector<int32_t> gfirst_q, gfirst_r;      // first group of every slot (+ one past the last)
     qslot.assign((size_t)n_tracks, -1);
     rslot.assign((size_t)n_tracks, -1);
@@ -770,19 +773,27 @@ void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_
         sb.ptab.resize(sb.ptab.size() + qs.size() * rs.size(), -1);
         // workgroup tiles (8 x 8 groups) that hold at least one pair, row-major: neighbours share their row operand
         const int tiles_y = (R.ng + 7) / 8, tiles_x = (R.nh + 7) / 8;
+        const int tiles_y2 = (R.ng + 15) / 16;
         mark.assign((size_t)tiles_y * tiles_x, 0);
+        mark2.assign((size_t)tiles_y2 * tiles_x, 0);
         for (const auto &m : members) {
             const int a = m.second / SEG_TRACKS, b = m.second % SEG_TRACKS;
             sb.ptab[(size_t)R.ptab0 + (size_t)a * R.ncols + b] = m.first;
             seen[(size_t)m.second] = 0;
             if (gfirst_q[a + 1] == gfirst_q[a] || gfirst_r[b + 1] == gfirst_r[b]) continue;     // (a track without blocks)
             for (int ty = gfirst_q[a] / 8; ty <= (gfirst_q[a + 1] - 1) / 8; ++ty)
-                for (int tx = gfirst_r[b] / 8; tx <= (gfirst_r[b + 1] - 1) / 8; ++tx) mark[(size_t)ty * tiles_x + tx] = 1;
+                for (int tx = gfirst_r[b] / 8; tx <= (gfirst_r[b + 1] - 1) / 8; ++tx) {
+                    mark[(size_t)ty * tiles_x + tx] = 1;
+                    mark2[(size_t)(ty / 2) * tiles_x + tx] = 1;
+                }
         }
         const int32_t rid = (int32_t)sb.rects.size();
         for (int ty = 0; ty < tiles_y; ++ty)
             for (int tx = 0; tx < tiles_x; ++tx)
                 if (mark[(size_t)ty * tiles_x + tx]) sb.wgs.push_back(acx::EfSegWg{rid, ty, tx, 0});
+        for (int ty = 0; ty < tiles_y2; ++ty)
+            for (int tx = 0; tx < tiles_x; ++tx)
+                if (mark2[(size_t)ty * tiles_x + tx]) sb.wgs2.push_back(acx::EfSegWg{rid, ty, tx, 0});
         sb.rects.push_back(R);
         for (int32_t t : qs) qslot[(size_t)t] = -1;
         for (int32_t t : rs) rslot[(size_t)t] = -1;
@@ -910,10 +921,23 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                         ACX_HIP(c, hipMemcpyAsync(c->d_segw, seg.wgs.data(), sizeof(acx::EfSegWg) * seg.wgs.size(), hipMemcpyHostToDevice, c->stream));
                         // (the copies above are staged before they return: `seg` may be rebuilt for the next batch)
                         if (seg.wgs.size() > 0x7fffffffu) return fail(c, ACX_ERR_UNSUPPORTED, "earlyfusion: batch too large for one launch");
-                        if (!seg.wgs.empty())
+                        static const bool rect256 = !(getenv("ACX_EF_RECT256") && atoi(getenv("ACX_EF_RECT256")) == 0);    // (A/B switch)
+                        if (!seg.wgs.empty() && !rect256)
                             hipLaunchKernelGGL(acx::ef_gemm_seg_bf16x3_kernel, dim3((unsigned)seg.wgs.size(), 1, 2), dim3(acx::EFB_THREADS), 0, c->stream,
                                                c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd, c->d_rects, c->d_segw,
                                                c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1]);
+                        if (!seg.wgs2.empty() && rect256) {
+                            if ((rc = ensure(c, c->d_segw2, c->segw2_cap, seg.wgs2.size())) != ACX_OK) return rc;
+                            ACX_HIP(c, hipMemcpyAsync(c->d_segw2, seg.wgs2.data(), sizeof(acx::EfSegWg) * seg.wgs2.size(), hipMemcpyHostToDevice, c->stream));
+                            if (!c->ef_rect_attr) {
+                                ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                                c->ef_rect_attr = true;
+                            }
+                            hipLaunchKernelGGL(acx::ef_gemm_rect_bf16x3_kernel, dim3((unsigned)seg.wgs2.size(), 1, 2), dim3(acx::EFR_THREADS),
+                                               acx::EFR_LDS_BYTES, c->stream, c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd,
+                                               c->d_rects, c->d_segw2, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1]);
+                        }
                         // chroma over the same rectangles (f32 MFMA; the pair's OTI roll applied when the operand is read)
                         if (!seg.wgs.empty())
                             hipLaunchKernelGGL(acx::ef_gemm_seg_f32_kernel, dim3((unsigned)seg.wgs.size()), dim3(256), 0, c->stream,
@@ -1122,9 +1146,22 @@ void acx_destroy(acx_ctx *c)
     if (c->d_rects) (void)hipFree(c->d_rects);
     if (c->d_ptab) (void)hipFree(c->d_ptab);
     if (c->d_segw) (void)hipFree(c->d_segw);
+    if (c->d_segw2) (void)hipFree(c->d_segw2);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+#ifdef ACX_EF_TIMING
+extern "C" int acx_ef_clk(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(acx::g_ef_clk), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(acx::g_ef_clk), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 const char *acx_last_error(const acx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
