@@ -428,9 +428,11 @@ class Context(object):
         self._check(self._L.acx_ef_pool_tracks(self._h, int(first), int(count), *[k[0] for k in keep]))
 
     def set_ef_gemm(self, mode):
-        """'bf16x3' (default: dense rectangles of pairs), 'f32', or 'bf16x3_pairwise' (one matrix at a time, same bits
-        as 'bf16x3'): EarlyFusion's two Euclidean GEMMs (acx_set_ef_gemm)."""
-        self._check(self._L.acx_set_ef_gemm(self._h, {"bf16x3": 0, "f32": 1, "bf16x3_pairwise": 2}.get(mode, mode)))
+        """'bf16x3' (default: dense rectangles of pairs, all three matrices on the bf16 pipe), 'f32', 'bf16x3_pairwise'
+        (one matrix at a time: mfccs / ssms with the default's bits, chroma f32) or 'bf16x3_chroma_f32' (rectangles,
+        chroma f32): EarlyFusion's cross-similarity GEMMs (acx_set_ef_gemm)."""
+        self._check(self._L.acx_set_ef_gemm(self._h, {"bf16x3": 0, "f32": 1, "bf16x3_pairwise": 2,
+                                                      "bf16x3_chroma_f32": 3}.get(mode, mode)))
 
     def ef_pool_end(self):
         self._check(self._L.acx_ef_pool_end(self._h))

@@ -91,8 +91,8 @@ struct acx_ctx {
     double *d_out64 = nullptr;  size_t out64_cap = 0;
     // EarlyFusion pool
     float *d_ef[3] = {nullptr, nullptr, nullptr};
-    unsigned short *d_efs[2] = {nullptr, nullptr};   // mfcc / ssm block features as three-term bf16 splits (ef_gemm_bf16x3_kernel)
-    int ef_kp[2] = {0, 0};                            // their row length (K rounded up to 32)
+    unsigned short *d_efs[3] = {nullptr, nullptr, nullptr};   // mfcc / ssm / chroma block features as three-term bf16 splits
+    int ef_kp[3] = {0, 0, 0};                         // their row length (K rounded up to 32); chroma: bin-major, 0 = no split (f32 kernel)
     float *d_efn[2] = {nullptr, nullptr};
     double *d_efmed = nullptr;
     int64_t *d_efoff = nullptr;
@@ -102,13 +102,14 @@ struct acx_ctx {
     int32_t ef_open = 0;                              // > 0: a pool of that many tracks is being filled (acx_ef_pool_begin .. _end)
     int32_t ef_dims[3] = {0, 0, 0};
     acx::EfPair *d_efpd = nullptr; size_t efpd_cap = 0;
-    // rectangles of the segment GEMM (ef_gemm_seg_bf16x3_kernel): row / column groups, rectangles, pair tables
+    // rectangles of the rectangle GEMM (ef_gemm_rect_bf16x3_kernel): row / column groups, rectangles, pair tables
     acx::EfSegGroup *d_segr = nullptr; size_t segr_cap = 0;
     acx::EfSegGroup *d_segc = nullptr; size_t segc_cap = 0;
     acx::EfSegRect *d_rects = nullptr; size_t rects_cap = 0;
     int32_t *d_ptab = nullptr;         size_t ptab_cap = 0;
     acx::EfSegWg *d_segw = nullptr;    size_t segw_cap = 0;
     acx::EfSegWg *d_segw2 = nullptr;   size_t segw2_cap = 0;
+    acx::EfSegWg *d_segw3 = nullptr;   size_t segw3_cap = 0;
     bool ef_rect_attr = false;
     // scratch (grow-only)
     float *d_scratch = nullptr; size_t scratch_cap = 0;   // floats
@@ -730,14 +731,17 @@ struct SegBatch {
     std::vector<acx::EfSegGroup> rowg, colg;
     std::vector<acx::EfSegRect> rects;
     std::vector<int32_t> ptab;
-    std::vector<acx::EfSegWg> wgs;          // workgroup tiles of 8 x 8 groups (128 x 128 cells)
-    std::vector<acx::EfSegWg> wgs2;         // workgroup tiles of 16 x 8 groups (256 x 128 cells: ef_gemm_rect_bf16x3_kernel)
+    std::vector<acx::EfSegWg> wgs;          // workgroup tiles of 8 x 8 groups (128 x 128 cells: ef_gemm_seg_f32_kernel)
+    std::vector<acx::EfSegWg> wgs2;         // tiles of 16 x 8 groups (256 x 128 cells: ef_gemm_rect_bf16x3_kernel<0>): ty, first column group, groups
+    std::vector<acx::EfSegWg> wgs3;         // the same for chroma (<1>): the columns of a tile stop at the end of their reference track
 };
 void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_t> &efoff, int n_tracks, SegBatch &sb,
                     std::vector<int32_t> &qslot, std::vector<int32_t> &rslot)
 {
-    sb.rowg.clear(); sb.colg.clear(); sb.rects.clear(); sb.ptab.clear(); sb.wgs.clear(); sb.wgs2.clear();
-    std::vector<uint8_t> mark, mark2;
+    sb.rowg.clear(); sb.colg.clear(); sb.rects.clear(); sb.ptab.clear(); sb.wgs.clear(); sb.wgs2.clear(); sb.wgs3.clear();
+    std::vector<uint8_t> mark, mark2, mark3;
+    std::vector<int32_t> cfirst;                  // chroma: first column chunk of every reference slot (+ one past the last)
+    std::vector<std::pair<int32_t, int32_t>> cchunk;     // (first group, groups) of every column chunk
     std::vector<int32_t> gfirst_q, gfirst_r;      // first group of every slot (+ one past the last)
     qslot.assign((size_t)n_tracks, -1);
     rslot.assign((size_t)n_tracks, -1);
@@ -776,6 +780,14 @@ void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_
         const int tiles_y2 = (R.ng + 15) / 16;
         mark.assign((size_t)tiles_y * tiles_x, 0);
         mark2.assign((size_t)tiles_y2 * tiles_x, 0);
+        cfirst.clear(); cchunk.clear();
+        for (size_t sl = 0; sl < rs.size(); ++sl) {
+            cfirst.push_back((int32_t)cchunk.size());
+            for (int g = gfirst_r[sl]; g < gfirst_r[sl + 1]; g += 8) cchunk.push_back({g, std::min(8, gfirst_r[sl + 1] - g)});
+        }
+        cfirst.push_back((int32_t)cchunk.size());
+        const int ncc = (int)cchunk.size();
+        mark3.assign((size_t)tiles_y2 * ncc, 0);
         for (const auto &m : members) {
             const int a = m.second / SEG_TRACKS, b = m.second % SEG_TRACKS;
             sb.ptab[(size_t)R.ptab0 + (size_t)a * R.ncols + b] = m.first;
@@ -786,6 +798,8 @@ void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_
                     mark[(size_t)ty * tiles_x + tx] = 1;
                     mark2[(size_t)(ty / 2) * tiles_x + tx] = 1;
                 }
+            for (int ty = gfirst_q[a] / 16; ty <= (gfirst_q[a + 1] - 1) / 16; ++ty)
+                for (int ci = cfirst[b]; ci < cfirst[b + 1]; ++ci) mark3[(size_t)ty * ncc + ci] = 1;
         }
         const int32_t rid = (int32_t)sb.rects.size();
         for (int ty = 0; ty < tiles_y; ++ty)
@@ -793,7 +807,10 @@ void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_
                 if (mark[(size_t)ty * tiles_x + tx]) sb.wgs.push_back(acx::EfSegWg{rid, ty, tx, 0});
         for (int ty = 0; ty < tiles_y2; ++ty)
             for (int tx = 0; tx < tiles_x; ++tx)
-                if (mark2[(size_t)ty * tiles_x + tx]) sb.wgs2.push_back(acx::EfSegWg{rid, ty, tx, 0});
+                if (mark2[(size_t)ty * tiles_x + tx]) sb.wgs2.push_back(acx::EfSegWg{rid, ty, 8 * tx, std::min(8, R.nh - 8 * tx)});
+        for (int ty = 0; ty < tiles_y2; ++ty)
+            for (int ci = 0; ci < ncc; ++ci)
+                if (mark3[(size_t)ty * ncc + ci]) sb.wgs3.push_back(acx::EfSegWg{rid, ty, cchunk[(size_t)ci].first, cchunk[(size_t)ci].second});
         sb.rects.push_back(R);
         for (int32_t t : qs) qslot[(size_t)t] = -1;
         for (int32_t t : rs) rslot[(size_t)t] = -1;
@@ -907,7 +924,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                                            c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
                                            c->d_scratch, c->ef_kp[0], c->ef_kp[1], tiles_x);
                     } else {
-                        // mfcc, ssm: the pairs of the batch laid out as dense rectangles (ef_gemm_seg_bf16x3_kernel)
+                        // the pairs of the batch laid out as dense rectangles (ef_gemm_rect_bf16x3_kernel)
                         ef_build_rects(pd, c->h_efoff, c->ef_ntracks, seg, qslot, rslot);
                         if ((rc = ensure(c, c->d_segr, c->segr_cap, seg.rowg.size())) != ACX_OK) return rc;
                         if ((rc = ensure(c, c->d_segc, c->segc_cap, seg.colg.size())) != ACX_OK) return rc;
@@ -917,32 +934,40 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                         ACX_HIP(c, hipMemcpyAsync(c->d_segc, seg.colg.data(), sizeof(acx::EfSegGroup) * seg.colg.size(), hipMemcpyHostToDevice, c->stream));
                         ACX_HIP(c, hipMemcpyAsync(c->d_rects, seg.rects.data(), sizeof(acx::EfSegRect) * seg.rects.size(), hipMemcpyHostToDevice, c->stream));
                         ACX_HIP(c, hipMemcpyAsync(c->d_ptab, seg.ptab.data(), sizeof(int32_t) * seg.ptab.size(), hipMemcpyHostToDevice, c->stream));
-                        if ((rc = ensure(c, c->d_segw, c->segw_cap, seg.wgs.size())) != ACX_OK) return rc;
-                        ACX_HIP(c, hipMemcpyAsync(c->d_segw, seg.wgs.data(), sizeof(acx::EfSegWg) * seg.wgs.size(), hipMemcpyHostToDevice, c->stream));
-                        // (the copies above are staged before they return: `seg` may be rebuilt for the next batch)
-                        if (seg.wgs.size() > 0x7fffffffu) return fail(c, ACX_ERR_UNSUPPORTED, "earlyfusion: batch too large for one launch");
-                        static const bool rect256 = !(getenv("ACX_EF_RECT256") && atoi(getenv("ACX_EF_RECT256")) == 0);    // (A/B switch)
-                        if (!seg.wgs.empty() && !rect256)
-                            hipLaunchKernelGGL(acx::ef_gemm_seg_bf16x3_kernel, dim3((unsigned)seg.wgs.size(), 1, 2), dim3(acx::EFB_THREADS), 0, c->stream,
-                                               c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd, c->d_rects, c->d_segw,
-                                               c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1]);
-                        if (!seg.wgs2.empty() && rect256) {
+                        // (the copies are staged before they return: `seg` may be rebuilt for the next batch)
+                        if (seg.wgs.size() > 0x7fffffffu || seg.wgs3.size() > 0x7fffffffu)
+                            return fail(c, ACX_ERR_UNSUPPORTED, "earlyfusion: batch too large for one launch");
+                        if (!c->ef_rect_attr) {
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel<0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel<1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            c->ef_rect_attr = true;
+                        }
+                        if (!seg.wgs2.empty()) {
                             if ((rc = ensure(c, c->d_segw2, c->segw2_cap, seg.wgs2.size())) != ACX_OK) return rc;
                             ACX_HIP(c, hipMemcpyAsync(c->d_segw2, seg.wgs2.data(), sizeof(acx::EfSegWg) * seg.wgs2.size(), hipMemcpyHostToDevice, c->stream));
-                            if (!c->ef_rect_attr) {
-                                ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
-                                c->ef_rect_attr = true;
-                            }
-                            hipLaunchKernelGGL(acx::ef_gemm_rect_bf16x3_kernel, dim3((unsigned)seg.wgs2.size(), 1, 2), dim3(acx::EFR_THREADS),
+                            hipLaunchKernelGGL(acx::ef_gemm_rect_bf16x3_kernel<0>, dim3((unsigned)seg.wgs2.size(), 1, 2), dim3(acx::EFR_THREADS),
                                                acx::EFR_LDS_BYTES, c->stream, c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd,
                                                c->d_rects, c->d_segw2, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1]);
                         }
-                        // chroma over the same rectangles (f32 MFMA; the pair's OTI roll applied when the operand is read)
-                        if (!seg.wgs.empty())
+                        // chroma (cosine, the first song rolled by the pair's OTI): the same kernel on the bin-major split
+                        // pool; ACX_EF_GEMM_BF16X3_CHROMA_F32 (and block shapes the split does not cover): f32 MFMAs
+                        if (c->ef_gemm == ACX_EF_GEMM_BF16X3 && c->ef_kp[2] > 0) {
+                            if (!seg.wgs3.empty()) {
+                                if ((rc = ensure(c, c->d_segw3, c->segw3_cap, seg.wgs3.size())) != ACX_OK) return rc;
+                                ACX_HIP(c, hipMemcpyAsync(c->d_segw3, seg.wgs3.data(), sizeof(acx::EfSegWg) * seg.wgs3.size(), hipMemcpyHostToDevice, c->stream));
+                                hipLaunchKernelGGL(acx::ef_gemm_rect_bf16x3_kernel<1>, dim3((unsigned)seg.wgs3.size(), 1, 1), dim3(acx::EFR_THREADS),
+                                                   acx::EFR_LDS_BYTES, c->stream, c->d_efs[2], c->d_efs[2], (const float *)nullptr, (const float *)nullptr,
+                                                   c->d_efpd, c->d_rects, c->d_segw3, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[2], c->ef_kp[2]);
+                            }
+                        } else if (!seg.wgs.empty()) {
+                            if ((rc = ensure(c, c->d_segw, c->segw_cap, seg.wgs.size())) != ACX_OK) return rc;
+                            ACX_HIP(c, hipMemcpyAsync(c->d_segw, seg.wgs.data(), sizeof(acx::EfSegWg) * seg.wgs.size(), hipMemcpyHostToDevice, c->stream));
                             hipLaunchKernelGGL(acx::ef_gemm_seg_f32_kernel, dim3((unsigned)seg.wgs.size()), dim3(256), 0, c->stream,
                                                c->d_ef[2], c->d_efpd, c->d_rects, c->d_segw, c->d_segr, c->d_segc, c->d_ptab,
                                                c->d_scratch, c->ef_dims[2]);
+                        }
                     }
                     if (c->ef_gemm == ACX_EF_GEMM_BF16X3_PAIRWISE)
                         hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 1), dim3(256), 0, c->stream,
@@ -1147,21 +1172,10 @@ void acx_destroy(acx_ctx *c)
     if (c->d_ptab) (void)hipFree(c->d_ptab);
     if (c->d_segw) (void)hipFree(c->d_segw);
     if (c->d_segw2) (void)hipFree(c->d_segw2);
+    if (c->d_segw3) (void)hipFree(c->d_segw3);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
-
-#ifdef ACX_EF_TIMING
-extern "C" int acx_ef_clk(unsigned long long *out, int reset)
-{
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(acx::g_ef_clk), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(acx::g_ef_clk), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 const char *acx_last_error(const acx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
@@ -1639,7 +1653,7 @@ static void ef_free_pool(acx_ctx *c)
 {
     for (int k = 0; k < 3; ++k) if (c->d_ef[k]) { (void)hipFree(c->d_ef[k]); c->d_ef[k] = nullptr; }
     for (int k = 0; k < 2; ++k) if (c->d_efn[k]) { (void)hipFree(c->d_efn[k]); c->d_efn[k] = nullptr; }
-    for (int k = 0; k < 2; ++k) if (c->d_efs[k]) { (void)hipFree(c->d_efs[k]); c->d_efs[k] = nullptr; }
+    for (int k = 0; k < 3; ++k) if (c->d_efs[k]) { (void)hipFree(c->d_efs[k]); c->d_efs[k] = nullptr; }
     if (c->d_efmed) { (void)hipFree(c->d_efmed); c->d_efmed = nullptr; }
     if (c->d_efoff) { (void)hipFree(c->d_efoff); c->d_efoff = nullptr; }
     c->ef_ntracks = 0;
@@ -1673,15 +1687,17 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
             hipLaunchKernelGGL(acx::ef_rownorm_kernel, dim3(g), dim3(256), 0, c->stream, c->d_ef[k], nb, dims[k], 0, c->d_efn[k]);
         ACX_HIP(c, hipGetLastError());
     }
-    // three-term bf16 splits of the two Euclidean features (the operands of ef_gemm_bf16x3_kernel)
-    for (int k = 0; k < 2; ++k) {
+    // three-term bf16 splits (the operands of the bf16 GEMM kernels): the two Euclidean features as they are, the
+    // normalised chroma rows bin-major (ef_gemm_rect_bf16x3_kernel<1>) when a block has a multiple of 8 frames
+    for (int k = 0; k < 3; ++k) {
         c->ef_kp[k] = (dims[k] + acx::EFB_BK - 1) / acx::EFB_BK * acx::EFB_BK;
+        if (k == 2 && dims[2] % 96 != 0) { c->ef_kp[2] = 0; continue; }
         const int64_t nel = std::max<int64_t>(1, nb) * 3 * c->ef_kp[k];
         ACX_HIP(c, hipMalloc((void **)&c->d_efs[k], sizeof(unsigned short) * nel));
         if (nb > 0) {
             const int64_t nthr = nb * c->ef_kp[k];
             hipLaunchKernelGGL(acx::ef_split_bf16_kernel, dim3((unsigned)std::min<int64_t>((nthr + 255) / 256, 1 << 22)), dim3(256), 0, c->stream,
-                               c->d_ef[k], c->d_efs[k], nb, dims[k], c->ef_kp[k]);
+                               c->d_ef[k], c->d_efs[k], nb, dims[k], c->ef_kp[k], k == 2 ? 1 : 0);
             ACX_HIP(c, hipGetLastError());
         }
     }
@@ -1696,7 +1712,7 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
 int acx_set_ef_gemm(acx_ctx *c, int32_t mode)
 {
     if (!c) return ACX_ERR_INVALID;
-    if (mode != ACX_EF_GEMM_BF16X3 && mode != ACX_EF_GEMM_F32 && mode != ACX_EF_GEMM_BF16X3_PAIRWISE)
+    if (mode != ACX_EF_GEMM_BF16X3 && mode != ACX_EF_GEMM_F32 && mode != ACX_EF_GEMM_BF16X3_PAIRWISE && mode != ACX_EF_GEMM_BF16X3_CHROMA_F32)
         return fail(c, ACX_ERR_INVALID, "set_ef_gemm: unknown mode");
     c->ef_gemm = mode;
     return ACX_OK;

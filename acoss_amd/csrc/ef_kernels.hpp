@@ -275,13 +275,16 @@ __device__ __forceinline__ unsigned ef_bf16_rne(float x)
 // (grid-stride: a launch carries at most 2^32 - 1 work-items per dimension, and a DA-TACOS-sized pool has 7.5e9
 // split values per feature -- a one-thread-per-value grid wraps silently and leaves the tail of the pool unwritten)
 __global__ __launch_bounds__(256) void ef_split_bf16_kernel(const float *__restrict__ f, unsigned short *__restrict__ out,
-                                                            int64_t nblocks, int K, int Kp)
+                                                            int64_t nblocks, int K, int Kp, int binmajor)
 {
     const int64_t total = nblocks * Kp, stride = (int64_t)gridDim.x * 256;
+    const int G = K / 12;                                             // (binmajor: frames of a chroma block)
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
         const int64_t row = idx / Kp;
         const int k = (int)(idx - row * Kp);
-        const float x = k < K ? f[row * K + k] : 0.0f;
+        // binmajor (chroma, K = 12 G): position k = G bin + frame of the split row takes value 12 frame + bin of the block
+        const int ks = binmajor ? 12 * (k % G) + k / G : k;
+        const float x = k < K ? f[row * K + ks] : 0.0f;
         const unsigned h1 = ef_bf16_rne(x);
         const float r1 = x - __uint_as_float(h1 << 16);            // exact
         const unsigned h2 = ef_bf16_rne(r1);
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 // ------------------------------------------------------------------------------------
-// E1c: the same two Euclidean products for a whole RECTANGLE of pairs at once (round 3).  The per-pair kernel
+// E1c: the cross-similarity products for a whole RECTANGLE of pairs at once (round 3).  The per-pair kernel
 // above tiles every (M x N) matrix on its own: a 400 x 400 matrix needs 16 workgroup tiles of 128 x 128 where 9.8
 // would hold its cells (measured: 92 TFLOP/s f32-equivalent at 400 blocks per track against 131 - 138 at 384 / 512),
 // and every pair re-reads its two tracks.  Here the blocks of up to 128 query tracks are laid end to end as the
@@ -416,185 +419,32 @@ struct EfSegRect {
     int32_t ncols;         // reference tracks of the rectangle (row length of its pair table)
     int32_t ptab0;         // offset of its pair table (nrows x ncols ints: index into the batch's EfPair array or -1)
 };
-struct EfSegWg { int32_t rect, ty, tx, pad; };      // one workgroup tile (8 x 8 groups) that holds at least one pair
-
-__global__ __launch_bounds__(EFB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ef_gemm_seg_bf16x3_kernel(
-    const unsigned short *__restrict__ split0, const unsigned short *__restrict__ split1, const float *__restrict__ nrm0,
-    const float *__restrict__ nrm1, const EfPair *__restrict__ pd, const EfSegRect *__restrict__ rects,
-    const EfSegWg *__restrict__ wgs, const EfSegGroup *__restrict__ rowg, const EfSegGroup *__restrict__ colg, const int32_t *__restrict__ pairtab,
-    float *__restrict__ scratch, int Kp0, int Kp1)
-{
-    __shared__ __attribute__((aligned(16))) unsigned short As[3 * EF_TILE * EFB_LP];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * EF_TILE * EFB_LP];
-    const EfSegWg W = wgs[blockIdx.x];               // (the host lists only tiles that hold at least one pair)
-    const EfSegRect R = rects[W.rect];
-    const int ty = W.ty, tx = W.tx;
-    const int s = blockIdx.z;                        // 0 mfcc, 1 ssm
-    const int Kp = s == 0 ? Kp0 : Kp1;
-    const unsigned short *S = s == 0 ? split0 : split1;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int lr = lane & 15, lk = lane >> 4;
-    constexpr int NA = 2;                            // 16-row sub-tiles per wave
-    const int gr0 = 8 * ty + 2 * wr, gc0 = 8 * tx + 4 * wc;      // this wave's first row / column group inside the rectangle
-    // pair of every sub-tile of the wave (-1: nothing to compute) -- wave-uniform
-    int pidx[NA][4];
-    bool any = false, full = true;
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            int p = -1;
-            if (gr0 + a < R.ng && gc0 + b < R.nh) {
-                const EfSegGroup ga = rowg[R.g0 + gr0 + a], gb = colg[R.h0 + gc0 + b];
-                if (ga.valid > 0 && gb.valid > 0) p = pairtab[R.ptab0 + ga.slot * R.ncols + gb.slot];
-            }
-            pidx[a][b] = __builtin_amdgcn_readfirstlane(p);
-            any = any || p >= 0;
-            full = full && p >= 0;
-        }
-    f32x4 acc[NA][4];
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // staging: thread -> (row = tid / 4, 8 consecutive k = 8 * (tid % 4) ...) of every term: one 16-byte piece each
-    const int srow = tid >> 2, sk = (tid & 3) * 8;
-    const int sg = srow >> 4, sr = srow & 15;
-    bool rowa = false, rowb = false;
-    const unsigned short *ap = S, *bp = S;
-    if (8 * ty + sg < R.ng) {
-        const EfSegGroup g = rowg[R.g0 + 8 * ty + sg];
-        rowa = sr < g.valid;
-        if (rowa) ap = S + (g.poolrow + sr) * 3 * Kp + sk;
-    }
-    if (8 * tx + sg < R.nh) {
-        const EfSegGroup g = colg[R.h0 + 8 * tx + sg];
-        rowb = sr < g.valid;
-        if (rowb) bp = S + (g.poolrow + sr) * 3 * Kp + sk;
-    }
-    u32x4 ra[3], rb[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { ra[q] = u32x4{0u, 0u, 0u, 0u}; rb[q] = u32x4{0u, 0u, 0u, 0u}; }
-    auto gload = [&]() {
-        if (rowa) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) ra[q] = *reinterpret_cast<const u32x4 *>(ap + q * EFB_BK);
-            ap += 3 * EFB_BK;
-        }
-        if (rowb) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) rb[q] = *reinterpret_cast<const u32x4 *>(bp + q * EFB_BK);
-            bp += 3 * EFB_BK;
-        }
-    };
-    const int skl = ((tid & 3) ^ ((srow >> 2) & 3)) * 8;             // swizzled piece of the row in LDS
-    unsigned short *as0 = As + srow * EFB_LP + skl, *bs0 = Bs + srow * EFB_LP + skl;
-    auto lstore = [&]() {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            *reinterpret_cast<u32x4 *>(as0 + q * EF_TILE * EFB_LP) = ra[q];        // (rows that do not exist: zeros)
-            *reinterpret_cast<u32x4 *>(bs0 + q * EF_TILE * EFB_LP) = rb[q];
-        }
-    };
-    const int lks = lk ^ ((lr >> 2) & 3);                             // (rows 16 a + lr: (row >> 2) & 3 == (lr >> 2) & 3)
-    const unsigned short *aop = As + (32 * wr + lr) * EFB_LP + 8 * lks;
-    const unsigned short *bop = Bs + (64 * wc + lr) * EFB_LP + 8 * lks;
-    gload();
-    for (int k0 = 0; k0 < Kp; k0 += EFB_BK) {
-        lstore();
-        __syncthreads();
-        if (k0 + EFB_BK < Kp) gload();                     // in flight during the MFMAs below
-        if (any) {
-            bf16x8 av[NA][3];
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    av[a][q] = *reinterpret_cast<const bf16x8 *>(aop + (q * EF_TILE + 16 * a) * EFB_LP);
-            auto mma = [&](auto full_tag) {
-                constexpr bool fullc = decltype(full_tag)::value;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (fullc || pidx[0][b] >= 0 || pidx[1][b] >= 0) {
-                        bf16x8 bv[3];
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) bv[q] = *reinterpret_cast<const bf16x8 *>(bop + (q * EF_TILE + 16 * b) * EFB_LP);
-#define ACX_EFB_TERM(TA_, TB_)                                                                                         \
-    _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                                     \
-        if (fullc || pidx[a][b] >= 0) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[a][TA_], bv[TB_], acc[a][b], 0, 0, 0);
-                        ACX_EFB_TERM(0, 2) ACX_EFB_TERM(2, 0) ACX_EFB_TERM(1, 1) ACX_EFB_TERM(0, 1) ACX_EFB_TERM(1, 0) ACX_EFB_TERM(0, 0)
-#undef ACX_EFB_TERM
-                    }
-                }
-            };
-            if (full) mma(std::true_type());
-            else mma(std::false_type());
-        }
-        __syncthreads();
-    }
-    // ---- epilogue: every sub-tile into the matrices of its own pair (get_csm: sqrt(max(0, |x|^2 + |y|^2 - 2 x.y)))
-    const float *nrm = s == 0 ? nrm0 : nrm1;
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (pidx[a][b] < 0) continue;                                  // wave-uniform
-            const EfPair P = pd[pidx[a][b]];
-            const EfSegGroup ga = rowg[R.g0 + gr0 + a], gb = colg[R.h0 + gc0 + b];
-            float *C = scratch + ef_c_off(P, s);
-            float *CT = scratch + ef_ct_off(P, s);
-            const int il = 4 * lk, jl = lr;                                // position inside the 16 x 16 sub-tile
-            const int ib = ga.local0 + il, j = gb.local0 + jl;
-            const bool jok = jl < gb.valid;
-            const float ny = jok ? nrm[gb.poolrow + jl] : 0.0f;
-            float v[4];
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const bool iok = il + reg < ga.valid;
-                const float nx = iok ? nrm[ga.poolrow + il + reg] : 0.0f;
-                float tq = (nx + ny) - 2.0f * acc[a][b][reg];
-                if (tq < 0.0f) tq = 0.0f;
-                v[reg] = __builtin_sqrtf(tq);
-                if (iok && jok) C[(size_t)(ib + reg) * P.pitchC + j] = v[reg];
-            }
-            if (jok) {
-                float *ct = CT + (size_t)j * P.pitchT + ib;
-                if (il + 3 < ga.valid) *reinterpret_cast<float4 *>(ct) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        if (il + reg < ga.valid) ct[reg] = v[reg];
-            }
-        }
-}
+struct EfSegWg { int32_t rect, ty, tx, pad; };      // one workgroup tile that holds at least one pair (units: see the kernels)
 
 // ------------------------------------------------------------------------------------
-// E1c': the rectangle GEMM at 256 x 128 cells per workgroup (round 3, second pass).  Counters of the 128 x 128 kernel
-// above: bf16 matrix pipe 38 % busy, LDS 38 % busy, a k chunk takes 8 k cycles where its MFMAs need 3 k -- the
-// workgroups wait for their operand loads (one chunk ahead, 22 % of them miss the XCD's L2) between two barriers per
-// chunk, and with 32 x 64 cells per wave the LDS reads alone would cap the pipe at its own rate.  This kernel:
+// E1c': the rectangle GEMM at 256 x 128 cells per workgroup (round 3, second pass).  Counters of its 128 x 128
+// predecessor (E1b's loop over rectangles): bf16 matrix pipe 38 % busy, LDS 38 % busy, a k chunk takes 8 k cycles where its MFMAs need 3 k -- every wave
+// of a workgroup stores, loads and multiplies in the same phase, two barriers per chunk, and the memory phases of
+// one workgroup do not fill the MFMA phases of the other.  This kernel:
 //   * 8 waves of 64 x 64 cells (24 operand reads feed 96 MFMAs: 2/3 of the LDS bytes per flop);
-//   * ONE workgroup per CU with 256 registers per lane, LDS double-buffered (2 x 72 KB): one barrier per chunk, and
-//     the loads of chunk k + 2 are in flight while chunk k is multiplied and chunk k + 1 sits in LDS;
-//   * same k chunks, same six MFMAs per cell in the same order: bit-identical matrices.
+//   * ONE workgroup per CU with 256 registers per lane, LDS double-buffered (2 x 72 KB): one barrier per chunk;
+//   * a chunk is ONE basic block of 24 groups of 4 MFMAs with the wave's memory instructions dealt between the
+//     groups -- the LDS stores of chunk k + 1, the global loads of chunk k + 2, the operand reads of the next column
+//     sub-tile -- so that the matrix pipe runs while they issue;
+//   * a cell's products in the order of E1b (same k chunks, same six MFMAs): bit-identical matrices for mfcc / ssm;
+//   * CH = 1: the CHROMA matrix from the same loop (round 3; f32 MFMAs before).  Chroma rows are unit vectors of
+//     G frames x 12 bins, and the first song's bins are rolled by the pair's OTI (get_csm_blocked_oti,
+//     cross_recurrence.py:105-134).  The split pool keeps them BIN-major (k'' = G bin + frame): the roll becomes a
+//     cyclic shift of the row by G r elements = G r / 8 of the 16-byte pieces the MFMA operands are made of, i.e. a
+//     rolled row is staged by reading every piece from a shifted place -- as long as all the columns of a tile
+//     belong to ONE reference track, so that a row has one roll: the chroma tile list breaks the columns at track
+//     ends (W.tx = first column group, W.pad = groups in the tile; mfcc / ssm tiles run across tracks).
 // ------------------------------------------------------------------------------------
-#ifndef ACX_EF_ABL
-#define ACX_EF_ABL 0
-#endif
-#ifdef ACX_EF_TIMING   /* development builds only (scripts/ab_build_acx.sh timing -DACX_EF_TIMING; scripts/ef_phase_timing.py) */
-__device__ unsigned long long g_ef_clk[16];
-#define ACX_EF_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
-        tacc_[slot] += now_ - tst_; tst_ = now_; } while (0)
-#else
-#define ACX_EF_STAMP(slot) do { } while (0)
-#endif
 constexpr int EFR_ROWS = 256, EFR_COLS = 128, EFR_THREADS = 512;
 constexpr int EFR_A = 3 * EFR_ROWS * EFB_LP, EFR_B = 3 * EFR_COLS * EFB_LP;      // bf16 elements of one buffer
 constexpr int EFR_LDS_BYTES = 2 * 2 * (EFR_A + EFR_B);                           // 147 456
 
+template <int CH>
 __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ef_gemm_rect_bf16x3_kernel(
     const unsigned short *__restrict__ split0, const unsigned short *__restrict__ split1, const float *__restrict__ nrm0,
     const float *__restrict__ nrm1, const EfPair *__restrict__ pd, const EfSegRect *__restrict__ rects,
@@ -602,34 +452,34 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     float *__restrict__ scratch, int Kp0, int Kp1)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short efr_lds[];
-    unsigned short *As = efr_lds;                    // [buffer][term][row][32 k], rows XOR-swizzled like E1b
+    unsigned short *As = efr_lds;                    // [buffer][term][row][32 k]
     unsigned short *Bs = efr_lds + 2 * EFR_A;
-    const EfSegWg W = wgs[blockIdx.x];               // ty in units of 16 groups, tx in units of 8 groups
+    const EfSegWg W = wgs[blockIdx.x];               // ty in units of 16 row groups; tx = first column group, pad = column groups
     const EfSegRect R = rects[W.rect];
-    const int ty = W.ty, tx = W.tx;
-    const int s = blockIdx.z;                        // 0 mfcc, 1 ssm
-    const int Kp = s == 0 ? Kp0 : Kp1;
-    const unsigned short *S = s == 0 ? split0 : split1;
+    const int ty = W.ty, tx = W.tx, ncg = W.pad;
+    const int s = CH ? 2 : (int)blockIdx.z;          // 0 mfcc, 1 ssm, 2 chroma
+    const int Kp = (CH || s == 0) ? Kp0 : Kp1;
+    const unsigned short *S = (CH || s == 0) ? split0 : split1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int lr = lane & 15, lk = lane >> 4;
     constexpr int NA = 4, NB = 4;
-    const int gr0 = 16 * ty + NA * wr, gc0 = 8 * tx + NB * wc;
+    const int gr0 = 16 * ty + NA * wr, gc0 = tx + NB * wc;
+    // pair of every sub-tile of the wave (-1: nothing to store) -- wave-uniform
     int pidx[NA][NB];
-    bool any = false, full = true;
+    bool any = false;
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             int p = -1;
-            if (gr0 + a < R.ng && gc0 + b < R.nh) {
+            if (gr0 + a < R.ng && NB * wc + b < ncg) {
                 const EfSegGroup ga = rowg[R.g0 + gr0 + a], gb = colg[R.h0 + gc0 + b];
                 if (ga.valid > 0 && gb.valid > 0) p = pairtab[R.ptab0 + ga.slot * R.ncols + gb.slot];
             }
             pidx[a][b] = __builtin_amdgcn_readfirstlane(p);
             any = any || p >= 0;
-            full = full && p >= 0;
         }
     f32x4 acc[NA][NB];
 #pragma unroll
@@ -638,36 +488,63 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // staging: thread -> 16-byte piece tid % 4 of rows tid / 4 and 128 + tid / 4 of A, row tid / 4 of B, every term.
-    // Rows that do not exist (behind the last block of a track's last group, behind the rectangle) read pool row 0:
-    // their products only reach cells that are never stored, and the loads stay unconditional.
-    const int srow = tid >> 2, sk = (tid & 3) * 8;
+    // Rows that do not exist (behind a track's last block, behind the rectangle) read pool row 0: their products only
+    // reach cells that are never stored, and the loads stay unconditional.
+    const int srow = tid >> 2, sp = tid & 3;
     const int sg = srow >> 4, sr = srow & 15;
-    const unsigned short *ap0 = S + sk, *ap1 = S + sk, *bp = S + sk;
-    if (16 * ty + sg < R.ng) {
-        const EfSegGroup g = rowg[R.g0 + 16 * ty + sg];
-        if (sr < g.valid) ap0 = S + (g.poolrow + sr) * 3 * Kp + sk;
-    }
-    if (16 * ty + 8 + sg < R.ng) {
-        const EfSegGroup g = rowg[R.g0 + 16 * ty + 8 + sg];
-        if (sr < g.valid) ap1 = S + (g.poolrow + sr) * 3 * Kp + sk;
-    }
-    if (8 * tx + sg < R.nh) {
-        const EfSegGroup g = colg[R.h0 + 8 * tx + sg];
-        if (sr < g.valid) bp = S + (g.poolrow + sr) * 3 * Kp + sk;
+    const int pieces = Kp / 8;                         // 16-byte pieces of a row (per term)
+    const unsigned short *ap0 = S, *ap1 = S, *bp = S + sp * 8;
+    int sp0 = sp, sp1 = sp;                            // (CH) the piece of the source row that lands at piece tid % 4 of the chunk
+    {
+        int rslot = 0;
+        if (CH) rslot = colg[R.h0 + tx].slot;          // the tile's one reference track
+        auto roll_of = [&](const EfSegGroup &g) {
+            const int p = pairtab[R.ptab0 + g.slot * R.ncols + rslot];
+            int r = p >= 0 ? pd[p].oti : 0;
+            r = (sp - (pieces / 12) * r) % pieces;     // piece - G r / 8, into [0, pieces)
+            return r < 0 ? r + pieces : r;
+        };
+        if (16 * ty + sg < R.ng) {
+            const EfSegGroup g = rowg[R.g0 + 16 * ty + sg];
+            if (sr < g.valid) { ap0 = S + (g.poolrow + sr) * 3 * Kp; if (CH) sp0 = roll_of(g); }
+        }
+        if (16 * ty + 8 + sg < R.ng) {
+            const EfSegGroup g = rowg[R.g0 + 16 * ty + 8 + sg];
+            if (sr < g.valid) { ap1 = S + (g.poolrow + sr) * 3 * Kp; if (CH) sp1 = roll_of(g); }
+        }
+        if (sg < ncg) {
+            const EfSegGroup g = colg[R.h0 + tx + sg];
+            if (sr < g.valid) bp = S + (g.poolrow + sr) * 3 * Kp + sp * 8;
+        }
+        if (!CH) { ap0 += sp * 8; ap1 += sp * 8; }
     }
     u32x4 st[9];                                      // pieces 0-2: A rows tid / 4, 3-5: A rows 128 + tid / 4, 6-8: B (one per term)
     auto gload_piece = [&](auto p_tag) {
         constexpr int p = decltype(p_tag)::value;
-        const unsigned short *src = p < 3 ? ap0 : (p < 6 ? ap1 : bp);
+        const unsigned short *src;
+        if (p >= 6) src = bp;
+        else if (!CH) src = p < 3 ? ap0 : ap1;
+        else {                                         // [k / 32][term][k % 32]: piece q of the row sits at 96 (q / 4) + 8 (q % 4)
+            const int q = p < 3 ? sp0 : sp1;
+            src = (p < 3 ? ap0 : ap1) + 96 * (q >> 2) + 8 * (q & 3);
+        }
         st[p] = *reinterpret_cast<const u32x4 *>(src + (p % 3) * EFB_BK);
     };
-    auto gload_advance = [&]() { ap0 += 3 * EFB_BK; ap1 += 3 * EFB_BK; bp += 3 * EFB_BK; };
+    auto gload_advance = [&]() {
+        bp += 3 * EFB_BK;
+        if (!CH) { ap0 += 3 * EFB_BK; ap1 += 3 * EFB_BK; }
+        else {
+            sp0 += 4; sp0 = sp0 >= pieces ? sp0 - pieces : sp0;
+            sp1 += 4; sp1 = sp1 >= pieces ? sp1 - pieces : sp1;
+        }
+    };
     // LDS rows are 64 bytes (32 k of one term); the four 16-byte pieces of a row sit at piece ^ swz(row / 4): a
     // ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH, LDS),
     // i.e. rows 0-3 and 12-15 at one k piece together with rows 4-11 at the next: swz = 0, 2, 3, 1 for row / 4 = 0 .. 3 puts
-    // the 16 lanes of every group on 16 different bank quads (piece ^ (row / 4), round 3's first choice, left them 2-way
-    // conflicted); the stores (4 pieces of a row per 4 lanes) are conflict free under any such permutation.
-    const int skl = ((tid & 3) ^ ((0x78 >> (2 * ((srow >> 2) & 3))) & 3)) * 8;
+    // the 16 lanes of every group on 16 different bank quads (piece ^ (row / 4), E1b's choice, leaves them 2-way
+    // conflicted: a third of that kernel's LDS cycles); the stores (the 4 pieces of a row by 4 neighbouring lanes) are
+    // conflict free under any such permutation.
+    const int skl = (sp ^ ((0x78 >> (2 * ((srow >> 2) & 3))) & 3)) * 8;
     unsigned short *as0 = As + srow * EFB_LP + skl, *bs0 = Bs + srow * EFB_LP + skl;
     auto lstore_piece = [&](int buf, auto p_tag) {
         constexpr int p = decltype(p_tag)::value;
@@ -684,14 +561,12 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     const unsigned short *aop = As + (64 * wr + lr) * EFB_LP + 8 * lks;
     const unsigned short *bop = Bs + (64 * wc + lr) * EFB_LP + 8 * lks;
 
-    // ---- one k chunk of a wave whose 16 sub-tiles are all wanted: 24 groups of 4 MFMAs (one term pair x 4 row
-    // sub-tiles) in ONE basic block; the LDS stores of chunk k + 1 and the global loads of chunk k + 2 are dealt
-    // between the groups (one piece behind every other group), the operand reads of the next column sub-tile behind
-    // the second group of the current one -- the matrix pipe runs while the wave's memory instructions issue.
-    // Order of a cell's six products: (0,2) (2,0) (1,1) (0,1) (1,0) (0,0), smallest first, as in E1b.
-    auto chunk_full = [&](int cur, auto st_tag, auto ld_tag) {
+    // ---- one k chunk: 24 groups of 4 MFMAs (one term pair x the 4 row sub-tiles); behind every other group one staging
+    // piece goes to LDS (chunk k + 1) and is loaded again (chunk k + 2); behind the second group of a column sub-tile the
+    // operands of the next one are read.  Sub-tiles without a pair are multiplied like the others (never stored).
+    auto chunk_mma = [&](int cur, auto st_tag, auto ld_tag) {
         constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
-        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};       // smallest products first, as in E1b
         const unsigned short *a_ = aop + cur * EFR_A, *b_ = bop + cur * EFR_B;
         bf16x8 av[NA][3], bv[2][3];
         auto rda = [&](int q) {
@@ -711,7 +586,6 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                 if (g == 1 && b + 1 < NB) { rdb((b + 1) & 1, b + 1, 2); rdb((b + 1) & 1, b + 1, 0); rdb((b + 1) & 1, b + 1, 1); }
                 const int slot = 6 * b + g;
                 if (slot >= 2 && slot <= 18 && (slot & 1) == 0) {
-                    // piece (slot - 2) / 2: its registers go to LDS and are loaded again at once
                     auto piece = [&](auto p_tag) {
                         if (ST) lstore_piece(cur ^ 1, p_tag);
                         if (LD) gload_piece(p_tag);
@@ -733,33 +607,11 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         }
         if (LD) gload_advance();
     };
-    // ---- the same chunk for a wave at the rim of its rectangle (some sub-tiles hold no pair): guarded MFMAs
-    auto chunk_rim = [&](int cur, auto st_tag, auto ld_tag) {
+    // ---- a wave without a pair (beside the rectangle, or beside the track of a chroma tile) only stages its share
+    auto chunk_idle = [&](int cur, auto st_tag, auto ld_tag) {
         constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
         if (ST) for9([&](auto p_tag) { lstore_piece(cur ^ 1, p_tag); });
         if (LD) { for9([&](auto p_tag) { gload_piece(p_tag); }); gload_advance(); }
-        if (!any) return;
-        const unsigned short *a_ = aop + cur * EFR_A, *b_ = bop + cur * EFR_B;
-        bf16x8 av[NA][3];
-#pragma unroll
-        for (int a = 0; a < NA; ++a)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) av[a][q] = *reinterpret_cast<const bf16x8 *>(a_ + (q * EFR_ROWS + 16 * a) * EFB_LP);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            bool col = false;
-#pragma unroll
-            for (int a = 0; a < NA; ++a) col = col || pidx[a][b] >= 0;
-            if (!col) continue;
-            bf16x8 bv[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) bv[q] = *reinterpret_cast<const bf16x8 *>(b_ + (q * EFR_COLS + 16 * b) * EFB_LP);
-#define ACX_EFB_TERM(TA_, TB_)                                                                                         \
-    _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                                     \
-        if (pidx[a][b] >= 0) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[a][TA_], bv[TB_], acc[a][b], 0, 0, 0);
-            ACX_EFB_TERM(0, 2) ACX_EFB_TERM(2, 0) ACX_EFB_TERM(1, 1) ACX_EFB_TERM(0, 1) ACX_EFB_TERM(1, 0) ACX_EFB_TERM(0, 0)
-#undef ACX_EFB_TERM
-        }
     };
     const int nk = Kp / EFB_BK;
     // prologue: chunk 0 into buffer 0, chunk 1 into the registers
@@ -768,18 +620,12 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     for9([&](auto p_tag) { lstore_piece(0, p_tag); });
     if (nk > 1) { for9([&](auto p_tag) { gload_piece(p_tag); }); gload_advance(); }
     __syncthreads();
-#ifdef ACX_EF_TIMING
-    unsigned long long tacc_[5] = {0, 0, 0, 0, 0};
-    unsigned long long tst_ = __builtin_readcyclecounter();
-#endif
     // (two copies of the loop, the same barriers in both: one loop with a per-chunk choice keeps two sets of accumulators)
     auto sweep = [&](auto &&chunk) {
         int kc = 0;
         for (; kc + 2 < nk; ++kc) {
             chunk(kc & 1, std::true_type(), std::true_type());
-            ACX_EF_STAMP(2);
             __syncthreads();
-            ACX_EF_STAMP(3);
         }
         if (kc + 1 < nk) {
             chunk(kc & 1, std::true_type(), std::false_type());
@@ -787,17 +633,18 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             ++kc;
         }
         chunk(kc & 1, std::false_type(), std::false_type());
-        ACX_EF_STAMP(2);
     };
-    if (full) sweep(chunk_full);
-    else sweep(chunk_rim);
-    // ---- epilogue: every sub-tile into the matrices of its own pair (get_csm: sqrt(max(0, |x|^2 + |y|^2 - 2 x.y))).
-    // A lane's four accumulator values are four consecutive ROWS of one column: the transposed matrix takes them as
-    // one 16-byte store; for the matrix itself the sub-tile is turned round through a wave-private 16 x 16 LDS tile
-    // (pitch 20 floats; two tiles alternate) so that a lane holds four consecutive COLUMNS of one row -- 32 wide
-    // stores per wave instead of 80 (16 x 4 narrow ones + 16 wide): with one workgroup per CU nothing else runs on the
-    // CU while the tail of stores issues.
+    if (any) sweep(chunk_mma);
+    else sweep(chunk_idle);
+
+    // ---- epilogue: every sub-tile into the matrices of its own pair (get_csm: sqrt(max(0, |x|^2 + |y|^2 - 2 x.y));
+    // get_csm_cosine of unit rows: 1 - x.y).  A lane's four accumulator values are four consecutive ROWS of one column:
+    // the transposed matrix takes them as one 16-byte store; for the matrix itself the sub-tile is turned round through a
+    // wave-private 16 x 16 LDS tile (pitch 20 floats; two tiles alternate) so that a lane holds four consecutive COLUMNS
+    // of one row -- 32 wide stores per wave instead of 16 x 4 narrow + 16 wide: with one workgroup per CU nothing else
+    // runs on the CU while the tail of stores issues.
     __syncthreads();                                     // (the operand buffers are dead: every wave has read its last chunk)
+    if (!any) return;
     float *T = reinterpret_cast<float *>(efr_lds) + wave * (2 * 16 * 20);
     const float *nrm = s == 0 ? nrm0 : nrm1;
     const int il = 4 * lk, jl = lr;                      // accumulator layout: rows il .. il + 3 of column jl
@@ -812,7 +659,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         const EfSegGroup ga = rowg[R.g0 + gr0 + a];
         float nx[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) nx[reg] = il + reg < ga.valid ? nrm[ga.poolrow + il + reg] : 0.0f;
+        for (int reg = 0; reg < 4; ++reg) nx[reg] = (!CH && il + reg < ga.valid) ? nrm[ga.poolrow + il + reg] : 0.0f;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (pidx[a][b] < 0) continue;                                  // wave-uniform
@@ -821,15 +668,18 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             float *C = scratch + ef_c_off(P, s);
             float *CT = scratch + ef_ct_off(P, s);
             const bool jok = jl < gb.valid;
-            const float ny = jok ? nrm[gb.poolrow + jl] : 0.0f;
+            const float ny = (!CH && jok) ? nrm[gb.poolrow + jl] : 0.0f;
             float *Tw = T + flip * (16 * 20);
             flip ^= 1;
             float v[4];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                float tq = (nx[reg] + ny) - 2.0f * acc[a][b][reg];
-                if (tq < 0.0f) tq = 0.0f;
-                v[reg] = __builtin_sqrtf(tq);
+                if (CH) v[reg] = 1.0f - acc[a][b][reg];
+                else {
+                    float tq = (nx[reg] + ny) - 2.0f * acc[a][b][reg];
+                    if (tq < 0.0f) tq = 0.0f;
+                    v[reg] = __builtin_sqrtf(tq);
+                }
                 Tw[(il + reg) * 20 + jl] = v[reg];
             }
             if (jok) {
@@ -852,13 +702,6 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             }
         }
     }
-    ACX_EF_STAMP(4);
-#ifdef ACX_EF_TIMING
-    if (lane == 0) {
-        for (int q = 0; q < 5; ++q) atomicAdd(&g_ef_clk[q], tacc_[q]);
-        atomicAdd(&g_ef_clk[15], (unsigned long long)nk);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------

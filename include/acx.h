@@ -288,19 +288,25 @@ int acx_earlyfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const a
                           float *out);
 
 /*
- * Arithmetic of the two Euclidean cross-similarity products (mfccs, ssms; get_csm, cross_recurrence.py:30-48 --
- * the reference's is one BLAS sgemm in f32):
+ * Arithmetic of the three cross-similarity products (mfccs, ssms: get_csm, cross_recurrence.py:30-48; chromas:
+ * get_csm_blocked_oti, :105-134 -- the reference's are BLAS sgemms in f32):
  *   ACX_EF_GEMM_BF16X3 (default)  three-term bf16 splits on the bf16 matrix pipe, f32 accumulation: the dropped
  *                                 terms are below one f32 rounding of the product; the pairs of a batch are laid
  *                                 out as dense rectangles (query tracks' blocks x reference tracks' blocks), so
- *                                 the 128 x 128 tiles of the GEMM are full and tracks are read once per rectangle
- *   ACX_EF_GEMM_F32               f32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation)
- * Both meet the same bound against the f64 truth (tests/test_gpu_earlyfusion.py); scores that differ between
+ *                                 the 256 x 128 tiles of the GEMM are full and tracks are read once per rectangle.
+ *                                 Chroma rows are kept bin-major, which turns the OTI roll into a shift of the
+ *                                 row by whole 16-byte pieces (blocks of a multiple of 8 frames; others: f32)
+ *   ACX_EF_GEMM_F32               f32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation), one
+ *                                 matrix at a time
+ *   ACX_EF_GEMM_BF16X3_CHROMA_F32 the rectangles of the default, chroma by f32 MFMAs (round 3's first kernel)
+ * All meet the same bound against the f64 truth (tests/test_gpu_earlyfusion.py); scores that differ between
  * them sit on a row-kappa threshold tie (profiles/r03_parity_ef.json holds the measured histogram).
  */
 enum { ACX_EF_GEMM_BF16X3 = 0, ACX_EF_GEMM_F32 = 1,
-       ACX_EF_GEMM_BF16X3_PAIRWISE = 2 /* the same arithmetic, one matrix at a time (round 2's kernel; bit-identical
-                                          results -- kept as the cross-check of the rectangle kernel) */ };
+       ACX_EF_GEMM_BF16X3_PAIRWISE = 2, /* mfccs / ssms in the default's arithmetic, one matrix at a time (round 2's
+                                           kernel; bit-identical matrices -- kept as the cross-check of the rectangle
+                                           kernel), chroma by f32 MFMAs */
+       ACX_EF_GEMM_BF16X3_CHROMA_F32 = 3 };
 int acx_set_ef_gemm(acx_ctx *ctx, int32_t mode);
 
 /* One pair with intermediates (tests): csm (3, M, N), fused (M, N), scores (4); any may be NULL. */

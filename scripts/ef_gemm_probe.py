@@ -19,6 +19,8 @@ def main():
     ctx = _lib.Context(0)
     tracks = synth.earlyfusion_set(n, seed=1, nb_range=(300, 500))
     ctx.ef_upload_pool(tracks)
+    if os.environ.get("ACX_PROBE_MODE"):
+        ctx.set_ef_gemm(os.environ["ACX_PROBE_MODE"])
     nb = np.array([t["mfccs"].shape[0] for t in tracks])
     plan = _lib.grid_plan(nb, _lib.ALGO_EARLYFUSION, True, world=1, tile=128, want_tiles=True)
     buf = torch.zeros(int(plan["floats_per_rank"][0]), dtype=torch.float32, device="cuda:0")

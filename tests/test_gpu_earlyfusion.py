@@ -225,7 +225,8 @@ def test_benchmark_end_to_end(tmp_path, monkeypatch):
 
 
 def test_rectangle_gemm_equals_pairwise_gemm(ctx):
-    """The dense-rectangle GEMM (ef_gemm_seg_bf16x3_kernel, the default) against the one-matrix-at-a-time kernel of
+    """The dense-rectangle GEMM (ef_gemm_rect_bf16x3_kernel; chroma by f32 MFMAs as in the one-matrix-at-a-time
+    kernels: mode 'bf16x3_chroma_f32') against the one-matrix-at-a-time kernels of
     round 2: the arithmetic of a cell is the same sequence of MFMAs, so the cross-similarity matrices -- and with
     them all four scores -- must be BIT-identical, whatever the shape of the pair list: full grid tiles, a
     triangular (diagonal) tile, repeated pairs, self pairs, pairs in both orders, tracks of 1 / 15 / 16 / 17 blocks,
@@ -255,29 +256,99 @@ def test_rectangle_gemm_equals_pairwise_gemm(ctx):
             pairs = np.ascontiguousarray(pairs, np.int32)
             ctx.set_ef_gemm("bf16x3_pairwise")
             want = ctx.earlyfusion_pairs(pairs)
-            ctx.set_ef_gemm("bf16x3")
+            ctx.set_ef_gemm("bf16x3_chroma_f32")
             got = ctx.earlyfusion_pairs(pairs)
             assert np.array_equal(got, want), int(np.sum(np.any(got != want, axis=1)))
         # the matrices themselves, through the debug entry (a one-pair rectangle)
         for (i, j) in [(7, 128 % n), (5, 6), (0, 7), (3, 2)]:
             ctx.set_ef_gemm("bf16x3_pairwise")
             a = ctx.ef_debug_pair(i, j)
-            ctx.set_ef_gemm("bf16x3")
+            ctx.set_ef_gemm("bf16x3_chroma_f32")
             b = ctx.ef_debug_pair(i, j)
             assert np.array_equal(a["csm"], b["csm"]) and np.array_equal(a["fused"], b["fused"])
         # through the pair grid (tile = 128 tracks: rectangles of 128 x 128 track slots; and a small tile)
         for tile in (0, 7):
             planes = {}
-            for mode in ("bf16x3_pairwise", "bf16x3"):
+            for mode in ("bf16x3_pairwise", "bf16x3_chroma_f32"):
                 ctx.set_ef_gemm(mode)
                 planes[mode] = [np.zeros((n, n), np.float32) for _ in range(4)]
                 ctx.pair_grid(_lib.ALGO_EARLYFUSION, True, _lib.EfParams(0.1, 10), planes[mode], mirror=True, tile=tile)
             for e in range(4):
-                assert np.array_equal(planes["bf16x3"][e], planes["bf16x3_pairwise"][e])
+                assert np.array_equal(planes["bf16x3_chroma_f32"][e], planes["bf16x3_pairwise"][e])
         # a track of more than 1024 blocks (streaming row statistics / Smith-Waterman behind the same GEMM)
         big = [track(1100), track(40), track(520)]
         ctx.ef_upload_pool(big)
         pr = np.array([[0, 1], [1, 0], [0, 2], [2, 1]], np.int32)
+        ctx.set_ef_gemm("bf16x3_pairwise")
+        want = ctx.earlyfusion_pairs(pr)
+        ctx.set_ef_gemm("bf16x3_chroma_f32")
+        assert np.array_equal(ctx.earlyfusion_pairs(pr), want)
+    finally:
+        ctx.set_ef_gemm("bf16x3")
+
+
+def test_chroma_on_the_bf16_pipe(ctx):
+    """The default's chroma matrix (ef_gemm_rect_bf16x3_kernel<1>: bin-major three-term bf16 splits, the OTI roll as a
+    shift of the staged row) against the f32-MFMA kernel and against the f64 truth: same bound for both; scores of
+    whole pair lists (several tracks per tile, every roll, tracks shorter than a group, column chunks that end with
+    their track) agree except on threshold ties."""
+    from acoss_amd import _lib
+    rng = np.random.default_rng(45)
+    nbs = [1, 15, 16, 17, 33, 128, 129, 300, 47, 250] + [int(v) for v in rng.integers(20, 90, 60)]
+
+    def track(nb):
+        mf = rng.standard_normal((nb, 650)).astype(np.float32)
+        ch = rng.random((nb, 480)).astype(np.float32) ** 3
+        return dict(mfccs=mf, ssms=(2 * rng.random((nb, 1225))).astype(np.float32), chromas=ch, chroma_med=rng.random(12) ** 2)
+    tracks = [track(nb) for nb in nbs]
+    ctx.ef_upload_pool(tracks)
+    n = len(tracks)
+    try:
+        otis = set()
+        for (i, j) in [(7, 8), (5, 6), (0, 7), (3, 2), (9, 7), (8, 9), (20, 30), (31, 21), (5, 5), (40, 9)]:
+            ctx.set_ef_gemm("bf16x3_chroma_f32")
+            a = ctx.ef_debug_pair(i, j)
+            ctx.set_ef_gemm("bf16x3")
+            b = ctx.ef_debug_pair(i, j)
+            assert a["oti"] == b["oti"]
+            otis.add(int(a["oti"]))
+            assert np.array_equal(a["csm"][0], b["csm"][0]) and np.array_equal(a["csm"][1], b["csm"][1])
+            X = tracks[i]["chromas"].astype(np.float64)
+            Y = tracks[j]["chromas"].astype(np.float64)
+            X = np.roll(X.reshape(len(X), 40, 12), a["oti"], axis=2).reshape(len(X), 480)
+            X /= np.linalg.norm(X, axis=1, keepdims=True)
+            Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+            truth = 1.0 - X @ Y.T
+            ea = float(np.max(np.abs(a["csm"][2] - truth))), float(np.max(np.abs(b["csm"][2] - truth)))
+            assert ea[0] <= 2e-6 and ea[1] <= 2e-6 and ea[1] <= 2 * ea[0] + 2e-7, ea       # (f32 unit rows, 480-term f32 sums)
+            assert float(np.max(np.abs(a["csm"][2] - b["csm"][2]))) <= 2e-6
+        assert len(otis) >= 5, otis                               # several different rolls were exercised
+        ii, jj = np.meshgrid(np.arange(0, 14), np.arange(5, 40), indexing="ij")
+        iu, ju = np.triu_indices(30, 1)
+        lists = [np.stack([ii.ravel(), jj.ravel()], 1), np.stack([iu, ju], 1), rng.integers(0, n, (500, 2)),
+                 np.array([[3, 4], [3, 4], [4, 3], [7, 7], [0, 1], [1, 0], [0, 0]])]
+        for pairs in lists:
+            pairs = np.ascontiguousarray(pairs, np.int32)
+            ctx.set_ef_gemm("bf16x3_chroma_f32")
+            want = ctx.earlyfusion_pairs(pairs)
+            ctx.set_ef_gemm("bf16x3")
+            got = ctx.earlyfusion_pairs(pairs)
+            assert np.array_equal(got[:, :2], want[:, :2])                                    # mfccs, ssms: the same kernel
+            same = np.all(got == want, axis=1)
+            assert same.mean() >= 0.97, same.mean()
+            assert np.max(np.abs(got - want)) <= 3.0
+        planes = {}
+        for mode in ("bf16x3_chroma_f32", "bf16x3"):
+            ctx.set_ef_gemm(mode)
+            planes[mode] = [np.zeros((n, n), np.float32) for _ in range(4)]
+            ctx.pair_grid(_lib.ALGO_EARLYFUSION, True, _lib.EfParams(0.1, 10), planes[mode], mirror=True, tile=0)
+        for e in range(4):
+            same = planes["bf16x3"][e] == planes["bf16x3_chroma_f32"][e]
+            assert same.mean() >= (1.0 if e < 2 else 0.97), (e, same.mean())
+        # blocks of a frame count the bin-major split does not cover (12 x 36 values): the f32 kernel takes over
+        odd = [dict(mfccs=t["mfccs"][:30], ssms=t["ssms"][:30], chromas=t["chromas"][:30, :432], chroma_med=t["chroma_med"]) for t in tracks[10:14]]
+        ctx.ef_upload_pool(odd)
+        pr = np.array([[0, 1], [2, 3], [1, 3]], np.int32)
         ctx.set_ef_gemm("bf16x3_pairwise")
         want = ctx.earlyfusion_pairs(pr)
         ctx.set_ef_gemm("bf16x3")
