@@ -855,6 +855,9 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
         else limit = std::min<int64_t>((int64_t)(0.40 * (double)c->total_mem), (int64_t)24 << 30);
     }
     const int64_t limit_floats = limit / 4;
+    // the column statistics (mean of the K smallest of every column) come from C itself up to K = 16 (ef_colstat_kernel);
+    // larger neighbourhoods keep the transposed matrices and take the row-selection kernels
+    const bool keep_ct = !ext_matrix && p.K > acx::EF_COLSTAT_MAXK;
     std::vector<EfPair> pd;
     SegBatch seg;
     std::vector<int32_t> qslot, rslot;
@@ -885,7 +888,9 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             if (p.kappa == 0.0) d.kbin = d.N;
             else if (p.kappa < 1.0) d.kbin = (int)std::nearbyint(p.kappa * (double)d.N);
             else d.kbin = (int)p.kappa;
-            const int64_t need = (int64_t)4 * d.M * d.pitchC + (int64_t)3 * d.N * d.pitchT;
+            d.ctN = keep_ct ? d.N : 0;
+            d.pad = 0;
+            const int64_t need = (int64_t)4 * d.M * d.pitchC + (int64_t)3 * d.ctN * d.pitchT;
             if (need > limit_floats) return fail(c, ACX_ERR_NOMEM, "earlyfusion: one pair does not fit the scratch limit");
             if (used + need > limit_floats) break;
             d.offC = used;
@@ -990,7 +995,11 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
         {
             ProfScope ps(c, KS_EFSTAT, cells);
             ACX_ROWSTAT(dim3(rows_g, B, nfeat), 0);
-            if (!ext_matrix) ACX_ROWSTAT(dim3(rows_g, B, 3), 1);
+            if (!ext_matrix) {
+                if (keep_ct) ACX_ROWSTAT(dim3(rows_g, B, 3), 1);
+                else if (p.K <= 10) hipLaunchKernelGGL((acx::ef_colstat_kernel<10>), dim3((maxN + 63) / 64, B, 3), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, p.K);
+                else hipLaunchKernelGGL((acx::ef_colstat_kernel<acx::EF_COLSTAT_MAXK>), dim3((maxN + 63) / 64, B, 3), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, p.K);
+            }
         }
         {
             ProfScope ps(c, KS_EFSW, cells);
@@ -1030,7 +1039,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                                        sizeof(float) * d.N, d.M, hipMemcpyDeviceToHost));
             if (dbg->fused)
                 ACX_HIP(c, hipMemcpy2D(dbg->fused, sizeof(float) * d.N,
-                                       c->d_scratch + d.offC + (int64_t)3 * d.M * d.pitchC + (int64_t)3 * d.N * d.pitchT,
+                                       c->d_scratch + d.offC + (int64_t)3 * d.M * d.pitchC + (int64_t)3 * d.ctN * d.pitchT,
                                        sizeof(float) * d.pitchC, sizeof(float) * d.N, d.M, hipMemcpyDeviceToHost));
         }
         k0 = k;
@@ -2001,7 +2010,7 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
     float sc[4] = {0, 0, 0, 0};
     acx::EfPair d;
     d.q = d.r = 0; d.M = M; d.N = N; d.oti = 0; d.pitchC = round_up(N, 64); d.pitchT = round_up(M, 64); d.kbin = 0;
-    d.offC = 0; d.offS = 0;
+    d.ctN = 0; d.pad = 0; d.offC = 0; d.offS = 0;
     int rc;
     ACX_HIP(c, hipSetDevice(c->device));
     if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)M * d.pitchC)) != ACX_OK) return rc;

@@ -26,6 +26,7 @@
 
 namespace acx {
 
+constexpr int EF_COLSTAT_MAXK = 16;   // neighbourhood sizes K the column statistics take from C itself (ef_colstat_kernel); beyond: C^T + row kernels
 constexpr int EF_MAXNB = 1024;    // blocks per track of the register-resident kernels (rows of <= 512 take the narrow ones);
                                   // longer tracks: ef_rowstat_long_kernel / sw_long_kernel (any length)
 
@@ -36,7 +37,9 @@ struct EfPair {
     int32_t pitchC;        // row pitch of C (multiple of 64, >= N)
     int32_t pitchT;        // row pitch of C^T (multiple of 64, >= M)
     int32_t kbin;          // neighbours per row of csm_to_binary (host: int(round(kappa * N)), half-to-even)
-    int64_t offC;          // float offset of the pair's matrices: [C x3][C^T x3][F]
+    int32_t ctN;           // N when the transposed matrices are kept (neighbourhoods of more than EF_COLSTAT_MAXK columns), else 0
+    int32_t pad;
+    int64_t offC;          // float offset of the pair's matrices: [C x3][C^T x3 (ctN rows each)][F]
     int64_t offS;          // float offset of the pair's vectors:
                            //   per feature s<3: [t rows][r rows][c cols][jcut rows]; then [t rows][jcut rows] of F
 };
@@ -44,11 +47,11 @@ struct EfPair {
 __device__ __forceinline__ int64_t ef_c_off(const EfPair &P, int s) { return P.offC + (int64_t)s * P.M * P.pitchC; }
 __device__ __forceinline__ int64_t ef_ct_off(const EfPair &P, int s)
 {
-    return P.offC + (int64_t)3 * P.M * P.pitchC + (int64_t)s * P.N * P.pitchT;
+    return P.offC + (int64_t)3 * P.M * P.pitchC + (int64_t)s * P.ctN * P.pitchT;
 }
 __device__ __forceinline__ int64_t ef_f_off(const EfPair &P)
 {
-    return P.offC + (int64_t)3 * P.M * P.pitchC + (int64_t)3 * P.N * P.pitchT;
+    return P.offC + (int64_t)3 * P.M * P.pitchC + (int64_t)3 * P.ctN * P.pitchT;
 }
 // vectors: feature s: t at +0, r at +pitchT, c at +2 pitchT (size pitchC), jcut (int) behind c; stride
 // per feature.  The fused matrix (4th slot) keeps t at +0 and jcut at +pitchT.
@@ -111,7 +114,7 @@ __device__ __forceinline__ void ef_gemm_epilogue(const f32x4 (&acc)[NA][4], cons
                 }
                 if (i < P.M && j < P.N) C[(size_t)i * P.pitchC + j] = v[reg];
             }
-            if (j < P.N) {
+            if (j < P.N && P.ctN) {
                 float *ct = CT + (size_t)j * P.pitchT + ib;
                 if (ib + 3 < P.M) *reinterpret_cast<float4 *>(ct) = make_float4(v[0], v[1], v[2], v[3]);
                 else
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             for (int g = 0; g < 6; ++g) {
 #pragma unroll
                 for (int a = 0; a < NA; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[a][TA[g]], bv[b & 1][TB[g]], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[b & 1][TB[g]], av[a][TA[g]], acc[a][b], 0, 0, 0);
                 if (g == 1 && b + 1 < NB) { rdb((b + 1) & 1, b + 1, 2); rdb((b + 1) & 1, b + 1, 0); rdb((b + 1) & 1, b + 1, 1); }
                 const int slot = 6 * b + g;
                 if (slot >= 2 && slot <= 18 && (slot & 1) == 0) {
@@ -637,19 +640,13 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     if (any) sweep(chunk_mma);
     else sweep(chunk_idle);
 
-    // ---- epilogue: every sub-tile into the matrices of its own pair (get_csm: sqrt(max(0, |x|^2 + |y|^2 - 2 x.y));
-    // get_csm_cosine of unit rows: 1 - x.y).  A lane's four accumulator values are four consecutive ROWS of one column:
-    // the transposed matrix takes them as one 16-byte store; for the matrix itself the sub-tile is turned round through a
-    // wave-private 16 x 16 LDS tile (pitch 20 floats; two tiles alternate) so that a lane holds four consecutive COLUMNS
-    // of one row -- 32 wide stores per wave instead of 16 x 4 narrow + 16 wide: with one workgroup per CU nothing else
-    // runs on the CU while the tail of stores issues.
-    __syncthreads();                                     // (the operand buffers are dead: every wave has read its last chunk)
+    // ---- epilogue: every sub-tile into the matrix of its own pair (get_csm: sqrt(max(0, |x|^2 + |y|^2 - 2 x.y));
+    // get_csm_cosine of unit rows: 1 - x.y).  The reference blocks are the MFMA's ROW operand, so a lane's four
+    // accumulator values are four consecutive COLUMNS of one row of C: one 16-byte store per sub-tile.  The transposed
+    // matrices are not written (the column statistics come from C, ef_colstat_kernel) unless the pair keeps them.
     if (!any) return;
-    float *T = reinterpret_cast<float *>(efr_lds) + wave * (2 * 16 * 20);
     const float *nrm = s == 0 ? nrm0 : nrm1;
-    const int il = 4 * lk, jl = lr;                      // accumulator layout: rows il .. il + 3 of column jl
-    const int ir = lane >> 2, jq = 4 * (lane & 3);       // after the turn: row ir, columns jq .. jq + 3
-    int flip = 0;
+    const int il = lr, jl = 4 * lk;                      // accumulator layout: row il, columns jl .. jl + 3 of the sub-tile
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         bool row = false;
@@ -657,47 +654,36 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         for (int b = 0; b < NB; ++b) row = row || pidx[a][b] >= 0;
         if (!row) continue;
         const EfSegGroup ga = rowg[R.g0 + gr0 + a];
-        float nx[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) nx[reg] = (!CH && il + reg < ga.valid) ? nrm[ga.poolrow + il + reg] : 0.0f;
+        const bool iok = il < ga.valid;
+        const float nx = (!CH && iok) ? nrm[ga.poolrow + il] : 0.0f;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (pidx[a][b] < 0) continue;                                  // wave-uniform
             const EfPair P = pd[pidx[a][b]];
             const EfSegGroup gb = colg[R.h0 + gc0 + b];
-            float *C = scratch + ef_c_off(P, s);
-            float *CT = scratch + ef_ct_off(P, s);
-            const bool jok = jl < gb.valid;
-            const float ny = (!CH && jok) ? nrm[gb.poolrow + jl] : 0.0f;
-            float *Tw = T + flip * (16 * 20);
-            flip ^= 1;
             float v[4];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 if (CH) v[reg] = 1.0f - acc[a][b][reg];
                 else {
-                    float tq = (nx[reg] + ny) - 2.0f * acc[a][b][reg];
+                    const float ny = jl + reg < gb.valid ? nrm[gb.poolrow + jl + reg] : 0.0f;
+                    float tq = (nx + ny) - 2.0f * acc[a][b][reg];
                     if (tq < 0.0f) tq = 0.0f;
                     v[reg] = __builtin_sqrtf(tq);
                 }
-                Tw[(il + reg) * 20 + jl] = v[reg];
             }
-            if (jok) {
-                float *ct = CT + (size_t)(gb.local0 + jl) * P.pitchT + ga.local0 + il;
-                if (il + 3 < ga.valid) *reinterpret_cast<float4 *>(ct) = make_float4(v[0], v[1], v[2], v[3]);
+            if (iok) {
+                float *cr = scratch + ef_c_off(P, s) + (size_t)(ga.local0 + il) * P.pitchC + gb.local0 + jl;
+                if (jl + 3 < gb.valid) *reinterpret_cast<float4 *>(cr) = make_float4(v[0], v[1], v[2], v[3]);
                 else
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg)
-                        if (il + reg < ga.valid) ct[reg] = v[reg];
-            }
-            const float4 w = *reinterpret_cast<const float4 *>(Tw + ir * 20 + jq);
-            if (ir < ga.valid) {
-                float *cr = C + (size_t)(ga.local0 + ir) * P.pitchC + gb.local0 + jq;
-                if (jq + 3 < gb.valid) *reinterpret_cast<float4 *>(cr) = w;
-                else {
-                    if (jq < gb.valid) cr[0] = w.x;
-                    if (jq + 1 < gb.valid) cr[1] = w.y;
-                    if (jq + 2 < gb.valid) cr[2] = w.z;
+                        if (jl + reg < gb.valid) cr[reg] = v[reg];
+                if (P.ctN) {                                               // (K > EF_COLSTAT_MAXK: rare, narrow stores)
+                    float *ct = scratch + ef_ct_off(P, s) + (size_t)(gb.local0 + jl) * P.pitchT + ga.local0 + il;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        if (jl + reg < gb.valid) ct[(size_t)reg * P.pitchT] = v[reg];
                 }
             }
         }
@@ -875,7 +861,7 @@ __global__ __launch_bounds__(256) void ef_gemm_seg_f32_kernel(const float *__res
                 v[reg] = 1.0f - acc[a][b][reg];
                 if (il + reg < ga.valid && jok) C[(size_t)(ib + reg) * P.pitchC + j] = v[reg];
             }
-            if (jok) {
+            if (jok && P.ctN) {
                 float *ct = CT + (size_t)j * P.pitchT + ib;
                 if (il + 3 < ga.valid) *reinterpret_cast<float4 *>(ct) = make_float4(v[0], v[1], v[2], v[3]);
                 else
@@ -1042,6 +1028,62 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         const float m = mean_k_smallest(x, kk, vk, lane);
         if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// E2c: the column statistic c_j = mean of the kw smallest values of column j (the neighbourhood means getWCSM takes over
+// the columns), from the ROWS of C: a lane owns one column and keeps its KW smallest values sorted in registers
+// while the rows stream past, 64 consecutive columns per wave and load (an insertion is KW - 1 v_med3_f32 and a
+// v_min_f32: new t[i] = med3(x, t[i-1], t[i])); the four waves of a workgroup take every fourth row and merge their
+// lists through LDS.  Replaces the transposed matrices (a second copy of every C written by the GEMM, read once by
+// a row-selection kernel) for kw <= EF_COLSTAT_MAXK; any track length.
+// ------------------------------------------------------------------------------------
+template <int KW>
+__global__ __launch_bounds__(256) void ef_colstat_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
+                                                         float *__restrict__ stat, int kw)
+{
+    __shared__ float part[3][KW][64];
+    const EfPair P = pd[blockIdx.y];
+    const int s = blockIdx.z;
+    if ((int)blockIdx.x * 64 >= P.N) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 64 + lane;                 // (j < pitchC: the load is inside the pair's matrix even behind column N)
+    const bool ok = j < P.N;
+    const float *C = scratch + ef_c_off(P, s) + j;
+    const float INF = __builtin_inff();
+    float t[KW];
+#pragma unroll
+    for (int e = 0; e < KW; ++e) t[e] = INF;
+    auto insert = [&](float x) {
+#pragma unroll
+        for (int e = KW - 1; e >= 1; --e) t[e] = __builtin_amdgcn_fmed3f(x, t[e - 1], t[e]);
+        t[0] = __builtin_fminf(t[0], x);
+    };
+    for (int i0 = wave; i0 < P.M; i0 += 32) {             // eight of the wave's rows in flight
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = i0 + 4 * e;
+            x[e] = (ok && i < P.M) ? C[(size_t)i * P.pitchC] : INF;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) insert(x[e]);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < KW; ++e) part[wave - 1][e][lane] = t[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int e = 0; e < KW; ++e) insert(part[w][e][lane]);
+    const int kk = kw < P.M ? kw : P.M;
+    float sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < KW; ++e) sum += e < kk ? t[e] : 0.0f;        // ascending
+    if (ok) stat[P.offS + s * ef_s_stride(P) + 2 * (int64_t)P.pitchT + j] = sum / (float)kk;
 }
 
 // ------------------------------------------------------------------------------------

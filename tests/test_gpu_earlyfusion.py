@@ -355,3 +355,25 @@ def test_chroma_on_the_bf16_pipe(ctx):
         assert np.array_equal(ctx.earlyfusion_pairs(pr), want)
     finally:
         ctx.set_ef_gemm("bf16x3")
+
+
+def test_neighbourhood_sizes(ctx):
+    """K (the neighbourhood of getWCSM's kernel widths) up to 16: the column means come from C itself
+    (ef_colstat_kernel); beyond: the transposed matrices and the row-selection kernel.  Both against the oracle's
+    getWCSM on the device's own matrices, for ragged pairs (the reference's np.partition needs more than K blocks per
+    track: the 7-block track only meets the small K)."""
+    import oracle
+    from acoss_amd import synth
+    tracks = synth.earlyfusion_set(5, seed=8, nb_range=(5, 150))
+    tracks[4] = {k: (v[:7] if hasattr(v, "shape") and v.ndim == 2 else v) for k, v in tracks[4].items()}      # 7 blocks
+    ctx.ef_upload_pool(tracks)
+    for K in (1, 3, 10, 11, 16, 17, 25):
+        for (i, j) in [(0, 1), (1, 0), (2, 3), (4, 0), (0, 4)]:
+            if min(len(tracks[i]["mfccs"]), len(tracks[j]["mfccs"])) <= K:
+                continue
+            d = ctx.ef_debug_pair(i, j, K=K)
+            ws = np.zeros_like(d["csm"][0])
+            for k in range(3):
+                ws += oracle.get_wcsm(d["csm"][k], K, K)
+            np.testing.assert_allclose(d["fused"], np.exp(-ws), rtol=2e-4, atol=1e-6, err_msg="K=%d pair %s" % (K, (i, j)))
+            assert round(oracle.sw_constrained(oracle.csm_to_binary(d["fused"], 0.1)) * 10) == round(float(d["scores"][3]) * 10)

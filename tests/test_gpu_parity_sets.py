@@ -181,9 +181,9 @@ def test_earlyfusion_cover_set_map(ctx):
         moved_hip = r["hip_vs_f64matrices"]["n"] - r["hip_vs_f64matrices"]["0"]
         moved_ref = r["oracle_vs_f64matrices"]["n"] - r["oracle_vs_f64matrices"]["0"]
         assert moved_hip <= 2 * moved_ref + 8, (s, moved_hip, moved_ref)
-        # the chroma plane is the f32 kernel in both modes: identical
-        if s == "chromas":
-            assert r["bf16x3_vs_f32gemm"]["max"] == 0.0
+        # the two arithmetics of the device (three-term bf16 splits / f32 MFMAs) against each other: ties only
+        h = r["bf16x3_vs_f32gemm"]
+        assert h["max"] <= EF_TOL + 1e-6 and h["0"] >= EF_MIN_SAME * h["n"], (s, h)
 
 
 def test_earlyfusion_scale_15000(ctx):
