@@ -1688,7 +1688,7 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
         }
     }
     for (int k = 0; k < 2; ++k)
-        ACX_HIP(c, hipMalloc((void **)&c->d_efn[k], sizeof(float) * std::max<int64_t>(1, nb)));
+        ACX_HIP(c, hipMalloc((void **)&c->d_efn[k], sizeof(float) * (nb + 32)));      // (+ slack: the rectangle GEMM reads a whole group of 16 norms)
     if (nb > 0) {
         const unsigned g = (unsigned)((nb + 3) / 4);
         hipLaunchKernelGGL(acx::ef_rownorm_kernel, dim3(g), dim3(256), 0, c->stream, c->d_ef[2], nb, dims[2], 1, (float *)nullptr);

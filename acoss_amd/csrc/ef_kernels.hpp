@@ -469,18 +469,29 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     const int lr = lane & 15, lk = lane >> 4;
     constexpr int NA = 4, NB = 4;
     const int gr0 = 16 * ty + NA * wr, gc0 = tx + NB * wc;
-    // pair of every sub-tile of the wave (-1: nothing to store) -- wave-uniform
+    // the wave's 4 row and 4 column groups, and the pair of every sub-tile (-1: nothing to store) -- wave-uniform.
+    // Straight-line loads with clamped indices (8 group records, then 16 table entries: two latencies, not 32)
+    EfSegGroup GA[NA], GB[NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const bool in = gr0 + a < R.ng;
+        GA[a] = rowg[R.g0 + (in ? gr0 + a : 0)];
+        if (!in) GA[a].valid = 0;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const bool in = NB * wc + b < ncg;
+        GB[b] = colg[R.h0 + (in ? gc0 + b : tx)];
+        if (!in) GB[b].valid = 0;
+    }
     int pidx[NA][NB];
     bool any = false;
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            int p = -1;
-            if (gr0 + a < R.ng && NB * wc + b < ncg) {
-                const EfSegGroup ga = rowg[R.g0 + gr0 + a], gb = colg[R.h0 + gc0 + b];
-                if (ga.valid > 0 && gb.valid > 0) p = pairtab[R.ptab0 + ga.slot * R.ncols + gb.slot];
-            }
+            int p = pairtab[R.ptab0 + GA[a].slot * R.ncols + GB[b].slot];
+            p = (GA[a].valid > 0 && GB[b].valid > 0) ? p : -1;
             pidx[a][b] = __builtin_amdgcn_readfirstlane(p);
             any = any || p >= 0;
         }
@@ -567,17 +578,32 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     // ---- one k chunk: 24 groups of 4 MFMAs (one term pair x the 4 row sub-tiles); behind every other group one staging
     // piece goes to LDS (chunk k + 1) and is loaded again (chunk k + 2); behind the second group of a column sub-tile the
     // operands of the next one are read.  Sub-tiles without a pair are multiplied like the others (never stored).
+    // The workgroup's ONE barrier of a chunk stands behind group 18 (the last LDS store of chunk k + 1); behind it the
+    // operands of the first two groups of chunk k + 1 are read into registers of their own while groups 19 - 23 run, so
+    // that the matrix pipe does not drain at the chunk boundary (8 waves x 15 reads after a barrier at the boundary
+    // kept it idle for ~10 % of a chunk).
+    bf16x8 pa0[NA], pa2[NA], pb0, pb2;                 // prefetched: av[.][0], av[.][2], bv[0][0], bv[0][2] of the next chunk
+    auto prefetch = [&](int buf) {
+        const unsigned short *a_ = aop + buf * EFR_A, *b_ = bop + buf * EFR_B;
+        pb2 = *reinterpret_cast<const bf16x8 *>(b_ + (2 * EFR_COLS) * EFB_LP);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) pa0[a] = *reinterpret_cast<const bf16x8 *>(a_ + (16 * a) * EFB_LP);
+        pb0 = *reinterpret_cast<const bf16x8 *>(b_);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) pa2[a] = *reinterpret_cast<const bf16x8 *>(a_ + (2 * EFR_ROWS + 16 * a) * EFB_LP);
+    };
     auto chunk_mma = [&](int cur, auto st_tag, auto ld_tag) {
         constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
         constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};       // smallest products first, as in E1b
         const unsigned short *a_ = aop + cur * EFR_A, *b_ = bop + cur * EFR_B;
         bf16x8 av[NA][3], bv[2][3];
-        auto rda = [&](int q) {
-#pragma unroll
-            for (int a = 0; a < NA; ++a) av[a][q] = *reinterpret_cast<const bf16x8 *>(a_ + (q * EFR_ROWS + 16 * a) * EFB_LP);
-        };
         auto rdb = [&](int e, int b, int q) { bv[e][q] = *reinterpret_cast<const bf16x8 *>(b_ + (q * EFR_COLS + 16 * b) * EFB_LP); };
-        rdb(0, 0, 2); rda(0); rdb(0, 0, 0); rda(2); rdb(0, 0, 1); rda(1);          // in the order the groups want them
+#pragma unroll
+        for (int a = 0; a < NA; ++a) { av[a][0] = pa0[a]; av[a][2] = pa2[a]; }
+        bv[0][2] = pb2; bv[0][0] = pb0;
+        rdb(0, 0, 1);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) av[a][1] = *reinterpret_cast<const bf16x8 *>(a_ + (EFR_ROWS + 16 * a) * EFB_LP);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -605,6 +631,10 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                     default: piece(std::integral_constant<int, 8>()); break;
                     }
                 }
+                if (ST && slot == 18) {
+                    __syncthreads();
+                    prefetch(cur ^ 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -615,6 +645,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
         if (ST) for9([&](auto p_tag) { lstore_piece(cur ^ 1, p_tag); });
         if (LD) { for9([&](auto p_tag) { gload_piece(p_tag); }); gload_advance(); }
+        if (ST) __syncthreads();
     };
     const int nk = Kp / EFB_BK;
     // prologue: chunk 0 into buffer 0, chunk 1 into the registers
@@ -626,68 +657,79 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     // (two copies of the loop, the same barriers in both: one loop with a per-chunk choice keeps two sets of accumulators)
     auto sweep = [&](auto &&chunk) {
         int kc = 0;
-        for (; kc + 2 < nk; ++kc) {
-            chunk(kc & 1, std::true_type(), std::true_type());
-            __syncthreads();
-        }
+        for (; kc + 2 < nk; ++kc) chunk(kc & 1, std::true_type(), std::true_type());
         if (kc + 1 < nk) {
             chunk(kc & 1, std::true_type(), std::false_type());
-            __syncthreads();
             ++kc;
         }
         chunk(kc & 1, std::false_type(), std::false_type());
     };
-    if (any) sweep(chunk_mma);
-    else sweep(chunk_idle);
+    if (any) {
+        prefetch(0);
+        sweep(chunk_mma);
+    } else sweep(chunk_idle);
 
     // ---- epilogue: every sub-tile into the matrix of its own pair (get_csm: sqrt(max(0, |x|^2 + |y|^2 - 2 x.y));
     // get_csm_cosine of unit rows: 1 - x.y).  The reference blocks are the MFMA's ROW operand, so a lane's four
     // accumulator values are four consecutive COLUMNS of one row of C: one 16-byte store per sub-tile.  The transposed
     // matrices are not written (the column statistics come from C, ef_colstat_kernel) unless the pair keeps them.
+    // With one workgroup per CU nothing hides this tail: the norms (8 loads per lane) and the 16 pair records are
+    // fetched in two batches before the first store instead of one dependent chain per sub-tile (measured in the
+    // round's first version of this epilogue: ~2 k cycles x 16 sub-tiles of a 180 k-cycle tile).
     if (!any) return;
     const float *nrm = s == 0 ? nrm0 : nrm1;
     const int il = lr, jl = 4 * lk;                      // accumulator layout: row il, columns jl .. jl + 3 of the sub-tile
+    float nx[NA];
+    f32x4 ny[NB];
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    if (!CH) {                                           // (rows behind a group's last block read the next track's norms
+#pragma unroll                                           //  or the slack behind the pool; their cells are not stored)
+        for (int a = 0; a < NA; ++a) nx[a] = nrm[GA[a].poolrow + il];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
-        bool row = false;
+        for (int b = 0; b < NB; ++b) ny[b] = *reinterpret_cast<const f32x4u *>(nrm + GB[b].poolrow + jl);
+    }
+    int64_t cbase[NA][NB];                               // float offset of the sub-tile's first cell in its pair's matrix
+    int cpitch[NA][NB], ctn[NA][NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) row = row || pidx[a][b] >= 0;
-        if (!row) continue;
-        const EfSegGroup ga = rowg[R.g0 + gr0 + a];
-        const bool iok = il < ga.valid;
-        const float nx = (!CH && iok) ? nrm[ga.poolrow + il] : 0.0f;
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const EfPair *P = pd + (pidx[a][b] < 0 ? 0 : pidx[a][b]);
+            const int pc = P->pitchC;
+            cbase[a][b] = P->offC + (int64_t)s * P->M * pc + (int64_t)GA[a].local0 * pc + GB[b].local0;
+            cpitch[a][b] = pc;
+            ctn[a][b] = P->ctN;
+        }
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (pidx[a][b] < 0) continue;                                  // wave-uniform
-            const EfPair P = pd[pidx[a][b]];
-            const EfSegGroup gb = colg[R.h0 + gc0 + b];
             float v[4];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 if (CH) v[reg] = 1.0f - acc[a][b][reg];
                 else {
-                    const float ny = jl + reg < gb.valid ? nrm[gb.poolrow + jl + reg] : 0.0f;
-                    float tq = (nx + ny) - 2.0f * acc[a][b][reg];
+                    float tq = (nx[a] + ny[b][reg]) - 2.0f * acc[a][b][reg];
                     if (tq < 0.0f) tq = 0.0f;
                     v[reg] = __builtin_sqrtf(tq);
                 }
             }
-            if (iok) {
-                float *cr = scratch + ef_c_off(P, s) + (size_t)(ga.local0 + il) * P.pitchC + gb.local0 + jl;
-                if (jl + 3 < gb.valid) *reinterpret_cast<float4 *>(cr) = make_float4(v[0], v[1], v[2], v[3]);
-                else
+            float *cr = scratch + cbase[a][b] + (int64_t)il * cpitch[a][b] + jl;
+            if (GA[a].valid == 16 && GB[b].valid == 16) *reinterpret_cast<float4 *>(cr) = make_float4(v[0], v[1], v[2], v[3]);
+            else if (il < GA[a].valid) {
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        if (jl + reg < gb.valid) cr[reg] = v[reg];
-                if (P.ctN) {                                               // (K > EF_COLSTAT_MAXK: rare, narrow stores)
-                    float *ct = scratch + ef_ct_off(P, s) + (size_t)(gb.local0 + jl) * P.pitchT + ga.local0 + il;
+                for (int reg = 0; reg < 4; ++reg)
+                    if (jl + reg < GB[b].valid) cr[reg] = v[reg];
+            }
+            if (ctn[a][b] && il < GA[a].valid) {                           // (K > EF_COLSTAT_MAXK: rare, narrow stores)
+                const EfPair P = pd[pidx[a][b]];
+                float *ct = scratch + ef_ct_off(P, s) + (size_t)(GB[b].local0 + jl) * P.pitchT + GA[a].local0 + il;
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        if (jl + reg < gb.valid) ct[(size_t)reg * P.pitchT] = v[reg];
-                }
+                for (int reg = 0; reg < 4; ++reg)
+                    if (jl + reg < GB[b].valid) ct[(size_t)reg * P.pitchT] = v[reg];
             }
         }
-    }
 }
 
 // ------------------------------------------------------------------------------------
