@@ -1186,6 +1186,18 @@ void acx_destroy(acx_ctx *c)
     delete c;
 }
 
+#ifdef ACX_EF_TIMING
+extern "C" int acx_ef_clk(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(acx::g_ef_clk), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(acx::g_ef_clk), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 const char *acx_last_error(const acx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int acx_set_scratch_limit(acx_ctx *c, int64_t bytes)

@@ -445,7 +445,12 @@ struct EfSegWg { int32_t rect, ty, tx, pad; };      // one workgroup tile that h
 // ------------------------------------------------------------------------------------
 constexpr int EFR_ROWS = 256, EFR_COLS = 128, EFR_THREADS = 512;
 constexpr int EFR_A = 3 * EFR_ROWS * EFB_LP, EFR_B = 3 * EFR_COLS * EFB_LP;      // bf16 elements of one buffer
-constexpr int EFR_LDS_BYTES = 2 * 2 * (EFR_A + EFR_B);                           // 147 456
+constexpr int EFR_TP = 32;                                                       // pitch (floats) of a wave's turning tile in the epilogue
+constexpr int EFR_LDS_BYTES = 2 * 2 * (EFR_A + EFR_B) + 8 * 16 * EFR_TP * 4;     // 147 456 + 16 384 = all 160 KB
+
+#ifdef ACX_EF_TIMING   /* development builds (scripts/ab_build_acx.sh timing -DACX_EF_TIMING; scripts/ef_phase_timing.py): where a tile's time goes */
+__device__ unsigned long long g_ef_clk[16];          // [0] start-up, [1] k loop, [2] epilogue until the last store is issued, [3] until it is acknowledged, [15] waves
+#endif
 
 template <int CH>
 __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ef_gemm_rect_bf16x3_kernel(
@@ -457,6 +462,9 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     extern __shared__ __attribute__((aligned(16))) unsigned short efr_lds[];
     unsigned short *As = efr_lds;                    // [buffer][term][row][32 k]
     unsigned short *Bs = efr_lds + 2 * EFR_A;
+#ifdef ACX_EF_TIMING
+    const unsigned long long clk0_ = __builtin_readcyclecounter();
+#endif
     const EfSegWg W = wgs[blockIdx.x];               // ty in units of 16 row groups; tx = first column group, pad = column groups
     const EfSegRect R = rects[W.rect];
     const int ty = W.ty, tx = W.tx, ncg = W.pad;
@@ -664,10 +672,16 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         }
         chunk(kc & 1, std::false_type(), std::false_type());
     };
+#ifdef ACX_EF_TIMING
+    const unsigned long long clk1_ = __builtin_readcyclecounter();
+#endif
     if (any) {
         prefetch(0);
         sweep(chunk_mma);
     } else sweep(chunk_idle);
+#ifdef ACX_EF_TIMING
+    const unsigned long long clk2_ = __builtin_readcyclecounter();
+#endif
 
     // ---- epilogue: every sub-tile into the matrix of its own pair (get_csm: sqrt(max(0, |x|^2 + |y|^2 - 2 x.y));
     // get_csm_cosine of unit rows: 1 - x.y).  The reference blocks are the MFMA's ROW operand, so a lane's four
@@ -700,36 +714,73 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             cpitch[a][b] = pc;
             ctn[a][b] = P->ctN;
         }
+    // A CU retires stores by the cache LINE (measured: ~140 cycles per store instruction that touches 16 lines, whatever
+    // it fills of them -- 7 B / cycle / CU; the tail of 128 such instructions per workgroup was a sixth of a tile's
+    // time).  A sub-tile's accumulators are 16 rows x 64 bytes: two neighbouring sub-tiles of the same pair are turned
+    // round through a wave-private LDS tile (16 rows x 32 columns, in the 16 KB of LDS the operand buffers leave free)
+    // so that an instruction writes 8 rows x 128 bytes = 8 FULL lines; non-temporal (the matrices are read again by
+    // the next kernels, long after the L2 has turned over).
+    float *Tw = reinterpret_cast<float *>(efr_lds + 2 * (EFR_A + EFR_B)) + wave * (16 * EFR_TP);
+    auto value = [&](int a, int b, float (&v)[4]) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (CH) v[reg] = 1.0f - acc[a][b][reg];
+            else {
+                float tq = (nx[a] + ny[b][reg]) - 2.0f * acc[a][b][reg];
+                if (tq < 0.0f) tq = 0.0f;
+                v[reg] = __builtin_sqrtf(tq);
+            }
+        }
+    };
+    auto narrow = [&](int a, int b) {                                      // one sub-tile by itself (rims, track ends)
+        if (pidx[a][b] < 0) return;                                        // wave-uniform
+        float v[4];
+        value(a, b, v);
+        float *cr = scratch + cbase[a][b] + (int64_t)il * cpitch[a][b] + jl;
+        if (GA[a].valid == 16 && GB[b].valid == 16) __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4 *>(cr));
+        else if (il < GA[a].valid) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (jl + reg < GB[b].valid) cr[reg] = v[reg];
+        }
+        if (ctn[a][b] && il < GA[a].valid) {                               // (K > EF_COLSTAT_MAXK: rare, narrow stores)
+            const EfPair P = pd[pidx[a][b]];
+            float *ct = scratch + ef_ct_off(P, s) + (size_t)(GB[b].local0 + jl) * P.pitchT + GA[a].local0 + il;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (jl + reg < GB[b].valid) ct[(size_t)reg * P.pitchT] = v[reg];
+        }
+    };
+    const int tr = lane >> 3, tc = 4 * (lane & 7);       // after the turn: rows tr and 8 + tr, columns tc .. tc + 3 of 32
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (pidx[a][b] < 0) continue;                                  // wave-uniform
-            float v[4];
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                if (CH) v[reg] = 1.0f - acc[a][b][reg];
-                else {
-                    float tq = (nx[a] + ny[b][reg]) - 2.0f * acc[a][b][reg];
-                    if (tq < 0.0f) tq = 0.0f;
-                    v[reg] = __builtin_sqrtf(tq);
-                }
-            }
-            float *cr = scratch + cbase[a][b] + (int64_t)il * cpitch[a][b] + jl;
-            if (GA[a].valid == 16 && GB[b].valid == 16) *reinterpret_cast<float4 *>(cr) = make_float4(v[0], v[1], v[2], v[3]);
-            else if (il < GA[a].valid) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    if (jl + reg < GB[b].valid) cr[reg] = v[reg];
-            }
-            if (ctn[a][b] && il < GA[a].valid) {                           // (K > EF_COLSTAT_MAXK: rare, narrow stores)
-                const EfPair P = pd[pidx[a][b]];
-                float *ct = scratch + ef_ct_off(P, s) + (size_t)(GB[b].local0 + jl) * P.pitchT + GA[a].local0 + il;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    if (jl + reg < GB[b].valid) ct[(size_t)reg * P.pitchT] = v[reg];
-            }
+        for (int b = 0; b < NB; b += 2) {
+            const bool wide = pidx[a][b] >= 0 && pidx[a][b] == pidx[a][b + 1] && GA[a].valid == 16 && GB[b].valid == 16 &&
+                              GB[b + 1].valid == 16 && GB[b + 1].local0 == GB[b].local0 + 16 && !ctn[a][b];
+            if (!wide) { narrow(a, b); narrow(a, b + 1); continue; }       // wave-uniform
+            float v0[4], v1[4];
+            value(a, b, v0);
+            value(a, b + 1, v1);
+            // (the eight 16-byte pieces of a tile row sit at piece ^ (row / 2): conflict free both ways)
+            const int wz = (il >> 1) & 7;
+            *reinterpret_cast<float4 *>(Tw + il * EFR_TP + 4 * (lk ^ wz)) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+            *reinterpret_cast<float4 *>(Tw + il * EFR_TP + 4 * ((4 + lk) ^ wz)) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(Tw + tr * EFR_TP + 4 * ((lane & 7) ^ ((tr >> 1) & 7)));
+            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(Tw + (8 + tr) * EFR_TP + 4 * ((lane & 7) ^ (((8 + tr) >> 1) & 7)));
+            float *cr = scratch + cbase[a][b] + (int64_t)tr * cpitch[a][b] + tc;
+            __builtin_nontemporal_store(w0, reinterpret_cast<f32x4 *>(cr));
+            __builtin_nontemporal_store(w1, reinterpret_cast<f32x4 *>(cr + (int64_t)8 * cpitch[a][b]));
         }
+#ifdef ACX_EF_TIMING
+    const unsigned long long clk3_ = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long clk4_ = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_ef_clk[0], clk1_ - clk0_); atomicAdd(&g_ef_clk[1], clk2_ - clk1_); atomicAdd(&g_ef_clk[2], clk3_ - clk2_);
+        atomicAdd(&g_ef_clk[3], clk4_ - clk3_); atomicAdd(&g_ef_clk[15], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
