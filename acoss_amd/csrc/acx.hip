@@ -114,6 +114,7 @@ struct acx_ctx {
     // scratch (grow-only)
     float *d_scratch = nullptr; size_t scratch_cap = 0;   // floats
     float *d_thr = nullptr;     size_t thr_cap = 0;
+    unsigned *d_efbits = nullptr; size_t efbits_cap = 0;     // EarlyFusion: the binarised matrices of a batch (ef_rowstat_kernel -> sw_bits_kernel)
     Serra09Slot slot[2];
     float *d_out = nullptr;     size_t out_cap = 0;
     unsigned long long *d_bits = nullptr; size_t bits_cap = 0;   // recurrence bitmaps (u64 words)
@@ -858,6 +859,18 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
     // the column statistics (mean of the K smallest of every column) come from C itself up to K = 16 (ef_colstat_kernel);
     // larger neighbourhoods keep the transposed matrices and take the row-selection kernels
     const bool keep_ct = !ext_matrix && p.K > acx::EF_COLSTAT_MAXK;
+    // tracks of up to EF_MAXNB blocks (rows that fit a wave's registers): the selection kernels leave the BINARISED rows
+    // behind, the fused matrix is made and binarised in registers (never stored, unless the debug entry asks for it) and
+    // the Smith-Waterman kernel walks bits; longer tracks keep the streaming kernels and the float matrices
+    bool bits_path = true;
+    if (ext_matrix) bits_path = extM <= acx::EF_MAXNB && extN <= acx::EF_MAXNB;
+    else
+        for (int64_t k = 0; k < K && bits_path; ++k) {
+            const int32_t q = pairs[2 * k], r = pairs[2 * k + 1];
+            if (q < 0 || r < 0 || q >= c->ef_ntracks || r >= c->ef_ntracks) break;      // (reported below)
+            if (c->h_efoff[q + 1] - c->h_efoff[q] > acx::EF_MAXNB || c->h_efoff[r + 1] - c->h_efoff[r] > acx::EF_MAXNB) bits_path = false;
+        }
+    const bool keep_f = !bits_path || (dbg && dbg->fused);
     std::vector<EfPair> pd;
     SegBatch seg;
     std::vector<int32_t> qslot, rslot;
@@ -865,7 +878,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
     int64_t k0 = 0;
     while (k0 < K) {
         pd.clear();
-        int64_t used = 0, used_s = 0, cells = 0;
+        int64_t used = 0, used_s = 0, used_b = 0, cells = 0;
         int maxM = 0, maxN = 0;
         int64_t k = k0;
         for (; k < K && pd.size() < 65535; ++k) {
@@ -890,11 +903,13 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             else d.kbin = (int)p.kappa;
             d.ctN = keep_ct ? d.N : 0;
             d.pad = 0;
-            const int64_t need = (int64_t)4 * d.M * d.pitchC + (int64_t)3 * d.ctN * d.pitchT;
+            const int64_t need = (int64_t)(keep_f ? 4 : 3) * d.M * d.pitchC + (int64_t)3 * d.ctN * d.pitchT;
             if (need > limit_floats) return fail(c, ACX_ERR_NOMEM, "earlyfusion: one pair does not fit the scratch limit");
             if (used + need > limit_floats) break;
             d.offC = used;
             d.offS = used_s;
+            d.offB = used_b;
+            used_b += (int64_t)4 * d.M * (d.pitchC / 32);
             used += need;
             used_s += acx::ef_s_total(d);
             maxM = std::max(maxM, d.M);
@@ -905,6 +920,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
         const int B = (int)pd.size();
         if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)used)) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)used_s)) != ACX_OK) return rc;
+        if ((rc = ensure(c, c->d_efbits, c->efbits_cap, (size_t)used_b)) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_efpd, c->efpd_cap, (size_t)B)) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_out, c->out_cap, (size_t)4 * B)) != ACX_OK) return rc;
         ACX_HIP(c, hipMemcpyAsync(c->d_efpd, pd.data(), sizeof(EfPair) * B, hipMemcpyHostToDevice, c->stream));
@@ -987,8 +1003,10 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
         const bool wide_rows = std::max(maxM, maxN) > 512, wide_cols = maxN > 512;
         const bool long_rows = std::max(maxM, maxN) > acx::EF_MAXNB, long_cols = maxN > acx::EF_MAXNB;
 #define ACX_ROWSTAT(grid_, mode_) do { if (long_rows) hipLaunchKernelGGL(acx::ef_rowstat_long_kernel, grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); \
-                                       else if (wide_rows) hipLaunchKernelGGL((acx::ef_rowstat_kernel<4>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); \
-                                       else hipLaunchKernelGGL((acx::ef_rowstat_kernel<2>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); } while (0)
+                                       else if (wide_rows) hipLaunchKernelGGL((acx::ef_rowstat_kernel<4, false>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_efbits, mode_, p.K, 0); \
+                                       else hipLaunchKernelGGL((acx::ef_rowstat_kernel<2, false>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_efbits, mode_, p.K, 0); } while (0)
+#define ACX_FUSESEL(grid_) do { if (wide_rows) hipLaunchKernelGGL((acx::ef_rowstat_kernel<4, true>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_efbits, 3, p.K, keep_f ? 1 : 0); \
+                                else hipLaunchKernelGGL((acx::ef_rowstat_kernel<2, true>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_efbits, 3, p.K, keep_f ? 1 : 0); } while (0)
 #define ACX_SW(grid_, src_) do { if (long_cols) hipLaunchKernelGGL(acx::sw_long_kernel, grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); \
                                  else if (wide_cols) hipLaunchKernelGGL((acx::sw_kernel<16>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); \
                                  else hipLaunchKernelGGL((acx::sw_kernel<8>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); } while (0)
@@ -1001,22 +1019,32 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                 else hipLaunchKernelGGL((acx::ef_colstat_kernel<acx::EF_COLSTAT_MAXK>), dim3((maxN + 63) / 64, B, 3), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, p.K);
             }
         }
-        {
-            ProfScope ps(c, KS_EFSW, cells);
-            ACX_SW(dim3(B, nfeat), 0);
-        }
-        if (!ext_matrix) {
-            {
+        if (bits_path) {
+            if (!ext_matrix) {
                 ProfScope ps(c, KS_EFFUSE, cells);
-                hipLaunchKernelGGL(acx::ef_fuse_kernel, dim3(maxM, B), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr);
+                ACX_FUSESEL(dim3((maxM + 3) / 4, B, 1));             // the fused matrix: made, thresholded and binarised row by row
             }
+            ProfScope ps(c, KS_EFSW, cells);
+            if (wide_cols) hipLaunchKernelGGL((acx::sw_bits_kernel<16>), dim3(B, ext_matrix ? 1 : 4), dim3(64), 0, c->stream, c->d_efpd, c->d_efbits, c->d_out, 0);
+            else hipLaunchKernelGGL((acx::sw_bits_kernel<8>), dim3(B, ext_matrix ? 1 : 4), dim3(64), 0, c->stream, c->d_efpd, c->d_efbits, c->d_out, 0);
+        } else {
             {
-                ProfScope ps(c, KS_EFSTAT, 0);
-                ACX_ROWSTAT(dim3(rows_g, B, 1), 2);
+                ProfScope ps(c, KS_EFSW, cells);
+                ACX_SW(dim3(B, nfeat), 0);
             }
-            {
-                ProfScope ps(c, KS_EFSW, 0);
-                ACX_SW(dim3(B, 1), 3);
+            if (!ext_matrix) {
+                {
+                    ProfScope ps(c, KS_EFFUSE, cells);
+                    hipLaunchKernelGGL(acx::ef_fuse_kernel, dim3(maxM, B), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr);
+                }
+                {
+                    ProfScope ps(c, KS_EFSTAT, 0);
+                    ACX_ROWSTAT(dim3(rows_g, B, 1), 2);
+                }
+                {
+                    ProfScope ps(c, KS_EFSW, 0);
+                    ACX_SW(dim3(B, 1), 3);
+                }
             }
         }
         ACX_HIP(c, hipGetLastError());
@@ -1046,6 +1074,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
         if (ext_matrix) break;
     }
 #undef ACX_ROWSTAT
+#undef ACX_FUSESEL
 #undef ACX_SW
     return ACX_OK;
 }
@@ -1175,6 +1204,7 @@ void acx_destroy(acx_ctx *c)
     if (c->d_out64) (void)hipFree(c->d_out64);
     ef_free_pool(c);
     if (c->d_efpd) (void)hipFree(c->d_efpd);
+    if (c->d_efbits) (void)hipFree(c->d_efbits);
     if (c->d_segr) (void)hipFree(c->d_segr);
     if (c->d_segc) (void)hipFree(c->d_segc);
     if (c->d_rects) (void)hipFree(c->d_rects);
@@ -2022,7 +2052,7 @@ int acx_sw_binary(acx_ctx *c, const uint8_t *B, int32_t M, int32_t N, float *sco
     float sc[4] = {0, 0, 0, 0};
     acx::EfPair d;
     d.q = d.r = 0; d.M = M; d.N = N; d.oti = 0; d.pitchC = round_up(N, 64); d.pitchT = round_up(M, 64); d.kbin = 0;
-    d.ctN = 0; d.pad = 0; d.offC = 0; d.offS = 0;
+    d.ctN = 0; d.pad = 0; d.offB = 0; d.offC = 0; d.offS = 0;
     int rc;
     ACX_HIP(c, hipSetDevice(c->device));
     if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)M * d.pitchC)) != ACX_OK) return rc;

@@ -39,6 +39,7 @@ struct EfPair {
     int32_t kbin;          // neighbours per row of csm_to_binary (host: int(round(kappa * N)), half-to-even)
     int32_t ctN;           // N when the transposed matrices are kept (neighbourhoods of more than EF_COLSTAT_MAXK columns), else 0
     int32_t pad;
+    int64_t offB;          // word offset of the pair's four binarised matrices (mfccs, ssms, chromas, fused): M rows of pitchC / 32 words
     int64_t offC;          // float offset of the pair's matrices: [C x3][C^T x3 (ctN rows each)][F]
     int64_t offS;          // float offset of the pair's vectors:
                            //   per feature s<3: [t rows][r rows][c cols][jcut rows]; then [t rows][jcut rows] of F
@@ -993,9 +994,20 @@ __device__ __forceinline__ float mean_k_smallest(const float (&x)[NX], int kw, f
     return (s + (float)(kw - tot) * vk) / (float)kw;
 }
 
-template <int NQ>
-__global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restrict__ pd, const float *__restrict__ scratch,
-                                                         float *__restrict__ stat, int mode, int kw)
+// getWCSM's kernel weight of one cell (similarity_fusion.py:15-46): exp(-C^2 / (2 (eps / 2)^2)), eps = (r_i + c_j + C) / 3, which
+// is exp(-18 (C / (r_i + c_j + C))^2): one reciprocal and one exp2 instead of two IEEE divisions and an expf (the
+// fused matrix is only RANKED afterwards; 1e-6 relative against the reference's f32 numpy, bound 2e-4 in the tests --
+// the exact form made the fusion kernels compute bound at ~150 instructions per cell).
+__device__ __forceinline__ float ef_wcsm_weight(float ri, float cj, float cv)
+{
+    const float q = cv * __builtin_amdgcn_rcpf((ri + cj) + cv);
+    return __builtin_amdgcn_exp2f(-25.968510740383334f * (q * q));       // 18 log2(e)
+}
+__device__ __forceinline__ float ef_fused_value(float wsum) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * wsum); }
+
+template <int NQ, bool FUSED>
+__global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
+                                                         float *__restrict__ stat, unsigned *__restrict__ bits, int mode, int kw, int store_f)
 {
     constexpr int NX = 4 * NQ;                        // values per lane
     __shared__ __attribute__((aligned(4096))) unsigned fhist[4][256];      // one-pass selection (wave_select_fast)
@@ -1033,19 +1045,56 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
     const int pitch = mode == 1 ? P.pitchT : P.pitchC;
     const int row = blockIdx.x * 4 + wave;
     if (row >= nrows) return;
-    const int64_t base = mode == 0 ? ef_c_off(P, s) : (mode == 1 ? ef_ct_off(P, s) : ef_f_off(P));
-    const float *v = scratch + base + (size_t)row * pitch;
     float x[NX];
     const float INF = __builtin_inff();
+    if constexpr (!FUSED) {
+        const int64_t base = mode == 0 ? ef_c_off(P, s) : (mode == 1 ? ef_ct_off(P, s) : ef_f_off(P));
+        const float *v = scratch + base + (size_t)row * pitch;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int j = 256 * q + 4 * lane;
-        float4 t = make_float4(INF, INF, INF, INF);
-        if (j < pitch) t = *reinterpret_cast<const float4 *>(v + j);
-        x[4 * q + 0] = (j + 0 < n) ? t.x : INF;
-        x[4 * q + 1] = (j + 1 < n) ? t.y : INF;
-        x[4 * q + 2] = (j + 2 < n) ? t.z : INF;
-        x[4 * q + 3] = (j + 3 < n) ? t.w : INF;
+        for (int q = 0; q < NQ; ++q) {
+            const int j = 256 * q + 4 * lane;
+            float4 t = make_float4(INF, INF, INF, INF);
+            if (j < pitch) t = *reinterpret_cast<const float4 *>(v + j);
+            x[4 * q + 0] = (j + 0 < n) ? t.x : INF;
+            x[4 * q + 1] = (j + 1 < n) ? t.y : INF;
+            x[4 * q + 2] = (j + 2 < n) ? t.z : INF;
+            x[4 * q + 3] = (j + 3 < n) ? t.w : INF;
+        }
+    } else {
+        // FUSED: the row of the fused matrix, F_ij = exp(-(W0 + W1 + W2)) with getWCSM's weights (ef_wcsm_weight, the
+        // arithmetic of ef_fuse_kernel to the operation), made in the registers the selection works on: the matrix is
+        // binarised without a trip to memory
+        float wsum[NX];
+#pragma unroll
+        for (int e = 0; e < NX; ++e) wsum[e] = 0.0f;
+#pragma unroll
+        for (int sf = 0; sf < 3; ++sf) {
+            const float *Sf = stat + P.offS + sf * ef_s_stride(P);
+            const float ri = Sf[P.pitchT + row];
+            const float *cj = Sf + 2 * P.pitchT;
+            const float *cv = scratch + ef_c_off(P, sf) + (size_t)row * pitch;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int j = 256 * q + 4 * lane;
+                float4 cc = make_float4(0.f, 0.f, 0.f, 0.f), vv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < pitch) { cc = *reinterpret_cast<const float4 *>(cj + j); vv = *reinterpret_cast<const float4 *>(cv + j); }
+                const float c4[4] = {cc.x, cc.y, cc.z, cc.w}, v4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wsum[4 * q + e] += ef_wcsm_weight(ri, c4[e], v4[e]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int j = 256 * q + 4 * lane;
+            float f4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f4[e] = ef_fused_value(wsum[4 * q + e]);
+                x[4 * q + e] = (j + e < n) ? f4[e] : INF;
+            }
+            if (store_f && j < pitch)                                      // (the debug entry point hands the matrix out)
+                *reinterpret_cast<float4 *>(scratch + ef_f_off(P) + (size_t)row * pitch + j) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+        }
     }
     {   // which lanes / lane pairs hold cells: a pair of lanes (16 slots) takes part in the pivot estimate when at
         // least three quarters of the slots it can have in a row of this length are cells (a pair with few cells has a large
@@ -1060,8 +1109,14 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         const int cap = 8 * ((n + 255) / 256);                 // slots of a lane pair that CAN be cells in a row of n (4 per lane and 256 columns)
         group_full = cells + __shfl_xor(cells, 1, 64) >= cap - cap / 4;
     }
-    float *S = stat + P.offS + (mode == 2 ? 3 * ef_s_stride(P) : s * ef_s_stride(P));
-    if (mode != 1) {
+    float *S = stat + P.offS + (mode >= 2 ? 3 * ef_s_stride(P) : s * ef_s_stride(P));
+    if (!FUSED && mode < 2) {                          // (before the threshold: nothing of it is alive during this selection)
+        const int kk = kw < n ? kw : n;
+        const float vk = kth(x, kk - 1, n);
+        const float m = mean_k_smallest(x, kk, vk, lane);
+        if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
+    }
+    if (FUSED || mode != 1) {
         const int kb = P.kbin;
         float t;
         int jcut = 0x7fffffff;
@@ -1112,14 +1167,27 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         }
         if (lane == 0) {
             S[row] = t;
-            reinterpret_cast<int *>(S)[ef_jcut_off(P, mode == 2 ? 3 : s) + row] = jcut;
+            reinterpret_cast<int *>(S)[ef_jcut_off(P, mode >= 2 ? 3 : s) + row] = jcut;
         }
-    }
-    if (mode != 2) {
-        const int kk = kw < n ? kw : n;
-        const float vk = kth(x, kk - 1, n);
-        const float m = mean_k_smallest(x, kk, vk, lane);
-        if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
+        // the binarised row (csm_to_binary: B_ij = C_ij < t_i, or C_ij == t_i and j <= jcut_i), bit j % 32 of word j / 32:
+        // a lane's nibble of every 256-column group, eight lanes to a word
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            unsigned nib = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 256 * q + 4 * lane + e;
+                const float d = x[4 * q + e];
+                nib |= ((j < n) && (d < t || (d == t && j <= jcut))) ? (1u << e) : 0u;
+            }
+            unsigned w = nib << (4 * (lane & 7));
+            w |= __shfl_xor(w, 1, 64);
+            w |= __shfl_xor(w, 2, 64);
+            w |= __shfl_xor(w, 4, 64);
+            const int word = 8 * q + (lane >> 3);
+            if ((lane & 7) == 0 && 32 * word < pitch)
+                bits[P.offB + ((int64_t)(mode >= 2 ? 3 : s) * P.M + row) * (pitch >> 5) + word] = w;
+        }
     }
 }
 
@@ -1203,15 +1271,9 @@ __global__ __launch_bounds__(256) void ef_fuse_kernel(const EfPair *__restrict__
         float wsum = 0.0f;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const float cv = C[s][j];
-            float eps = (r[s] + c[s][j]) + cv;
-            eps = eps / 3.0f;
-            const float h = 0.5f * eps;
-            const float den = 2.0f * (h * h);
-            const float w = expf(-(cv * cv) / den);
-            wsum += w;
+            wsum += ef_wcsm_weight(r[s], c[s][j], C[s][j]);
         }
-        F[j] = expf(-wsum);
+        F[j] = ef_fused_value(wsum);
     }
 }
 
@@ -1300,6 +1362,89 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
                         }
                     }
                     issue(i + SW_PF, ring[sl], tring[sl], jring[sl]);
+                    const int l1a = __shfl(U1[CPL - 1], prev, 64), l1b = __shfl(U1[CPL - 2], prev, 64), l2a = __shfl(U2[CPL - 1], prev, 64);
+                    int Tn[CPL];
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        const int c2 = (e >= 1) ? U1[e - 1] : l1a;                        // U[i-1][j-1]
+                        const int c3 = (e >= 1) ? U2[e - 1] : l2a;                        // U[i-2][j-1]
+                        const int c4 = (e >= 2) ? U1[e - 2] : (e == 1 ? l1a : l1b);       // U[i-1][j-2]
+                        int mx = c2 > c3 ? c2 : c3;
+                        mx = mx > c4 ? mx : c4;
+                        int t = (b[e] ? 10 : -10) + mx;
+                        t = t > 0 ? t : 0;
+                        const int j = j0 + e;
+                        if (j < 2) t = 0;                  // columns 0, 1 (lane 0 only; its shuffled inputs are unused)
+                        Tn[e] = t;
+                        if (j <= N - 2) best = best > t ? best : t;
+                    }
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        U2[e] = U1[e];
+                        U1[e] = Tn[e] + (b[e] ? 0 : -7);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int t = __shfl_xor(best, o, 64);
+            best = best > t ? best : t;
+        }
+        result = (float)best / 10.0f;
+    }
+    if (lane == 0) out[(size_t)blockIdx.x * 4 + src] = result;
+}
+
+// ------------------------------------------------------------------------------------
+// E4b: the same recursion on the BINARISED rows the selection kernels leave behind (round 3): a lane's CPL columns of a
+// row are CPL bits -- one byte (CPL = 8) or two (16) -- instead of CPL floats, a threshold and a tie column; the four
+// matrices of a pair in one launch.  out[pair * 4 + src].
+// ------------------------------------------------------------------------------------
+template <int CPL>
+__global__ __launch_bounds__(64) void sw_bits_kernel(const EfPair *__restrict__ pd, const unsigned *__restrict__ bits,
+                                                     float *__restrict__ out, int src_base)
+{
+    const int lane = threadIdx.x;
+    const EfPair P = pd[blockIdx.x];
+    const int src = src_base + blockIdx.y;
+    const int M = P.M, N = P.N, pitch = P.pitchC;
+    float result = 0.0f;
+    if (M >= 4 && N >= 4) {
+        typedef unsigned short bits_t;                               // (CPL = 8 uses the low byte)
+        const unsigned char *rows = reinterpret_cast<const unsigned char *>(bits + P.offB + (int64_t)src * M * (pitch >> 5));
+        const int rowbytes = pitch >> 3;
+        const int j0 = CPL * lane;
+        const bool inrow = j0 < pitch;
+        auto load = [&](int row) -> unsigned {
+            const int r = row < M ? row : M - 1;                     // (rows past the last one: a valid address, never used)
+            if (!inrow) return 0u;
+            if (CPL == 8) return rows[(size_t)r * rowbytes + lane];
+            return *reinterpret_cast<const bits_t *>(rows + (size_t)r * rowbytes + 2 * lane);
+        };
+        int U1[CPL], U2[CPL];      // U of rows i-1, i-2
+        const int prev = (lane + 63) & 63;
+        unsigned w = load(0);
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) U2[e] = ((w >> e) & 1u) ? 0 : -7;
+        w = load(1);
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) U1[e] = ((w >> e) & 1u) ? 0 : -7;
+        int best = 0;
+        constexpr int SW_PF = 8;
+        unsigned ring[SW_PF];
+#pragma unroll
+        for (int sl = 0; sl < SW_PF; ++sl) ring[sl] = load(2 + sl);
+        for (int i0 = 2; i0 <= M - 2; i0 += SW_PF) {
+#pragma unroll
+            for (int sl = 0; sl < SW_PF; ++sl) {
+                const int i = i0 + sl;
+                if (i <= M - 2) {                            // wave-uniform
+                    const unsigned wb = ring[sl];
+                    ring[sl] = load(i + SW_PF);
+                    bool b[CPL];
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) b[e] = ((wb >> e) & 1u) != 0u;
                     const int l1a = __shfl(U1[CPL - 1], prev, 64), l1b = __shfl(U1[CPL - 2], prev, 64), l2a = __shfl(U2[CPL - 1], prev, 64);
                     int Tn[CPL];
 #pragma unroll

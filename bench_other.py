@@ -101,9 +101,9 @@ def simple_leg(ctx, steps=3, warmup=1, n=512, cpu_pairs=64):
                                    "GPU's f32 scores %.1e" % (len(cp), err)}}
 
 
-def earlyfusion_leg(ctx, steps=3, warmup=1, n=48, cpu_pairs=4):
+def earlyfusion_leg(ctx, steps=3, warmup=1, n=128, cpu_pairs=4):
     """EarlyFusion per-pair chain (earlyfusion_traile.py:157-198) at 300-500 blocks per track: all pairs of `n`
-    tracks through the pair grid into a device buffer."""
+    tracks through the pair grid into a device buffer (n = 128: one diagonal tile of the production grid, 8128 pairs)."""
     import torch
     import oracle
     from acoss_amd import _lib, synth

@@ -1,6 +1,8 @@
 #!/bin/bash
 # GPU box: kernel stats + PMC passes (each in its own run, counters never together with a trace) of
-# scripts/ef_gemm_probe.py; per-kernel averages -> gpurun_out/prof_ef_<tag>/summary.txt
+# scripts/ef_gemm_probe.py N 2 (default) or of the python program given behind the tag ("other": bench_other.py);
+# per-kernel averages of every acx kernel -> gpurun_out/prof_ef_<tag>/summary.txt
+#   scripts/profile_ef.sh TAG [N | other]
 set -u
 TAG=${1:-x}
 N=${2:-48}
@@ -9,6 +11,7 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp; cd - > /dev/null
 PY=$(which python3)
 ARGS="scripts/ef_gemm_probe.py $N 2"
+if [ "$N" = other ]; then ARGS="bench_other.py --steps 2 --warmup 1"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $PY $ARGS > $OUT/stats.log 2>&1
 i=0
 for set in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" \
@@ -31,7 +34,7 @@ for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         st[r["Name"].split("(")[0].replace("void ", "")] = (int(r["Calls"]), float(r["AverageNs"]) / 1e6)
 for k in sorted(agg):
-    if not k.startswith("acx::ef_") and "sw_kernel" not in k: continue
+    if "acx::" not in k and "anonymous" not in k: continue
     print("==", k, "calls %d avg_ms %.3f" % st.get(k, (0, 0)))
     for c in sorted(agg[k]):
         v = agg[k][c]
