@@ -994,6 +994,146 @@ __device__ __forceinline__ float mean_k_smallest(const float (&x)[NX], int kw, f
     return (s + (float)(kw - tot) * vk) / (float)kw;
 }
 
+// Two order statistics of a row from ONE pivot-filtered histogram (wave_select_pivot, serra09_kernels.hpp, with 256 bins
+// and lane pairs): the row statistics want rank K - 1 (the neighbourhood mean) and rank kappa N - 1 (the threshold) of
+// the same row, both far below the pivot -- minimum, pivot estimate, binning, the masked atomics and the scan are shared,
+// only the two target bins are gathered and ranked one after the other.  false: the caller selects them separately.
+template <int NV>
+__device__ __forceinline__ bool ef_select_pivot2(const float (&x)[NV], int k1, int k2, unsigned hist_addr, float *cand, int lane,
+                                                 float &v1, float &v2, bool lane_has_data, bool group_full, float delta)
+{
+    constexpr int NB = 256, BPL = 4;
+    const float INF = __builtin_inff();
+    unsigned mnl = 0xFFFFFFFFu;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const unsigned b = __float_as_uint(x[t]);
+        mnl = b < mnl ? b : mnl;
+    }
+    unsigned gmn = mnl;
+    {
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)gmn, (int)gmn, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        gmn = o < gmn ? o : gmn;
+    }
+    const unsigned mnu = (unsigned)__builtin_amdgcn_readlane(wave_scan_bits((int)mnl, -1, OpMinU()), 63);
+    const int mxg = __builtin_amdgcn_readlane(wave_scan_bits(group_full ? (int)gmn : (int)0x80000000, (int)0x80000000, OpMaxI()), 63);
+    if (mxg < 0 || (int)mnu < 0) return false;
+    const float mn = __uint_as_float(mnu);
+    const float gm = __uint_as_float((unsigned)mxg);
+    const float range = __builtin_fmaf(delta, gm - mn, gm) - mn;
+    if (!(range >= 1e-30f) || !(range <= 1e30f) || !(mn <= 2048.0f * range)) return false;
+    constexpr unsigned MAGIC = 0x4B000000u;            // 2^23: the bin comes out of the fma as MAGIC + bin (see wave_select_pivot)
+    const float scale = ((float)NB - 3.0f) * __builtin_amdgcn_rcpf(range);
+    const float offm = lane_has_data ? (8388609.0f - mn * scale) : INF;
+    unsigned off[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) off[t] = __float_as_uint(__builtin_fmaf(x[t], scale, offm));
+    {
+        const unsigned nb = __builtin_amdgcn_readfirstlane(MAGIC + NB);
+        const unsigned hb = __builtin_amdgcn_readfirstlane(hist_addr - 4u * MAGIC);
+        unsigned one = 1u;
+        asm volatile("" : "+v"(one));
+        static_assert(NV % 4 == 0, "atomics go in groups of 4");
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            unsigned long long m0, m1, m2, m3, sv;
+            unsigned a0, a1, a2, a3;
+            asm volatile("v_cmp_gt_u32_e64 %[m0], %[nb], %[q0]\n\t"
+                         "v_cmp_gt_u32_e64 %[m1], %[nb], %[q1]\n\t"
+                         "v_cmp_gt_u32_e64 %[m2], %[nb], %[q2]\n\t"
+                         "v_cmp_gt_u32_e64 %[m3], %[nb], %[q3]\n\t"
+                         "v_lshl_add_u32 %[a0], %[q0], 2, %[hb]\n\t"
+                         "v_lshl_add_u32 %[a1], %[q1], 2, %[hb]\n\t"
+                         "v_lshl_add_u32 %[a2], %[q2], 2, %[hb]\n\t"
+                         "v_lshl_add_u32 %[a3], %[q3], 2, %[hb]\n\t"
+                         "s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b64 exec, %[m0]\n\t"
+                         "ds_add_u32 %[a0], %[one]\n\t"
+                         "s_mov_b64 exec, %[m1]\n\t"
+                         "ds_add_u32 %[a1], %[one]\n\t"
+                         "s_mov_b64 exec, %[m2]\n\t"
+                         "ds_add_u32 %[a2], %[one]\n\t"
+                         "s_mov_b64 exec, %[m3]\n\t"
+                         "ds_add_u32 %[a3], %[one]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [sv] "=&s"(sv),
+                           [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+                         : [q0] "v"(off[t]), [q1] "v"(off[t + 1]), [q2] "v"(off[t + 2]), [q3] "v"(off[t + 3]),
+                           [nb] "s"(nb), [hb] "s"(hb), [one] "v"(one)
+                         : "memory");
+        }
+    }
+    wave_lds_fence();
+    // scan: lane owns bins [4 lane, +4)
+    const u32x4 h = *(const lds_u32x4 *)(hist_addr + (unsigned)(lane * 4) * 4u);
+    const int lsum = (int)(h.x + h.y) + (int)(h.z + h.w);
+    const int incl = wave_incl_scan_i(lsum);
+    const int L1 = __ffsll((long long)__ballot(incl > k1)) - 1;
+    const int L2 = __ffsll((long long)__ballot(incl > k2)) - 1;
+    if (L1 < 0 || L2 < 0) return false;              // fewer than k2 + 1 cells at or below the pivot
+    const int ex1 = __builtin_amdgcn_readlane(incl - lsum, L1);
+    const int ex2 = __builtin_amdgcn_readlane(incl - lsum, L2);
+    // second level: lanes 0..3 look at lane L1's bins, lanes 16..19 at lane L2's
+    const int e = lane & 15;
+    const bool lo16 = lane < 16;
+    int c = 0;
+    if (lane < 32 && e < BPL) c = (int)*(const lds_u32 *)(hist_addr + (unsigned)((lo16 ? L1 : L2) * BPL + e) * 4u);
+    int Pp = c;
+    Pp += __builtin_amdgcn_update_dpp(0, Pp, 0x111, 0xf, 0xf, false);
+    Pp += __builtin_amdgcn_update_dpp(0, Pp, 0x112, 0xf, 0xf, false);
+    const int l1 = __ffsll((long long)__ballot(lo16 && e < BPL && ex1 + Pp > k1)) - 1;
+    const int l2 = __ffsll((long long)__ballot(!lo16 && lane < 32 && e < BPL && ex2 + Pp > k2)) - 1;
+    if (l1 < 0 || l2 < 0) return false;
+    const int cnt1 = __builtin_amdgcn_readlane(c, l1), cnt2 = __builtin_amdgcn_readlane(c, l2);
+    const int cum1 = ex1 + __builtin_amdgcn_readlane(Pp, l1) - cnt1, cum2 = ex2 + __builtin_amdgcn_readlane(Pp, l2) - cnt2;
+    const int bin1 = L1 * BPL + l1, bin2 = L2 * BPL + (l2 - 16);
+    if (cnt1 > 64 || cnt2 > 64) return false;
+    // the members of one bin, gathered and ranked (LDS broadcasts); value of rank `want` among them
+    auto resolve = [&](int bin, int ncand, int want, float &out) -> bool {
+        const unsigned a1 = MAGIC + (unsigned)bin;
+        int n = 0;
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            const bool h0 = off[t] == a1, h1 = off[t + 1] == a1, h2 = off[t + 2] == a1, h3 = off[t + 3] == a1;
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            if ((m0 | m1 | m2 | m3) != 0ull) {       // most groups hold no member of the target bin
+                const unsigned long long mm[4] = {m0, m1, m2, m3};
+                const bool hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (mm[u] != 0ull) {
+                        if (hh[u]) {
+                            const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mm[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm[u], 0u));
+                            cand[(n + (int)pos) & 63] = x[t + u];
+                        }
+                        n += __popcll(mm[u]);
+                    }
+            }
+        }
+        wave_lds_fence();
+        if (lane >= ncand) cand[lane] = INF;
+        wave_lds_fence();
+        const float mine = cand[lane];
+        int rank = 0;
+#pragma unroll 1
+        for (int t = 0; t < ncand; t += 4) {
+            const float4 o = *reinterpret_cast<const float4 *>(cand + t);
+            rank += (o.x < mine || (o.x == mine && t + 0 < lane)) ? 1 : 0;
+            rank += (o.y < mine || (o.y == mine && t + 1 < lane)) ? 1 : 0;
+            rank += (o.z < mine || (o.z == mine && t + 2 < lane)) ? 1 : 0;
+            rank += (o.w < mine || (o.w == mine && t + 3 < lane)) ? 1 : 0;
+        }
+        const int s1 = __ffsll((long long)__ballot(lane < ncand && rank == want)) - 1;
+        wave_lds_fence();
+        if (s1 < 0) return false;
+        out = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), s1));
+        return true;
+    };
+    if (!resolve(bin1, cnt1, k1 - cum1, v1)) return false;
+    if (!resolve(bin2, cnt2, k2 - cum2, v2)) return false;
+    return true;
+}
+
 // getWCSM's kernel weight of one cell (similarity_fusion.py:15-46): exp(-C^2 / (2 (eps / 2)^2)), eps = (r_i + c_j + C) / 3, which
 // is exp(-18 (C / (r_i + c_j + C))^2): one reciprocal and one exp2 instead of two IEEE divisions and an expf (the
 // fused matrix is only RANKED afterwards; 1e-6 relative against the reference's f32 numpy, bound 2e-4 in the tests --
@@ -1110,9 +1250,21 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         group_full = cells + __shfl_xor(cells, 1, 64) >= cap - cap / 4;
     }
     float *S = stat + P.offS + (mode >= 2 ? 3 * ef_s_stride(P) : s * ef_s_stride(P));
+    // mode 0 wants two order statistics of the row: rank K - 1 (neighbourhood mean) and rank kbin - 1 (threshold).  Both
+    // from one histogram when the row is long enough for the pivot filter (ef_select_pivot2), else one after the other.
+    float vk2 = 0.0f, t2 = 0.0f;
+    bool have2 = false;
+    if (!FUSED && mode == 0) {
+        const int kk = kw < n ? kw : n, kb = P.kbin;
+        if (kb > kk && kb < n && (kb + 1) * 6 <= n) {
+            *reinterpret_cast<uint4 *>(&fhist[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+            wave_lds_fence();
+            have2 = ef_select_pivot2<NX>(x, kk - 1, kb - 1, fh_addr, cand[wave], lane, vk2, t2, lane_has_data, group_full, 0.15f);
+        }
+    }
     if (!FUSED && mode < 2) {                          // (before the threshold: nothing of it is alive during this selection)
         const int kk = kw < n ? kw : n;
-        const float vk = kth(x, kk - 1, n);
+        const float vk = have2 ? vk2 : kth(x, kk - 1, n);
         const float m = mean_k_smallest(x, kk, vk, lane);
         if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
     }
@@ -1123,7 +1275,7 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         if (kb <= 0) t = -INF;                         // no neighbours: empty rows
         else if (kb >= n) t = INF;
         else {
-            t = kth(x, kb - 1, n);
+            t = have2 ? t2 : kth(x, kb - 1, n);
             // cells equal to t: if there are more than the row may still take, find the column of
             // the last one taken (column of x[4 q + e] = 256 q + 4 lane + e)
             int lt = 0, eq[NQ];
