@@ -851,7 +851,8 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
     if (limit <= 0) {
         const char *env = getenv("ACX_SCRATCH_GB");
         if (env && atof(env) > 0) limit = (int64_t)(atof(env) * (double)(1ull << 30));
-        // default: 24 GB (about 4 500 pairs of 400 x 400 blocks per batch).  Larger batches buy nothing (measured: 98 k
+        // default: 24 GB (about 12 000 pairs of 400 x 400 blocks per batch: three float matrices per pair since the
+        // transposed and the fused matrices are gone).  Larger batches buy nothing (measured with the 7-matrix layout: 98 k
         // pairs/s at 24 GB, 101 k at 115 GB, 94 k at 8 GB) and the first hipMalloc of a 100 GB arena costs 3.4 s
         else limit = std::min<int64_t>((int64_t)(0.40 * (double)c->total_mem), (int64_t)24 << 30);
     }

@@ -504,6 +504,10 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             pidx[a][b] = __builtin_amdgcn_readfirstlane(p);
             any = any || p >= 0;
         }
+#ifdef ACX_EF_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long clkA_ = __builtin_readcyclecounter();     // the wave's groups and pairs are known
+#endif
     f32x4 acc[NA][NB];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
@@ -541,6 +545,10 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         }
         if (!CH) { ap0 += sp * 8; ap1 += sp * 8; }
     }
+#ifdef ACX_EF_TIMING
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long clkB_ = __builtin_readcyclecounter();     // the staging rows are known
+#endif
     u32x4 st[9];                                      // pieces 0-2: A rows tid / 4, 3-5: A rows 128 + tid / 4, 6-8: B (one per term)
     auto gload_piece = [&](auto p_tag) {
         constexpr int p = decltype(p_tag)::value;
@@ -660,6 +668,10 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     // prologue: chunk 0 into buffer 0, chunk 1 into the registers
     for9([&](auto p_tag) { gload_piece(p_tag); });
     gload_advance();
+#ifdef ACX_EF_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long clkC_ = __builtin_readcyclecounter();     // the first chunk has arrived
+#endif
     for9([&](auto p_tag) { lstore_piece(0, p_tag); });
     if (nk > 1) { for9([&](auto p_tag) { gload_piece(p_tag); }); gload_advance(); }
     __syncthreads();
@@ -780,6 +792,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&g_ef_clk[0], clk1_ - clk0_); atomicAdd(&g_ef_clk[1], clk2_ - clk1_); atomicAdd(&g_ef_clk[2], clk3_ - clk2_);
         atomicAdd(&g_ef_clk[3], clk4_ - clk3_); atomicAdd(&g_ef_clk[15], 1ull);
+        atomicAdd(&g_ef_clk[5], clkA_ - clk0_); atomicAdd(&g_ef_clk[6], clkB_ - clkA_); atomicAdd(&g_ef_clk[7], clkC_ - clkB_); atomicAdd(&g_ef_clk[8], clk1_ - clkC_);
     }
 #endif
 }

@@ -34,7 +34,9 @@ def main():
     w = max(1, v[15])
     print(json.dumps({"waves_with_a_pair": w, "cycles_per_wave": {"start_up": round(v[0] / w), "k_loop": round(v[1] / w),
                                                                   "epilogue_to_last_store_issued": round(v[2] / w),
-                                                                  "last_store_issued_to_acknowledged": round(v[3] / w)}}))
+                                                                  "last_store_issued_to_acknowledged": round(v[3] / w)},
+                      "start_up_parts": {"groups_and_pairs": round(v[5] / w), "staging_rows": round(v[6] / w),
+                                         "first_chunk_arrives": round(v[7] / w), "lds_store_second_loads_barrier": round(v[8] / w)}}))
     ctx.close()
 
 
