@@ -377,3 +377,14 @@ def test_neighbourhood_sizes(ctx):
                 ws += oracle.get_wcsm(d["csm"][k], K, K)
             np.testing.assert_allclose(d["fused"], np.exp(-ws), rtol=2e-4, atol=1e-6, err_msg="K=%d pair %s" % (K, (i, j)))
             assert round(oracle.sw_constrained(oracle.csm_to_binary(d["fused"], 0.1)) * 10) == round(float(d["scores"][3]) * 10)
+
+
+def test_fuzz_small(ctx):
+    """A few rounds of tests/fuzz_earlyfusion.py: ragged pools, odd feature widths, chroma blocks of 8 / 16 / 40 frames,
+    random kappa / K and pair lists -- default arithmetic against the exact-f32 kernels, the oracle and the pair grid."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_earlyfusion", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_earlyfusion.py"))
+    fuzz_earlyfusion = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz_earlyfusion)
+    assert fuzz_earlyfusion.run(rounds=12, seed=5, ctx=ctx) > 0
