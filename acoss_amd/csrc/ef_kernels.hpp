@@ -1289,22 +1289,25 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
         else if (kb >= n) t = INF;
         else {
             t = have2 ? t2 : kth(x, kb - 1, n);
-            // cells equal to t: if there are more than the row may still take, find the column of
-            // the last one taken (column of x[4 q + e] = 256 q + 4 lane + e)
-            int lt = 0, eq[NQ];
+            // cells equal to t: if there are more than the row may still take, find the column of the last one taken
+            // (column of x[4 q + e] = 256 q + 4 lane + e).  Almost always the row has exactly kb cells <= t: one count decides
+            int le = 0;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) eq[q] = 0;
+            for (int e = 0; e < NX; ++e) le += x[e] <= t ? 1 : 0;
+            if (wave_sum_i(le) > kb) {                              // wave-uniform: surplus ties
+                int lt = 0, eq[NQ];
 #pragma unroll
-            for (int e = 0; e < NX; ++e) {
-                lt += x[e] < t ? 1 : 0;
-                eq[e >> 2] += x[e] == t ? 1 : 0;
-            }
-            const int budget = kb - wave_sum_i(lt);
-            int before[NQ + 1];                                     // ties in the groups before group q
-            before[0] = 0;
+                for (int q = 0; q < NQ; ++q) eq[q] = 0;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) before[q + 1] = before[q] + wave_sum_i(eq[q]);
-            if (before[NQ] > budget) {
+                for (int e = 0; e < NX; ++e) {
+                    lt += x[e] < t ? 1 : 0;
+                    eq[e >> 2] += x[e] == t ? 1 : 0;
+                }
+                const int budget = kb - wave_sum_i(lt);
+                int before[NQ + 1];                                     // ties in the groups before group q
+                before[0] = 0;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) before[q + 1] = before[q] + wave_sum_i(eq[q]);
                 int cand_j = -1;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -1339,11 +1342,16 @@ __global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restric
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             unsigned nib = 0;
+            if (jcut == 0x7fffffff && t < INF) {                   // wave-uniform: every tie is taken, the pads (+inf) are not
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = 256 * q + 4 * lane + e;
-                const float d = x[4 * q + e];
-                nib |= ((j < n) && (d < t || (d == t && j <= jcut))) ? (1u << e) : 0u;
+                for (int e = 0; e < 4; ++e) nib |= x[4 * q + e] <= t ? (1u << e) : 0u;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 256 * q + 4 * lane + e;
+                    const float d = x[4 * q + e];
+                    nib |= ((j < n) && (d < t || (d == t && j <= jcut))) ? (1u << e) : 0u;
+                }
             }
             unsigned w = nib << (4 * (lane & 7));
             w |= __shfl_xor(w, 1, 64);
