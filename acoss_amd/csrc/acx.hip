@@ -969,7 +969,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                         if (!seg.wgs2.empty()) {
                             if ((rc = ensure(c, c->d_segw2, c->segw2_cap, seg.wgs2.size())) != ACX_OK) return rc;
                             ACX_HIP(c, hipMemcpyAsync(c->d_segw2, seg.wgs2.data(), sizeof(acx::EfSegWg) * seg.wgs2.size(), hipMemcpyHostToDevice, c->stream));
-                            hipLaunchKernelGGL(acx::ef_gemm_rect_bf16x3_kernel<0>, dim3((unsigned)seg.wgs2.size(), 1, 1), dim3(acx::EFR_THREADS),
+                            hipLaunchKernelGGL(acx::ef_gemm_rect_bf16x3_kernel<0>, dim3((unsigned)seg.wgs2.size(), 1, 2), dim3(acx::EFR_THREADS),
                                                acx::EFR_LDS_BYTES, c->stream, c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd,
                                                c->d_rects, c->d_segw2, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1]);
                         }
@@ -1216,6 +1216,18 @@ void acx_destroy(acx_ctx *c)
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+#ifdef ACX_EF_TIMING
+extern "C" int acx_ef_clk(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(acx::g_ef_clk), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(acx::g_ef_clk), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 const char *acx_last_error(const acx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 

@@ -449,6 +449,9 @@ constexpr int EFR_A = 3 * EFR_ROWS * EFB_LP, EFR_B = 3 * EFR_COLS * EFB_LP;     
 constexpr int EFR_TP = 32;                                                       // pitch (floats) of a wave's turning tile in the epilogue
 constexpr int EFR_LDS_BYTES = 2 * 2 * (EFR_A + EFR_B) + 8 * 16 * EFR_TP * 4;     // 147 456 + 16 384 = all 160 KB
 
+#ifdef ACX_EF_TIMING   /* development builds (scripts/ab_build_acx.sh timing -DACX_EF_TIMING; scripts/ef_phase_timing.py): where a tile's time goes */
+__device__ unsigned long long g_ef_clk[16];          // [0] start-up, [1] k loop, [2] epilogue until the last store is issued, [3] until it is acknowledged, [15] waves
+#endif
 
 template <int CH>
 __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ef_gemm_rect_bf16x3_kernel(
@@ -460,14 +463,15 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     extern __shared__ __attribute__((aligned(16))) unsigned short efr_lds[];
     unsigned short *As = efr_lds;                    // [buffer][term][row][32 k]
     unsigned short *Bs = efr_lds + 2 * EFR_A;
+#ifdef ACX_EF_TIMING
+    const unsigned long long clk0_ = __builtin_readcyclecounter();
+#endif
     const EfSegWg W = wgs[blockIdx.x];               // ty in units of 16 row groups; tx = first column group, pad = column groups
     const EfSegRect R = rects[W.rect];
     const int ty = W.ty, tx = W.tx, ncg = W.pad;
-    // CH = 0: TWO passes over the tile, ssm (the longer k loop) then mfcc -- groups, pairs and staging rows are the same,
-    // and the first operands of the second pass travel while the first pass stores its matrix
-    int s = CH ? 2 : 1;                              // matrix of the current pass: 0 mfcc, 1 ssm, 2 chroma
-    int Kp = CH ? Kp0 : Kp1;
-    const unsigned short *S = CH ? split0 : split1;
+    const int s = CH ? 2 : (int)blockIdx.z;          // 0 mfcc, 1 ssm, 2 chroma
+    const int Kp = (CH || s == 0) ? Kp0 : Kp1;
+    const unsigned short *S = (CH || s == 0) ? split0 : split1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -500,6 +504,10 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             pidx[a][b] = __builtin_amdgcn_readfirstlane(p);
             any = any || p >= 0;
         }
+#ifdef ACX_EF_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long clkA_ = __builtin_readcyclecounter();     // the wave's groups and pairs are known
+#endif
     f32x4 acc[NA][NB];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
@@ -511,41 +519,36 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     // reach cells that are never stored, and the loads stay unconditional.
     const int srow = tid >> 2, sp = tid & 3;
     const int sg = srow >> 4, sr = srow & 15;
-    int pieces = Kp / 8;                               // 16-byte pieces of a row (per term)
-    int64_t prow0 = 0, prow1 = 0, prowb = 0;           // pool rows of the thread's three staging rows
-    int roll0 = 0, roll1 = 0;                          // (CH) OTI of the pair its A rows belong to
+    const int pieces = Kp / 8;                         // 16-byte pieces of a row (per term)
+    const unsigned short *ap0 = S, *ap1 = S, *bp = S + sp * 8;
+    int sp0 = sp, sp1 = sp;                            // (CH) the piece of the source row that lands at piece tid % 4 of the chunk
     {
         int rslot = 0;
         if (CH) rslot = colg[R.h0 + tx].slot;          // the tile's one reference track
         auto roll_of = [&](const EfSegGroup &g) {
             const int p = pairtab[R.ptab0 + g.slot * R.ncols + rslot];
-            return p >= 0 ? pd[p].oti : 0;
+            int r = p >= 0 ? pd[p].oti : 0;
+            r = (sp - (pieces / 12) * r) % pieces;     // piece - G r / 8, into [0, pieces)
+            return r < 0 ? r + pieces : r;
         };
         if (16 * ty + sg < R.ng) {
             const EfSegGroup g = rowg[R.g0 + 16 * ty + sg];
-            if (sr < g.valid) { prow0 = g.poolrow + sr; if (CH) roll0 = roll_of(g); }
+            if (sr < g.valid) { ap0 = S + (g.poolrow + sr) * 3 * Kp; if (CH) sp0 = roll_of(g); }
         }
         if (16 * ty + 8 + sg < R.ng) {
             const EfSegGroup g = rowg[R.g0 + 16 * ty + 8 + sg];
-            if (sr < g.valid) { prow1 = g.poolrow + sr; if (CH) roll1 = roll_of(g); }
+            if (sr < g.valid) { ap1 = S + (g.poolrow + sr) * 3 * Kp; if (CH) sp1 = roll_of(g); }
         }
         if (sg < ncg) {
             const EfSegGroup g = colg[R.h0 + tx + sg];
-            if (sr < g.valid) prowb = g.poolrow + sr;
+            if (sr < g.valid) bp = S + (g.poolrow + sr) * 3 * Kp + sp * 8;
         }
+        if (!CH) { ap0 += sp * 8; ap1 += sp * 8; }
     }
-    const unsigned short *ap0, *ap1, *bp;
-    int sp0, sp1;                                      // (CH) the piece of the source row that lands at piece tid % 4 of the chunk
-    auto pass_setup = [&]() {                          // pointers of the pass whose S / Kp are set
-        pieces = Kp / 8;
-        ap0 = S + prow0 * 3 * Kp; ap1 = S + prow1 * 3 * Kp; bp = S + prowb * 3 * Kp + sp * 8;
-        if (!CH) { ap0 += sp * 8; ap1 += sp * 8; sp0 = sp1 = sp; }
-        else {
-            sp0 = (sp - (pieces / 12) * roll0) % pieces; sp0 = sp0 < 0 ? sp0 + pieces : sp0;     // piece - G r / 8, into [0, pieces)
-            sp1 = (sp - (pieces / 12) * roll1) % pieces; sp1 = sp1 < 0 ? sp1 + pieces : sp1;
-        }
-    };
-    pass_setup();
+#ifdef ACX_EF_TIMING
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long clkB_ = __builtin_readcyclecounter();     // the staging rows are known
+#endif
     u32x4 st[9];                                      // pieces 0-2: A rows tid / 4, 3-5: A rows 128 + tid / 4, 6-8: B (one per term)
     auto gload_piece = [&](auto p_tag) {
         constexpr int p = decltype(p_tag)::value;
@@ -661,14 +664,14 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         if (LD) { for9([&](auto p_tag) { gload_piece(p_tag); }); gload_advance(); }
         if (ST) __syncthreads();
     };
-    // prologue of the first pass: chunk 0 into the registers
+    const int nk = Kp / EFB_BK;
+    // prologue: chunk 0 into buffer 0, chunk 1 into the registers
     for9([&](auto p_tag) { gload_piece(p_tag); });
     gload_advance();
-    const int npass = CH ? 1 : 2;
-    for (int pass = 0; pass < npass; ++pass) {
-    const int nk = Kp / EFB_BK;
-    const int s_cur = s;
-    // chunk 0 into buffer 0, chunk 1 into the registers
+#ifdef ACX_EF_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long clkC_ = __builtin_readcyclecounter();     // the first chunk has arrived
+#endif
     for9([&](auto p_tag) { lstore_piece(0, p_tag); });
     if (nk > 1) { for9([&](auto p_tag) { gload_piece(p_tag); }); gload_advance(); }
     __syncthreads();
@@ -682,16 +685,16 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         }
         chunk(kc & 1, std::false_type(), std::false_type());
     };
+#ifdef ACX_EF_TIMING
+    const unsigned long long clk1_ = __builtin_readcyclecounter();
+#endif
     if (any) {
         prefetch(0);
         sweep(chunk_mma);
     } else sweep(chunk_idle);
-    if (pass + 1 < npass) {                              // the next pass's first chunk: in flight during the stores below
-        s = 0; Kp = Kp0; S = split0;
-        pass_setup();
-        for9([&](auto p_tag) { gload_piece(p_tag); });
-        gload_advance();
-    }
+#ifdef ACX_EF_TIMING
+    const unsigned long long clk2_ = __builtin_readcyclecounter();
+#endif
 
     // ---- epilogue: every sub-tile into the matrix of its own pair (get_csm: sqrt(max(0, |x|^2 + |y|^2 - 2 x.y));
     // get_csm_cosine of unit rows: 1 - x.y).  The reference blocks are the MFMA's ROW operand, so a lane's four
@@ -700,8 +703,8 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     // With one workgroup per CU nothing hides this tail: the norms (8 loads per lane) and the 16 pair records are
     // fetched in two batches before the first store instead of one dependent chain per sub-tile (measured in the
     // round's first version of this epilogue: ~2 k cycles x 16 sub-tiles of a 180 k-cycle tile).
-    if (any) {
-    const float *nrm = s_cur == 0 ? nrm0 : nrm1;
+    if (!any) return;
+    const float *nrm = s == 0 ? nrm0 : nrm1;
     const int il = lr, jl = 4 * lk;                      // accumulator layout: row il, columns jl .. jl + 3 of the sub-tile
     float nx[NA];
     f32x4 ny[NB];
@@ -720,7 +723,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         for (int b = 0; b < NB; ++b) {
             const EfPair *P = pd + (pidx[a][b] < 0 ? 0 : pidx[a][b]);
             const int pc = P->pitchC;
-            cbase[a][b] = P->offC + (int64_t)s_cur * P->M * pc + (int64_t)GA[a].local0 * pc + GB[b].local0;
+            cbase[a][b] = P->offC + (int64_t)s * P->M * pc + (int64_t)GA[a].local0 * pc + GB[b].local0;
             cpitch[a][b] = pc;
             ctn[a][b] = P->ctN;
         }
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         }
         if (ctn[a][b] && il < GA[a].valid) {                               // (K > EF_COLSTAT_MAXK: rare, narrow stores)
             const EfPair P = pd[pidx[a][b]];
-            float *ct = scratch + ef_ct_off(P, s_cur) + (size_t)(GB[b].local0 + jl) * P.pitchT + GA[a].local0 + il;
+            float *ct = scratch + ef_ct_off(P, s) + (size_t)(GB[b].local0 + jl) * P.pitchT + GA[a].local0 + il;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
                 if (jl + reg < GB[b].valid) ct[(size_t)reg * P.pitchT] = v[reg];
@@ -782,15 +785,16 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             __builtin_nontemporal_store(w0, reinterpret_cast<f32x4 *>(cr));
             __builtin_nontemporal_store(w1, reinterpret_cast<f32x4 *>(cr + (int64_t)8 * cpitch[a][b]));
         }
-    }                                                    // (any)
-    if (pass + 1 < npass) {
-#pragma unroll
-        for (int a = 0; a < NA; ++a)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();                                 // every wave is done with the operand buffers of this pass
+#ifdef ACX_EF_TIMING
+    const unsigned long long clk3_ = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long clk4_ = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_ef_clk[0], clk1_ - clk0_); atomicAdd(&g_ef_clk[1], clk2_ - clk1_); atomicAdd(&g_ef_clk[2], clk3_ - clk2_);
+        atomicAdd(&g_ef_clk[3], clk4_ - clk3_); atomicAdd(&g_ef_clk[15], 1ull);
+        atomicAdd(&g_ef_clk[5], clkA_ - clk0_); atomicAdd(&g_ef_clk[6], clkB_ - clkA_); atomicAdd(&g_ef_clk[7], clkC_ - clkB_); atomicAdd(&g_ef_clk[8], clk1_ - clkC_);
     }
-    }                                                    // (pass)
+#endif
 }
 
 // ------------------------------------------------------------------------------------
