@@ -851,10 +851,10 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
     if (limit <= 0) {
         const char *env = getenv("ACX_SCRATCH_GB");
         if (env && atof(env) > 0) limit = (int64_t)(atof(env) * (double)(1ull << 30));
-        // default: 24 GB (about 12 000 pairs of 400 x 400 blocks per batch: three float matrices per pair since the
-        // transposed and the fused matrices are gone).  Larger batches buy nothing (measured with the 7-matrix layout: 98 k
-        // pairs/s at 24 GB, 101 k at 115 GB, 94 k at 8 GB) and the first hipMalloc of a 100 GB arena costs 3.4 s
-        else limit = std::min<int64_t>((int64_t)(0.40 * (double)c->total_mem), (int64_t)24 << 30);
+        // default: 36 GB (a whole 128 x 128 grid tile of 400-block tracks -- 16 384 pairs, three float matrices each since
+        // the transposed and the fused matrices are gone -- in one batch).  Much larger batches buy nothing (measured with
+        // the 7-matrix layout: 98 k pairs/s at 24 GB, 101 k at 115 GB, 94 k at 8 GB) and the first hipMalloc of a 100 GB arena costs 3.4 s
+        else limit = std::min<int64_t>((int64_t)(0.40 * (double)c->total_mem), (int64_t)36 << 30);
     }
     const int64_t limit_floats = limit / 4;
     // the column statistics (mean of the K smallest of every column) come from C itself up to K = 16 (ef_colstat_kernel);
@@ -872,6 +872,23 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             if (c->h_efoff[q + 1] - c->h_efoff[q] > acx::EF_MAXNB || c->h_efoff[r + 1] - c->h_efoff[r] > acx::EF_MAXNB) bits_path = false;
         }
     const bool keep_f = !bits_path || (dbg && dbg->fused);
+    // Batches of EQUAL size: a list that needs 1.3 limits runs as 0.65 + 0.65, not 1.0 + 0.3 (the last kernels of a batch
+    // run on a draining device; a small trailing batch pays that for little work -- a 128 x 128 grid tile of 400-block
+    // tracks is 16 384 pairs = 31 GB of matrices)
+    int64_t batch_floats = limit_floats;
+    if (!ext_matrix && K > 1) {
+        double total = 0.0;
+        for (int64_t k = 0; k < K; ++k) {
+            const int32_t q = pairs[2 * k], r = pairs[2 * k + 1];
+            if (q < 0 || r < 0 || q >= c->ef_ntracks || r >= c->ef_ntracks) { total = 0.0; break; }      // (reported below)
+            const double M = (double)(c->h_efoff[q + 1] - c->h_efoff[q]), N = (double)(c->h_efoff[r + 1] - c->h_efoff[r]);
+            total += (keep_f ? 4.0 : 3.0) * M * (double)round_up((int)N, 64) + (keep_ct ? 3.0 * N * (double)round_up((int)M, 64) : 0.0);
+        }
+        if (total > (double)limit_floats) {
+            const double nb = std::ceil(total / (double)limit_floats);
+            batch_floats = std::min<int64_t>(limit_floats, (int64_t)(total / nb * 1.02) + ((int64_t)1 << 22));
+        }
+    }
     std::vector<EfPair> pd;
     SegBatch seg;
     std::vector<int32_t> qslot, rslot;
@@ -906,7 +923,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             d.pad = 0;
             const int64_t need = (int64_t)(keep_f ? 4 : 3) * d.M * d.pitchC + (int64_t)3 * d.ctN * d.pitchT;
             if (need > limit_floats) return fail(c, ACX_ERR_NOMEM, "earlyfusion: one pair does not fit the scratch limit");
-            if (used + need > limit_floats) break;
+            if (used + need > batch_floats && !pd.empty()) break;
             d.offC = used;
             d.offS = used_s;
             d.offB = used_b;
