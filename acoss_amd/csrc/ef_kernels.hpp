@@ -518,7 +518,8 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     // Rows that do not exist (behind a track's last block, behind the rectangle) read pool row 0: their products only
     // reach cells that are never stored, and the loads stay unconditional.
     const int srow = tid >> 2, sp = tid & 3;
-    const int sg = srow >> 4, sr = srow & 15;
+    const int sg = wave, sr = srow & 15;               // (srow / 16 == the wave's number: its group records arrive by scalar loads,
+                                                       //  in the same batch as GA / GB above)
     const int pieces = Kp / 8;                         // 16-byte pieces of a row (per term)
     const unsigned short *ap0 = S, *ap1 = S, *bp = S + sp * 8;
     int sp0 = sp, sp1 = sp;                            // (CH) the piece of the source row that lands at piece tid % 4 of the chunk
