@@ -12,7 +12,7 @@ def main():
     import torch
     from acoss_amd import _lib
     npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
-    N = 1500
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
     rng = np.random.default_rng(3)
     nb = rng.integers(300, 501, N).astype(np.int64)
     ctx = _lib.Context(0)
@@ -33,15 +33,17 @@ def main():
     pairs = rng.integers(0, N, (npairs, 2)).astype(np.int32)
     pairs = pairs[pairs[:, 0] != pairs[:, 1]]
     ctx.earlyfusion_pairs(pairs[:2000])
-    for rep in range(2):
+    for mode in ("bf16x3", "bf16x3_pairwise"):
+      ctx.set_ef_gemm(mode)
+      for rep in range(2):
         ctx.profile_enable(True)
         ctx.profile_reset()
         t0 = time.time()
         out = ctx.earlyfusion_pairs(pairs)
         dt = time.time() - t0
         prof = ctx.profile()
-        print("random list: %d pairs %.2f s = %.0f pairs/s; kernels ms: %s; checksum %.1f" % (
-            len(pairs), dt, len(pairs) / dt, {k: round(v["ms"], 1) for k, v in prof.items() if v["launches"]}, float(out.sum())))
+        print("%s random list of %d tracks: %d pairs %.2f s = %.0f pairs/s; kernels ms: %s; checksum %.1f" % (
+            mode, N, len(pairs), dt, len(pairs) / dt, {k: round(v["ms"], 1) for k, v in prof.items() if v["launches"]}, float(out.sum())))
     ctx.close()
 
 
