@@ -111,7 +111,32 @@ class Serra09(CoverAlgorithm):
                 lens = np.diff(self._ctx.upload_raw_pool(np.concatenate(raw, axis=0), offsets, self.downsample_fac))
             self._pooled_len = np.asarray(lens, dtype=np.int64)
             self._pool_ready = True
+            self._warn_exact_percentile_positions()
         return self._ctx
+
+    def exact_percentile_tracks(self):
+        """Tracks whose embedded length M puts the kappa-percentile of a row / column of M cells on an EXACT-INTEGER
+        position k = (M - 1) kappa (f32, as the kernels compute it): with kappa = 0.095f that is M - 1 = 200, 400, 600,
+        i.e. pooled lengths 210 / 410 / 610.  There -- and only there -- the two recalled forms of essentia's percentile
+        differ: engine pct_mode 0 (default) takes the order statistic d_(k), pct_mode 1 (the d0 + d1 form as recalled,
+        include/acx.h) yields 0 and the row binarises to nothing.  Neither is evidenced while essentia is absent
+        (DESIGN.md section 2): every pair such a track takes part in depends on the choice."""
+        p = self._params()
+        span = (int(self.m) - 1) * int(self.tau) if p.embed_full else int(self.m) * int(self.tau)
+        M = (self._pooled_lengths().astype(np.int64) - span + int(self.tau) - 1) // int(self.tau)   # acx_serra09_embed_len
+        k = (np.maximum(M, 2) - 1).astype(np.float32) * np.float32(self.kappa)
+        return np.nonzero((M > 1) & (k == np.floor(k)))[0]
+
+    def _warn_exact_percentile_positions(self):
+        if "pct_mode" in self._engine:
+            return                                      # the caller chose
+        hit = self.exact_percentile_tracks()
+        if len(hit):
+            import warnings
+            warnings.warn("Serra09: %d of %d tracks (first: %s) have an embedded length whose kappa-percentile position is an "
+                          "exact integer, where the recalled forms of essentia's percentile differ (engine={'pct_mode': 0} "
+                          "order statistic -- used -- vs {'pct_mode': 1} zero threshold); pass engine={'pct_mode': ...} to "
+                          "choose explicitly" % (len(hit), self.N, hit[:8].tolist()), RuntimeWarning, stacklevel=3)
 
     def _pooled_lengths(self):
         if self._pool_ready:

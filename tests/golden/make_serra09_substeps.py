@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""
+Sub-step goldens for the Serra09 chain from the reference's OWN numpy code.  RUNS ONLY IN THE
+AUTHORING CONTAINER (needs /root/reference); writes tests/golden/serra09_substeps.npz -- seeded
+synthetic inputs and the reference's outputs on them, no reference source.
+
+essentia (where the chain's arithmetic lives, rqa_serra09.py:9,60-67) is absent, so the chain as a
+whole stays unpinned.  What the reference itself holds of it:
+
+  * acoss/algorithms/utils/cross_recurrence.py:30-48  get_csm -- the Euclidean cross-similarity
+    matrix, here on the 108-dimensional delay-embedded frames (m = 9 stacked chroma frames);
+  * cross_recurrence.py:75-103  get_oti -- the optimal transposition index on the global chroma;
+  * acoss/algorithms/rqa_serra09.py:71-83  Serra09.normalize_by_length -- run through the
+    reference class itself (the module imports with a stub `essentia.standard` whose two classes
+    are never called; features are injected into the class's own cache `all_feats`, so
+    librosa.util.sync is not called either).
+
+The delay embedding (x_i = the m consecutive frames i .. i + m - 1 concatenated, Serra et al. 2009
+eq. 1) and the global chroma (frame sum, divided by its max) are built here with numpy, by
+definition; everything downstream of them is the reference's code.
+
+    python tests/golden/make_serra09_substeps.py
+"""
+import importlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+
+def embed(x, m=9, tau=1, full=True):
+    """(T, 12) -> (M, 12 m): rows i .. i + (m - 1) tau concatenated.  full: M = T - (m - 1) tau (every
+    window that fits, the paper's count); the essentia-recalled count T - m tau is its first M - 1 rows."""
+    T = x.shape[0]
+    M = T - (m - 1) * tau
+    return np.concatenate([x[k * tau:k * tau + M] for k in range(m)], axis=1)
+
+
+def main():
+    import make_goldens
+    dd = make_goldens.install_stubs()
+    # rqa_serra09.py:9-10 imports essentia.standard and librosa.util.sync at module level
+    ess = types.ModuleType("essentia")
+    std = types.ModuleType("essentia.standard")
+
+    class _Absent(object):
+        def __init__(self, *a, **k):
+            raise RuntimeError("essentia is absent: the stub must never be instantiated")
+    std.ChromaCrossSimilarity = _Absent
+    std.CoverSongSimilarity = _Absent
+    ess.standard = std
+    sys.modules["essentia"] = ess
+    sys.modules["essentia.standard"] = std
+
+    def _no_sync(*a, **k):
+        raise RuntimeError("librosa is absent: features are injected, sync must not be called")
+    sys.modules["librosa.util"].sync = _no_sync
+
+    cr = importlib.import_module("acoss.algorithms.utils.cross_recurrence")
+    rq = importlib.import_module("acoss.algorithms.rqa_serra09")
+    from acoss_amd import synth
+
+    out = {}
+    # ---------------------------------------------------------------- stacked CSM + OTI
+    d = synth.cover_set(n_works=3, versions=2, seed=20260201, t_range=(60, 130))
+    big = synth.cover_set(n_works=1, versions=2, seed=20260202, t_range=(280, 320))
+    rng = np.random.default_rng(20260203)
+    iid = [(rng.random((T, 12), dtype=np.float32)) for T in (75, 90)]
+    iid = [x / x.max(axis=1, keepdims=True) for x in iid]
+    tr = [d["frames"][d["offsets"][k]:d["offsets"][k + 1]] for k in range(6)]
+    bg = [big["frames"][big["offsets"][k]:big["offsets"][k + 1]] for k in range(2)]
+    pairs = [(tr[0], tr[1]), (tr[1], tr[0]), (tr[0], tr[2]), (tr[3], tr[4]), (tr[5], tr[2]), (iid[0], iid[1]), (bg[0], bg[1])]
+    out["n_pairs"] = np.array(len(pairs))
+    for k, (q, r) in enumerate(pairs):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        r = np.ascontiguousarray(r, dtype=np.float32)
+        gq = q.sum(axis=0, dtype=np.float64)
+        gr = r.sum(axis=0, dtype=np.float64)
+        gq, gr = gq / gq.max(), gr / gr.max()
+        # get_oti(C1, C2): "an index by which to rotate the FIRST chroma vector to match the second" -- the chain
+        # transposes the reference track toward the query, so C1 = reference, C2 = query
+        oti = int(cr.get_oti(gr, gq))
+        oti_q = int(cr.get_oti(gq, gr))                 # the other convention (oti_target = 1)
+        rr = np.roll(r, oti, axis=1)
+        Xq, Xr = embed(q), embed(rr)
+        out["p%d_q" % k], out["p%d_r" % k] = q, r
+        out["p%d_gq" % k], out["p%d_gr" % k] = gq, gr
+        out["p%d_oti" % k] = np.array(oti)
+        out["p%d_oti_query" % k] = np.array(oti_q)
+        out["p%d_csm32" % k] = cr.get_csm(Xq, Xr)                                              # f32 in -> f32 out
+        out["p%d_csm64" % k] = cr.get_csm(Xq.astype(np.float64), Xr.astype(np.float64)).astype(np.float64)
+        assert out["p%d_csm32" % k].dtype == np.float32
+    # all 12 shift scores of one pair (first maximum wins; an exact tie: every shift scores the same)
+    out["oti_tie"] = np.array(cr.get_oti(np.ones(12), np.ones(12)))
+
+    # ---------------------------------------------------------------- normalize_by_length through the reference class
+    rng = np.random.default_rng(20260204)
+    n = 14
+    labels = ["a"] * 4 + ["b"] * 3 + ["c"] * 3 + ["d"] * 2 + ["e", "f"]
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    with open("toy.csv", "w") as f:
+        f.write("work_id,track_id\n")
+        for k, l in enumerate(labels):
+            f.write("%s,t%d\n" % (l, k))
+    alg = rq.Serra09("toy.csv", tmp + "/", shortname="toy")
+    lengths = rng.integers(150, 651, n)
+    lengths[3], lengths[7] = 210, 401                       # the exact-integer percentile lengths of DESIGN section 2
+    for j in range(n):
+        alg.all_feats[j] = np.zeros((int(lengths[j]), 12), np.float32)        # the class's own feature cache
+    D_in = (rng.integers(0, 400, (n, n)) * 0.5).astype(np.float32)            # Qmax scores are multiples of 0.5
+    np.fill_diagonal(D_in, 0)
+    alg.Ds["main"][:] = D_in
+    alg.normalize_by_length()
+    out["norm_lengths"] = lengths.astype(np.int64)
+    out["norm_D_in"] = D_in
+    out["norm_D_out"] = np.array(alg.Ds["main"], dtype=np.float32)
+    os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "serra09_substeps.npz"), **out)
+    print("written", os.path.join(HERE, "serra09_substeps.npz"),
+          os.path.getsize(os.path.join(HERE, "serra09_substeps.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()
