@@ -418,7 +418,10 @@ class Context(object):
 
     def ef_pool_tracks(self, first, count, mfccs, ssms, chromas, chroma_med):
         """Rows of tracks [first, first + count).  Every argument is a C-contiguous numpy array (f32 / f64 for
-        the medians) OR anything with data_ptr() -- a torch tensor on this GPU is copied device to device."""
+        the medians) OR anything with data_ptr() -- a torch tensor on this GPU is copied device to device.
+        A device source must be COMPLETE when this is called (the copy is a blocking hipMemcpy that only orders
+        against the NULL stream): call torch.cuda.synchronize() after the kernels that produced it.  ef_pool_end()
+        fails (AcxError naming the first missing track, pool still open) unless every track was handed over."""
         def ptr(a, dtype):
             if hasattr(a, "data_ptr"):
                 return ctypes.c_void_p(int(a.data_ptr())), a

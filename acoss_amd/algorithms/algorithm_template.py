@@ -79,6 +79,23 @@ class CoverAlgorithm(object):
             self._dmat_paths[s] = "%s_%s_dmat%s" % (self.get_cacheprefix(), s, "" if rank == 0 else ".rank%d" % rank)
         return self._dmat_paths[s]
 
+    def _bind_collective_device(self, device):
+        """Device-backed classes call this from their constructor with the GPU their libacx context will use (None:
+        LOCAL_RANK's): under a process group, torch's collectives are bound to THAT device before the first of them
+        runs (the clique-table broadcast can precede the first kernel).  A second, different device in one process is
+        refused right here, in the constructor, on the rank that asked for it -- not in the middle of all_pairwise
+        with the other ranks already waiting in a collective.  Without a process group nothing happens (and torch is
+        not imported)."""
+        dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
+        if not _dist.single():
+            try:
+                import torch.distributed as tdist
+                if tdist.get_backend() == "nccl":
+                    _dist.bind_device(dev)
+            except ImportError:
+                pass
+        return dev
+
     def owns_result(self):
         """True on the rank that holds the filled matrices (rank 0, or the only process).  The N x N
         post-processing steps (normalize_by_length, do_late_fusion) return at once everywhere else:
@@ -100,9 +117,8 @@ class CoverAlgorithm(object):
         file -- or builds it from the feature files -- and broadcasts the table; the other ranks touch
         neither the feature files nor the cache (no shared file system is assumed)."""
         path = "%s_clique_info.txt" % self.get_cacheprefix()
-        rank, ws = _dist.world()
-        table = None
-        if rank == 0:
+
+        def build():
             table = []
             if os.path.exists(path):
                 with open(path) as fin:
@@ -120,7 +136,8 @@ class CoverAlgorithm(object):
                         fout.write("%i,%s\n" % (i, feats["label"]))
                         table.append((i, str(feats["label"]).strip()))
                 os.replace(tmp, path)
-        table = _dist.broadcast_object(table)
+            return table
+        table = _dist.on_root(build)          # a failure on rank 0 is re-raised on every rank (no rank is left waiting)
         for i, label in table:
             self._register_label(int(i), label)
 
@@ -235,11 +252,11 @@ class CoverAlgorithm(object):
         writes the CSV, the tuple is broadcast and returned on every rank -- so every rank must call it
         (`if rank == 0: algo.getEvalStatistics(...)` would leave rank 0 waiting in the broadcast)."""
         rank, ws = _dist.world()
-        res = None
-        if rank == 0:
+
+        def evaluate():
             D = np.array(self.Ds[similarity_type], dtype=np.float32)
-            res = eval_statistics(D, [sorted(self.cliques[s]) for s in self.cliques], topsidx)
-        MR, MRR, MDR, MAP, tops = _dist.broadcast_object(res)
+            return eval_statistics(D, [sorted(self.cliques[s]) for s in self.cliques], topsidx)
+        MR, MRR, MDR, MAP, tops = _dist.on_root(evaluate)
         if rank != 0:
             return MR, MRR, MDR, MAP, tops
         print("%s %s STATS\n-------------------------\nMR = %.3g\nMRR = %.3g\nMDR = %.3g\nMAP = %.3g"

@@ -50,6 +50,7 @@ class EarlyFusion(CoverAlgorithm):
         self._nonfinite = nonfinite
         self._ctx = None
         self._pool_ready = False
+        self._bind_collective_device(self._device)      # before the first collective of this object
         CoverAlgorithm.__init__(self, dataset_csv=dataset_csv, name="EarlyFusionTraile", datapath=datapath,
                                 shortname=shortname, similarity_types=["mfccs", "ssms", "chromas", "early"])
 

@@ -32,6 +32,7 @@ class ChenFusion(Serra09):
         self._ctx = None
         self._pool_ready = False
         self._pooled_len = None
+        self._bind_collective_device(self._device)      # before the first collective of this object
         CoverAlgorithm.__init__(self, dataset_csv=dataset_csv, name="LateFusionChen", datapath=datapath,
                                 shortname=shortname, similarity_types=["qmax", "dmax"])
 

@@ -65,6 +65,7 @@ class Serra09(CoverAlgorithm):
         self._ctx = None
         self._pool_ready = False
         self._pooled_len = None
+        self._bind_collective_device(self._device)      # before the first collective of this object
         CoverAlgorithm.__init__(self, dataset_csv=dataset_csv, name="Serra09", datapath=datapath,
                                 shortname=shortname)
 

@@ -100,6 +100,7 @@ struct acx_ctx {
     int32_t ef_ntracks = 0;
     int32_t ef_gemm = ACX_EF_GEMM_BF16X3;             // arithmetic of the two Euclidean cross-similarity GEMMs
     int32_t ef_open = 0;                              // > 0: a pool of that many tracks is being filled (acx_ef_pool_begin .. _end)
+    std::vector<uint8_t> ef_filled;                   // per track of the open pool: handed over by acx_ef_pool_tracks yet?
     int32_t ef_dims[3] = {0, 0, 0};
     acx::EfPair *d_efpd = nullptr; size_t efpd_cap = 0;
     // rectangles of the rectangle GEMM (ef_gemm_rect_bf16x3_kernel): row / column groups, rectangles, pair tables
@@ -1808,6 +1809,7 @@ int acx_ef_pool_begin(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, cons
     c->h_efoff.assign(offsets, offsets + n_tracks + 1);
     for (int k = 0; k < 3; ++k) c->ef_dims[k] = dims[k];
     c->ef_open = n_tracks;
+    c->ef_filled.assign((size_t)n_tracks, 0);          // the arrays come from hipMalloc: what _tracks never wrote is garbage
     return ACX_OK;
 }
 
@@ -1827,6 +1829,7 @@ int acx_ef_pool_tracks(acx_ctx *c, int32_t first_track, int32_t count, const flo
         ACX_HIP(c, hipMemcpy(c->d_ef[k] + b0 * c->ef_dims[k], src[k], sizeof(float) * nb * c->ef_dims[k], hipMemcpyDefault));
     }
     ACX_HIP(c, hipMemcpy(c->d_efmed + (size_t)12 * first_track, chroma_med, sizeof(double) * 12 * count, hipMemcpyDefault));
+    std::fill(c->ef_filled.begin() + first_track, c->ef_filled.begin() + first_track + count, (uint8_t)1);
     return ACX_OK;
 }
 
@@ -1835,7 +1838,17 @@ int acx_ef_pool_end(acx_ctx *c)
     if (!c) return ACX_ERR_INVALID;
     if (c->ef_open <= 0) return fail(c, ACX_ERR_STATE, "ef_pool_end: no pool is being filled (acx_ef_pool_begin)");
     const int n_tracks = c->ef_open;
+    {   // every track must have been handed over: the pool stays open (the missing slices can still be supplied)
+        int64_t missing = 0, first = -1;
+        for (int i = 0; i < n_tracks; ++i)
+            if (!c->ef_filled[(size_t)i]) { if (first < 0) first = i; ++missing; }
+        if (missing)
+            return fail(c, ACX_ERR_STATE, "ef_pool_end: " + std::to_string(missing) + " of " + std::to_string(n_tracks) +
+                        " tracks were never handed over by acx_ef_pool_tracks (first: track " + std::to_string(first) +
+                        "); the pool is still open");
+    }
     c->ef_open = 0;
+    c->ef_filled.clear();
     ACX_HIP(c, hipSetDevice(c->device));
     {   // the chroma medians: one row of 12 per track
         const int rc = scan_nonfinite<double>(c, "ef pool", "chroma median", c->d_efmed, (int64_t)12 * n_tracks, 12, 0, nullptr, n_tracks);

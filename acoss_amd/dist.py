@@ -8,7 +8,7 @@ RCCL, no host staging.  Rank 0 then scatters the tiles into the N x N matrices.
 """
 import numpy as np
 
-__all__ = ["world", "bind_device", "barrier", "broadcast_object", "any_rank", "shard_bounds", "gather_scores",
+__all__ = ["world", "bind_device", "barrier", "broadcast_object", "on_root", "any_rank", "shard_bounds", "gather_scores",
            "gather_tiles"]
 
 # The GPU this process works on (set by bind_device).  Under "nccl" EVERY collective needs a device:
@@ -100,6 +100,29 @@ def broadcast_object(obj, src=0):
     else:
         dist.broadcast_object_list(box, src=src)
     return box[0]
+
+
+def on_root(fn, src=0):
+    """Run `fn()` on rank `src` only and hand its result to every rank (a collective: every rank must call it).
+    An exception on the root is broadcast too and re-raised on EVERY rank -- a rank-0-only section that fails (a
+    missing feature file while the clique table is built, a bad matrix in the statistics) must not leave the other
+    ranks waiting in the broadcast for ever."""
+    rank, ws = world()
+    if single():
+        return fn()
+    box, err = None, None
+    if rank == src:
+        try:
+            box = ("ok", fn())
+        except Exception as e:                        # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+            err = e
+            box = ("err", "%s: %s" % (type(e).__name__, e))
+    kind, payload = broadcast_object(box, src=src)
+    if kind == "err":
+        if err is not None:
+            raise err
+        raise RuntimeError("rank %d failed in a rank-%d-only section: %s" % (src, src, payload))
+    return payload
 
 
 def any_rank(flag):

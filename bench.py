@@ -32,22 +32,116 @@ Also in the line:
                 initialised (the worker processes are forks).
 """
 import argparse
+import contextlib
+import faulthandler
 import json
 import os
+import signal
 import subprocess
 import sys
+import threading
 import time
 
-import numpy as np
+_T_START = time.perf_counter()
+
+
+def _cpus_allowed():
+    """CPUs this process may use (affinity mask capped by the cgroup CPU quota) -- the same rule as
+    acoss_amd.utils.effective_cpus, restated here because it has to run BEFORE numpy is imported."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            with open(path) as f:
+                q, per = f.read().split()[:2]
+            if q != "max":
+                n = max(1, min(n, int(float(q) / float(per) + 0.999)))
+        except (OSError, ValueError):
+            try:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                    q = float(f.read())
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = float(f.read())
+                if q > 0:
+                    n = max(1, min(n, int(q / per + 0.999)))
+            except (OSError, ValueError):
+                pass
+    return n
+
+
+# Every BLAS / OpenMP pool of this process (numpy's OpenBLAS, torch's CPU pool, MKL of an Anaconda numpy) is sized
+# BEFORE the libraries load: a container allowed 16 of a host's 256 hardware threads otherwise starts 256 spinning
+# workers per pool, and the untimed host phases (synthetic sets, the numpy oracles of the `other` legs) crawl.
+HOST_THREADS = max(1, min(_cpus_allowed(), 16))
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS", "VECLIB_MAXIMUM_THREADS"):
+    os.environ.setdefault(_v, str(HOST_THREADS))
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# wall budgets of the UNTIMED phases (seconds).  A phase that runs past its budget is abandoned and reported as
+# null / {"error": ...}; the headline line is printed regardless (and by a watchdog if an `other` leg hangs).
+BUDGET_CPU_1CORE_S = 10.0          # work budget of the one-core oracle figure
+BUDGET_CPU_ALL_S = 15.0            # work budget of the all-core oracle figure
+HARD_CPU_POOL_S = 120.0            # hard wall limit of one pool round (pilot or timed)
+HARD_OTHER_LEG_S = 150.0           # hard wall limit of one `other` leg
+
+
+class Clock(object):
+    """Phase clock: `with clock.phase("name")` records the wall seconds of an untimed phase in `phases` (the
+    `phases_s` object of the JSON line) and stamps start / end on stderr as they happen, so that a run that is
+    killed from outside still shows where its time went."""
+
+    def __init__(self, verbose=True):
+        self.phases = {}
+        self.verbose = verbose
+
+    def stamp(self, msg):
+        if self.verbose:
+            sys.stderr.write("[bench +%7.1fs] %s\n" % (time.perf_counter() - _T_START, msg))
+            sys.stderr.flush()
+
+    @contextlib.contextmanager
+    def phase(self, name):
+        self.stamp("%s ..." % name)
+        t0 = time.perf_counter()
+        try:
+            yield
+        finally:
+            dt = time.perf_counter() - t0
+            self.phases[name] = round(self.phases.get(name, 0.0) + dt, 3)
+            self.stamp("%s: %.2f s" % (name, dt))
+
+
+class BudgetExceeded(Exception):
+    pass
+
+
+@contextlib.contextmanager
+def wall_limit(seconds, what):
+    """Abandon the enclosed (main-thread) work with BudgetExceeded once `seconds` of wall time are gone: SIGALRM,
+    delivered between two bytecodes (a running libacx / BLAS call finishes first -- they are all short)."""
+    def on_alarm(signum, frame):
+        raise BudgetExceeded("%s ran past its %.0f s wall budget" % (what, seconds))
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.setitimer(signal.ITIMER_REAL, seconds)
+    try:
+        yield
+    finally:
+        signal.setitimer(signal.ITIMER_REAL, 0)
+        signal.signal(signal.SIGALRM, old)
 
 T_FRAMES = 2000
 N_TRACKS = 5000
 TILE = 64
 TILES_PER_STEP = 2             # per rank: 2 x 64 x 64 = 8192 pairs per GPU per step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = f32 vector rate
 M_STACK = 9
 
 # algorithmic bytes per matrix cell by kernel (DESIGN.md "Roofline model"; SURVEY.md 8d).
@@ -112,69 +206,90 @@ def _cpu_triad(_):
     return reps * 5 * 8 * n / (time.perf_counter() - t0)      # multiply: read c, write a; add: read a, b, write a
 
 
-def cpu_baseline(frames, offsets, pairs, n_tracks, budget_s=15.0):
+def cpu_baseline(frames, offsets, pairs, n_tracks, clock):
     """SURVEY 8d's two CPU figures, both from the oracle (a C port of the chain, gcc -O3) and both timed BEFORE
     the GPU is initialised (the workers are forks):
-      (1) one process, one thread, on randomly chosen pairs of the same synthetic pool (seeded; 64 of them -- 8d
-          names 256, which at ~0.2 s per pair would be a minute of the bench's budget) -> value_1core;
+      (1) one process, one thread, on randomly chosen pairs of the same synthetic pool (seeded), four at a time until
+          BUDGET_CPU_1CORE_S seconds of work are done or 256 pairs (the count 8d names; at ~0.2 s per pair that is
+          ~50 s, so the time budget is what ends the loop and the count is stated in `sample`) -> value_1core;
       (2) every host core through a process fan-out over max(45, cores) chunks (the reference's joblib scheme,
-          algorithm_template.py:172-177, has 45) -> value.  Bounded: a pilot round of one pair per worker measures
-          the rate under full load, the timed round is sized from it to about `budget_s` seconds.
+          algorithm_template.py:172-177, has 45) -> value.  Bounded: a pilot round of one pair per chunk measures
+          the rate under full load, the timed round is sized from it to about BUDGET_CPU_ALL_S seconds.
+    Every pool round has a hard wall limit (HARD_CPU_POOL_S): past it the pool is terminated and the figure is null.
+    The pool is closed and joined before this function returns, i.e. before any GPU call of the process.
     If (2) is less than half of cores x (1), a one-second STREAM triad on the same workers is reported beside it
     (the oracle streams a 16 MB distance matrix per pair three times; hundreds of copies of it share the memory
     controllers)."""
     import multiprocessing as mp
     import oracle
-    oracle.lib()
+    with clock.phase("oracle_build_load"):
+        oracle.lib()
     _CPU["frames"], _CPU["offsets"] = frames, offsets
     cores = effective_cpus()
-    rng = np.random.default_rng(8)
-    rnd = rng.integers(0, n_tracks, (2 * 64, 2))
-    rnd = np.ascontiguousarray(rnd[rnd[:, 0] != rnd[:, 1]][:64].astype(np.int32))
-    t0 = time.perf_counter()
-    rnd_scores = oracle.serra09_pairs(frames, offsets, rnd[:4])
-    t4 = time.perf_counter() - t0
-    n1 = int(min(64, max(4, 4 * round(0.25 * budget_s / max(t4, 1e-3)))))     # ~budget_s of single-core work
-    t0 = time.perf_counter()
-    rnd_scores = oracle.serra09_pairs(frames, offsets, rnd[:n1])
-    t_1core = time.perf_counter() - t0
-    stream = None
-    with mp.get_context("fork").Pool(cores, initializer=_cpu_init) as pool:
-        nchunks = max(45, cores)                                  # the reference's joblib scheme has 45 chunks
-        pilot = np.ascontiguousarray(pairs[:nchunks])
-        t0 = time.perf_counter()
-        parts = pool.map(_cpu_chunk, [pilot[k:k + 1] for k in range(len(pilot))], chunksize=1)
-        dt = time.perf_counter() - t0
-        sample, scores = pilot, np.concatenate(parts)
-        per_chunk = int(budget_s / dt) if dt > 0 else 0
-        if per_chunk >= 2:                                         # room for a longer timed round
-            n = min(len(pairs), nchunks * per_chunk)
-            n -= n % nchunks
-            sample = np.ascontiguousarray(pairs[:n])
-            chunks = [c for c in np.array_split(sample, nchunks) if len(c)]
+    with clock.phase("cpu_1core"):
+        rng = np.random.default_rng(8)
+        rnd = rng.integers(0, n_tracks, (2 * 256, 2))
+        rnd = np.ascontiguousarray(rnd[rnd[:, 0] != rnd[:, 1]][:256].astype(np.int32))
+        parts, n1, t_1core = [], 0, 0.0
+        while n1 < len(rnd) and t_1core < BUDGET_CPU_1CORE_S:
             t0 = time.perf_counter()
-            parts = pool.map(_cpu_chunk, chunks, chunksize=1)
+            parts.append(oracle.serra09_pairs(frames, offsets, rnd[n1:n1 + 4]))
+            t_1core += time.perf_counter() - t0
+            n1 += len(parts[-1])
+        rnd_scores = np.concatenate(parts)
+        v1 = n1 / t_1core
+    stream, vall, dt, n, note = None, None, None, 0, ""
+    sample, scores = rnd[:0], np.zeros(0, np.float32)
+    nchunks = max(45, cores)                                      # the reference's joblib scheme has 45 chunks
+    with clock.phase("cpu_all_cores"):
+        pool = mp.get_context("fork").Pool(cores, initializer=_cpu_init)
+        try:
+            pilot = np.ascontiguousarray(pairs[:nchunks])
+            t0 = time.perf_counter()
+            parts = pool.map_async(_cpu_chunk, [pilot[k:k + 1] for k in range(len(pilot))], chunksize=1).get(HARD_CPU_POOL_S)
             dt = time.perf_counter() - t0
-            scores = np.concatenate(parts)
-        n = len(sample)
-        v1, vall = n1 / t_1core, n / dt
-        if vall < 0.5 * cores * v1:
-            stream = round(sum(pool.map(_cpu_triad, range(cores), chunksize=1)) / 1e9, 1)
+            clock.stamp("cpu_all_cores pilot: %d pairs in %.2f s" % (len(pilot), dt))
+            sample, scores = pilot, np.concatenate(parts)
+            per_chunk = int(BUDGET_CPU_ALL_S / dt) if dt > 0 else 0
+            if per_chunk >= 2:                                     # room for a longer timed round
+                n = min(len(pairs), nchunks * per_chunk)
+                n -= n % nchunks
+                big = np.ascontiguousarray(pairs[:n])
+                chunks = [c for c in np.array_split(big, nchunks) if len(c)]
+                t0 = time.perf_counter()
+                parts = pool.map_async(_cpu_chunk, chunks, chunksize=1).get(HARD_CPU_POOL_S)
+                dt = time.perf_counter() - t0
+                sample, scores = big, np.concatenate(parts)
+            n = len(sample)
+            vall = n / dt
+            if vall < 0.5 * cores * v1:
+                stream = round(sum(pool.map_async(_cpu_triad, range(cores), chunksize=1).get(30.0)) / 1e9, 1)
+            pool.close()
+        except mp.TimeoutError:
+            pool.terminate()
+            note = "; a pool round ran past its %.0f s wall limit and was terminated: all-core figure abandoned" % HARD_CPU_POOL_S
+            clock.stamp("cpu_all_cores: pool round past its wall limit, terminated")
+            if vall is None:
+                sample, scores = rnd[:0], np.zeros(0, np.float32)
+        finally:
+            pool.join()
     model = ""
     try:
-        for line in subprocess.run(["lscpu"], capture_output=True, text=True).stdout.splitlines():
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
             if line.startswith("Model name"):
                 model = line.split(":", 1)[1].strip()
-    except OSError:
+    except (OSError, subprocess.SubprocessError):
         pass
     check = np.concatenate([sample, rnd[:n1]]), np.concatenate([scores, rnd_scores])
     return check[0], check[1], {
-        "value": round(vall, 3), "unit": "track-pairs/s", "cores": cores, "kind": "port",
-        "sample": "first %d pairs of step 0's tiles of the same workload (T=%d), C oracle (gcc -O3), %d worker "
-                  "processes over %d chunks (reference scheme: 45 joblib chunks), %.1f s; value_1core: %d randomly chosen "
-                  "pairs of the pool (seed 8) in one process, %.1f s; all scores bit-identical to the GPU's"
-                  % (n, T_FRAMES, cores, max(45, cores), dt, n1, t_1core),
-        "value_1core": round(v1, 3), "parallel_efficiency": round(vall / (cores * v1), 3),
+        "value": None if vall is None else round(vall, 3), "unit": "track-pairs/s", "cores": cores, "kind": "port",
+        "sample": "first %d pairs of the first timed step's tiles of the same workload (T=%d), C oracle (gcc -O3), %d worker "
+                  "processes over %d chunks (reference scheme: 45 joblib chunks), %s s; value_1core: %d randomly chosen "
+                  "pairs of the pool (seed 8) in one process, %.1f s (SURVEY 8d names 256 pairs: ~50 s at this rate; the loop "
+                  "stops at a %.0f s work budget); all scores bit-identical to the GPU's%s"
+                  % (n, T_FRAMES, cores, nchunks, "%.1f" % dt if dt else "-", n1, t_1core, BUDGET_CPU_1CORE_S, note),
+        "value_1core": round(v1, 3),
+        "parallel_efficiency": None if vall is None else round(vall / (cores * v1), 3),
         "stream_triad_gbs_all_workers": stream, "cpu_model": model, "host_cpus": os.cpu_count(),
         "cores_note": "cores = CPUs this process may use (affinity mask and cgroup CPU quota), one worker process each"}
 
@@ -206,14 +321,186 @@ def json_only_stdout():
     return os.fdopen(keep, "w")
 
 
+def derive_bound(real_bound):
+    """The unit that is busiest in the committed counter record of the kernel: "valu" | "mfma" | "lds" | "hbm".
+    None when no record of this build's kernel sources exists (then `bound` falls back to the byte model's "hbm")."""
+    if not real_bound:
+        return None
+    units = {"valu": real_bound.get("valu_busy"), "mfma": real_bound.get("mfma_busy"),
+             "lds": real_bound.get("lds_busy"), "hbm": real_bound.get("hbm_util")}
+    units = {k: v for k, v in units.items() if isinstance(v, (int, float))}
+    return max(units, key=units.get) if units else None
+
+
+def init_torch(clock, local_rank, world, backend, collective):
+    with clock.phase("import_torch"):
+        import torch
+        import torch.distributed as dist
+        torch.set_num_threads(HOST_THREADS)
+    with clock.phase("gpu_init"):
+        if backend != "nccl":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        if collective:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend)
+        torch.zeros(1, device=torch.device("cuda", local_rank))
+        torch.cuda.synchronize()
+    return torch, dist, local_rank
+
+
+def run_strong(args, clock, out, rank, world, local_rank):
+    """`--strong`: the WHOLE pair grid of the pool (5 000 tracks: 12 497 500 pairs) once, split over the N ranks the
+    way all_pairwise splits it (algorithm_template.py:168-192 in the reference; here acx_grid_plan's cost-balanced
+    deal, acoss_amd/algorithms/algorithm_template.py:_all_pairwise_grid): every rank runs ALL its tiles into one device
+    buffer (acx_grid_run), then the ONE collective of the path -- all_gather_into_tensor of the real per-rank buffers --
+    and rank 0 scatters + mirrors the tiles into the N x N float32 memmap (acx_grid_scatter).  Strong scaling: total
+    work fixed.  `value` = pairs / (kernels + gather), max over ranks; `strong.value_incl_scatter` adds the device-to-
+    host copy and rank 0's scatter, the only serial part.  Reports plan imbalance, gather ms / bytes, scatter s."""
+    import tempfile
+    from acoss_amd import _lib
+    with clock.phase("pool_gen"):
+        frames, offsets = make_pool(args.tracks, args.frames)
+    backend = os.environ.get("ACX_BENCH_BACKEND", "nccl")
+    collective = world > 1 or os.environ.get("ACX_BENCH_FORCE_COLLECTIVE") == "1"
+    torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
+    dev = torch.device("cuda", local_rank)
+    with clock.phase("context_and_upload"):
+        ctx = _lib.Context(local_rank)
+        ctx.upload_pool(frames, offsets)
+    params = _lib.serra09_params()
+    lengths = np.full(args.tracks, args.frames, np.int64)
+    plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=world, tile=args.tile, want_tiles=True)
+    spec = plan["spec"]
+    stride = int(max(1, plan["floats_per_rank"].max()))
+    local = torch.zeros(stride, dtype=torch.float32, device=dev)
+    gathered = torch.empty(world * stride, dtype=torch.float32, device=dev) if collective else None
+    n_mine = sum(1 for t in plan["tiles"] if t.rank == rank)
+
+    def fence():
+        if collective:
+            dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
+
+    with clock.phase("warmup"):
+        for _ in range(max(1, args.warmup)):                     # arena, code objects, clocks: the rank's first tile(s)
+            ctx.grid_run(spec, params, rank, local.data_ptr(), first=0, count=min(2, n_mine))
+        local.zero_()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    fence()
+    clock.stamp("timed region (whole grid) ...")
+    t0 = time.perf_counter()
+    ctx.grid_run(spec, params, rank, local.data_ptr())           # all tiles of this rank; returns after its stream drained
+    t_compute = time.perf_counter() - t0
+    tg0 = time.perf_counter()
+    host_gather = None
+    if collective:
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, local)
+            torch.cuda.synchronize()
+        else:                                                    # development: ranks sharing a GPU, gather through the host
+            loc = local.cpu()
+            outs = [torch.empty_like(loc) for _ in range(world)]
+            dist.all_gather(outs, loc)
+            host_gather = torch.cat(outs).numpy()
+    t_gather = time.perf_counter() - tg0
+    fence()
+    elapsed = time.perf_counter() - t0
+    clock.stamp("timed region: %.2f s (kernels %.2f s, gather %.4f s)" % (elapsed, t_compute, t_gather))
+    prof = ctx.profile()
+    # ---- the serial tail: rank 0 brings the gathered buffers to the host and scatters them into the memmap
+    t_d2h = t_scatter = None
+    check = None
+    if rank == 0:
+        ts0 = time.perf_counter()
+        if host_gather is None:
+            host_gather = (gathered if collective else local).cpu().numpy()
+        t_d2h = time.perf_counter() - ts0
+        tmp = tempfile.mkdtemp(prefix="acx_strong_")
+        D = np.lib.format.open_memmap(os.path.join(tmp, "D.npy"), mode="w+", dtype=np.float32, shape=(args.tracks, args.tracks))
+        ts1 = time.perf_counter()
+        _lib.grid_scatter(lengths, spec, host_gather, stride, [D], mirror=True)
+        t_scatter = time.perf_counter() - ts1
+        # the matrix against the pair-LIST path of the library on sampled pairs (and its own transpose)
+        rng = np.random.default_rng(5)
+        smp = rng.integers(0, args.tracks, (512, 2))
+        smp = np.sort(smp[smp[:, 0] != smp[:, 1]][:256], axis=1)       # (i < j): the triangle all_pairwise computes
+        smp = np.ascontiguousarray(smp.astype(np.int32))
+        got = ctx.serra09_pairs(smp, params)
+        check = {"sampled_pairs": len(smp),
+                 "matrix_equals_pair_list": bool(np.array_equal(D[smp[:, 0], smp[:, 1]], got)),
+                 "cells_equal": int(np.sum(D[smp[:, 0], smp[:, 1]] == got)),
+                 "symmetric": bool(np.array_equal(D[smp[:, 0], smp[:, 1]], D[smp[:, 1], smp[:, 0]])),
+                 "nonzero_fraction_offdiag": float(np.count_nonzero(D) / max(1, args.tracks * (args.tracks - 1)))}
+        del D
+        try:
+            os.remove(os.path.join(tmp, "D.npy"))
+            os.rmdir(tmp)
+        except OSError:
+            pass
+    per_rank = [t_compute]
+    if collective:
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tc = torch.tensor([t_compute], dtype=torch.float64, device=cdev)
+        outs = [torch.zeros_like(tc) for _ in range(world)]
+        dist.all_gather(outs, tc)
+        per_rank = [float(o.item()) for o in outs]
+    if rank == 0:
+        pairs = args.tracks * (args.tracks - 1) // 2
+        kname, kst = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        line = {
+            "metric": "track-pairs/sec on N x N Serra09 Qmax (HPCP, T=%d)" % args.frames,
+            "value": round(pairs / elapsed, 1), "unit": "track-pairs/s", "n_gpus": world,
+            "ranks_seen": dist.get_world_size() if collective else 1, "collectives": (backend if collective else None),
+            "steps": 1, "warmup": max(1, args.warmup), "ms_per_step": round(1e3 * elapsed, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2] as ONE job: synthetic %d tracks x %d-frame HPCP (seed 1234), Serra09 Qmax, the whole "
+                                   "%d x %d upper-triangle grid (%d pairs) in %d x %d tiles dealt to %d rank(s) by cost; every rank "
+                                   "runs all its tiles, ONE all-gather of the per-rank score buffers, rank 0 scatters"
+                                   % (args.tracks, args.frames, args.tracks, args.tracks, pairs, spec.tile, spec.tile, world),
+                       "pairs": pairs, "frames_per_track": args.frames, "pool_tracks": args.tracks,
+                       "parallelism": "pair-grid tiles over %d GPU(s), strong scaling" % world},
+            "strong": {
+                "kernels_s_per_rank": [round(t, 3) for t in per_rank],
+                "plan_imbalance_max_over_mean": round(max(per_rank) / (sum(per_rank) / len(per_rank)), 4),
+                "plan_cost_per_rank": [float(c) for c in plan["cost_per_rank"]],
+                "tiles": int(plan["n_tiles"]), "tile": int(spec.tile),
+                "gather_ms": round(1e3 * t_gather, 3), "gather_bytes": int(world * stride * 4),
+                "gather_bytes_per_rank": int(stride * 4),
+                "d2h_s": round(t_d2h, 3), "scatter_mirror_s": round(t_scatter, 3),
+                "value_incl_scatter": round(pairs / (elapsed + t_d2h + t_scatter), 1),
+                "check": check,
+                "dominant_kernel": kname, "dominant_kernel_ms": round(kst["ms"], 1)},
+            "phases_s": clock.phases,
+        }
+        print(json.dumps(line), file=out, flush=True)
+    ctx.close()
+    if collective:
+        fence()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tracks", type=int, default=N_TRACKS)
+    ap.add_argument("--frames", type=int, default=T_FRAMES, help="frames per track (--strong only; the headline is fixed at 2000)")
+    ap.add_argument("--tile", type=int, default=TILE, help="grid tile edge in tracks (--strong only)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the whole pair grid of the pool once, split over the ranks, ONE final all-gather of "
+                         "the per-rank score buffers, rank-0 scatter reported beside it (minutes at 5000 tracks on one GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-other", action="store_true", help="skip the SiMPle / EarlyFusion legs (the `other` object)")
+    ap.add_argument("--no-other", action="store_true", help="skip the SiMPle / EarlyFusion / covers-shaped legs (the `other` object)")
     ap.add_argument("--plan-only", action="store_true",
                     help="rendezvous, deal the tiles, print the plan as one JSON line and stop: no GPU work "
                          "(checks a multi-rank launch on any box; ACX_BENCH_BACKEND=gloo without GPUs)")
@@ -231,10 +518,19 @@ def main():
         raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d: start exactly one rank per GPU "
                          "(python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...)"
                          % (args.gpus, world, args.gpus, args.gpus))
+    clock = Clock(verbose=(rank == 0))
+    # a run that hangs anywhere says where: every thread's stack on stderr every 4 minutes
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
+    clock.stamp("start: rank %d of %d, %d host threads for BLAS / OpenMP pools (of %d hardware threads)"
+                % (rank, world, HOST_THREADS, os.cpu_count() or 0))
+    clock.phases["interpreter_and_numpy"] = round(time.perf_counter() - _T_START, 3)
+    if args.strong:
+        return run_strong(args, clock, out, rank, world, local_rank)
 
-    from acoss_amd import _lib
-    lengths = np.full(args.tracks, T_FRAMES, np.int64)
-    plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=world, tile=TILE, want_tiles=True)
+    with clock.phase("libacx_load_and_plan"):
+        from acoss_amd import _lib
+        lengths = np.full(args.tracks, T_FRAMES, np.int64)
+        plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=world, tile=TILE, want_tiles=True)
     spec = plan["spec"]
     mine = [t for t in plan["tiles"] if t.rank == rank]
     nslices = len(mine) // TILES_PER_STEP
@@ -277,34 +573,30 @@ def main():
                               "cost_per_rank": [float(c) for c in plan["cost_per_rank"]]}), file=out, flush=True)
         return
 
-    frames, offsets = make_pool(args.tracks, T_FRAMES)
-    # ---- CPU baseline first: worker processes are forked before any GPU state exists
+    with clock.phase("pool_gen"):
+        frames, offsets = make_pool(args.tracks, T_FRAMES)
+    # ---- CPU baseline first: worker processes are forked (and joined) before any GPU state exists
     cpu = cpu_sample = cpu_scores = None
     if world == 1 and rank == 0 and not args.no_cpu:
-        cpu_sample, cpu_scores, cpu = cpu_baseline(frames, offsets, pairs_of(slice_of(args.warmup)[1]), args.tracks)
+        try:
+            cpu_sample, cpu_scores, cpu = cpu_baseline(frames, offsets, pairs_of(slice_of(args.warmup)[1]), args.tracks, clock)
+        except Exception as e:                       # the reported baseline must not take the measurement with it
+            cpu = {"value": None, "unit": "track-pairs/s", "cores": effective_cpus(), "kind": "port",
+                   "sample": "failed: %s: %s" % (type(e).__name__, e)}
+            cpu_sample = cpu_scores = None
 
-    import torch
-    import torch.distributed as dist
     # ACX_BENCH_BACKEND=gloo (development): functional run of the N > 1 path on a box with fewer
     # GPUs than ranks -- ranks share the devices and the gather goes through host memory
     backend = os.environ.get("ACX_BENCH_BACKEND", "nccl")
     # ACX_BENCH_FORCE_COLLECTIVE=1: a world of ONE still forms its process group and runs every collective of the
     # N > 1 step (RCCL all_gather_into_tensor, device barrier, all-reduce) -- the multi-GPU code path on a 1-GPU box
     collective = world > 1 or os.environ.get("ACX_BENCH_FORCE_COLLECTIVE") == "1"
-    if backend != "nccl":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    if collective:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend)
+    torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
     dev = torch.device("cuda", local_rank)
 
-    ctx = _lib.Context(local_rank)
-    ctx.upload_pool(frames, offsets)                 # pool resident in HBM before timing
+    with clock.phase("context_and_upload"):
+        ctx = _lib.Context(local_rank)
+        ctx.upload_pool(frames, offsets)                 # pool resident in HBM before timing
     params = _lib.serra09_params()
     slice_floats = max(sum(t.rows * t.cols for t in mine[k:k + TILES_PER_STEP]) for k in range(0, nslices * TILES_PER_STEP, TILES_PER_STEP))
     local = torch.zeros(slice_floats, dtype=torch.float32, device=dev)
@@ -334,16 +626,20 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        step(s)
+    with clock.phase("warmup"):
+        for s in range(args.warmup):
+            step(s)
     ctx.profile_enable(True)
     ctx.profile_reset()
     fence()
+    clock.stamp("timed region ...")
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
         pairs_per_step.append(step(s))
     fence()
     elapsed = time.perf_counter() - t0
+    clock.phases["timed_region"] = round(elapsed, 3)
+    clock.stamp("timed region: %.3f s" % elapsed)
     my_pairs = float(sum(pairs_per_step))
     if collective:
         cdev = dev if backend == "nccl" else torch.device("cpu")
@@ -396,20 +692,35 @@ def main():
             except Exception:
                 real_bound = None
         bpp = chain_bytes_per_pair(T_FRAMES, T_FRAMES)
-        roofline = {"bound": "hbm", "model": "hbm byte model of SURVEY 8d: a throughput proxy -- the pipeline keeps the distance matrix out of "
-                                              "HBM, what the SIMDs wait for is in real_bound (valu + f32 mfma issue)",
+        # SURVEY 8d's flop model of the same kernel: 2 x 108 flop per cell (the reference's 108-dim formulation of
+        # the cross-similarity matrix), per launch, against the f32-input MFMA peak
+        flops_pair = 2.0 * 12 * M_STACK * float((T_FRAMES - M_STACK) ** 2)
+        mfma_tf = value / world * flops_pair / 1e12
+        bound = derive_bound(real_bound)
+        roofline = {"bound": bound or "hbm",
+                    "bound_source": ("busiest unit in the counter record of this kernel (real_bound)" if bound else
+                                     "no counter record of this build's kernel sources: the byte model's own bound"),
+                    "model": "`achieved` / `frac` price the kernel with the HBM byte model of SURVEY 8d (4 B per cell and launch: a "
+                             "THROUGHPUT PROXY -- the pipeline keeps the distance matrix out of HBM, see `traffic`); what the SIMDs "
+                             "wait for is `bound` / real_bound; the 8d flop model of the same launch is in mfma_model",
                     "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": traffic_source, "real_bound": real_bound,
+                    "mfma_model": {"flops_per_pair": flops_pair, "achieved": round(mfma_tf, 2),
+                                   "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(mfma_tf / F32_MFMA_PEAK_TF, 4),
+                                   "note": "SURVEY 8d: 2 x 108 flop per cell of the pair's matrix, once per pair, over the whole chain's "
+                                           "time per pair; the kernels contract K = 12 per frame pair (window sums give the 108-dim "
+                                           "product) but sweep the matrix twice (column pass, row pass)"},
                     "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
                     "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
                     "chain": {"algorithmic_bytes_per_pair": bpp,
                               "achieved": round(value / world * bpp / 1e9, 1),
                               "frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 4)}}
-        if cpu is not None:
-            got = ctx.serra09_pairs(cpu_sample, params)
-            if not np.array_equal(got, cpu_scores):
-                raise SystemExit("bench: GPU scores differ from the CPU oracle on the sampled pairs")
+        if cpu_sample is not None and len(cpu_sample):
+            with clock.phase("self_check"):
+                got = ctx.serra09_pairs(cpu_sample, params)
+                if not np.array_equal(got, cpu_scores):
+                    raise SystemExit("bench: GPU scores differ from the CPU oracle on the sampled pairs")
         line = {
             "metric": "track-pairs/sec on N x N Serra09 Qmax (HPCP, T=2000)",
             "value": round(value, 1), "unit": "track-pairs/s", "n_gpus": world, "ranks_seen": ranks_seen, "collectives": (backend if collective else None), "steps": args.steps,
@@ -424,23 +735,55 @@ def main():
                                       int(pairs_per_step[0])),
                        "pairs_per_step": int(round(total_pairs / args.steps)), "frames_per_track": T_FRAMES,
                        "pool_tracks": args.tracks, "parallelism": "pair-grid tiles over %d GPU(s)" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "phases_s": clock.phases,
         }
+        printed = threading.Lock()
+
+        def emit():
+            if printed.acquire(False):
+                line["phases_s"]["total_wall"] = round(time.perf_counter() - _T_START, 3)
+                print(json.dumps(line), file=out, flush=True)
+
         if world == 1 and not args.no_other:
-            # the other two algorithms of the path, outside the timed region above: 2 steps each at their
-            # BASELINE configs[3] / [4] per-track shapes (bench_other.py), each with its own roofline and CPU baseline
+            # the companion legs, outside the timed region above (bench_other.py): Serra09 on covers80-shaped lengths and the
+            # other two algorithms at their BASELINE configs[3] / [4] per-track shapes, each with its own roofline and CPU
+            # baseline, each under a hard wall limit.  A leg that hangs in native code cannot take the headline with it:
+            # the watchdog prints the line as it stands and ends the process.
             import bench_other
             line["other"] = {}
-            for key, leg in (("simple", bench_other.simple_leg), ("earlyfusion", bench_other.earlyfusion_leg)):
+            legs = (("serra09_covers", bench_other.serra09_covers_leg), ("simple", bench_other.simple_leg),
+                    ("earlyfusion", bench_other.earlyfusion_leg))
+
+            def watchdog():
+                clock.stamp("watchdog: the `other` legs hang; printing the headline line without them")
+                for key, _ in legs:
+                    line["other"].setdefault(key, {"error": "abandoned by the watchdog"})
+                emit()
+                os._exit(0)
+
+            dog = threading.Timer(len(legs) * HARD_OTHER_LEG_S + 60.0, watchdog)
+            dog.daemon = True
+            dog.start()
+            for key, leg in legs:
                 try:
-                    line["other"][key] = leg(ctx, steps=2, warmup=1)
+                    with clock.phase("other_" + key), wall_limit(HARD_OTHER_LEG_S, "other." + key):
+                        line["other"][key] = leg(ctx)
                 except Exception as e:            # a failing companion leg must not take the headline line with it
                     line["other"][key] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(line), file=out, flush=True)
-    ctx.close()
-    if collective:
-        fence()
-        dist.destroy_process_group()
+            dog.cancel()
+            sc = line["other"].get("serra09_covers", {})
+            if "gcells_per_s" in sc:                   # cells per second of the short-track sets against the headline's
+                head = value / world * float((T_FRAMES - M_STACK) ** 2) / 1e9
+                sc["headline_gcells_per_s"] = round(head, 1)
+                sc["cell_rate_vs_T2000"] = round(sc["gcells_per_s"] / head, 3)
+        emit()
+    with clock.phase("teardown"):
+        ctx.close()
+        if collective:
+            fence()
+            dist.destroy_process_group()
+    clock.stamp("done")
+    faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

@@ -36,9 +36,105 @@ def _one_thread():
         return contextlib.nullcontext()
 
 
-def simple_leg(ctx, steps=3, warmup=1, n=512, cpu_pairs=64):
-    """SiMPle (simple_silva.py:120-126): all ordered pairs of `n` tracks of 12 x 150-250 pooled frames through the
-    pair grid (acx_grid_run: pairs enumerated on the device, f64 kernel, f32 scatter into a device buffer)."""
+def _tile_pairs(t):
+    """(row, col) track pairs of one grid tile, in the row-major order of its cells in the device buffer."""
+    return [(t.row0 + a, t.col0 + b) for a in range(t.rows) for b in range(t.cols)
+            if (t.row0 + a < t.col0 + b if t.diagonal else t.row0 + a != t.col0 + b)]
+
+
+def serra09_covers_leg(ctx, steps=5, warmup=1, cpu_pairs=192):
+    """Serra09 on the lengths real collections have (covers80 tracks are ~150-650 pooled
+    frames; rqa_serra09.py:44-69): `steps + warmup` covers80-shaped sets (164 tracks / 80 works each, cover structure,
+    T ~ U{150..650}, one seed per step) in one pool, all 13 366 pairs of a different set per step through
+    acx_serra09_pairs (the pair-list entry point similarity() uses); and once, beside it, a DA-TACOS-like length mix
+    (no length statistics of DA-TACOS are available offline: log-normal around 450 frames, sigma 0.35, clipped to
+    120 .. 1600 -- an assumption, stated).  Cells per second against the T = 2000 rate is the figure to watch: the
+    selection's per-row chain does not shrink with the row."""
+    import oracle
+    from acoss_amd import _lib, synth
+    sets = [synth.covers80_shaped(seed=100 + s, t_range=(150, 650)) for s in range(steps + warmup)]
+    frames = np.concatenate([d["frames"] for d in sets])
+    lens = np.concatenate([np.diff(d["offsets"]) for d in sets])
+    # the DA-TACOS-like mix rides in the same pool, after the covers80-shaped sets
+    rng = np.random.default_rng(77)
+    mix_T = np.clip(np.round(np.exp(rng.normal(np.log(450.0), 0.35, 328))), 120, 1600).astype(np.int64)
+    mix = synth.cover_set(clique_sizes=[2] * 164, seed=78, t_range=(150, 650))       # structure donor: re-cut to mix_T
+    mix_frames = []
+    mfr, moff = mix["frames"], mix["offsets"]
+    for k, T in enumerate(mix_T):
+        src_ = mfr[moff[k]:moff[k + 1]]
+        mix_frames.append(src_[np.arange(T) % len(src_)])
+    frames = np.concatenate([frames] + mix_frames)
+    lens = np.concatenate([lens, mix_T])
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ctx.upload_pool(frames, offs)
+    params = _lib.serra09_params()
+    n = 164
+    iu, ju = np.triu_indices(n, 1)
+    base = np.stack([iu, ju], 1).astype(np.int32)
+    L = lens - 9
+
+    def cells_of(p):
+        return float(np.sum(L[p[:, 0]].astype(np.float64) * L[p[:, 1]]))
+
+    for s in range(warmup):
+        ctx.serra09_pairs(base + s * n, params)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    dt, cells, got0 = 0.0, 0.0, None
+    for s in range(warmup, warmup + steps):
+        p = np.ascontiguousarray(base + s * n)
+        t0 = time.perf_counter()
+        got = ctx.serra09_pairs(p, params)
+        dt += time.perf_counter() - t0
+        cells += cells_of(p)
+        if got0 is None:
+            got0, p0 = got, p
+    prof = ctx.profile()
+    npairs = steps * len(base)
+    # the length mix: all pairs of its 328 tracks, twice (first call untimed)
+    m0 = (steps + warmup) * n
+    im, jm = np.triu_indices(len(mix_T), 1)
+    pm = np.ascontiguousarray(np.stack([im + m0, jm + m0], 1).astype(np.int32))
+    ctx.serra09_pairs(pm[:4096], params)
+    t0 = time.perf_counter()
+    gm = ctx.serra09_pairs(pm, params)
+    dtm = time.perf_counter() - t0
+    # CPU oracle, one core, bounded sample of the first timed set; bit-for-bit check of both workloads
+    with _one_thread():
+        tc = time.perf_counter()
+        ref = oracle.serra09_pairs(frames, offs, p0[:cpu_pairs])
+        tcpu = time.perf_counter() - tc
+        refm = oracle.serra09_pairs(frames, offs, pm[:32])
+    if not (np.array_equal(ref, got0[:cpu_pairs]) and np.array_equal(refm, gm[:32])):
+        raise AssertionError("serra09_covers: GPU scores differ from the CPU oracle")
+    kname, kst = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    kbytes = 4.0 * kst["cells"]                       # the byte model of bench.py: 4 B per cell and band_kernel launch
+    return {
+        "metric": "track-pairs/sec, Serra09 Qmax on covers80-shaped lengths (164 tracks of 150-650 pooled frames, all 13 366 pairs)",
+        "value": round(npairs / dt, 1), "unit": "track-pairs/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1] shape: %d covers80-shaped sets (seeds 100..%d) in one pool, a different set per step, "
+                               "acx_serra09_pairs on the pair list (scores to the host)" % (steps + warmup, 100 + steps + warmup - 1)},
+        "gcells_per_s": round(cells / dt / 1e9, 1),
+        "length_mix": {"workload": "328 tracks, lengths log-normal around 450 frames (sigma 0.35, clipped 120..1600: assumed, DA-TACOS "
+                                   "length statistics are not available offline), all %d pairs in one call" % len(pm),
+                       "value": round(len(pm) / dtm, 1), "gcells_per_s": round(cells_of(pm) / dtm / 1e9, 1)},
+        "roofline": {"bound": "valu (selection: per-row latency chain) + f32 mfma", "kernel": kname,
+                     "achieved": round(kbytes / (kst["ms"] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(kbytes / (kst["ms"] * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                     "model": "same 4 B per cell and launch byte model as the headline's band_kernel (a throughput proxy)",
+                     "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]}},
+        "cpu_baseline": {"value": round(cpu_pairs / tcpu, 2), "unit": "track-pairs/s", "cores": 1, "kind": "port",
+                         "sample": "first %d pairs of the first timed set, C oracle (gcc -O3), one thread, %.1f s; scores "
+                                   "bit-identical to the GPU's (also 32 pairs of the length mix)" % (cpu_pairs, tcpu)}}
+
+
+def simple_leg(ctx, steps=5, warmup=1, n=1536, tiles_per_step=16, cpu_pairs=64):
+    """SiMPle (simple_silva.py:120-126): ordered pairs of tracks of 12 x 150-250 pooled frames through the pair grid
+    (acx_grid_run: pairs enumerated on the device, f64 kernel, f32 scatter into a device buffer).  The pool holds
+    `n` tracks; every step runs the next `tiles_per_step` 128 x 128 tiles of the grid (16 tiles = 262 144 ordered
+    pairs, other tracks every step)."""
     import torch
     import oracle                      # the checker / timed CPU baseline only
     from acoss_amd import _lib
@@ -50,31 +146,42 @@ def simple_leg(ctx, steps=3, warmup=1, n=512, cpu_pairs=64):
     offs = np.concatenate([[0], np.cumsum(na)]).astype(np.int64)
     ctx.upload_pool_f64(np.concatenate(tm), offs)
     plan = _lib.grid_plan(na, _lib.ALGO_SIMPLE, False, world=1, tile=128, want_tiles=True)
+    tiles = list(plan["tiles"])
+    assert len(tiles) >= (steps + warmup) * tiles_per_step
     buf = torch.zeros(int(plan["floats_per_rank"][0]), dtype=torch.float32, device=torch.device("cuda", ctx.device))
     torch.cuda.synchronize()
     sp = _lib.SimpleParams(10, 1)
-    for _ in range(warmup):
-        ctx.grid_run(plan["spec"], sp, 0, buf.data_ptr())
+    for s in range(warmup):
+        ctx.grid_run(plan["spec"], sp, 0, buf.data_ptr(), first=s * tiles_per_step, count=tiles_per_step)
     ctx.profile_enable(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        ctx.grid_run(plan["spec"], sp, 0, buf.data_ptr())          # returns after the stream has drained
+    for s in range(warmup, warmup + steps):
+        ctx.grid_run(plan["spec"], sp, 0, buf.data_ptr(), first=s * tiles_per_step, count=tiles_per_step)   # returns after the stream has drained
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.profile()
     host = buf.cpu().numpy()
-    npairs = n * (n - 1)
-    cells = float(np.sum(np.outer(na - 9.0, na - 9.0)) - np.sum((na - 9.0) ** 2))
+    timed = tiles[warmup * tiles_per_step:(warmup + steps) * tiles_per_step]
+    w = na - 9.0
+    npairs, cells = 0, 0.0
+    for t in timed:
+        r, c = w[t.row0:t.row0 + t.rows], w[t.col0:t.col0 + t.cols]
+        npairs += t.rows * t.cols - (t.rows if t.row0 == t.col0 else 0)
+        cells += float(r.sum() * c.sum()) - (float(np.sum(r * c)) if t.row0 == t.col0 else 0.0)
+    npairs /= float(steps)
+    cells /= float(steps)
     # f64 work per profile cell.  The reference's STOMP update (simple_silva.py:107-110) is two 12-term products
     # (the frame entering and the frame leaving the window) + update + distance + running minimum = 54 flop; the
     # kernel EXECUTES one product (24 flop) + 6 per cell on 64 lanes of which 54 are rows = 35.6: the leaving
     # product is handed over by the lane SSLEN below.  SURVEY 8d's model (a 120-term product per cell, 240 flop)
-    # counts work nobody does.  `achieved` is the executed figure.
+    # counts work nobody does.  `achieved` / `frac` are the executed figure; the other two models have their own
+    # frac_* fields.
     executed = 30.0 * 64.0 / 54.0 * cells
     kst = prof["simple_kernel"]
-    kms = kst["ms"] / steps                                                    # kernel time per step (one launch per 4 M pairs)
-    # CPU baseline + check: the first pairs of tile 0 (row-major cells of the device buffer)
-    t = plan["tiles"][0]
+    kms = kst["ms"] / steps                                                    # kernel time per step
+    ks = kms * 1e-3
+    # CPU baseline + check: the first pairs of the first timed tile (row-major cells of the device buffer)
+    t = timed[0]
     cp = [(t.row0 + a, t.col0 + b) for a in range(t.rows) for b in range(t.cols) if t.row0 + a != t.col0 + b][:cpu_pairs]
     with _one_thread():
         tc = time.perf_counter()
@@ -88,48 +195,60 @@ def simple_leg(ctx, steps=3, warmup=1, n=512, cpu_pairs=64):
         "value": round(npairs / dt, 1), "unit": "track-pairs/s", "n_gpus": 1, "steps": steps,
         "warmup": warmup, "ms_per_step": round(1e3 * dt, 3), "higher_is_better": True, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "configs[3] per-track shape: %d tracks, all %d ordered pairs per step through acx_grid_run "
-                               "(128 x 128 tiles, scores scattered into a device buffer)" % (n, npairs)},
+        "config": {"workload": "configs[3] per-track shape: pool of %d tracks, %d tiles of 128 x 128 tracks (%d ordered pairs) per step "
+                               "through acx_grid_run, other tiles every step (scores scattered into a device buffer)"
+                               % (n, tiles_per_step, int(npairs))},
         "roofline": {"bound": "valu-f64 issue (~ 0.6 - 0.7 busy) next to the LDS permutes of the sliding dot product (0.46 busy); not the scalar cache: one second track for every pair runs at the same rate (scripts/simple_probe2.py)", "kernel": "simple_kernel",
-                     "achieved": round(executed / (kms * 1e-3) / 1e12, 2), "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": round(executed / (kms * 1e-3) / 1e12 / F64_VALU_PEAK_TF, 4), "traffic": None,
+                     "achieved": round(executed / ks / 1e12, 2), "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(executed / ks / 1e12 / F64_VALU_PEAK_TF, 4), "traffic": None,
                      "kernel_ms_per_step": round(kms, 3), "executed_flop_per_cell": round(30.0 * 64.0 / 54.0, 2),
-                     "reference_stomp_tflops_54_per_cell": round(54.0 * cells / (kms * 1e-3) / 1e12, 2),
-                     "survey_8d_model_tflops_240_per_cell": round(240.0 * cells / (kms * 1e-3) / 1e12, 2)},
+                     "frac_executed_35_6_flop_per_cell": round(executed / ks / 1e12 / F64_VALU_PEAK_TF, 4),
+                     "frac_reference_stomp_54_flop_per_cell": round(54.0 * cells / ks / 1e12 / F64_VALU_PEAK_TF, 4),
+                     "frac_survey_8d_model_240_flop_per_cell": round(240.0 * cells / ks / 1e12 / F64_VALU_PEAK_TF, 4),
+                     "frac_note": "the 8d model counts a 120-term product per cell that neither the reference's STOMP update nor the "
+                                  "kernel performs: its `frac` > 1 says the model over-counts, not that the kernel beats the peak",
+                     "reference_stomp_tflops_54_per_cell": round(54.0 * cells / ks / 1e12, 2),
+                     "survey_8d_model_tflops_240_per_cell": round(240.0 * cells / ks / 1e12, 2)},
         "cpu_baseline": {"value": round(len(cp) / tcpu, 2), "unit": "track-pairs/s", "cores": 1, "kind": "port",
-                         "sample": "first %d pairs of tile 0, numpy oracle, BLAS limited to one thread; max relative |diff| vs the "
+                         "sample": "first %d pairs of the first timed tile, numpy oracle, BLAS limited to one thread; max relative |diff| vs the "
                                    "GPU's f32 scores %.1e" % (len(cp), err)}}
 
 
-def earlyfusion_leg(ctx, steps=3, warmup=1, n=128, cpu_pairs=4):
-    """EarlyFusion per-pair chain (earlyfusion_traile.py:157-198) at 300-500 blocks per track: all pairs of `n`
-    tracks through the pair grid into a device buffer (n = 128: one diagonal tile of the production grid, 8128 pairs)."""
+def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
+    """EarlyFusion per-pair chain (earlyfusion_traile.py:157-198) at 300-500 blocks per track through the pair grid into a
+    device buffer: a pool of `n` tracks in 128 x 128 tiles (n = 384: three diagonal tiles of 8128 pairs, three
+    off-diagonal ones of 16 384), ONE tile per step, another tile every step."""
     import torch
     import oracle
     from acoss_amd import _lib, synth
     tracks = synth.earlyfusion_set(n, seed=1, nb_range=(300, 500))
     ctx.ef_upload_pool(tracks)
     nb = np.array([t["mfccs"].shape[0] for t in tracks])
-    plan = _lib.grid_plan(nb, _lib.ALGO_EARLYFUSION, True, world=1, tile=n, want_tiles=True)
+    plan = _lib.grid_plan(nb, _lib.ALGO_EARLYFUSION, True, world=1, tile=128, want_tiles=True)
+    tiles = list(plan["tiles"])
+    assert len(tiles) >= steps + warmup, len(tiles)
     buf = torch.zeros(int(plan["floats_per_rank"][0]), dtype=torch.float32, device=torch.device("cuda", ctx.device))
     torch.cuda.synchronize()
     ep = _lib.EfParams(0.1, 10)
-    for _ in range(warmup):
-        ctx.grid_run(plan["spec"], ep, 0, buf.data_ptr())
+    for s in range(warmup):
+        ctx.grid_run(plan["spec"], ep, 0, buf.data_ptr(), first=s, count=1)
     ctx.profile_enable(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        ctx.grid_run(plan["spec"], ep, 0, buf.data_ptr())
-    dt = (time.perf_counter() - t0) / steps
+    for s in range(warmup, warmup + steps):
+        ctx.grid_run(plan["spec"], ep, 0, buf.data_ptr(), first=s, count=1)
+    dt = time.perf_counter() - t0
     prof = ctx.profile()
-    host = buf.cpu().numpy().reshape(n, n, 4)
-    i, j = np.triu_indices(n, 1)
-    npairs = len(i)
-    flops = float(np.sum(2.0 * (650 + 1225 + 480) * nb[i] * nb[j]))
+    host = buf.cpu().numpy()
+    timed = tiles[warmup:warmup + steps]
+    allp = [p for t in timed for p in _tile_pairs(t)]
+    npairs = len(allp)
+    pi, pj = np.array(allp).T
+    flops = float(np.sum(2.0 * (650 + 1225 + 480) * nb[pi] * nb[pj]))
     g = prof["ef_gemm_kernel"]
-    kms = g["ms"] / steps
-    cp = list(zip(i[:cpu_pairs], j[:cpu_pairs]))
+    ks = g["ms"] * 1e-3
+    t = timed[0]
+    cp = _tile_pairs(t)[:cpu_pairs]
     with _one_thread():
         tc = time.perf_counter()
         ref = []
@@ -138,43 +257,45 @@ def earlyfusion_leg(ctx, steps=3, warmup=1, n=128, cpu_pairs=4):
             ref.append([sc["mfccs"], sc["ssms"], sc["chromas"], sc["early"]])
         tcpu = time.perf_counter() - tc
     ref = np.array(ref)
-    got = np.array([host[a, b] for a, b in cp])
+    got = np.array([host[t.offset + 4 * ((a - t.row0) * t.cols + (b - t.col0)):][:4] for a, b in cp])
     diff = float(np.max(np.abs(ref - got)))
-    assert diff <= 2.0, diff
+    same = float(np.mean(np.abs(ref - got) < 1e-4))          # scores are multiples of 0.1: f32 store of the f64 value
+    assert diff <= 3.0, diff
     return {
         "metric": "track-pairs/sec, EarlyFusion per-pair chain (3 CSMs, 4 x binarise + Smith-Waterman, kernel fusion) at 300-500 blocks",
         "value": round(npairs / dt, 1), "unit": "track-pairs/s", "n_gpus": 1, "steps": steps,
-        "warmup": warmup, "ms_per_step": round(1e3 * dt, 3), "higher_is_better": True, "dtype": "f32",
+        "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "configs[4] per-track shape: %d tracks of 300-500 blocks, all %d pairs per step through acx_grid_run "
-                               "(scores scattered into a device buffer)" % (n, npairs)},
+        "config": {"workload": "configs[4] per-track shape: pool of %d tracks of 300-500 blocks, one 128 x 128 grid tile per step "
+                               "(diagonal: 8128 pairs, off-diagonal: 16 384), another tile every step, %d pairs in %d steps through "
+                               "acx_grid_run (scores scattered into a device buffer)" % (n, npairs, steps)},
         # all three cross-similarity GEMMs run on the bf16 matrix pipe from three-term splits: six bf16 products per
         # f32-equivalent multiply-add are what the pipe executes, and what is priced against its dense peak
         "roofline": {"bound": "mfma", "kernel": "ef_gemm_rect_bf16x3_kernel<0> (mfcc / ssm) + <1> (chroma): three-term bf16 splits, "
                                                 "256 x 128 tiles over dense rectangles of pairs",
-                     "achieved": round(6.0 * flops / (kms * 1e-3) / 1e12, 1), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": round(6.0 * flops / (kms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4), "traffic": None,
-                     "flops": "executed bf16 flops = 6 x the f32-equivalent 2 (650 + 1225 + 480) nb1 nb2 per pair (SURVEY 8d); the k loop "
-                              "alone sustains 1.39 PFLOP/s at the 1.87 GHz the chip clocks to under this load (scripts/ef_kloop_probe.py), "
-                              "the rest is the store tail and the prologue of every tile",
-                     "f32_equivalent_tflops": round(flops / (kms * 1e-3) / 1e12, 2), "f32_mfma_peak_tflops": F32_MFMA_PEAK_TF,
-                     "kernel_ms_per_step": round(kms, 3),
+                     "achieved": round(6.0 * flops / ks / 1e12, 1), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(6.0 * flops / ks / 1e12 / BF16_MFMA_PEAK_TF, 4), "traffic": None,
+                     "flops": "executed bf16 flops = 6 x the f32-equivalent 2 (650 + 1225 + 480) nb1 nb2 per pair (SURVEY 8d)",
+                     "f32_equivalent_tflops": round(flops / ks / 1e12, 2), "f32_mfma_peak_tflops": F32_MFMA_PEAK_TF,
+                     "kernel_ms_per_step": round(g["ms"] / steps, 3),
                      "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]}},
         "cpu_baseline": {"value": round(len(cp) / tcpu, 3), "unit": "track-pairs/s", "cores": 1, "kind": "port",
-                         "sample": "first %d pairs, numpy + C oracle, BLAS limited to one thread; max |score diff| vs GPU %.3g"
-                                   % (len(cp), diff)}}
+                         "sample": "first %d pairs of the first timed tile, numpy + C oracle, BLAS limited to one thread, %.1f s; "
+                                   "%.4f of the 4 x %d scores identical to the GPU's, max |diff| %.3g"
+                                   % (len(cp), tcpu, same, len(cp), diff)}}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-pairs", type=int, default=4)
+    ap.add_argument("--cpu-pairs", type=int, default=32)
     args = ap.parse_args()
     from acoss_amd import _lib
     ctx = _lib.Context(0)
-    print(json.dumps(simple_leg(ctx, args.steps, args.warmup)))
-    print(json.dumps(earlyfusion_leg(ctx, args.steps, args.warmup, cpu_pairs=args.cpu_pairs)))
+    print(json.dumps(serra09_covers_leg(ctx, args.steps, args.warmup)), flush=True)
+    print(json.dumps(simple_leg(ctx, args.steps, args.warmup)), flush=True)
+    print(json.dumps(earlyfusion_leg(ctx, args.steps, args.warmup, cpu_pairs=args.cpu_pairs)), flush=True)
     ctx.close()
 
 

@@ -48,12 +48,14 @@ void acx_destroy(acx_ctx *ctx);
 /* Last error message of this context (ctx == NULL: of the last failed acx_create). */
 const char *acx_last_error(const acx_ctx *ctx);
 int acx_abi_version(void);
-/* HIP_VERSION the library was compiled against and the version of the HIP runtime it is running on (0: unknown);
- * the ctypes shim warns when their major.minor differ (a process that also holds PyTorch-ROCm runs on the
- * runtime torch bundles). */
+/* HIP_VERSION the library was compiled against and the version of the HIP runtime it is running on (0: unknown).
+ * The ctypes shim records both (acoss_amd._lib.HIP_VERSIONS) and warns when the MAJOR versions differ; a process
+ * that also holds PyTorch-ROCm runs on the runtime torch bundles (this image: built against 7.2, runs on 7.0 --
+ * same major, recorded, no warning). */
 int acx_hip_versions(int *build, int *runtime);
-/* Upper bound (bytes) for the per-batch device scratch; 0 restores the default
- * (env ACX_SCRATCH_GB, else 40 % of device memory). */
+/* Upper bound (bytes) for the per-batch device scratch; 0 restores the default: env ACX_SCRATCH_GB, else 40 % of
+ * device memory for the Serra09 batches and min(40 %, 36 GB) for the EarlyFusion arena (what one 128 x 128 grid tile
+ * of 300-500-block tracks needs; larger arenas only cost allocation time). */
 int acx_set_scratch_limit(acx_ctx *ctx, int64_t bytes);
 
 /* ---- feature pool ------------------------------------------------------- */
@@ -231,8 +233,14 @@ int acx_ef_upload_pool(acx_ctx *ctx, const float *mfccs, const float *ssms, cons
  *   acx_ef_pool_tracks  tracks [first_track, first_track + count): their rows of the three feature arrays
  *                       and their chroma medians, packed as in acx_ef_upload_pool.  The pointers may be
  *                       HOST or DEVICE memory (features that already live on the GPU, e.g. in a torch
- *                       tensor, are copied device to device)
- *   acx_ef_pool_end     non-finite scan, row norms, bf16 splits; the pool is usable from here on
+ *                       tensor, are copied device to device).  STREAM CONTRACT: the copy is a blocking
+ *                       hipMemcpy(hipMemcpyDefault) ordered against the NULL stream only -- a device source
+ *                       written by kernels on another (non-blocking) stream must be COMPLETE before the call:
+ *                       synchronise that stream (torch.cuda.synchronize() / hipStreamSynchronize) first.
+ *                       Slices may arrive in any order and may be handed over again (the last copy wins)
+ *   acx_ef_pool_end     checks that EVERY track was handed over (else ACX_ERR_STATE naming the first missing
+ *                       track; the pool stays open, so the missing slices can still be supplied), then the
+ *                       non-finite scan, row norms, bf16 splits; the pool is usable from here on
  */
 int acx_ef_pool_begin(acx_ctx *ctx, const int64_t *offsets, int32_t n_tracks, const int32_t *dims);
 int acx_ef_pool_tracks(acx_ctx *ctx, int32_t first_track, int32_t count, const float *mfccs, const float *ssms,

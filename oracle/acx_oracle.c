@@ -149,8 +149,9 @@ static float select_kth(float *w, int n, int k)
         float pv = (a < b) ? ((b < c) ? b : (a < c ? c : a)) : ((a < c) ? a : (b < c ? c : b));
         int i = lo, j = hi;
         while (i <= j) {
-            while (w[i] < pv) ++i;
-            while (w[j] > pv) --j;
+            /* bounded scans: a NaN in the row (every comparison false) cannot run them off the array */
+            while (i <= hi && w[i] < pv) ++i;
+            while (j >= lo && w[j] > pv) --j;
             if (i <= j) { float t = w[i]; w[i] = w[j]; w[j] = t; ++i; --j; }
         }
         if (k <= j) hi = j;
@@ -227,6 +228,8 @@ float acx_o_serra09_pair(const float *Q, int32_t Tq, const float *Rf, int32_t Tr
                          uint8_t *bin_out, int32_t *oti_out)
 {
     const int m = p->m, tau = p->tau;
+    /* tree_w sums windows of up to 64 terms on the stack (the device supports m <= 33) */
+    if (m < 1 || m > 64 || tau < 1) return -1.0f;
     const int Mq = acx_o_embed_len(Tq, p), Mr = acx_o_embed_len(Tr, p);
     if (Mq <= 0 || Mr <= 0) return -1.0f;
 

@@ -280,3 +280,44 @@ def test_shard_bounds_cover_everything():
             assert all(spans[k][1] == spans[k + 1][0] for k in range(ws - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_root_fails(rank, ws, port, workdir, out):
+    sys.path.insert(0, ROOT)
+    os.chdir(workdir)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=ws)
+    try:
+        from acoss_amd import dist as adist
+        from acoss_amd.algorithms.algorithm_template import CoverAlgorithm
+        assert adist.on_root(lambda: {"n": 3}) == {"n": 3}
+        # a dataset whose feature files do not exist: rank 0 fails while it builds the clique table -- every rank
+        # must see an exception (and none may be left waiting in the broadcast)
+        toy = CoverAlgorithm(os.path.join(workdir, "nofiles.csv"), name="Toy", datapath=workdir + "/missing/", shortname="nf")
+        try:
+            toy.get_all_clique_ids()
+            msg = "no exception"
+        except Exception as e:                       # noqa: BLE001
+            msg = "%s: %s" % (type(e).__name__, e)
+        with open(os.path.join(out, "rank%d.txt" % rank), "w") as f:
+            f.write(msg)
+        dist.barrier()                               # both ranks are still in step after the failure
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_root_failure_reaches_every_rank(tmp_path):
+    """An exception in a rank-0-only section (acoss_amd.dist.on_root: clique table, statistics) is re-raised on every
+    rank instead of leaving the others blocked in the broadcast."""
+    import torch.multiprocessing as mp
+    wd = str(tmp_path)
+    with open(os.path.join(wd, "nofiles.csv"), "w") as f:
+        f.write("work_id,track_id\nw0,t0\nw0,t1\n")
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    mp.spawn(_worker_root_fails, args=(2, _free_port(), wd, out), nprocs=2, join=True)
+    m0 = open(os.path.join(out, "rank0.txt")).read()
+    m1 = open(os.path.join(out, "rank1.txt")).read()
+    assert m0 != "no exception" and m1 != "no exception", (m0, m1)
+    assert m1.startswith("RuntimeError: rank 0 failed in a rank-0-only section"), m1

@@ -388,3 +388,30 @@ def test_fuzz_small(ctx):
     fuzz_earlyfusion = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz_earlyfusion)
     assert fuzz_earlyfusion.run(rounds=12, seed=5, ctx=ctx) > 0
+
+
+def test_pool_slices_must_cover_every_track(ctx):
+    """acx_ef_pool_end refuses a pool some track of which was never handed over (the arrays come from hipMalloc: what
+    acx_ef_pool_tracks did not write is garbage), names the first missing track and leaves the pool open; the missing
+    slice supplied afterwards -- in any order -- gives the pool a whole upload gives."""
+    from acoss_amd import _lib, synth
+    tracks = synth.earlyfusion_set(5, seed=11, nb_range=(20, 40))
+    pairs = np.array([[0, 2], [1, 3], [2, 4], [3, 4]], np.int32)
+    ctx.ef_upload_pool(tracks)
+    want = ctx.earlyfusion_pairs(pairs)
+    nb = [t["mfccs"].shape[0] for t in tracks]
+
+    def hand_over(a, b):
+        part = tracks[a:b]
+        ctx.ef_pool_tracks(a, b - a, *[np.concatenate([t[k] for t in part]) for k in ("mfccs", "ssms", "chromas")],
+                           np.stack([np.asarray(t["chroma_med"], np.float64) for t in part]))
+    ctx.ef_pool_begin(nb)
+    hand_over(3, 5)
+    hand_over(0, 2)
+    with pytest.raises(_lib.AcxError, match="first: track 2"):
+        ctx.ef_pool_end()
+    with pytest.raises(_lib.AcxError):                 # no usable pool in between
+        ctx.earlyfusion_pairs(pairs)
+    hand_over(2, 3)
+    ctx.ef_pool_end()
+    assert np.array_equal(ctx.earlyfusion_pairs(pairs), want)

@@ -283,3 +283,53 @@ def test_grid_run_ranks_simple_and_earlyfusion(ctx):
             _lib.grid_scatter(lengths, plan["spec"], np.concatenate(bufs), stride, D, mirror=sym)
             for e in range(w):
                 assert np.array_equal(D[e], want[e]), (algo, sym, sliced, e)
+
+
+def _bench_strong(env_extra, nproc, tracks=160, frames=400, tile=32):
+    """`bench.py --strong` as a child process (nproc > 1: one torch.distributed.run launch on 127.0.0.1);
+    returns the parsed JSON line."""
+    import json
+    import os
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    args = ["--gpus", str(nproc), "--strong", "--tracks", str(tracks), "--frames", str(frames), "--tile", str(tile), "--warmup", "1"]
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    else:
+        env.update(MASTER_PORT=str(_free_port()))
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_strong_nccl_world_of_one():
+    """bench.py --strong through RCCL as far as one GPU allows (ACX_BENCH_FORCE_COLLECTIVE=1: a one-rank "nccl" group):
+    the whole grid into the rank's buffer, all_gather_into_tensor of the REAL buffer, rank-0 scatter + mirror into
+    the memmap; the matrix must equal the pair-list path on the sampled pairs."""
+    line = _bench_strong({"ACX_BENCH_FORCE_COLLECTIVE": "1"}, 1)
+    s = line["strong"]
+    assert line["scaling"] == "strong" and line["collectives"] == "nccl" and line["ranks_seen"] == 1
+    assert line["config"]["pairs"] == 160 * 159 // 2
+    assert s["check"]["matrix_equals_pair_list"] and s["check"]["symmetric"], s["check"]
+    assert s["check"]["nonzero_fraction_offdiag"] == 1.0
+    assert s["gather_bytes"] >= 4 * line["config"]["pairs"] and s["gather_ms"] > 0
+    assert "phases_s" in line and line["value"] > 0
+
+
+def test_bench_strong_gloo_world_of_two():
+    """The N > 1 route of bench.py --strong with two REAL ranks (sharing the one GPU of the box, gather through gloo):
+    cost-balanced deal, per-rank buffers of the plan's stride, the gathered buffers scattered by rank 0 -- the
+    matrix equals the pair-list path, both ranks' kernel times are reported."""
+    line = _bench_strong({"ACX_BENCH_BACKEND": "gloo"}, 2)
+    s = line["strong"]
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["collectives"] == "gloo"
+    assert len(s["kernels_s_per_rank"]) == 2 and min(s["kernels_s_per_rank"]) > 0
+    assert s["check"]["matrix_equals_pair_list"] and s["check"]["symmetric"], s["check"]
+    assert s["gather_bytes"] == 2 * s["gather_bytes_per_rank"]
+    c = s["plan_cost_per_rank"]
+    assert max(c) / (sum(c) / 2) < 1.1                                # the deal balances the modelled cost
