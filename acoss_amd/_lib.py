@@ -30,7 +30,11 @@ EXPORTS = [
     "acx_ef_block_features", "acx_ef_upload_raw_pool", "acx_snf_fuse_dists", "acx_grid_plan", "acx_pool_lengths", "acx_grid_run", "acx_grid_scatter", "acx_pair_grid",
     "acx_set_nonfinite_policy", "acx_nonfinite_zeroed", "acx_ef_pool_begin", "acx_ef_pool_tracks", "acx_ef_pool_end",
     "acx_set_ef_gemm", "acx_hip_versions",
+    "acx_dev_alloc", "acx_dev_free", "acx_dev_read", "acx_dev_sync",
+    "acx_comm_id", "acx_comm_init", "acx_comm_destroy", "acx_grid_allgather", "acx_pair_grid_ranks",
 ]
+ABI_VERSION = 2           # include/acx.h ACX_ABI_VERSION this shim was written against
+COMM_ID_BYTES = 128
 
 ALGO_SERRA09, ALGO_CHENFUSION, ALGO_SIMPLE, ALGO_EARLYFUSION = 0, 1, 2, 3
 GRID_PLANES = {ALGO_SERRA09: 1, ALGO_CHENFUSION: 2, ALGO_SIMPLE: 1, ALGO_EARLYFUSION: 4}
@@ -150,6 +154,18 @@ def load():
     pp = ctypes.POINTER(Serra09Params)
     vp = ctypes.c_void_p
     L.acx_abi_version.restype = ctypes.c_int
+    if L.acx_abi_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, this shim needs %d: rebuild it (make -C acoss_amd/csrc)"
+                          % (LIB_PATH, L.acx_abi_version(), ABI_VERSION))
+    L.acx_dev_alloc.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]
+    L.acx_dev_free.argtypes = [vp, vp]
+    L.acx_dev_read.argtypes = [vp, vp, vp, ctypes.c_int64]
+    L.acx_dev_sync.argtypes = [vp]
+    L.acx_comm_id.argtypes = [vp]
+    L.acx_comm_init.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32]
+    L.acx_comm_destroy.argtypes = [vp]
+    L.acx_grid_allgather.argtypes = [vp, vp, vp, ctypes.c_int64]
+    L.acx_pair_grid_ranks.argtypes = [vp, ctypes.POINTER(GridSpec), vp, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_int32]
     L.acx_create.restype = vp
     L.acx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.acx_destroy.restype = None
@@ -267,6 +283,42 @@ def grid_scatter(lengths, spec, gathered, rank_stride, planes, mirror, first=0, 
                             int(count), ptrs, n, int(bool(mirror)))
     if rc != ACX_OK:
         raise ValueError("acx_grid_scatter: bad argument")
+
+
+def comm_id():
+    """acx_comm_id: a fresh RCCL communicator id (128 bytes) -- rank 0 calls it and the host hands the bytes to every rank."""
+    L = load()
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    rc = L.acx_comm_id(buf)
+    if rc != ACX_OK:
+        msg = L.acx_last_error(None)
+        raise AcxError("acx_comm_id failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+    return buf.raw
+
+
+class DevBuf(object):
+    """A device buffer owned by a libacx context (Context.dev_alloc)."""
+
+    def __init__(self, ctx, ptr, nbytes):
+        self._ctx, self.ptr, self.nbytes = ctx, ptr, nbytes
+
+    def data_ptr(self):
+        return self.ptr
+
+    def read(self, dtype=np.float32, count=None, offset_bytes=0):
+        """Copy `count` items of `dtype` starting `offset_bytes` into the buffer back to the host (drains the library's stream first)."""
+        dt = np.dtype(dtype)
+        if count is None:
+            count = (self.nbytes - offset_bytes) // dt.itemsize
+        out = np.empty(int(count), dt)
+        self._ctx._check(self._ctx._L.acx_dev_read(self._ctx._h, ctypes.c_void_p(out.ctypes.data),
+                                                   ctypes.c_void_p(self.ptr + int(offset_bytes)), int(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self._ctx._check(self._ctx._L.acx_dev_free(self._ctx._h, ctypes.c_void_p(self.ptr)))
+            self.ptr = 0
 
 
 class Context(object):
@@ -528,6 +580,47 @@ class Context(object):
         self._check(self._L.acx_snf_fuse(self._h, arr(Ws), arr(Js), arr(Vs), m, n, K, int(niters), float(reg_diag),
                                          out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return out
+
+    # ------------------------------------------------------------------ device buffers without torch
+    def dev_alloc(self, nbytes):
+        """acx_dev_alloc: a zero-filled device buffer on this context's GPU (DevBuf: .ptr, .read(dtype, count), .free())
+        -- what acx_grid_run / acx_grid_allgather write into when the host holds no torch."""
+        p = ctypes.c_void_p(0)
+        self._check(self._L.acx_dev_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        return DevBuf(self, int(p.value), int(nbytes))
+
+    def dev_sync(self):
+        """hipDeviceSynchronize on this context's GPU."""
+        self._check(self._L.acx_dev_sync(self._h))
+
+    # ------------------------------------------------------------------ RCCL inside the library (no torch.distributed)
+    def comm_init(self, comm_id, rank, world):
+        """Join the communicator `comm_id` (bytes from comm_id(), carried to every rank by the host) as rank `rank` of
+        `world`: a collective."""
+        buf = ctypes.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        self._check(self._L.acx_comm_init(self._h, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self._L.acx_comm_destroy(self._h))
+
+    def grid_allgather(self, local_ptr, gathered_ptr, floats_per_rank):
+        """acx_grid_allgather on device pointers: rank r's floats_per_rank floats land at gathered + r * floats_per_rank."""
+        self._check(self._L.acx_grid_allgather(self._h, ctypes.c_void_p(int(local_ptr)), ctypes.c_void_p(int(gathered_ptr)),
+                                               int(floats_per_rank)))
+
+    def pair_grid_ranks(self, algo, symmetric, params, planes, mirror, tile=0):
+        """acx_pair_grid_ranks: the whole grid over the ranks of this context's communicator; `planes` (the (N, N) float32
+        matrices) are filled on rank 0 and may be None elsewhere."""
+        spec = GridSpec(int(algo), int(bool(symmetric)), int(tile), 1)
+        ptrs, ld = None, 0
+        if planes is not None:
+            n = planes[0].shape[0]
+            for P in planes:
+                if P.dtype != np.float32 or P.shape != (n, n) or not P.flags["C_CONTIGUOUS"]:
+                    raise ValueError("pair_grid_ranks: planes must be C-contiguous (N, N) float32")
+            ptrs, ld = (ctypes.c_void_p * len(planes))(*[P.ctypes.data for P in planes]), n
+        self._check(self._L.acx_pair_grid_ranks(self._h, ctypes.byref(spec), ctypes.cast(ctypes.byref(params), ctypes.c_void_p),
+                                                ptrs, int(ld), int(bool(mirror))))
 
     # ------------------------------------------------------------------ the N x N pair grid
     def torch_device(self):

@@ -15,10 +15,27 @@ import numpy as np
 __all__ = ["doSimilarityFusion"]
 
 
+_DEFAULT_CTX = {}
+
+
+def _default_context():
+    """The context a bare doSimilarityFusion(Scores, K, niters, reg_diag) call -- the reference's signature,
+    similarity_fusion.py:188 -- runs on: one per process and GPU (LOCAL_RANK's, else device 0), created on first use
+    and kept, so that a caller written against acoss needs no libacx vocabulary.  No GPU / no libacx.so: the
+    constructor raises (there is no host implementation)."""
+    import os
+    from .. import _lib
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    if dev not in _DEFAULT_CTX:
+        _DEFAULT_CTX[dev] = _lib.Context(dev)
+    return _DEFAULT_CTX[dev]
+
+
 def doSimilarityFusion(Scores, K=5, niters=5, reg_diag=1, ctx=None, want_ws=True):
-    """(affinity matrices, fused matrix) from a list of N x N distance matrices.  `ctx`: a libacx
-    context (acoss_amd._lib.Context); want_ws=False skips copying the affinity matrices back (at
-    N = 15 000 they are 1.8 GB each) and returns None in their place."""
+    """(affinity matrices, fused matrix) from a list of N x N distance matrices -- the reference's signature and
+    return value.  Extra keywords: `ctx`, a libacx context to run on (default: the process's default context, see
+    _default_context); want_ws=False skips copying the affinity matrices back (at N = 15 000 they are 1.8 GB each)
+    and returns None in their place."""
     if ctx is None:
-        raise RuntimeError("doSimilarityFusion runs on the GPU: pass ctx=acoss_amd._lib.Context(device)")
+        ctx = _default_context()
     return ctx.snf_fuse_dists([np.asarray(D) for D in Scores], K=K, niters=niters, reg_diag=reg_diag, want_ws=want_ws)

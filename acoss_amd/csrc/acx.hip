@@ -4,6 +4,8 @@
 // and drives the kernels of serra09_kernels.hpp over batches of track pairs.  No torch, no
 // CPU fallback: if the device or a launch fails the call returns an error code.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl is dlopen()ed when a communicator is asked for (acx_comm_init)
 
 #include <algorithm>
 #include <cmath>
@@ -101,6 +103,10 @@ struct acx_ctx {
     int32_t ef_gemm = ACX_EF_GEMM_BF16X3;             // arithmetic of the two Euclidean cross-similarity GEMMs
     int32_t ef_open = 0;                              // > 0: a pool of that many tracks is being filled (acx_ef_pool_begin .. _end)
     std::vector<uint8_t> ef_filled;                   // per track of the open pool: handed over by acx_ef_pool_tracks yet?
+    // multi-GPU inside the library (acx_comm_*): one RCCL communicator rank per context
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    std::vector<void *> dev_bufs;                      // acx_dev_alloc'ed buffers still alive (freed with the context)
     int32_t ef_dims[3] = {0, 0, 0};
     acx::EfPair *d_efpd = nullptr; size_t efpd_cap = 0;
     // rectangles of the rectangle GEMM (ef_gemm_rect_bf16x3_kernel): row / column groups, rectangles, pair tables
@@ -264,11 +270,12 @@ int check_params(acx_ctx *c, const acx_serra09_params &p)
 constexpr int64_t POOL_SLACK = 96;      // frames (rotated pool) / floats (norm table) on either side
 
 // band_kernel is launched from its own translation unit (acx_band.hip)
-bool launch_band(acx_ctx *c, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, const acx_serra09_params &p, int role, int write_d2)
+bool launch_band(acx_ctx *c, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, const acx_serra09_params &p, int role, int write_d2,
+                 int want_eps)
 {
     acx::BandLaunch L{c->stream, c->d_frot + POOL_SLACK * acx::FROT, c->d_toff, c->d_normtab + POOL_SLACK, c->d_noff, c->d_scratch, c->d_thr,
                       c->d_bits, p.kappa, p.pct_mode, p.inclusive, p.oti_target};
-    return acx::launch_band_kernel(L, m, dpd, B, maxRows, maxCols, role, write_d2);
+    return acx::launch_band_kernel(L, m, dpd, B, maxRows, maxCols, role, write_d2, want_eps);
 }
 
 template <int M>
@@ -535,32 +542,42 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             pd.push_back(d);
         }
         const int B = (int)pd.size();
-        // Pairs are processed in size classes: rows of <= 505 / 1017 / 2041 cells -> the band kernel with
-        // 8 / 16 / 32 values per lane (a batch of mixed track lengths does not run its short pairs
-        // through the widest kernel); longer rows -> class 3, the streaming kernels.
-        // `perm[k]` = position in the batch of sorted pair k.
+        // Pairs are processed in size classes PER PASS: a pass whose rows hold <= 505 / 1017 / 2041 cells runs the band
+        // kernel with 8 / 16 / 32 values per lane.  The row pass (and the alignment sweep behind it) has rows of Mr cells,
+        // the column pass rows of Mq cells, so a pair carries two classes (cr, cq) and the batch is sorted by the key
+        // 3 cr + cq: the row pass and the sweep take the three keys of one cr in ONE launch, the column pass one launch per
+        // key -- a short track paired with a long one no longer drags BOTH passes through the wider kernel (round 4;
+        // before, both passes were dispatched on the longer side).  Key 9: a side beyond 2041 cells (or m > 16), the
+        // streaming kernels.  `perm[k]` = position in the batch of sorted pair k.
         std::vector<int> &perm = S.perm;
         perm.resize(B);
-        int cls_begin[5] = {0, 0, 0, 0, B};
+        int key_begin[11];
         {
-            auto cls_of = [&](const PairDesc &d) {
-                const int nd = (std::max(d.Mq, d.Mr) + acx::BAND - 1 + 63) / 64;
-                if (!band_ok || nd > 32) return 3;
-                return nd <= 8 ? 0 : (nd <= 16 ? 1 : 2);
+            auto cls1 = [&](int M) {
+                const int nd = (M + acx::BAND - 1 + 63) / 64;
+                return nd <= 8 ? 0 : (nd <= 16 ? 1 : (nd <= 32 ? 2 : 3));
             };
-            int cnt[4] = {0, 0, 0, 0};
-            for (const PairDesc &d : pd) cnt[cls_of(d)]++;
-            for (int cl = 1; cl < 4; ++cl) cls_begin[cl] = cls_begin[cl - 1] + cnt[cl - 1];
-            int fill[4] = {cls_begin[0], cls_begin[1], cls_begin[2], cls_begin[3]};
+            auto key_of = [&](const PairDesc &d) {
+                const int cr = cls1(d.Mr), cq = cls1(d.Mq);
+                return (!band_ok || cr == 3 || cq == 3) ? 9 : 3 * cr + cq;
+            };
+            int cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (const PairDesc &d : pd) cnt[key_of(d)]++;
+            key_begin[0] = 0;
+            for (int kk = 0; kk < 10; ++kk) key_begin[kk + 1] = key_begin[kk] + cnt[kk];
+            int fill[10];
+            for (int kk = 0; kk < 10; ++kk) fill[kk] = key_begin[kk];
             std::vector<PairDesc> &sorted = S.sorted;
             sorted.resize(B);
             for (int k2 = 0; k2 < B; ++k2) {
-                const int cl = cls_of(pd[k2]);
-                perm[fill[cl]] = k2;
-                sorted[fill[cl]++] = pd[k2];
+                const int kk = key_of(pd[k2]);
+                perm[fill[kk]] = k2;
+                sorted[fill[kk]++] = pd[k2];
             }
             pd.swap(sorted);
         }
+        // row-pass classes (keys 3 cr .. 3 cr + 2) + the long class, as [begin, end) ranges
+        const int cls_begin[5] = {key_begin[0], key_begin[3], key_begin[6], key_begin[9], B};
         if (cls_begin[3] > 0 && (rc = ensure_normtab(c, p)) != ACX_OK) return rc;
         // (the band kernel reads its column thresholds 16 bytes at a time without a bounds check, up to
         // 64 x 32 floats behind a pair's column-threshold row: the arena carries that much slack)
@@ -582,7 +599,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
         {   // K0
             ProfScope ps(c, KS_OTI, cells);
             hipLaunchKernelGGL(acx::oti_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream,
-                               S.d_pd, B, c->d_gch, p.oti, p.oti_target);
+                               S.d_pd, B, c->d_gch, p.oti, p.oti_target, c->d_toff, c->d_noff);
         }
         for (int cl = 0; cl < 4; ++cl) {
             const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
@@ -594,16 +611,23 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                 ccells += (int64_t)pd[k2].Mq * pd[k2].Mr;
             }
             if (cl < 3) {
-                // both roles are dispatched on the class (the longer side of the pair)
-                const int cmax = std::max(cMq, cMr);
-                bool ok;
-                {   // K1' role 1: rows = reference frames -> column thresholds
-                    ProfScope ps(c, KS_BAND, ccells);
-                    ok = launch_band(c, p.m, S.d_pd + b0, Bc, cMr, cmax, p, 1, 0);
+                bool ok = true;
+                // K1' role 1: rows = reference frames (Mq cells each) -> column thresholds; one launch per (cr, cq) key
+                for (int cq = 0; cq < 3; ++cq) {
+                    const int q0 = key_begin[3 * cl + cq], Bq = key_begin[3 * cl + cq + 1] - q0;
+                    if (Bq <= 0) continue;
+                    int qMq = 0, qMr = 0;
+                    int64_t qcells = 0;
+                    for (int k2 = q0; k2 < q0 + Bq; ++k2) {
+                        qMq = std::max(qMq, pd[k2].Mq); qMr = std::max(qMr, pd[k2].Mr);
+                        qcells += (int64_t)pd[k2].Mq * pd[k2].Mr;
+                    }
+                    ProfScope ps(c, KS_BAND, qcells);
+                    ok = ok && launch_band(c, p.m, S.d_pd + q0, Bq, qMr, qMq, p, 1, 0, dbg ? 1 : 0);
                 }
-                {   // K1' role 0: rows = query frames -> row thresholds + recurrence bitmap (needs role 1)
+                {   // K1' role 0: rows = query frames (Mr cells each) -> row thresholds + recurrence bitmap (needs role 1)
                     ProfScope ps(c, KS_BAND, ccells);
-                    ok = ok && launch_band(c, p.m, S.d_pd + b0, Bc, cMq, cmax, p, 0, dbg ? 1 : 0);
+                    ok = ok && launch_band(c, p.m, S.d_pd + b0, Bc, cMq, cMr, p, 0, dbg ? 1 : 0, dbg ? 1 : 0);
                 }
                 if (!ok) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: this build of libacx has no band kernel for the requested m");
             } else {
@@ -1191,11 +1215,16 @@ acx_ctx *acx_create(int device, int *err)
     return c;
 }
 
+static void comm_release(acx_ctx *c);
+
 void acx_destroy(acx_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    comm_release(c);
+    for (void *b : c->dev_bufs) (void)hipFree(b);
+    c->dev_bufs.clear();
     drain_profile(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     free_pool(c);
@@ -2518,6 +2547,208 @@ int acx_pair_grid(acx_ctx *c, const acx_grid_spec *spec, const void *params, flo
     }
     (void)hipFree(d);
     (void)hipHostFree(h);
+    return rc;
+}
+
+// ---- device buffers for hosts that hold no GPU runtime of their own ------------------------------------------
+int acx_dev_alloc(acx_ctx *c, int64_t bytes, void **d_ptr)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (bytes < 0 || !d_ptr) return fail(c, ACX_ERR_INVALID, "dev_alloc: bad argument");
+    ACX_HIP(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    const hipError_t e = hipMalloc(&p, (size_t)std::max<int64_t>(bytes, 4));
+    if (e != hipSuccess) return fail(c, ACX_ERR_NOMEM, std::string("dev_alloc: ") + hipGetErrorString(e));
+    ACX_HIP(c, hipMemsetAsync(p, 0, (size_t)std::max<int64_t>(bytes, 4), c->stream));
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    c->dev_bufs.push_back(p);
+    *d_ptr = p;
+    return ACX_OK;
+}
+
+int acx_dev_free(acx_ctx *c, void *d_ptr)
+{
+    if (!c) return ACX_ERR_INVALID;
+    auto it = std::find(c->dev_bufs.begin(), c->dev_bufs.end(), d_ptr);
+    if (it == c->dev_bufs.end()) return fail(c, ACX_ERR_INVALID, "dev_free: not a buffer of this context");
+    ACX_HIP(c, hipSetDevice(c->device));
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    c->dev_bufs.erase(it);
+    ACX_HIP(c, hipFree(d_ptr));
+    return ACX_OK;
+}
+
+int acx_dev_read(acx_ctx *c, void *host_dst, const void *d_src, int64_t bytes)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!host_dst || !d_src || bytes < 0) return fail(c, ACX_ERR_INVALID, "dev_read: bad argument");
+    ACX_HIP(c, hipSetDevice(c->device));
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    if (bytes > 0) ACX_HIP(c, hipMemcpy(host_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return ACX_OK;
+}
+
+int acx_dev_sync(acx_ctx *c)
+{
+    if (!c) return ACX_ERR_INVALID;
+    ACX_HIP(c, hipSetDevice(c->device));
+    ACX_HIP(c, hipDeviceSynchronize());
+    return ACX_OK;
+}
+
+// ---- RCCL inside the library: a C host gets the multi-GPU pair grid without torch ---------------------------
+// librccl is found at run time (no link dependency: single-GPU users never load it): ACX_RCCL_LIB, a copy the
+// process already holds (PyTorch-ROCm bundles one), the one next to the HIP runtime in use, the system's.
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string path, error;
+};
+RcclApi g_rccl;
+
+bool rccl_load()
+{
+    if (g_rccl.handle) return true;
+    std::vector<std::string> cand;
+    if (const char *e = getenv("ACX_RCCL_LIB")) cand.push_back(e);
+    void *h = nullptr;
+    for (const char *n : {"librccl.so", "librccl.so.1"})                 // a copy this process already holds
+        if (!h && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) g_rccl.path = std::string(n) + " (already loaded)";
+    if (!h) {
+        Dl_info info;
+        if (dladdr((void *)hipGetDeviceCount, &info) && info.dli_fname) {       // next to the HIP runtime in use
+            std::string d(info.dli_fname);
+            const size_t k = d.rfind('/');
+            if (k != std::string::npos) { cand.push_back(d.substr(0, k) + "/librccl.so"); cand.push_back(d.substr(0, k) + "/librccl.so.1"); }
+        }
+        cand.push_back("librccl.so.1");
+        cand.push_back("librccl.so");
+        cand.push_back("/opt/rocm/lib/librccl.so");
+        for (const std::string &p : cand)
+            if ((h = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL))) { g_rccl.path = p; break; }
+    }
+    if (!h) { g_rccl.error = std::string("librccl.so not found (set ACX_RCCL_LIB): ") + (dlerror() ? dlerror() : ""); return false; }
+#define ACX_SYM(F_) g_rccl.F_ = reinterpret_cast<decltype(g_rccl.F_)>(dlsym(h, "nccl" #F_)); \
+    if (!g_rccl.F_) { g_rccl.error = "librccl (" + g_rccl.path + ") lacks nccl" #F_; dlclose(h); return false; }
+    ACX_SYM(GetUniqueId) ACX_SYM(CommInitRank) ACX_SYM(AllGather) ACX_SYM(CommDestroy) ACX_SYM(GetErrorString)
+#undef ACX_SYM
+    g_rccl.handle = h;
+    return true;
+}
+}  // namespace
+
+static void comm_release(acx_ctx *c)
+{
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+    c->comm_world = 0;
+    c->comm_rank = 0;
+}
+
+int acx_comm_id(void *id_out)
+{
+    if (!id_out) return ACX_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) == ACX_COMM_ID_BYTES, "ACX_COMM_ID_BYTES is sizeof(ncclUniqueId)");
+    if (!rccl_load()) { g_create_error = g_rccl.error; return ACX_ERR_UNSUPPORTED; }
+    ncclUniqueId id;
+    const ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return ACX_ERR_HIP; }
+    memcpy(id_out, &id, sizeof(id));
+    return ACX_OK;
+}
+
+int acx_comm_init(acx_ctx *c, const void *id, int32_t rank, int32_t world)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(c, ACX_ERR_INVALID, "comm_init: bad argument");
+    if (c->comm) return fail(c, ACX_ERR_STATE, "comm_init: this context already holds a communicator (acx_comm_destroy first)");
+    if (!rccl_load()) return fail(c, ACX_ERR_UNSUPPORTED, "comm_init: " + g_rccl.error);
+    ACX_HIP(c, hipSetDevice(c->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = g_rccl.CommInitRank(&comm, world, uid, rank);
+    if (r != ncclSuccess) return fail(c, ACX_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return ACX_OK;
+}
+
+int acx_comm_destroy(acx_ctx *c)
+{
+    if (!c) return ACX_ERR_INVALID;
+    ACX_HIP(c, hipSetDevice(c->device));
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    comm_release(c);
+    return ACX_OK;
+}
+
+int acx_grid_allgather(acx_ctx *c, const float *d_local, float *d_gathered, int64_t floats_per_rank)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!c->comm) return fail(c, ACX_ERR_STATE, "grid_allgather: no communicator (acx_comm_init)");
+    if (!d_local || !d_gathered || floats_per_rank < 1) return fail(c, ACX_ERR_INVALID, "grid_allgather: bad argument");
+    ACX_HIP(c, hipSetDevice(c->device));
+    // on the library's own stream: ordered behind the kernels of acx_grid_run, no host fence in between
+    const ncclResult_t r = g_rccl.AllGather(d_local, d_gathered, (size_t)floats_per_rank, ncclFloat32, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(c, ACX_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
+    return ACX_OK;
+}
+
+// The whole N x N grid over the ranks of the communicator: plan (identical on every rank), this rank's tiles
+// into its device buffer, ONE all-gather of the rank buffers over RCCL, rank 0 copies the gathered buffers to
+// the host and scatters them into the caller's planes -- acoss_amd/algorithms/algorithm_template.py
+// `_all_pairwise_grid` for a host without Python (reference: algorithm_template.py:168-192).
+int acx_pair_grid_ranks(acx_ctx *c, const acx_grid_spec *spec_in, const void *params, float *const *D, int64_t ld, int32_t mirror)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!c->comm) return fail(c, ACX_ERR_STATE, "pair_grid_ranks: no communicator (acx_comm_init)");
+    if (!spec_in || !params) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: bad argument");
+    acx_grid_spec spec = *spec_in;
+    spec.world = c->comm_world;
+    if (!acx::grid_spec_ok(&spec)) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: bad grid spec");
+    const int w = acx::grid_planes(spec.algo);
+    if (c->comm_rank == 0) {
+        if (!D) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: rank 0 needs the planes");
+        for (int e = 0; e < w; ++e) if (!D[e]) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: null plane");
+    }
+    std::vector<int64_t> len;
+    int rc = pool_lengths(c, spec.algo, len);
+    if (rc != ACX_OK) return rc;
+    if (c->comm_rank == 0 && ld < (int64_t)len.size()) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: leading dimension smaller than the number of tracks");
+    std::vector<acx_grid_tile> tiles;
+    std::vector<int64_t> fl;
+    std::vector<double> co;
+    acx::grid_plan(len.data(), (int)len.size(), spec, tiles, fl, co);
+    int64_t stride = 1;
+    for (int r = 0; r < spec.world; ++r) stride = std::max(stride, fl[r]);
+    ACX_HIP(c, hipSetDevice(c->device));
+    float *d_local = nullptr, *d_all = nullptr;
+    ACX_HIP(c, hipMalloc((void **)&d_local, sizeof(float) * (size_t)stride));
+    if (hipMalloc((void **)&d_all, sizeof(float) * (size_t)stride * spec.world) != hipSuccess) {
+        (void)hipFree(d_local);
+        return fail(c, ACX_ERR_NOMEM, "pair_grid_ranks: the gathered score buffers do not fit the device");
+    }
+    (void)hipMemsetAsync(d_local, 0, sizeof(float) * (size_t)stride, c->stream);
+    rc = acx_grid_run(c, &spec, params, c->comm_rank, 0, -1, d_local);
+    // (every rank reaches the collective even if its own tiles failed: the others must not be left waiting)
+    const int rg = acx_grid_allgather(c, d_local, d_all, stride);
+    if (rc == ACX_OK) rc = rg;
+    if (rc == ACX_OK && c->comm_rank == 0) {
+        std::vector<float> h((size_t)stride * spec.world);
+        const hipError_t e = hipMemcpy(h.data(), d_all, sizeof(float) * h.size(), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, ACX_ERR_HIP, std::string("pair_grid_ranks: ") + hipGetErrorString(e));
+        else acx::grid_scatter(tiles, spec, h.data(), stride, 0, -1, D, ld, mirror);
+    }
+    (void)hipFree(d_local);
+    (void)hipFree(d_all);
     return rc;
 }
 

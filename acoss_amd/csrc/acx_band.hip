@@ -10,13 +10,13 @@ namespace acx {
 namespace {
 
 template <int M>
-void launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2)
+void launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2, int want_eps)
 {
     const dim3 grid((maxRows + BAND - 1) / BAND, B, 1);
     const int ndata = (maxCols + BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
 #define ACX_BAND_K(V4_, R_, W_) hipLaunchKernelGGL((band_kernel<M, V4_, R_, W_>), grid, dim3(BAND_THREADS), 0, L.stream, \
                                                   L.frot, L.toff, L.normtab, L.noff, dpd, L.scratch, L.thr, L.bits, L.kappa, \
-                                                  L.pct_mode, L.inclusive, L.oti_target)
+                                                  L.pct_mode, L.inclusive, L.oti_target, want_eps)
     // (the variant that also writes D2 exists for the row pass only: the debug entry point)
 #define ACX_BAND(V4_) do { if (role) ACX_BAND_K(V4_, 1, false); else if (write_d2) ACX_BAND_K(V4_, 0, true); else ACX_BAND_K(V4_, 0, false); } while (0)
     if (ndata <= 8) ACX_BAND(2);
@@ -28,10 +28,10 @@ void launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows,
 
 }  // namespace
 
-bool launch_band_kernel(const BandLaunch &L, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2)
+bool launch_band_kernel(const BandLaunch &L, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2, int want_eps)
 {
     switch (m) {
-#define ACX_CASE(M_) case M_: launch_band_m<M_>(L, dpd, B, maxRows, maxCols, role, write_d2); return true;
+#define ACX_CASE(M_) case M_: launch_band_m<M_>(L, dpd, B, maxRows, maxCols, role, write_d2, want_eps); return true;
 #ifdef ACX_FAST_BUILD   /* development builds: only the default stack size */
 #ifndef ACX_FAST_BUILD_M
 #define ACX_FAST_BUILD_M 9

@@ -67,6 +67,9 @@ struct PairDesc {
     int64_t offL;          // long tracks: float offset of D2^T (Mr rows x pitchT) in the scratch arena,
                            // followed by the DP's strip-boundary records (2 x 4 floats per row)
     PctPos pos_q, pos_r;   // percentile position in a row of Mq cells (column pass) / of Mr cells (row pass)
+    int64_t fq, fr;        // filled by K0: first frame of the query / reference track in the active pool (toff[q], toff[r])
+    int64_t nq, nr;        //               and their rows of the embedded-norm table (noff[q], noff[r]; 0 without a table):
+                           //               the band kernel starts its operand loads one dependent memory round trip earlier
 };
 
 __device__ __forceinline__ float wave_shfl(float v, int src)
@@ -117,10 +120,13 @@ __device__ __forceinline__ float tree_sum(const float *s)
 // ------------------------------------------------------------------------------------
 // K0: OTI.  argmax_s <ga, roll(gb, s)>, s = 0..12, first max wins; separate mul / add.
 // ------------------------------------------------------------------------------------
-static __global__ void oti_kernel(PairDesc *pd, int B, const float *__restrict__ gch, int oti_on, int oti_target)
+static __global__ void oti_kernel(PairDesc *pd, int B, const float *__restrict__ gch, int oti_on, int oti_target,
+                                  const int64_t *__restrict__ toff, const int64_t *__restrict__ noff)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
+    pd[p].fq = toff[pd[p].q]; pd[p].fr = toff[pd[p].r];
+    pd[p].nq = noff ? noff[pd[p].q] : 0; pd[p].nr = noff ? noff[pd[p].r] : 0;
     int best = 0;
     if (oti_on) {
         const float *ga = gch + (size_t)NBIN * (oti_target == 0 ? pd[p].q : pd[p].r);
@@ -790,12 +796,12 @@ __device__ __forceinline__ bool wave_select_pivot(const float (&x)[NV], int k, b
 
 // eps from the two order statistics d2_(ilo) <= d2_(ihi) (oracle percentile_f32)
 __device__ __forceinline__ float percentile_eps2(float slo, float shi, int pct_mode, int ilo, int ihi,
-                                                 float kf, float fl, float ce)
+                                                 float kf, float fl, float ce, float &dlo, float &dhi)
 {
     // (slo and shi are wave-uniform: odd lanes root shi, even lanes slo -- one sqrt expansion instead of two)
     const float dboth = __builtin_sqrtf((__lane_id() & 1u) ? shi : slo);
-    const float dlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dboth), 0));
-    const float dhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dboth), 1));
+    dlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dboth), 0));
+    dhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dboth), 1));
     if (!(pct_mode == 0 || pct_mode == 1)) return dlo;
     if (pct_mode == 0 && ihi == ilo) return dlo;
     const float d0 = __fmul_rn(dlo, __fsub_rn(ce, kf));
@@ -919,8 +925,9 @@ struct BandLaunch {
     int pct_mode, inclusive, oti_target;
 };
 // role 1 / 0 over B pairs of one size class; false when the stack size m has no instantiation
+// (want_eps: also evaluate and store every row's eps -- the debug entry point; the production passes skip it where they can)
 bool launch_band_kernel(const BandLaunch &L, int m, const struct PairDesc *dpd, int B, int maxRows, int maxCols, int role,
-                        int write_d2);
+                        int write_d2, int want_eps);
 
 #ifdef ACX_TIMING   /* development builds only (scripts/ab_build.sh timing -DACX_TIMING; experiments/phase_timing.py) */
 __device__ unsigned long long g_band_clk[32];      // [0, 16): band_kernel (slot 15 = waves); [16, 32): spare
@@ -931,13 +938,25 @@ struct StampT { unsigned long long t; int base; };
 #define ACX_STAMP(slot) do { } while (0)
 #endif
 
-template <int M>
+#ifndef ACX_NARROW_WAVES
+#define ACX_NARROW_WAVES 8      /* waves per SIMD of the narrowest class (m <= 9): 8 = four workgroups per CU, 6 = three */
+#endif
+template <int M, int V4 = 8>
 struct BandGeom {
     static constexpr int NRT = (BAND + M - 1 + 15) / 16;            // 16-row MFMA tiles of row frames
     static constexpr int NCT = (64 + BAND - 1 + M - 1 + 15) / 16;   // 16-col MFMA tiles of column frames
     static constexpr int AROWS = 16 * NRT;
     static constexpr int BW = 16 * NCT;
-    static constexpr int SP = BW + 4;                              // S pitch: 16-byte aligned rows; 84 % 32 = 20 keeps the 16-byte tile stores conflict-free
+    // S pitch: 16-byte aligned rows; 84 % 32 = 20 keeps the 16-byte tile stores conflict-free.  The narrowest class
+    // (rows of <= 505 cells, m <= 9) drops the pad: 8 slabs of 16 x 80 floats are exactly 40 KB, a quarter of the
+    // CU's LDS, so that FOUR workgroups share a CU instead of three (the tile stores then collide four ways -- 5
+    // stores per tile -- which the extra workgroup in flight more than pays for: that class waits on latencies,
+    // not on the LDS pipe, which is 26 % busy; profiles/r04_narrow_classes.md)
+#ifndef ACX_MID_WAVES
+#define ACX_MID_WAVES 6         /* waves per SIMD of the middle class (rows of <= 1017 cells, m <= 9) */
+#endif
+    static constexpr bool PACKED = M <= 9 && ((V4 <= 2 && ACX_NARROW_WAVES >= 8) || (V4 == 4 && ACX_MID_WAVES >= 8));
+    static constexpr int SP = PACKED ? BW : BW + 4;
 };
 
 // eps from the selected order statistics (oracle percentile_f32)
@@ -987,6 +1006,77 @@ struct RowGeom {
     }
 };
 
+// The bitmap step of band_row_tail (row pass only): the row in registers against min(row threshold, column thresholds).
+template <int NV, int ROLE, bool TC_VIA_LDS, typename TCG>
+__device__ __forceinline__ void band_row_bits(const float (&xr)[NV], const TCG (&tcg)[NV / 4], float thr_row, float *myrow, int lane,
+                                              int row, int MB, int cshift, const PairDesc &P, float *__restrict__ thr,
+                                              unsigned long long *__restrict__ bits)
+{
+    using RG = RowGeom<NV>;
+    constexpr int CH = NV / 4;
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    float *X = thr + P.offX;
+    // ---- rows = query frames (the column thresholds of the pair are already there): binarise the row the
+    // wave still holds in registers and emit it as a bitmap.  256 bytes per row instead of 8 KB of f32.
+    // A lane owns NV consecutive slots, i.e. NV consecutive bits: R = [d2 <= min(thr_row, thr_col)] is
+    // shifted into the lane's own word bit by bit (compare -> carry -> add-with-carry), no cross-lane traffic.
+    if (ROLE == 0 && bits) {
+        // column thresholds (d2 domain) of the lane's NV slots.  In the wide class, read straight from memory, they
+        // are 128 contiguous bytes per lane -- every load instruction would touch 64 different lines, and those eight
+        // loads measured 4.5 of the band kernels' 47.8 ms.  So the wave reads the row's thresholds
+        // lane-interleaved (granule 64 q + lane: 1 KB of contiguous memory per instruction, issued right after
+        // the selection, see above) and turns them round through its own exchange row, which the selection no
+        // longer needs: 16-byte stores at the granule's padded place, 16-byte loads of the lane's own slots.
+        // (no bounds check: columns -7 .. 64 ntiles + 63 of the threshold arena are inside the pair's arena)
+        float tcv[NV];
+        if constexpr (TC_VIA_LDS) {
+            float *tr = myrow + 4 * lane + 4 * ((4 * lane) / NV);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) *reinterpret_cast<float4 *>(tr + q * (256 + 4 * (256 / NV))) = make_float4(tcg[q].x, tcg[q].y, tcg[q].z, tcg[q].w);
+            wave_lds_fence();
+            const float *mine = myrow + lane * RG::LNP;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float4 v = *reinterpret_cast<const float4 *>(mine + 4 * j);
+                tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
+            }
+        } else {
+            const float *tc = X + P.pitchT + (lane * NV - cshift);      // (the compiler hoists these loads above the selection)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const f32x4_u v = *reinterpret_cast<const f32x4_u *>(tc + 4 * j);
+                tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
+            }
+        }
+        // slots of this lane whose column exists: t in [lo, hi)
+        int lo = cshift - lane * NV, hi = MB + cshift - lane * NV;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > NV ? NV : hi;
+        unsigned valid = 0u;
+        if (hi > lo) valid = (hi - lo >= 32 ? ~0u : ((1u << (hi - lo)) - 1u)) << lo;
+        unsigned acc = 0u;
+#pragma unroll
+        for (int t = NV - 1; t >= 0; --t) {
+            float mthr;
+            asm("v_min_f32 %0, %1, %2" : "=v"(mthr) : "v"(tcv[t]), "v"(thr_row));
+            asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(xr[t]), "v"(mthr) : "vcc");
+        }
+        acc &= valid;
+        // NV < 32: neighbouring lanes complete a dword
+        if constexpr (NV == 16) {
+            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 16;
+        } else if constexpr (NV == 8) {
+            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 8;
+            acc |= (unsigned)__shfl_down((int)acc, 2, 64) << 16;
+        }
+        constexpr int LPD = 32 / NV;                                    // lanes per dword
+        unsigned *rowbits = reinterpret_cast<unsigned *>(bits + P.offT + (size_t)row * P.nw);
+        const int ndw = 2 * P.nw, d = lane / LPD;
+        if ((lane & (LPD - 1)) == 0 && d < ndw) rowbits[d] = acc;
+        for (int z = 2 * NV + lane; z < ndw; z += 64) rowbits[z] = 0u;  // words beyond this size class
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // The part of the band pipeline that follows the exchange: wave `wave` holds one complete row of the
 // pair's matrix in registers (xr[t] = slot NV lane + t; slot s <-> column s - cshift; slots without a
@@ -1007,7 +1097,7 @@ template <int NV, int ROLE>
 __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int wave, int lane, int row, int MA, int MB,
                                               int cshift, const PairDesc &P, float *__restrict__ thr,
                                               unsigned long long *__restrict__ bits, const PctPos &pp, int pct_mode,
-                                              int inclusive ACX_STAMP_PARM)
+                                              int inclusive, int want_eps ACX_STAMP_PARM)
 {
     using RG = RowGeom<NV>;
     constexpr int ROWP = RG::ROWP, FBINS = RG::FBINS, FCOPIES = RG::FCOPIES, PBINS = RG::PBINS, PGRP = RG::PGRP, GBINS = RG::GBINS;
@@ -1069,8 +1159,32 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
             for (int q = 0; q < CH; ++q) tcg[q] = *reinterpret_cast<const f32x4_u *>(tc + 256 * q);
         }
     }
-    const float eps = percentile_eps2(slo, shi, pct_mode, ilo, ihi, kf, fl, ce);
-    const float thr_row = d2_threshold(eps, inclusive);
+    // Most rows do not even need the roots.  With interpolation weights w0 = ce - kf and w1 = kf - fl of at least 2^-8 each
+    // (host-known, the same for every row of the pass) and a relative gap shi - slo > 2^-12 shi between the two order
+    // statistics, eps = fl(fl(dlo w0) + fl(dhi w1)) lies in [dlo, dhi) whatever the three roundings do: (dhi - dlo) / dhi >
+    // 2^-13 - 2^-23 > 2^-14, so w0 (dhi - dlo) and w1 (dhi - dlo) exceed 2^-22 dhi, four times what the roundings of the two
+    // products, the sum and the two correctly rounded roots can move (each <= 2^-24 relative).  Then thr = slo (see below) and
+    // neither sqrtf expansion nor eps is evaluated -- unless the caller wants eps itself (the debug entry point).
+    const bool weights_ok = interp && ihi == ilo + 1 && inclusive && fl >= 1.0f && (ce - kf) >= 0.00390625f && (kf - fl) >= 0.00390625f;
+    if (!want_eps && weights_ok && shi < INF && (shi - slo) > shi * 0.000244140625f) {
+        ACX_STAMP(6);
+        if (lane == 0) (thr + P.offX)[role ? P.pitchT + row : row] = slo;
+        band_row_bits<NV, ROLE, TC_VIA_LDS>(xr, tcg, slo, myrow, lane, row, MB, cshift, P, thr, bits);
+        ACX_STAMP(7);
+        return;
+    }
+    float dlo, dhi;
+    const float eps = percentile_eps2(slo, shi, pct_mode, ilo, ihi, kf, fl, ce, dlo, dhi);
+    // The threshold in the d2 domain only has to separate THIS row's cells the way `sqrtf(d2) <= eps` does.  slo and shi are
+    // CONSECUTIVE order statistics of the row (ranks ilo and ilo + 1), so with dlo <= eps < dhi (dlo = sqrtf(slo), dhi =
+    // sqrtf(shi): what the interpolation gives unless it collapses onto dhi) a cell qualifies iff d2 <= slo: cells <= slo have
+    // sqrtf(d2) <= dlo <= eps, every other cell is >= shi and has sqrtf(d2) >= dhi > eps.  thr = slo then -- no f64 midpoint
+    // arithmetic (d2_threshold: ~35 VALU operations, some at the f64 rate, per row and pass).  Anything else -- the
+    // interpolation collapsed (eps == dhi: ties, an exact-integer position, adjacent roots), eps outside [dlo, dhi) (pct_mode 1
+    // at an exact-integer position), the exclusive comparison -- takes the closed form; the branch is wave-uniform.
+    float thr_row;
+    if (inclusive && dlo <= eps && eps < dhi) thr_row = slo;
+    else thr_row = d2_threshold(eps, inclusive);
     ACX_STAMP(6);        // eps + threshold
     float *X = thr + P.offX;
     if (lane == 0) {
@@ -1078,70 +1192,12 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
         X[o] = thr_row;
         X[P.pitchT + P.pitchD + o] = eps;
     }
-    // ---- rows = query frames (the column thresholds of the pair are already there): binarise the row the
-    // wave still holds in registers and emit it as a bitmap.  256 bytes per row instead of 8 KB of f32.
-    // A lane owns NV consecutive slots, i.e. NV consecutive bits: R = [d2 <= min(thr_row, thr_col)] is
-    // shifted into the lane's own word bit by bit (compare -> carry -> add-with-carry), no cross-lane traffic.
-    if (role == 0 && bits) {
-        // column thresholds (d2 domain) of the lane's NV slots.  In the wide class, read straight from memory, they
-        // are 128 contiguous bytes per lane -- every load instruction would touch 64 different lines, and those eight
-        // loads measured 4.5 of the band kernels' 47.8 ms.  So the wave reads the row's thresholds
-        // lane-interleaved (granule 64 q + lane: 1 KB of contiguous memory per instruction, issued right after
-        // the selection, see above) and turns them round through its own exchange row, which the selection no
-        // longer needs: 16-byte stores at the granule's padded place, 16-byte loads of the lane's own slots.
-        // (no bounds check: columns -7 .. 64 ntiles + 63 of the threshold arena are inside the pair's arena)
-        float tcv[NV];
-        if constexpr (TC_VIA_LDS) {
-            float *tr = myrow + 4 * lane + 4 * ((4 * lane) / NV);
-#pragma unroll
-            for (int q = 0; q < CH; ++q) *reinterpret_cast<float4 *>(tr + q * (256 + 4 * (256 / NV))) = make_float4(tcg[q].x, tcg[q].y, tcg[q].z, tcg[q].w);
-            wave_lds_fence();
-            const float *mine = myrow + lane * RG::LNP;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const float4 v = *reinterpret_cast<const float4 *>(mine + 4 * j);
-                tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
-            }
-        } else {
-            const float *tc = X + P.pitchT + (lane * NV - cshift);      // (the compiler hoists these loads above the selection)
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const f32x4_u v = *reinterpret_cast<const f32x4_u *>(tc + 4 * j);
-                tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
-            }
-        }
-        // slots of this lane whose column exists: t in [lo, hi)
-        int lo = cshift - lane * NV, hi = MB + cshift - lane * NV;
-        lo = lo < 0 ? 0 : lo;
-        hi = hi > NV ? NV : hi;
-        unsigned valid = 0u;
-        if (hi > lo) valid = (hi - lo >= 32 ? ~0u : ((1u << (hi - lo)) - 1u)) << lo;
-        unsigned acc = 0u;
-#pragma unroll
-        for (int t = NV - 1; t >= 0; --t) {
-            float mthr;
-            asm("v_min_f32 %0, %1, %2" : "=v"(mthr) : "v"(tcv[t]), "v"(thr_row));
-            asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(xr[t]), "v"(mthr) : "vcc");
-        }
-        acc &= valid;
-        // NV < 32: neighbouring lanes complete a dword
-        if constexpr (NV == 16) {
-            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 16;
-        } else if constexpr (NV == 8) {
-            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 8;
-            acc |= (unsigned)__shfl_down((int)acc, 2, 64) << 16;
-        }
-        constexpr int LPD = 32 / NV;                                    // lanes per dword
-        unsigned *rowbits = reinterpret_cast<unsigned *>(bits + P.offT + (size_t)row * P.nw);
-        const int ndw = 2 * P.nw, d = lane / LPD;
-        if ((lane & (LPD - 1)) == 0 && d < ndw) rowbits[d] = acc;
-        for (int z = 2 * NV + lane; z < ndw; z += 64) rowbits[z] = 0u;  // words beyond this size class
-    }
+    band_row_bits<NV, ROLE, TC_VIA_LDS>(xr, tcg, thr_row, myrow, lane, row, MB, cshift, P, thr, bits);
     ACX_STAMP(7);        // threshold store + bitmap
 }
 
 // (short-row variants: 6 waves / SIMD = 3 workgroups per CU; m >= 10 needs two MFMA row tiles and is LDS-limited anyway)
-constexpr int band_waves_per_simd(int m, int v4) { return (v4 <= 4 && m <= 9) ? 6 : 4; }
+constexpr int band_waves_per_simd(int m, int v4) { return (v4 <= 2 && m <= 9) ? ACX_NARROW_WAVES : ((v4 <= 4 && m <= 9) ? ACX_MID_WAVES : 4); }
 // WD2: the debug entry point's variant, which also writes the band's distances to HBM (D2, query-major) -- a
 // template parameter, not a flag: as a run-time flag hipcc folds it into the per-cell store predicates and every
 // tile of the production kernel pays 24 VALU + 40 SALU instructions for stores that never happen.
@@ -1154,10 +1210,10 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
                                                             float *__restrict__ scratch,
                                                             float *__restrict__ thr,
                                                             unsigned long long *__restrict__ bits,
-                                                            float kappa, int pct_mode, int inclusive, int oti_target)
+                                                            float kappa, int pct_mode, int inclusive, int oti_target, int want_eps)
 {
     constexpr bool write_d2 = WD2;
-    using G = BandGeom<M>;
+    using G = BandGeom<M, V4>;
     constexpr int role = ROLE;           // 1: rows = reference frames (column thresholds); 0: rows = query frames
     constexpr int NV = 4 * V4;           // values per lane of a complete row
     constexpr int NSTEP = NV / 8;        // tiles per wave
@@ -1180,8 +1236,8 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     const int rota = (rows_are_ref == (oti_target == 0)) ? P.oti : 0;
     const int rotb = (rows_are_ref == (oti_target == 0)) ? 0 : P.oti;
     // embedded norms of the row / column track in this pair's rotation (normtab_kernel)
-    const float *nrow = normtab + noff[role ? P.r : P.q] + (int64_t)rota * (MA + NGUARD);
-    const float *ncol = normtab + noff[role ? P.q : P.r] + (int64_t)rotb * (MB + NGUARD);
+    const float *nrow = normtab + (role ? P.nr : P.nq) + (int64_t)rota * (MA + NGUARD);
+    const float *ncol = normtab + (role ? P.nq : P.nr) + (int64_t)rotb * (MB + NGUARD);
     const float INF = __builtin_inff();
     // Cells outside the matrix are +inf, and they get there by themselves: the norm of a nonexistent column
     // (the table's guard entries) or row (below) is +inf, so d2 = (xx - 2 xy) + yy is.  The bit pattern of
@@ -1200,14 +1256,14 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     int c0b = lk - rotb; if (c0b < 0) c0b += NBIN;
     const int offA = (c0a >> 2) * NBIN + (c0a & 3) * 3;
     const int offB = (c0b >> 2) * NBIN + (c0b & 3) * 3;
-    const float *fra = frot + toff[role ? P.r : P.q] * FROT + offA;
+    const float *fra = frot + (role ? P.fr : P.fq) * FROT + offA;
     // column-frame operands go through a buffer descriptor: scalar base + scalar offset (the tile) + one 32-bit
     // lane offset -- no 64-bit VALU address arithmetic in the tile loop.  The descriptor starts 8 frames before
     // the track (a tile reaches back 7 frames: pool slack / the neighbouring track), no range check.
     const __amdgpu_buffer_rsrc_t rsB =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(frot + (toff[role ? P.q : P.r] - 8) * FROT), 0, -1, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)(frot + ((role ? P.fq : P.fr) - 8) * FROT), 0, -1, 0x00020000);
     const unsigned voffB = (unsigned)(offB + lr * FROT) * 4u;     // this lane's byte offset inside a 16-frame block
-    const float *frb = frot + toff[role ? P.q : P.r] * FROT + offB;   // (short-row classes: per-lane pointer, plain global loads)
+    const float *frb = frot + (role ? P.fq : P.fr) * FROT + offB;   // (short-row classes: per-lane pointer, plain global loads)
     typedef float f32x3 __attribute__((ext_vector_type(3)));
     typedef f32x3 f32x3_u __attribute__((aligned(4)));
     float areg[G::NRT][3];
@@ -1434,7 +1490,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row has left LDS
     ACX_STAMP(4);        // row read
     band_row_tail<NV, ROLE>(xr, smem, wave, lane, i0 + wave, MA, MB, (BAND - 1) - wave, P, thr, role == 0 ? bits : nullptr,
-                            pp, pct_mode, inclusive ACX_STAMP_ARG);
+                            pp, pct_mode, inclusive, want_eps ACX_STAMP_ARG);
 }
 
 // One DP row for the CPL columns of a lane (descending column order, in place): QA = row i-1,

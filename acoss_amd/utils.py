@@ -5,8 +5,6 @@ path: create_dataset_filepaths (utils.py:87-102) and log (utils.py:24-35).
 import logging
 import os
 
-import pandas as pd
-
 __all__ = ["create_dataset_filepaths", "log"]
 
 
@@ -30,6 +28,7 @@ def create_dataset_filepaths(dataset_csv, root_audio_dir, file_format=".mp3"):
     """CSV with exactly the columns work_id, track_id -> root + work_id/track_id + ext.
     Like the reference, `root_audio_dir` is string-concatenated (it must end with '/'),
     and any other column raises IOError."""
+    import pandas as pd                       # (here, not at module level: importing the package must stay light)
     table = pd.read_csv(dataset_csv)
     for col in table.columns.tolist():
         if col not in ("work_id", "track_id"):

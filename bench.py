@@ -367,8 +367,10 @@ def run_strong(args, clock, out, rank, world, local_rank):
         frames, offsets = make_pool(args.tracks, args.frames)
     backend = os.environ.get("ACX_BENCH_BACKEND", "nccl")
     collective = world > 1 or os.environ.get("ACX_BENCH_FORCE_COLLECTIVE") == "1"
-    torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
-    dev = torch.device("cuda", local_rank)
+    torch = dist = None
+    if collective:
+        torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
+        dev = torch.device("cuda", local_rank)
     with clock.phase("context_and_upload"):
         ctx = _lib.Context(local_rank)
         ctx.upload_pool(frames, offsets)
@@ -377,19 +379,25 @@ def run_strong(args, clock, out, rank, world, local_rank):
     plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=world, tile=args.tile, want_tiles=True)
     spec = plan["spec"]
     stride = int(max(1, plan["floats_per_rank"].max()))
-    local = torch.zeros(stride, dtype=torch.float32, device=dev)
-    gathered = torch.empty(world * stride, dtype=torch.float32, device=dev) if collective else None
+    if collective:
+        local = torch.zeros(stride, dtype=torch.float32, device=dev)
+        gathered = torch.empty(world * stride, dtype=torch.float32, device=dev)
+    else:                                                        # one rank, no collective: no torch in the process
+        local = ctx.dev_alloc(4 * stride)
+        gathered = None
     n_mine = sum(1 for t in plan["tiles"] if t.rank == rank)
 
     def fence():
         if collective:
             dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+        else:
+            ctx.dev_sync()
 
     with clock.phase("warmup"):
         for _ in range(max(1, args.warmup)):                     # arena, code objects, clocks: the rank's first tile(s)
             ctx.grid_run(spec, params, rank, local.data_ptr(), first=0, count=min(2, n_mine))
-        local.zero_()
+        # (acx_grid_run zeroes the slice it fills: the warm-up's scores are overwritten by the timed pass)
     ctx.profile_enable(True)
     ctx.profile_reset()
     fence()
@@ -419,7 +427,7 @@ def run_strong(args, clock, out, rank, world, local_rank):
     if rank == 0:
         ts0 = time.perf_counter()
         if host_gather is None:
-            host_gather = (gathered if collective else local).cpu().numpy()
+            host_gather = gathered.cpu().numpy() if collective else local.read(np.float32, stride)
         t_d2h = time.perf_counter() - ts0
         tmp = tempfile.mkdtemp(prefix="acx_strong_")
         D = np.lib.format.open_memmap(os.path.join(tmp, "D.npy"), mode="w+", dtype=np.float32, shape=(args.tracks, args.tracks))
@@ -549,10 +557,10 @@ def main():
         return np.concatenate(out).astype(np.int32)
 
     if args.plan_only:
-        import torch
-        import torch.distributed as dist
         seen = 1
         if world > 1:
+            import torch
+            import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(os.environ.get("ACX_BENCH_BACKEND", "gloo"))
             t = torch.tensor([len(mine)], dtype=torch.int64)
@@ -591,17 +599,29 @@ def main():
     # ACX_BENCH_FORCE_COLLECTIVE=1: a world of ONE still forms its process group and runs every collective of the
     # N > 1 step (RCCL all_gather_into_tensor, device barrier, all-reduce) -- the multi-GPU code path on a 1-GPU box
     collective = world > 1 or os.environ.get("ACX_BENCH_FORCE_COLLECTIVE") == "1"
-    torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
-    dev = torch.device("cuda", local_rank)
+    # One GPU, no collective: this process never imports torch.  The score buffer comes from libacx (acx_dev_alloc =
+    # hipMalloc) and the fences around the timed region are hipDeviceSynchronize (acx_dev_sync) -- what
+    # torch.cuda.synchronize() is.  `import torch` pages in gigabytes of shared libraries; on a box with a cold or slow
+    # image store that alone has been seen to take minutes with the GPU idle (round 3's driver run: 1662 s for a 1.7 s
+    # timed region).  N > 1 needs torch.distributed and imports it.
+    torch = dist = None
+    if collective:
+        torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
+        dev = torch.device("cuda", local_rank)
 
     with clock.phase("context_and_upload"):
         ctx = _lib.Context(local_rank)
         ctx.upload_pool(frames, offsets)                 # pool resident in HBM before timing
     params = _lib.serra09_params()
     slice_floats = max(sum(t.rows * t.cols for t in mine[k:k + TILES_PER_STEP]) for k in range(0, nslices * TILES_PER_STEP, TILES_PER_STEP))
-    local = torch.zeros(slice_floats, dtype=torch.float32, device=dev)
-    gathered = torch.zeros(world * slice_floats, dtype=torch.float32, device=dev) if collective else None
-    torch.cuda.synchronize()
+    if collective:
+        local = torch.zeros(slice_floats, dtype=torch.float32, device=dev)
+        gathered = torch.zeros(world * slice_floats, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+    else:
+        local = ctx.dev_alloc(4 * slice_floats)
+        gathered = None
+        ctx.dev_sync()
     pairs_per_step = []
 
     def step(s):
@@ -624,7 +644,9 @@ def main():
                 dist.barrier(device_ids=[local_rank])
             else:
                 dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+        else:
+            ctx.dev_sync()                          # hipDeviceSynchronize
 
     with clock.phase("warmup"):
         for s in range(args.warmup):
@@ -727,6 +749,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
+            "fence": ("dist.barrier + torch.cuda.synchronize on both sides of the timed region" if collective else
+                      "hipDeviceSynchronize (libacx acx_dev_sync) on both sides of the timed region; one rank, no torch in the process"),
             "config": {"workload": "configs[2]: synthetic %d tracks x %d-frame HPCP (seed 1234), Serra09 Qmax "
                                    "(m=9, tau=1, kappa=0.095, OTI); the %d x %d pair grid in %d x %d tiles dealt to %d rank(s) "
                                    "by cost (acx_grid_plan); %d tiles = %d pairs per GPU per step, different tiles every "

@@ -135,7 +135,6 @@ def simple_leg(ctx, steps=5, warmup=1, n=1536, tiles_per_step=16, cpu_pairs=64):
     (acx_grid_run: pairs enumerated on the device, f64 kernel, f32 scatter into a device buffer).  The pool holds
     `n` tracks; every step runs the next `tiles_per_step` 128 x 128 tiles of the grid (16 tiles = 262 144 ordered
     pairs, other tracks every step)."""
-    import torch
     import oracle                      # the checker / timed CPU baseline only
     from acoss_amd import _lib
     from acoss_amd.algorithms.simple_silva import Simple
@@ -148,8 +147,7 @@ def simple_leg(ctx, steps=5, warmup=1, n=1536, tiles_per_step=16, cpu_pairs=64):
     plan = _lib.grid_plan(na, _lib.ALGO_SIMPLE, False, world=1, tile=128, want_tiles=True)
     tiles = list(plan["tiles"])
     assert len(tiles) >= (steps + warmup) * tiles_per_step
-    buf = torch.zeros(int(plan["floats_per_rank"][0]), dtype=torch.float32, device=torch.device("cuda", ctx.device))
-    torch.cuda.synchronize()
+    buf = ctx.dev_alloc(4 * int(plan["floats_per_rank"][0]))          # (no torch in this process: libacx's own device buffer)
     sp = _lib.SimpleParams(10, 1)
     for s in range(warmup):
         ctx.grid_run(plan["spec"], sp, 0, buf.data_ptr(), first=s * tiles_per_step, count=tiles_per_step)
@@ -160,7 +158,8 @@ def simple_leg(ctx, steps=5, warmup=1, n=1536, tiles_per_step=16, cpu_pairs=64):
         ctx.grid_run(plan["spec"], sp, 0, buf.data_ptr(), first=s * tiles_per_step, count=tiles_per_step)   # returns after the stream has drained
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.profile()
-    host = buf.cpu().numpy()
+    host = buf.read(np.float32)
+    buf.free()
     timed = tiles[warmup * tiles_per_step:(warmup + steps) * tiles_per_step]
     w = na - 9.0
     npairs, cells = 0, 0.0
@@ -218,7 +217,6 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
     """EarlyFusion per-pair chain (earlyfusion_traile.py:157-198) at 300-500 blocks per track through the pair grid into a
     device buffer: a pool of `n` tracks in 128 x 128 tiles (n = 384: three diagonal tiles of 8128 pairs, three
     off-diagonal ones of 16 384), ONE tile per step, another tile every step."""
-    import torch
     import oracle
     from acoss_amd import _lib, synth
     tracks = synth.earlyfusion_set(n, seed=1, nb_range=(300, 500))
@@ -227,8 +225,7 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
     plan = _lib.grid_plan(nb, _lib.ALGO_EARLYFUSION, True, world=1, tile=128, want_tiles=True)
     tiles = list(plan["tiles"])
     assert len(tiles) >= steps + warmup, len(tiles)
-    buf = torch.zeros(int(plan["floats_per_rank"][0]), dtype=torch.float32, device=torch.device("cuda", ctx.device))
-    torch.cuda.synchronize()
+    buf = ctx.dev_alloc(4 * int(plan["floats_per_rank"][0]))
     ep = _lib.EfParams(0.1, 10)
     for s in range(warmup):
         ctx.grid_run(plan["spec"], ep, 0, buf.data_ptr(), first=s, count=1)
@@ -239,7 +236,8 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
         ctx.grid_run(plan["spec"], ep, 0, buf.data_ptr(), first=s, count=1)
     dt = time.perf_counter() - t0
     prof = ctx.profile()
-    host = buf.cpu().numpy()
+    host = buf.read(np.float32)
+    buf.free()
     timed = tiles[warmup:warmup + steps]
     allp = [p for t in timed for p in _tile_pairs(t)]
     npairs = len(allp)

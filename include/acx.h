@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define ACX_ABI_VERSION 1
+/* 2 (round 4): + acx_dev_alloc / _free / _read / _sync, acx_comm_id / _init / _destroy, acx_grid_allgather,
+ *              acx_pair_grid_ranks; acx_ef_pool_end fails on tracks never handed over; uploads reject non-finite input
+ *              (since the round-3 library, which still said 1).  The ctypes shim refuses a library of another version. */
+#define ACX_ABI_VERSION 2
 
 enum {
     ACX_OK = 0,
@@ -433,6 +436,45 @@ int acx_grid_scatter(const int64_t *lengths, int32_t n_tracks, const acx_grid_sp
  * (e.g. the float32 memmaps CoverAlgorithm.Ds holds). */
 int acx_pair_grid(acx_ctx *ctx, const acx_grid_spec *spec, const void *params, float *const *D, int64_t ld,
                   int32_t mirror);
+
+/* ---- multi-GPU inside the library: RCCL over xGMI, no Python ------------- */
+
+/*
+ * The reference fans its pair list out over joblib processes (algorithm_template.py:172-177); the Python host of this
+ * library runs one process per GPU under torch.distributed (acoss_amd/dist.py).  A host WITHOUT Python gets the same path
+ * from the library itself: one context (one GPU) per process or thread, one RCCL communicator rank per context.  librccl
+ * is dlopen()ed on first use (env ACX_RCCL_LIB, a copy the process already holds, the one next to the HIP runtime, the
+ * system's): single-GPU users never load it.
+ *   acx_comm_id         rank 0: a fresh communicator id (ACX_COMM_ID_BYTES = sizeof(ncclUniqueId)); the HOST carries
+ *                       it to the other ranks by whatever means it has (MPI, a socket, a file)
+ *   acx_comm_init       every rank: join (collective: returns when all `world` ranks have called it)
+ *   acx_grid_allgather  the one exchange of the path: every rank's score buffer (floats_per_rank floats at d_local,
+ *                       what acx_grid_run filled) into d_gathered (world x floats_per_rank floats, DEVICE memory, rank r
+ *                       at r * floats_per_rank) -- ncclAllGather on the library's stream, behind the kernels, device
+ *                       to device over xGMI; returns when the buffer is complete
+ *   acx_pair_grid_ranks the whole grid: plan, this rank's tiles, the all-gather, rank 0 scatters into its planes
+ *                       (spec->world is ignored: the communicator's size is used; D may be NULL on ranks > 0).
+ *                       A collective: every rank calls it with the same spec and params after uploading the same pool.
+ *   acx_comm_destroy    leave (also done by acx_destroy)
+ */
+#define ACX_COMM_ID_BYTES 128
+int acx_comm_id(void *id_out);
+int acx_comm_init(acx_ctx *ctx, const void *id, int32_t rank, int32_t world);
+int acx_comm_destroy(acx_ctx *ctx);
+int acx_grid_allgather(acx_ctx *ctx, const float *d_local, float *d_gathered, int64_t floats_per_rank);
+int acx_pair_grid_ranks(acx_ctx *ctx, const acx_grid_spec *spec, const void *params, float *const *D, int64_t ld,
+                        int32_t mirror);
+
+/* ---- device buffers for hosts without a GPU runtime of their own -------- */
+
+/* acx_grid_run / acx_grid_allgather work on DEVICE buffers the caller owns.  A Python host takes them from torch; a host
+ * that links no GPU runtime (and bench.py at one GPU, which then never imports torch) takes them from here: zero-filled
+ * hipMalloc on the context's device; acx_dev_read drains the library's stream and copies to the host; acx_dev_sync =
+ * hipDeviceSynchronize.  Buffers still alive are freed with the context. */
+int acx_dev_alloc(acx_ctx *ctx, int64_t bytes, void **d_ptr);
+int acx_dev_free(acx_ctx *ctx, void *d_ptr);
+int acx_dev_read(acx_ctx *ctx, void *host_dst, const void *d_src, int64_t bytes);
+int acx_dev_sync(acx_ctx *ctx);
 
 /* ---- measurement -------------------------------------------------------- */
 

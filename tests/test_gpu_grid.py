@@ -333,3 +333,59 @@ def test_bench_strong_gloo_world_of_two():
     assert s["gather_bytes"] == 2 * s["gather_bytes_per_rank"]
     c = s["plan_cost_per_rank"]
     assert max(c) / (sum(c) / 2) < 1.1                                # the deal balances the modelled cost
+
+
+def test_rccl_inside_libacx_world_of_one():
+    """The library's own multi-GPU route (include/acx.h "multi-GPU inside the library"), as far as one GPU allows: a
+    process that never imports torch gets a communicator id, joins as rank 0 of 1, runs acx_grid_run into a buffer from
+    acx_dev_alloc, all-gathers it over RCCL on the library's stream (acx_grid_allgather), and acx_pair_grid_ranks fills
+    the matrices -- equal to the one-GPU acx_pair_grid for Serra09 (one plane) and ChenFusion (two planes)."""
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from acoss_amd import _lib, synth
+d = synth.cover_set(clique_sizes=[2] * 9, seed=5, t_range=(60, 260))
+n = len(d["offsets"]) - 1
+ctx = _lib.Context(0)
+ctx.upload_pool(d["frames"], d["offsets"])
+p = _lib.serra09_params()
+want = np.zeros((n, n), np.float32)
+ctx.pair_grid(_lib.ALGO_SERRA09, True, p, [want], mirror=True)
+cid = _lib.comm_id()
+assert len(cid) == _lib.COMM_ID_BYTES
+ctx.comm_init(cid, 0, 1)
+try:
+    ctx.comm_init(cid, 0, 1)
+    raise SystemExit("a second communicator on one context must be refused")
+except _lib.AcxError:
+    pass
+# the pieces: tiles into a libacx buffer, the all-gather, the host scatter
+lengths = ctx.pool_lengths(_lib.ALGO_SERRA09)
+plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=1, tile=4, want_tiles=True)
+stride = int(plan["floats_per_rank"][0])
+loc, allb = ctx.dev_alloc(4 * stride), ctx.dev_alloc(4 * stride)
+ctx.grid_run(plan["spec"], p, 0, loc.ptr)
+ctx.grid_allgather(loc.ptr, allb.ptr, stride)
+got = np.zeros((n, n), np.float32)
+_lib.grid_scatter(lengths, plan["spec"], allb.read(np.float32, stride), stride, [got], mirror=True)
+assert np.array_equal(got, want) and float(want.max()) > 10.0
+loc.free(); allb.free()
+# the whole thing in one call, one and two planes
+got2 = np.zeros((n, n), np.float32)
+ctx.pair_grid_ranks(_lib.ALGO_SERRA09, True, p, [got2], mirror=True, tile=5)
+assert np.array_equal(got2, want)
+q, dm = np.zeros((n, n), np.float32), np.zeros((n, n), np.float32)
+ctx.pair_grid_ranks(_lib.ALGO_CHENFUSION, True, p, [q, dm], mirror=True)
+q1, d1 = np.zeros((n, n), np.float32), np.zeros((n, n), np.float32)
+ctx.pair_grid(_lib.ALGO_CHENFUSION, True, p, [q1, d1], mirror=True)
+assert np.array_equal(q, q1) and np.array_equal(dm, d1) and np.array_equal(q, want)
+ctx.comm_destroy()
+ctx.close()
+assert "torch" not in sys.modules
+print("ok rccl inside libacx")
+""" % ROOT
+    env = dict(__import__("os").environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok rccl inside libacx" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -5,9 +5,10 @@ What BASELINE.json's metric asks of every algorithm is "MAP parity vs CPU": the 
 (algorithm_template.py:205-290) of the HIP distance matrix against those of the CPU oracle's on a set
 where cliques exist and MAP is not trivially 1.
 
-  * EarlyFusion, 150 tracks / 30 works in block space (synth.earlyfusion_cover_set): all 11 175 pairs
+  * EarlyFusion, 500 tracks / 100 works in block space (synth.earlyfusion_cover_set): all 124 750 pairs
     through acx_pair_grid, four score planes; the oracle (numpy f32 + C Smith-Waterman, golden-pinned
-    to the reference's own outputs) on a process pool.  MR / Top-1 identical, |dMAP| <= 5e-4 per plane;
+    to the reference's own outputs) on a process pool.  MR / Top-1 identical, |dMAP| <= 1e-4 per plane
+    (north_star's bar; at 500 tracks one moved pair is well below it);
     >= 99.8 % of the scores identical to the oracle's, the movers capped at EF_TOL (see the constants
     below; the histograms HIP vs oracle, exact-f32 GEMM vs oracle, bf16x3 vs f32 and both against
     f64-evaluated matrices go to gpurun_out/parity_ef.json -> profiles/).
@@ -34,13 +35,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # three cross-similarity matrices is exact integer / order-statistic work, so two evaluations either agree
 # exactly or differ because a 650- / 1225-term f32 product came out one ulp apart where the k-th and
 # (k+1)-th smallest of a row are that close: the binary matrix gains / loses a cell and an alignment path
-# may move.  Measured on the 150-track cover set below (profiles/r03_parity_ef.json): 11 175 pairs x 4
-# planes, 11 scores differ from the oracle's (mfccs 0, ssms 9, chromas 1, early 1), the largest by 2.7 --
-# and the reference's own f32 arithmetic (numpy sgemm) moves as many against the f64-evaluated matrices.
-# So the bar is a FRACTION of identical scores plus a cap on the rare movers, not a tighter +-:
+# may move.  Measured in round 3 on a 150-track cover set (profiles/r03_parity_ef.json at commit 4d15a37): 11 175
+# pairs x 4 planes, 13 scores differ from the oracle's, the largest by 2.7, |dMAP| <= 2.2e-6 -- and the reference's
+# own f32 arithmetic (numpy sgemm) moves 5 against the f64-evaluated matrices.  Round 4: 500 tracks, the bars at
+# north_star's values.  The bar is a FRACTION of identical scores plus a cap on the rare movers, not a tighter +-:
 EF_TOL = 3.0            # cap on a single score difference (measured max 2.7)
 EF_MIN_SAME = 0.998     # fraction of scores identical to the oracle's, per plane (measured >= 0.9992)
-EF_MAP_TOL = 5e-4       # |dMAP| on a 150-track set: one moved pair shifts MAP by up to ~3e-4 at this size
+EF_MAP_TOL = 1e-4       # |dMAP|: north_star's "MAP within 1e-4 of CPU"
+EF_MOVED_SLACK = 8      # scores the device may move against f64-evaluated matrices beyond what the reference's f32 moves
 
 
 @pytest.fixture(scope="module")
@@ -128,9 +130,9 @@ def _oracle_pool(fn, tracks, pairs, workers=None):
 def test_earlyfusion_cover_set_map(ctx):
     import oracle
     from acoss_amd import synth, _lib
-    tracks, labels = synth.earlyfusion_cover_set(n_works=30, versions=5, seed=2024, nb_range=(60, 100), noise=4.0)
+    tracks, labels = synth.earlyfusion_cover_set(n_works=100, versions=5, seed=2024, nb_range=(60, 100), noise=4.0)
     n = len(tracks)
-    assert n == 150
+    assert n == 500
     pairs = oracle.all_pairs(n, True).astype(np.int32)
     ref = _oracle_pool(_ef_chunk, tracks, pairs)
     ctx.ef_upload_pool(tracks)
@@ -147,7 +149,7 @@ def test_earlyfusion_cover_set_map(ctx):
         P32 = grid("f32")
     finally:
         ctx.set_ef_gemm("bf16x3")
-    rec = {"tracks": n, "works": 30, "pairs": int(len(pairs)), "noise": 4.0}
+    rec = {"tracks": n, "works": 100, "pairs": int(len(pairs)), "noise": 4.0}
     for e, s in enumerate(names):
         Dref = np.zeros((n, n), np.float32)
         Dref[pairs[:, 0], pairs[:, 1]] = ref[:, e]
@@ -167,7 +169,7 @@ def test_earlyfusion_cover_set_map(ctx):
                   "MAP_oracle": st_ref[3], "MAP_hip": st_hip[3], "MAP_hip_f32gemm": st_f32[3], "MAP_f64matrices": st_64[3],
                   "MR_oracle": st_ref[0], "MR_hip": st_hip[0], "MRR_oracle": st_ref[1], "MRR_hip": st_hip[1],
                   "top1_oracle": float(st_ref[4][0]), "top1_hip": float(st_hip[4][0])}
-    _record("parity_ef.json", "earlyfusion_cover150", rec)
+    _record("parity_ef.json", "earlyfusion_cover500", rec)
     for e, s in enumerate(names):
         r = rec[s]
         assert 0.3 < r["MAP_oracle"] < 0.999, (s, r["MAP_oracle"])            # the set is neither trivial nor noise
@@ -180,7 +182,7 @@ def test_earlyfusion_cover_set_map(ctx):
         # does (+ slack for a handful of pairs either way)
         moved_hip = r["hip_vs_f64matrices"]["n"] - r["hip_vs_f64matrices"]["0"]
         moved_ref = r["oracle_vs_f64matrices"]["n"] - r["oracle_vs_f64matrices"]["0"]
-        assert moved_hip <= 2 * moved_ref + 8, (s, moved_hip, moved_ref)
+        assert moved_hip <= moved_ref + EF_MOVED_SLACK, (s, moved_hip, moved_ref)
         # the two arithmetics of the device (three-term bf16 splits / f32 MFMAs) against each other: ties only
         h = r["bf16x3_vs_f32gemm"]
         assert h["max"] <= EF_TOL + 1e-6 and h["0"] >= EF_MIN_SAME * h["n"], (s, h)

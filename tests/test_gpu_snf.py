@@ -41,6 +41,9 @@ def test_fused_matrix_matches_oracle(ctx, n, m, K, niters):
         np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-300)
     np.testing.assert_allclose(dev, want, rtol=1e-10, atol=1e-14)
     assert sf.doSimilarityFusion(Scores, K=K, niters=1, reg_diag=1, ctx=ctx, want_ws=False)[0] is None
+    if n == 30:     # the reference's own call, positional, no libacx vocabulary (similarity_fusion.py:188): default context
+        Ws_b, bare = sf.doSimilarityFusion(Scores, K, niters, 1)
+        assert np.array_equal(bare, dev) and all(np.array_equal(a, b) for a, b in zip(Ws_b, Ws_d))
     lists = [oracle.snf_knn_lists(W, K) for W in Ws_o]
     dev2 = ctx.snf_fuse(Ws_o, [l[0] for l in lists], [l[1] for l in lists], niters, 1.0)
     np.testing.assert_allclose(dev2, want, rtol=1e-10, atol=1e-14)
