@@ -929,6 +929,15 @@ struct BandLaunch {
 bool launch_band_kernel(const BandLaunch &L, int m, const struct PairDesc *dpd, int B, int maxRows, int maxCols, int role,
                         int write_d2, int want_eps);
 
+// development builds only (scripts/ab_build.sh ablN -DACX_ABL=N): the band kernel stops behind stage N -- 1 sweep, 2 exchange +
+// row read, 3 selection, 4 eps / threshold -- so that instruction counters (rocprofv3 --pmc SQ_INSTS_*) can be read per stage
+// (profiles/r04_narrow_classes.md).  `val` keeps the stage's result alive.
+#ifdef ACX_ABL
+#define ACX_ABL_EXIT(n_, val_) do { if (ACX_ABL == (n_)) { if ((val_) == 1.2345e-30f) thr[0] = 1.0f; return; } } while (0)
+#else
+#define ACX_ABL_EXIT(n_, val_) do { } while (0)
+#endif
+
 #ifdef ACX_TIMING   /* development builds only (scripts/ab_build.sh timing -DACX_TIMING; experiments/phase_timing.py) */
 __device__ unsigned long long g_band_clk[32];      // [0, 16): band_kernel (slot 15 = waves); [16, 32): spare
 struct StampT { unsigned long long t; int base; };
@@ -1145,6 +1154,7 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
         shi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;     // rank ihi is the next distinct value
     }
     ACX_STAMP(5);        // selection
+    ACX_ABL_EXIT(3, slo + shi);
     // (row pass: the column thresholds of the row, lane-interleaved, requested here -- behind the selection, whose
     // registers they would otherwise compete for, and ahead of the eps / threshold arithmetic that covers their
     // latency; see the bitmap step)
@@ -1168,6 +1178,7 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
     const bool weights_ok = interp && ihi == ilo + 1 && inclusive && fl >= 1.0f && (ce - kf) >= 0.00390625f && (kf - fl) >= 0.00390625f;
     if (!want_eps && weights_ok && shi < INF && (shi - slo) > shi * 0.000244140625f) {
         ACX_STAMP(6);
+        ACX_ABL_EXIT(4, slo);
         if (lane == 0) (thr + P.offX)[role ? P.pitchT + row : row] = slo;
         band_row_bits<NV, ROLE, TC_VIA_LDS>(xr, tcg, slo, myrow, lane, row, MB, cshift, P, thr, bits);
         ACX_STAMP(7);
@@ -1442,6 +1453,11 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
         }
     }
     ACX_STAMP(0);        // sweep
+#ifdef ACX_ABL
+    { float keep_ = 0.0f;
+      for (int a = 0; a < BAND; ++a) for (int st = 0; st < NSTEP; ++st) keep_ += xv[a][st];
+      ACX_ABL_EXIT(1, keep_); }
+#endif
     __syncthreads();     // all slabs dead -> reuse LDS as the exchange rows + the fast histograms
     ACX_STAMP(1);        // wait B1
     // ---- exchange: row a of the band becomes a row of LDS in POSITION order (position p = 64 tile +
@@ -1489,6 +1505,11 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     // slot s of the row = position s = column s - 7 + w
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the row has left LDS
     ACX_STAMP(4);        // row read
+#ifdef ACX_ABL
+    { float keep_ = 0.0f;
+      for (int t = 0; t < NV; ++t) keep_ += xr[t];
+      ACX_ABL_EXIT(2, keep_); }
+#endif
     band_row_tail<NV, ROLE>(xr, smem, wave, lane, i0 + wave, MA, MB, (BAND - 1) - wave, P, thr, role == 0 ? bits : nullptr,
                             pp, pct_mode, inclusive, want_eps ACX_STAMP_ARG);
 }
