@@ -159,9 +159,9 @@ class CoverAlgorithm(object):
         return np.stack([i, j], axis=1).astype(np.int64)
 
     def all_pairwise(self, parallel=0, n_cores=12, symmetric=False, precomputed=False):
-        """All pairwise comparisons.  `parallel` / `n_cores` are accepted for signature
-        compatibility; the fan-out unit here is the GPU (one process per GPU under
-        torch.distributed), not joblib workers."""
+        """All pairwise comparisons.  Device-backed classes ignore `parallel` / `n_cores`: their fan-out unit is the GPU
+        (one process per GPU under torch.distributed).  User subclasses that bring their own CPU `similarity()` get the
+        reference's behaviour: `parallel=1` spreads the 45 chunks over `n_cores` joblib workers (single process group only)."""
         npz = "%s_Ds.npz" % self.get_cacheprefix()
         h5 = "%s_Ds.h5" % self.get_cacheprefix()          # the reference's cache file (algorithm_template.py:163-166,192)
         if precomputed:
@@ -187,8 +187,11 @@ class CoverAlgorithm(object):
             pairs = self.pair_list(self.N, symmetric)
             lo, hi = _dist.shard_bounds(len(pairs), rank, ws)
             mine = pairs[lo:hi]
-            for chunk in np.array_split(mine, max(1, min(self.n_chunks, len(mine)))):
-                if len(chunk):
+            chunks = [c for c in np.array_split(mine, max(1, min(self.n_chunks, len(mine)))) if len(c)]
+            if parallel and n_cores != 1 and ws == 1 and self._joblib_fanout(chunks, n_cores):
+                pass                                           # the reference's joblib fan-out (algorithm_template.py:172-177)
+            else:
+                for chunk in chunks:
                     self.similarity(chunk)
             if not _dist.single():
                 keys = list(self.Ds.keys())
@@ -206,6 +209,23 @@ class CoverAlgorithm(object):
         if rank == 0:
             np.savez(npz, **{s: np.asarray(self.Ds[s]) for s in self.Ds})
             save_matrices_h5(h5, self.Ds)                      # also in the reference's own format when h5py exists
+
+    def _joblib_fanout(self, chunks, n_cores):
+        """User subclasses with their own CPU `similarity()` (README "how to add an algorithm"): `parallel=1` fans the 45
+        chunks out over joblib worker processes like the reference does (algorithm_template.py:172-177) -- every worker
+        gets a pickled copy of `self` whose `Ds` memmaps joblib re-opens on the same files, so the scores land in the
+        owner's matrices.  Returns False (caller runs the chunks serially) when joblib is missing or a matrix is not
+        file-backed.  Device-backed classes never come here: their fan-out unit is the GPU."""
+        try:
+            from joblib import Parallel, delayed
+        except ImportError:
+            return False
+        if not all(isinstance(D, np.memmap) for D in self.Ds.values()):
+            return False
+        for D in self.Ds.values():
+            D.flush()
+        Parallel(n_jobs=n_cores, verbose=0)(delayed(self.similarity)(c) for c in chunks)
+        return True
 
     def _all_pairwise_grid(self, symmetric):
         """Device-backed classes: `self._grid()` -> (context with the pool uploaded, ACX_ALGO_*, params

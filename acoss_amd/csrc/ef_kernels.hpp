@@ -1159,8 +1159,13 @@ __device__ __forceinline__ float ef_wcsm_weight(float ri, float cj, float cv)
 }
 __device__ __forceinline__ float ef_fused_value(float wsum) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * wsum); }
 
+#ifndef ACX_EF_ROWSTAT_WAVES
+#define ACX_EF_ROWSTAT_WAVES 8      /* waves per SIMD the narrow variant (NQ = 2: rows of <= 512 cells) is compiled for: 64 registers instead of 78-80,
+                                       no spills, 8 instead of 6 waves per SIMD -- the selection's chain waits on latencies: 15.3 -> 13.9 ms per 5 grid tiles */
+#endif
+constexpr int ef_rowstat_min_waves(int nq) { return (nq <= 2 && ACX_EF_ROWSTAT_WAVES > 0) ? ACX_EF_ROWSTAT_WAVES : 1; }
 template <int NQ, bool FUSED>
-__global__ __launch_bounds__(256) void ef_rowstat_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
+__global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
                                                          float *__restrict__ stat, unsigned *__restrict__ bits, int mode, int kw, int store_f)
 {
     constexpr int NX = 4 * NQ;                        // values per lane
@@ -1576,7 +1581,10 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
 // matrices of a pair in one launch.  out[pair * 4 + src].
 // ------------------------------------------------------------------------------------
 template <int CPL>
-__global__ __launch_bounds__(64) void sw_bits_kernel(const EfPair *__restrict__ pd, const unsigned *__restrict__ bits,
+#ifndef ACX_SW_BITS_WAVES
+#define ACX_SW_BITS_WAVES 1
+#endif
+__global__ __launch_bounds__(64, ACX_SW_BITS_WAVES) void sw_bits_kernel(const EfPair *__restrict__ pd, const unsigned *__restrict__ bits,
                                                      float *__restrict__ out, int src_base)
 {
     const int lane = threadIdx.x;

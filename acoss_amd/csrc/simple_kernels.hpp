@@ -87,7 +87,10 @@ __device__ __forceinline__ unsigned long long simple_select_key(const unsigned l
 // about the same time and share their scalar-cache misses.
 constexpr int SIMPLE_WPB = 4;
 template <int L>
-__global__ __launch_bounds__(64 * SIMPLE_WPB) void simple_kernel(const double *__restrict__ pool,
+#ifndef ACX_SIMPLE_WAVES
+#define ACX_SIMPLE_WAVES 1
+#endif
+__global__ __launch_bounds__(64 * SIMPLE_WPB, ACX_SIMPLE_WAVES) void simple_kernel(const double *__restrict__ pool,
                                                                  const int64_t *__restrict__ toff,
                                                                  const double *__restrict__ prof,
                                                                  const double *__restrict__ wn,

@@ -407,3 +407,32 @@ def test_eval_statistics_counting_equals_sorting():
     a = eval_statistics(D, cl, (1, 10))
     o = oracle.eval_statistics(D, cl, (1, 10))
     assert np.allclose(a[:4], o[:4], rtol=1e-12) and np.array_equal(a[4], o[4])
+
+
+from acoss_amd.algorithms.algorithm_template import CoverAlgorithm as _CoverAlgorithm  # noqa: E402
+
+
+class UserAlgo(_CoverAlgorithm):
+    """Module-level (picklable by joblib's workers) user subclass in the README's style: its own CPU similarity()."""
+
+    def similarity(self, idxs):
+        for i, j in zip(idxs[:, 0], idxs[:, 1]):
+            self.Ds["main"][i, j] = 100.0 * i + j + 0.5
+
+
+def test_user_subclass_parallel_fanout(tmp_path, monkeypatch):
+    """`all_pairwise(parallel=1, n_cores=2)` of a user subclass with its own CPU similarity(): the reference's joblib
+    fan-out over the 45 chunks (algorithm_template.py:172-177) -- worker processes write through the re-opened memmaps --
+    gives the serial result."""
+    pytest.importorskip("joblib")
+    csv, root = _toy_dataset(tmp_path, ["a", "a", "b", "b", "c", "a", "b"])
+    monkeypatch.chdir(tmp_path)
+    out = {}
+    for par in (0, 1):
+        alg = UserAlgo(csv, name="User", datapath=root, shortname="u%d" % par)
+        alg.all_pairwise(parallel=par, n_cores=2, symmetric=False)
+        out[par] = np.array(alg.Ds["main"])
+        alg.cleanup_memmap()
+    n = out[0].shape[0]
+    want = np.array([[0.0 if i == j else 100.0 * i + j + 0.5 for j in range(n)] for i in range(n)], np.float32)
+    assert np.array_equal(out[0], want) and np.array_equal(out[1], want)
