@@ -962,7 +962,7 @@ struct BandGeom {
     // stores per tile -- which the extra workgroup in flight more than pays for: that class waits on latencies,
     // not on the LDS pipe, which is 26 % busy; profiles/r04_narrow_classes.md)
 #ifndef ACX_MID_WAVES
-#define ACX_MID_WAVES 6         /* waves per SIMD of the middle class (rows of <= 1017 cells, m <= 9) */
+#define ACX_MID_WAVES 8         /* waves per SIMD of the middle class (rows of <= 1017 cells, m <= 9): packed slabs + ONE operand register set (SINGLE_BV) */
 #endif
     static constexpr bool PACKED = M <= 9 && ((V4 <= 2 && ACX_NARROW_WAVES >= 8) || (V4 == 4 && ACX_MID_WAVES >= 8));
     static constexpr int SP = PACKED ? BW : BW + 4;
@@ -1403,7 +1403,11 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     const int cpw = (ntiles + 7) >> 3;                   // tiles per wave (<= NSTEP)
     // tile of step st: a computed one, or (st >= cpw) one of the tiles past all data that this wave pads
     auto tile_of = [&](int st) { return st < cpw ? wave * cpw + st : 8 * cpw + wave * (NSTEP - cpw) + (st - cpw); };
-    BvT bvbuf[2];
+    // Operand registers: two sets (the next tile's loads are issued BEFORE the current tile's MFMAs) -- or, SINGLE_BV, one set that
+    // the next tile's loads refill right behind the MFMAs that consumed it (their latency still overlaps the tile's LDS round trip
+    // and walk): 15 registers less, which is what lets the middle class hold four workgroups per CU without spilling.
+    constexpr bool SINGLE_BV = G::PACKED && V4 == 4;
+    BvT bvbuf[SINGLE_BV ? 1 : 2];
     f32x4 halo[G::NRT][HB];
     if (wave * cpw < ntiles) load_operands(wave * cpw, bvbuf[0], std::integral_constant<int, 0>());
     static_for<0, NSTEP>([&](auto st_tag) {
@@ -1413,8 +1417,10 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
         if (st < cpw && tile < ntiles) {      // wave-uniform
             float yv[BAND];
             load_norms(tile, yv);
-            if (st + 1 < NSTEP && st + 1 < cpw && tile + 1 < ntiles)
-                load_operands(tile + 1, bvbuf[(st + 1) & 1], std::integral_constant<int, HB>());
+            if constexpr (!SINGLE_BV) {
+                if (st + 1 < NSTEP && st + 1 < cpw && tile + 1 < ntiles)
+                    load_operands(tile + 1, bvbuf[(st + 1) & 1], std::integral_constant<int, HB>());
+            }
             if constexpr (st > 0) {
                 // inherit the halo: block 4 + h of the previous tile is block h of this one (still in registers)
 #pragma unroll
@@ -1425,7 +1431,11 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
             }
             {
                 AccT acc;
-                gram(bvbuf[st & 1], acc, std::integral_constant<int, tb0>());
+                gram(bvbuf[SINGLE_BV ? 0 : (st & 1)], acc, std::integral_constant<int, tb0>());
+                if constexpr (SINGLE_BV) {
+                    if (st + 1 < NSTEP && st + 1 < cpw && tile + 1 < ntiles)
+                        load_operands(tile + 1, bvbuf[0], std::integral_constant<int, HB>());
+                }
                 store_gram(acc, std::integral_constant<int, tb0>());
 #pragma unroll
                 for (int ta = 0; ta < G::NRT; ++ta)
