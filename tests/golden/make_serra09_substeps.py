@@ -124,6 +124,38 @@ def main():
     out["norm_lengths"] = lengths.astype(np.int64)
     out["norm_D_in"] = D_in
     out["norm_D_out"] = np.array(alg.Ds["main"], dtype=np.float32)
+    # ---------------------------------------------------------------- LateFusionChen through the reference class
+    # (latefusion_chen.py:75-91: D = sqrt(T_j) / D -- the unfilled diagonal becomes inf --, SNF of the two distance matrices
+    # with K = 20 neighbours and 20 iterations, inputs negated afterwards)
+    lc = importlib.import_module("acoss.algorithms.latefusion_chen")
+    n2 = 26
+    with open("toy26.csv", "w") as f:
+        f.write("work_id,track_id\n")
+        for k in range(n2):
+            f.write("w%d,t%d\n" % (k // 2, k))
+    chen = lc.ChenFusion("toy26.csv", tmp + "/", shortname="toy26") if hasattr(lc, "ChenFusion") else lc.LateFusionChen("toy26.csv", tmp + "/", shortname="toy26")
+    len2 = rng.integers(150, 651, n2)
+    for j in range(n2):
+        chen.all_feats[j] = np.zeros((int(len2[j]), 12), np.float32)
+    base = (rng.integers(4, 300, (n2, n2)) * 0.5).astype(np.float32)
+    base = np.maximum(base, base.T)                       # all_pairwise(symmetric=True) leaves a symmetric matrix
+    for k in range(0, n2, 2):                             # covers score higher
+        base[k, k + 1] = base[k + 1, k] = base[k, k + 1] + 150.0
+    np.fill_diagonal(base, 0)
+    q_in, d_in = base.copy(), (base * 1.25 + 1.0).astype(np.float32)
+    np.fill_diagonal(d_in, 0)
+    chen.Ds["qmax"][:] = q_in
+    chen.Ds["dmax"][:] = d_in
+    with np.errstate(divide="ignore"):
+        chen.normalize_by_length()
+    out["chen_lengths"] = len2.astype(np.int64)
+    out["chen_q_in"], out["chen_d_in"] = q_in, d_in
+    out["chen_q_norm"] = np.array(chen.Ds["qmax"], dtype=np.float32)
+    out["chen_d_norm"] = np.array(chen.Ds["dmax"], dtype=np.float32)
+    with np.errstate(all="ignore"):
+        chen.do_late_fusion()
+    out["chen_late"] = np.array(chen.Ds["Late"], dtype=np.float64)
+    out["chen_q_after"] = np.array(chen.Ds["qmax"], dtype=np.float32)
     os.chdir(cwd)
     np.savez_compressed(os.path.join(HERE, "serra09_substeps.npz"), **out)
     print("written", os.path.join(HERE, "serra09_substeps.npz"),

@@ -186,3 +186,60 @@ def test_exact_percentile_positions_are_reported():
         assert (not np.array_equal(e0, e1)) == differs
         if differs:
             assert np.all(e1 == 0)
+
+
+class _BareChen(object):
+    """ChenFusion holding only what normalize_by_length / do_late_fusion read (no dataset files)."""
+
+    @staticmethod
+    def make(z, device=None):
+        from acoss_amd.algorithms.latefusion_chen import ChenFusion
+
+        class Bare(ChenFusion):
+            def __init__(self):
+                lengths = z["chen_lengths"]
+                self.N = len(lengths)
+                self.Ds = {"qmax": z["chen_q_in"].copy(), "dmax": z["chen_d_in"].copy()}
+                self._pool_ready = False
+                self._ctx = None
+                self._device = device
+                self._nonfinite = "raise"
+                self.all_feats = {j: np.zeros((int(lengths[j]), 12), np.float32) for j in range(self.N)}
+
+            def owns_result(self):
+                return True
+        return Bare()
+
+
+def test_chenfusion_normalisation_against_reference_class(golden):
+    """latefusion_chen.py:75-85 run through the reference class (D = sqrt(T_j) / D, the unfilled diagonal -> inf): the
+    product's vectorised host code reproduces it bit for bit; the oracle's restatement of the fusion that follows
+    (latefusion_chen.py:87-91) reproduces the reference's fused matrix."""
+    import oracle
+    z = _z(golden)
+    b = _BareChen.make(z)
+    with np.errstate(divide="ignore"):
+        b.normalize_by_length()
+    assert np.array_equal(b.Ds["qmax"], z["chen_q_norm"]) and np.array_equal(b.Ds["dmax"], z["chen_d_norm"])
+    assert np.isinf(np.diag(b.Ds["qmax"])).all()
+    with np.errstate(all="ignore"):
+        F = oracle.snf_fuse([z["chen_q_norm"], z["chen_d_norm"]], K=20, niters=20, reg_diag=1)[1]
+    # the reference fuses in the dtype of its float32 memmaps, the oracle in f64: agreement to f32 rounding
+    np.testing.assert_allclose(F, z["chen_late"], rtol=2e-5, atol=1e-7)
+    assert np.array_equal(z["chen_q_after"], -z["chen_q_norm"])
+
+
+@pytest.mark.gpu
+def test_chenfusion_late_fusion_against_reference_class(golden):
+    """ChenFusion.normalize_by_length + do_late_fusion of the product (SNF on the device) against the matrices the
+    REFERENCE class produced from the same score matrices."""
+    z = _z(golden)
+    b = _BareChen.make(z, device=0)
+    with np.errstate(divide="ignore"):
+        b.normalize_by_length()
+    b.do_late_fusion()
+    try:
+        np.testing.assert_allclose(np.asarray(b.Ds["Late"]), z["chen_late"], rtol=2e-5, atol=1e-7)
+        assert np.array_equal(b.Ds["qmax"], z["chen_q_after"])
+    finally:
+        b._ctx.close()
