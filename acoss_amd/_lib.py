@@ -31,7 +31,7 @@ EXPORTS = [
     "acx_set_nonfinite_policy", "acx_nonfinite_zeroed", "acx_ef_pool_begin", "acx_ef_pool_tracks", "acx_ef_pool_end",
     "acx_set_ef_gemm", "acx_hip_versions",
     "acx_dev_alloc", "acx_dev_free", "acx_dev_read", "acx_dev_sync",
-    "acx_comm_id", "acx_comm_init", "acx_comm_destroy", "acx_grid_allgather", "acx_pair_grid_ranks",
+    "acx_comm_id", "acx_comm_init", "acx_comm_destroy", "acx_grid_allgather", "acx_pair_grid_ranks", "acx_set_ef_fuse",
 ]
 ABI_VERSION = 2           # include/acx.h ACX_ABI_VERSION this shim was written against
 COMM_ID_BYTES = 128
@@ -204,6 +204,7 @@ def load():
     L.acx_ef_pool_tracks.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp]
     L.acx_ef_pool_end.argtypes = [vp]
     L.acx_set_ef_gemm.argtypes = [vp, ctypes.c_int32]
+    L.acx_set_ef_fuse.argtypes = [vp, ctypes.c_int32]
     L.acx_earlyfusion_pairs.argtypes = [vp, ip, ctypes.c_int64, ep, fp]
     L.acx_ef_debug_pair.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ep, fp, fp, fp, ip]
     L.acx_sw_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, fp]
@@ -488,6 +489,12 @@ class Context(object):
         chroma f32): EarlyFusion's cross-similarity GEMMs (acx_set_ef_gemm)."""
         self._check(self._L.acx_set_ef_gemm(self._h, {"bf16x3": 0, "f32": 1, "bf16x3_pairwise": 2,
                                                       "bf16x3_chroma_f32": 3}.get(mode, mode)))
+
+    def set_ef_fuse(self, mode):
+        """'fast' (default: reciprocal + exp2 per kernel weight) or 'exact' (the reference's operation order with IEEE
+        divisions and expf) for getWCSM's weights and the fused matrix (acx_set_ef_fuse)."""
+        code = {"fast": 0, "exact": 1}.get(mode, mode)
+        self._check(self._L.acx_set_ef_fuse(self._h, int(code)))
 
     def ef_pool_end(self):
         self._check(self._L.acx_ef_pool_end(self._h))

@@ -101,6 +101,7 @@ struct acx_ctx {
     std::vector<int64_t> h_efoff;
     int32_t ef_ntracks = 0;
     int32_t ef_gemm = ACX_EF_GEMM_BF16X3;             // arithmetic of the two Euclidean cross-similarity GEMMs
+    int32_t ef_fuse = ACX_EF_FUSE_FAST;               // arithmetic of getWCSM's weights and the fused matrix (acx_set_ef_fuse)
     int32_t ef_open = 0;                              // > 0: a pool of that many tracks is being filled (acx_ef_pool_begin .. _end)
     std::vector<uint8_t> ef_filled;                   // per track of the open pool: handed over by acx_ef_pool_tracks yet?
     // multi-GPU inside the library (acx_comm_*): one RCCL communicator rank per context
@@ -1048,8 +1049,10 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
 #define ACX_ROWSTAT(grid_, mode_) do { if (long_rows) hipLaunchKernelGGL(acx::ef_rowstat_long_kernel, grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, mode_, p.K); \
                                        else if (wide_rows) hipLaunchKernelGGL((acx::ef_rowstat_kernel<4, false>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_efbits, mode_, p.K, 0); \
                                        else hipLaunchKernelGGL((acx::ef_rowstat_kernel<2, false>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_efbits, mode_, p.K, 0); } while (0)
-#define ACX_FUSESEL(grid_) do { if (wide_rows) hipLaunchKernelGGL((acx::ef_rowstat_kernel<4, true>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_efbits, 3, p.K, keep_f ? 1 : 0); \
-                                else hipLaunchKernelGGL((acx::ef_rowstat_kernel<2, true>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_efbits, 3, p.K, keep_f ? 1 : 0); } while (0)
+#define ACX_FUSESEL_K(NQ_, EX_, grid_) hipLaunchKernelGGL((acx::ef_rowstat_kernel<NQ_, true, EX_>), grid_, dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_efbits, 3, p.K, keep_f ? 1 : 0)
+#define ACX_FUSESEL(grid_) do { const bool ex_ = c->ef_fuse == ACX_EF_FUSE_EXACT; \
+                                if (wide_rows) { if (ex_) ACX_FUSESEL_K(4, true, grid_); else ACX_FUSESEL_K(4, false, grid_); } \
+                                else { if (ex_) ACX_FUSESEL_K(2, true, grid_); else ACX_FUSESEL_K(2, false, grid_); } } while (0)
 #define ACX_SW(grid_, src_) do { if (long_cols) hipLaunchKernelGGL(acx::sw_long_kernel, grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); \
                                  else if (wide_cols) hipLaunchKernelGGL((acx::sw_kernel<16>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); \
                                  else hipLaunchKernelGGL((acx::sw_kernel<8>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); } while (0)
@@ -1078,7 +1081,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             if (!ext_matrix) {
                 {
                     ProfScope ps(c, KS_EFFUSE, cells);
-                    hipLaunchKernelGGL(acx::ef_fuse_kernel, dim3(maxM, B), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr);
+                    hipLaunchKernelGGL(acx::ef_fuse_kernel, dim3(maxM, B), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->ef_fuse == ACX_EF_FUSE_EXACT ? 1 : 0);
                 }
                 {
                     ProfScope ps(c, KS_EFSTAT, 0);
@@ -1118,6 +1121,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
     }
 #undef ACX_ROWSTAT
 #undef ACX_FUSESEL
+#undef ACX_FUSESEL_K
 #undef ACX_SW
     return ACX_OK;
 }
@@ -1814,6 +1818,14 @@ int acx_set_ef_gemm(acx_ctx *c, int32_t mode)
     if (mode != ACX_EF_GEMM_BF16X3 && mode != ACX_EF_GEMM_F32 && mode != ACX_EF_GEMM_BF16X3_PAIRWISE && mode != ACX_EF_GEMM_BF16X3_CHROMA_F32)
         return fail(c, ACX_ERR_INVALID, "set_ef_gemm: unknown mode");
     c->ef_gemm = mode;
+    return ACX_OK;
+}
+
+int acx_set_ef_fuse(acx_ctx *c, int32_t mode)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (mode != ACX_EF_FUSE_FAST && mode != ACX_EF_FUSE_EXACT) return fail(c, ACX_ERR_INVALID, "set_ef_fuse: unknown mode");
+    c->ef_fuse = mode;
     return ACX_OK;
 }
 

@@ -1158,13 +1158,23 @@ __device__ __forceinline__ float ef_wcsm_weight(float ri, float cj, float cv)
     return __builtin_amdgcn_exp2f(-25.968510740383334f * (q * q));       // 18 log2(e)
 }
 __device__ __forceinline__ float ef_fused_value(float wsum) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * wsum); }
+// The same two in the reference's own operation order (acx_set_ef_fuse(ACX_EF_FUSE_EXACT); similarity_fusion.py:50-54 on float32
+// arrays): Eps = (r_i + c_j + C) / 3, W = exp(-C^2 / (2 (0.5 Eps)^2)) with IEEE divisions and expf; fused = exp(-sum W).
+// ~150 instructions per cell instead of ~12; differs from numpy only by the last bit of the two exponentials.
+__device__ __forceinline__ float ef_wcsm_weight_exact(float ri, float cj, float cv)
+{
+    const float eps = ((ri + cj) + cv) / 3.0f;
+    const float t = 0.5f * eps;
+    return expf(-(cv * cv) / (2.0f * (t * t)));
+}
+__device__ __forceinline__ float ef_fused_value_exact(float wsum) { return expf(-wsum); }
 
 #ifndef ACX_EF_ROWSTAT_WAVES
 #define ACX_EF_ROWSTAT_WAVES 8      /* waves per SIMD the narrow variant (NQ = 2: rows of <= 512 cells) is compiled for: 64 registers instead of 78-80,
                                        no spills, 8 instead of 6 waves per SIMD -- the selection's chain waits on latencies: 15.3 -> 13.9 ms per 5 grid tiles */
 #endif
 constexpr int ef_rowstat_min_waves(int nq) { return (nq <= 2 && ACX_EF_ROWSTAT_WAVES > 0) ? ACX_EF_ROWSTAT_WAVES : 1; }
-template <int NQ, bool FUSED>
+template <int NQ, bool FUSED, bool EXACT = false>
 __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
                                                          float *__restrict__ stat, unsigned *__restrict__ bits, int mode, int kw, int store_f)
 {
@@ -1239,7 +1249,7 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
                 if (j < pitch) { cc = *reinterpret_cast<const float4 *>(cj + j); vv = *reinterpret_cast<const float4 *>(cv + j); }
                 const float c4[4] = {cc.x, cc.y, cc.z, cc.w}, v4[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) wsum[4 * q + e] += ef_wcsm_weight(ri, c4[e], v4[e]);
+                for (int e = 0; e < 4; ++e) wsum[4 * q + e] += EXACT ? ef_wcsm_weight_exact(ri, c4[e], v4[e]) : ef_wcsm_weight(ri, c4[e], v4[e]);
             }
         }
 #pragma unroll
@@ -1248,7 +1258,7 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
             float f4[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                f4[e] = ef_fused_value(wsum[4 * q + e]);
+                f4[e] = EXACT ? ef_fused_value_exact(wsum[4 * q + e]) : ef_fused_value(wsum[4 * q + e]);
                 x[4 * q + e] = (j + e < n) ? f4[e] : INF;
             }
             if (store_f && j < pitch)                                      // (the debug entry point hands the matrix out)
@@ -1430,7 +1440,7 @@ __global__ __launch_bounds__(256) void ef_colstat_kernel(const EfPair *__restric
 // E3: fused = exp(-(W0 + W1 + W2)), elementwise over the pair's M x N cells
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ef_fuse_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
-                                                      const float *__restrict__ stat)
+                                                      const float *__restrict__ stat, int exact)
 {
     const EfPair P = pd[blockIdx.y];
     const int i = blockIdx.x;
@@ -1450,9 +1460,9 @@ __global__ __launch_bounds__(256) void ef_fuse_kernel(const EfPair *__restrict__
         float wsum = 0.0f;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            wsum += ef_wcsm_weight(r[s], c[s][j], C[s][j]);
+            wsum += exact ? ef_wcsm_weight_exact(r[s], c[s][j], C[s][j]) : ef_wcsm_weight(r[s], c[s][j], C[s][j]);
         }
-        F[j] = ef_fused_value(wsum);
+        F[j] = exact ? ef_fused_value_exact(wsum) : ef_fused_value(wsum);
     }
 }
 

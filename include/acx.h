@@ -320,6 +320,18 @@ enum { ACX_EF_GEMM_BF16X3 = 0, ACX_EF_GEMM_F32 = 1,
        ACX_EF_GEMM_BF16X3_CHROMA_F32 = 3 };
 int acx_set_ef_gemm(acx_ctx *ctx, int32_t mode);
 
+/*
+ * Arithmetic of getWCSM's kernel weights and of the fused matrix exp(-(W_mfcc + W_ssm + W_chroma)) (similarity_fusion.py:38-54,
+ * earlyfusion_traile.py:176-183).  The fused matrix is only RANKED (csm_to_binary) afterwards.
+ *   ACX_EF_FUSE_FAST (default)  exp(-C^2 / (2 (eps / 2)^2)) = exp2(-18 log2(e) (C / (r + c + C))^2): one v_rcp_f32, one v_exp_f32
+ *                               per weight (about 1e-6 relative against the reference's numpy f32)
+ *   ACX_EF_FUSE_EXACT           the reference's own operation order in f32 with IEEE divisions and expf (~12 x the instructions):
+ *                               differs from numpy by the last bit of the exponentials only, so that a regression in the
+ *                               selection / alignment kernels can be told from an approximation tie
+ */
+enum { ACX_EF_FUSE_FAST = 0, ACX_EF_FUSE_EXACT = 1 };
+int acx_set_ef_fuse(acx_ctx *ctx, int32_t mode);
+
 /* One pair with intermediates (tests): csm (3, M, N), fused (M, N), scores (4); any may be NULL. */
 int acx_ef_debug_pair(acx_ctx *ctx, int32_t i, int32_t j, const acx_ef_params *params,
                       float *csm, float *fused, float *scores, int32_t *oti);

@@ -415,3 +415,48 @@ def test_pool_slices_must_cover_every_track(ctx):
     hand_over(2, 3)
     ctx.ef_pool_end()
     assert np.array_equal(ctx.earlyfusion_pairs(pairs), want)
+
+
+def test_exact_fuse_mode(ctx, golden):
+    """acx_set_ef_fuse(EXACT): getWCSM's weights and the fused matrix in the reference's own operation order (IEEE divisions,
+    expf) instead of reciprocal + exp2.  The fused matrix then sits closer to numpy's on the DEVICE's cross-similarity
+    matrices (what is left is the summation order of the neighbourhood means, which numpy's introselect leaves arbitrary, and
+    the last bit of the exponentials); the alignment of the device's fused matrix by the oracle equals the device's score in
+    both modes; and the two modes agree on the `early` score of (nearly) every pair -- the approximation only moves ties."""
+    import oracle
+    from acoss_amd import synth
+    g = golden("ef_chain")
+    worst = {}
+    for mode in ("fast", "exact"):
+        ctx.set_ef_fuse(mode)
+        try:
+            w = 0.0
+            for pk in (0, 1):
+                f1, f2 = _golden_feats(g, pk)
+                ctx.ef_upload_pool([f1, f2])
+                d = ctx.ef_debug_pair(0, 1)
+                ws = np.zeros_like(d["csm"][0])
+                for k in range(3):
+                    ws += oracle.get_wcsm(d["csm"][k], 10, 10)
+                ref = np.exp(-ws)
+                w = max(w, float(np.max(np.abs(d["fused"] - ref) / np.maximum(ref, 1e-30))))
+                assert round(oracle.sw_constrained(oracle.csm_to_binary(d["fused"], 0.1)) * 10) == round(float(d["scores"][3]) * 10)
+                assert abs(float(d["scores"][3]) - float(g["p%d_scores" % pk][3])) <= 2.0
+            worst[mode] = w
+        finally:
+            ctx.set_ef_fuse("fast")
+    assert worst["exact"] <= 5e-5 and worst["fast"] <= 2e-4, worst
+    tracks = synth.earlyfusion_set(24, seed=9, nb_range=(60, 140))
+    ctx.ef_upload_pool(tracks)
+    pairs = oracle.all_pairs(24, True).astype(np.int32)
+    fast = ctx.earlyfusion_pairs(pairs)
+    ctx.set_ef_fuse("exact")
+    try:
+        exact = ctx.earlyfusion_pairs(pairs)
+    finally:
+        ctx.set_ef_fuse("fast")
+    assert np.array_equal(fast[:, :3], exact[:, :3])                     # the three feature planes do not depend on the mode
+    same = np.mean(fast[:, 3] == exact[:, 3])
+    assert same >= 0.97 and np.max(np.abs(fast[:, 3] - exact[:, 3])) <= 2.0, (same, np.max(np.abs(fast[:, 3] - exact[:, 3])))
+    with pytest.raises(ValueError):
+        ctx.set_ef_fuse(7)
