@@ -58,3 +58,42 @@ def test_product_package_never_touches_the_oracle():
                 assert not re.search(r"(CDLL|LoadLibrary|-l\s*acx_oracle|libacx_oracle)", txt) or name in ("_lib.py", "hdf5.py"), (dirpath, name)
                 if name in ("_lib.py", "hdf5.py"):
                     assert "oracle" not in txt
+
+
+def _build_c_host(tmp_path):
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "c_host")
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c_host.c"), "-L", lib_dir, "-lacx", "-Wl,-rpath," + lib_dir, "-lm", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_c99_and_a_c_host_links(tmp_path):
+    """include/acx.h is a C header (strict C99, -pedantic -Werror) and a host written in C links libacx.so alone
+    (examples/c_host.c: pool upload, acx_serra09_pairs, acx_pair_grid).  Without a GPU the program fails LOUDLY in
+    acx_create (exit code 3, the library's message on stderr) -- there is no fallback to fall back to."""
+    import subprocess
+    import torch
+    exe = _build_c_host(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "covers rank first: yes" in r.stdout, (r.stdout, r.stderr)
+    else:
+        assert r.returncode == 3 and "acx_create failed" in r.stderr, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_host_on_the_gpu(tmp_path):
+    """The C host's scores on the GPU: the two cover pairs rank first, and its Qmax values are what the Python shim gets
+    for the same frames (the program prints them)."""
+    import subprocess
+    exe = _build_c_host(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "covers rank first: yes" in r.stdout, (r.stdout, r.stderr)
+    assert r.stdout.count("Qmax") == 6
