@@ -78,7 +78,7 @@ class Serra09Params(ctypes.Structure):
         ("m", ctypes.c_int32), ("tau", ctypes.c_int32), ("kappa", ctypes.c_float),
         ("oti", ctypes.c_int32), ("gamma_o", ctypes.c_float), ("gamma_e", ctypes.c_float),
         ("embed_full", ctypes.c_int32), ("pct_mode", ctypes.c_int32), ("oti_target", ctypes.c_int32),
-        ("dp_start", ctypes.c_int32), ("inclusive", ctypes.c_int32), ("dmax", ctypes.c_int32),
+        ("dp_start", ctypes.c_int32), ("inclusive", ctypes.c_int32), ("dmax", ctypes.c_int32), ("arith", ctypes.c_int32),
     ]
 
 
@@ -232,10 +232,16 @@ def load():
     return L
 
 
+ARITH = {"exact": 0, "f16x2": 1}
+
+
 def serra09_params(m=9, tau=1, kappa=0.095, oti=True, gamma_o=0.5, gamma_e=0.5, embed_full=0,
-                   pct_mode=0, oti_target=0, dp_start=2, inclusive=1, dmax=0):
+                   pct_mode=0, oti_target=0, dp_start=2, inclusive=1, dmax=0, arith="exact"):
+    """acx_serra09_params.  arith: "exact" (default: the f32 Gram of the arithmetic spec) or "f16x2" (opt-in, m = 9:
+    two-term fp16 splits on the f16 matrix pipe -- f32-accurate, not bit-identical; include/acx.h ACX_ARITH_F16X2)."""
     return Serra09Params(int(m), int(tau), float(kappa), int(bool(oti)), float(gamma_o), float(gamma_e),
-                         int(embed_full), int(pct_mode), int(oti_target), int(dp_start), int(inclusive), int(dmax))
+                         int(embed_full), int(pct_mode), int(oti_target), int(dp_start), int(inclusive), int(dmax),
+                         int(ARITH.get(arith, arith)))
 
 
 def _fptr(a):

@@ -46,6 +46,11 @@ class Serra09(CoverAlgorithm):
                    dp_start    2 (default) or 3: first row / column of the alignment recursion
                    inclusive   1 (default) d <= eps, 0: d <
                    gamma_o, gamma_e  gap penalties (essentia's defaults 0.5 / 0.5)
+                 and, not an essentia detail but a speed option of the device (include/acx.h ACX_ARITH_F16X2):
+                   arith       "exact" (default: the f32 Gram the CPU oracle reproduces bit for bit) or "f16x2" (m = 9 only):
+                               the frame Gram from two-term fp16 splits on the f16 matrix pipe -- as accurate against f64,
+                               +14 ... 27 % pairs/s, but not the same bits: about one score in seven moves (by 0.5 - 4.5), MAP
+                               stays within 1e-4 on the cover sets of tests/test_gpu_serra09.py
                  tests/test_essentia_pin.py finds the combination that reproduces essentia wherever it is installed.
     """
     n_chunks = 1      # the whole pair list goes to the GPU in one similarity() call

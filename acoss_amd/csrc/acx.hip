@@ -74,6 +74,7 @@ struct acx_ctx {
     int pool_tau = 0;
     float *d_frames = nullptr;
     float *d_frot = nullptr;      // rotated frame pool (band kernel MFMA operands), 36 floats per frame
+    _Float16 *d_fh = nullptr;     // the f16 operand pool of the opt-in f16x2 Gram (acx::FH halfs per frame), built on first use
     float *d_normtab = nullptr;   // embedded norms per (track, rotation, frame) for normtab_m / normtab_span
     int64_t *d_noff = nullptr;
     int normtab_m = 0, normtab_span = -1;
@@ -262,6 +263,8 @@ int check_params(acx_ctx *c, const acx_serra09_params &p)
     if (p.pct_mode < 0 || p.pct_mode > 3) return fail(c, ACX_ERR_INVALID, "serra09: pct_mode must be 0..3");
     if (p.oti_target != 0 && p.oti_target != 1) return fail(c, ACX_ERR_INVALID, "serra09: oti_target must be 0 or 1");
     if (!(p.gamma_o >= 0.0f) || !(p.gamma_e >= 0.0f)) return fail(c, ACX_ERR_INVALID, "serra09: gammas must be >= 0");
+    if (p.arith != ACX_ARITH_EXACT && p.arith != ACX_ARITH_F16X2) return fail(c, ACX_ERR_INVALID, "serra09: arith must be ACX_ARITH_EXACT or ACX_ARITH_F16X2");
+    if (p.arith == ACX_ARITH_F16X2 && p.m != 9) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: the f16x2 Gram exists for the default stack size m = 9 only");
     return ACX_OK;
 }
 
@@ -274,9 +277,10 @@ constexpr int64_t POOL_SLACK = 96;      // frames (rotated pool) / floats (norm 
 bool launch_band(acx_ctx *c, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, const acx_serra09_params &p, int role, int write_d2,
                  int want_eps)
 {
-    acx::BandLaunch L{c->stream, c->d_frot + POOL_SLACK * acx::FROT, c->d_toff, c->d_normtab + POOL_SLACK, c->d_noff, c->d_scratch, c->d_thr,
+    const float *operands = p.arith == ACX_ARITH_F16X2 ? reinterpret_cast<const float *>(c->d_fh + POOL_SLACK * acx::FH) : c->d_frot + POOL_SLACK * acx::FROT;
+    acx::BandLaunch L{c->stream, operands, c->d_toff, c->d_normtab + POOL_SLACK, c->d_noff, c->d_scratch, c->d_thr,
                       c->d_bits, p.kappa, p.pct_mode, p.inclusive, p.oti_target};
-    return acx::launch_band_kernel(L, m, dpd, B, maxRows, maxCols, role, write_d2, want_eps);
+    return acx::launch_band_kernel(L, m, dpd, B, maxRows, maxCols, role, write_d2, want_eps, p.arith);
 }
 
 template <int M>
@@ -313,6 +317,7 @@ int ensure_tau(acx_ctx *c, int tau)
     if (c->d_toff && c->d_toff != c->d_toff0) { ACX_HIP(c, hipFree(c->d_toff)); }
     c->d_frames = nullptr; c->d_toff = nullptr;
     if (c->d_frot) { ACX_HIP(c, hipFree(c->d_frot)); c->d_frot = nullptr; }
+    if (c->d_fh) { ACX_HIP(c, hipFree(c->d_fh)); c->d_fh = nullptr; }
     if (c->d_normtab) { ACX_HIP(c, hipFree(c->d_normtab)); c->d_normtab = nullptr; }
     if (c->d_noff) { ACX_HIP(c, hipFree(c->d_noff)); c->d_noff = nullptr; }
     c->normtab_m = 0; c->normtab_span = -1;
@@ -353,6 +358,24 @@ int ensure_tau(acx_ctx *c, int tau)
     }
     ACX_HIP(c, hipStreamSynchronize(c->stream));
     c->pool_tau = tau;
+    return ACX_OK;
+}
+
+// The f16 operand pool of the opt-in f16x2 Gram (192 B per frame of the ACTIVE pool): built on first use, dropped with the pool.
+int ensure_f16pool(acx_ctx *c)
+{
+    if (c->d_fh) return ACX_OK;
+    const int64_t total = c->h_off[c->n_tracks];
+    const size_t halfs = (size_t)(std::max<int64_t>(1, total) + 2 * POOL_SLACK) * acx::FH;
+    const hipError_t e = hipMalloc((void **)&c->d_fh, sizeof(_Float16) * halfs);
+    if (e != hipSuccess) { c->d_fh = nullptr; return fail(c, ACX_ERR_NOMEM, std::string("serra09: the f16 operand pool does not fit the device: ") + hipGetErrorString(e)); }
+    ACX_HIP(c, hipMemsetAsync(c->d_fh, 0, sizeof(_Float16) * halfs, c->stream));
+    if (total > 0) {
+        hipLaunchKernelGGL(acx::rotpool_f16_kernel, dim3((unsigned)std::min<int64_t>((total * 12 + 255) / 256, 1 << 22)), dim3(256), 0, c->stream,
+                           c->d_frames, c->d_fh + POOL_SLACK * acx::FH, total);
+        ACX_HIP(c, hipGetLastError());
+    }
+    ACX_HIP(c, hipStreamSynchronize(c->stream));
     return ACX_OK;
 }
 
@@ -580,6 +603,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
         // row-pass classes (keys 3 cr .. 3 cr + 2) + the long class, as [begin, end) ranges
         const int cls_begin[5] = {key_begin[0], key_begin[3], key_begin[6], key_begin[9], B};
         if (cls_begin[3] > 0 && (rc = ensure_normtab(c, p)) != ACX_OK) return rc;
+        if (cls_begin[3] > 0 && p.arith == ACX_ARITH_F16X2 && (rc = ensure_f16pool(c)) != ACX_OK) return rc;
         // (the band kernel reads its column thresholds 16 bytes at a time without a bounds check, up to
         // 64 x 32 floats behind a pair's column-threshold row: the arena carries that much slack)
         if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)std::max<int64_t>(used, 1))) != ACX_OK) return rc;
@@ -1135,6 +1159,8 @@ static void free_pool(acx_ctx *c)
     if (c->d_frames0) (void)hipFree(c->d_frames0);
     if (c->d_toff0) (void)hipFree(c->d_toff0);
     if (c->d_frot) (void)hipFree(c->d_frot);
+    if (c->d_fh) (void)hipFree(c->d_fh);
+    c->d_fh = nullptr;
     if (c->d_normtab) (void)hipFree(c->d_normtab);
     if (c->d_noff) (void)hipFree(c->d_noff);
     if (c->d_gch) (void)hipFree(c->d_gch);
@@ -1455,7 +1481,7 @@ void acx_serra09_default_params(acx_serra09_params *p)
 {
     if (!p) return;
     p->m = 9; p->tau = 1; p->kappa = 0.095f; p->oti = 1; p->gamma_o = 0.5f; p->gamma_e = 0.5f;
-    p->embed_full = 0; p->pct_mode = 0; p->oti_target = 0; p->dp_start = 2; p->inclusive = 1; p->dmax = 0;
+    p->embed_full = 0; p->pct_mode = 0; p->oti_target = 0; p->dp_start = 2; p->inclusive = 1; p->dmax = 0; p->arith = ACX_ARITH_EXACT;
 }
 
 int32_t acx_serra09_embed_len(int32_t T, const acx_serra09_params *p)

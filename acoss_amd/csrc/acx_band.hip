@@ -10,28 +10,40 @@ namespace acx {
 namespace {
 
 template <int M>
-void launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2, int want_eps)
+bool launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2, int want_eps, int arith)
 {
     const dim3 grid((maxRows + BAND - 1) / BAND, B, 1);
     const int ndata = (maxCols + BAND - 1 + 63) / 64;      // tiles per band that hold matrix cells
-#define ACX_BAND_K(V4_, R_, W_) hipLaunchKernelGGL((band_kernel<M, V4_, R_, W_>), grid, dim3(BAND_THREADS), 0, L.stream, \
+#define ACX_BAND_K(V4_, R_, W_, A_) hipLaunchKernelGGL((band_kernel<M, V4_, R_, W_, A_>), grid, dim3(BAND_THREADS), 0, L.stream, \
                                                   L.frot, L.toff, L.normtab, L.noff, dpd, L.scratch, L.thr, L.bits, L.kappa, \
                                                   L.pct_mode, L.inclusive, L.oti_target, want_eps)
     // (the variant that also writes D2 exists for the row pass only: the debug entry point)
-#define ACX_BAND(V4_) do { if (role) ACX_BAND_K(V4_, 1, false); else if (write_d2) ACX_BAND_K(V4_, 0, true); else ACX_BAND_K(V4_, 0, false); } while (0)
-    if (ndata <= 8) ACX_BAND(2);
-    else if (ndata <= 16) ACX_BAND(4);
-    else ACX_BAND(8);
+#define ACX_BAND(V4_, A_) do { if (role) ACX_BAND_K(V4_, 1, false, A_); else if (write_d2) ACX_BAND_K(V4_, 0, true, A_); else ACX_BAND_K(V4_, 0, false, A_); } while (0)
+    if (arith == 0) {
+        if (ndata <= 8) ACX_BAND(2, 0);
+        else if (ndata <= 16) ACX_BAND(4, 0);
+        else ACX_BAND(8, 0);
+        return true;
+    }
+    // the opt-in f16x2 Gram: the default stack size only
+    if constexpr (M == 9) {
+        if (arith != 1) return false;
+        if (ndata <= 8) ACX_BAND(2, 1);
+        else if (ndata <= 16) ACX_BAND(4, 1);
+        else ACX_BAND(8, 1);
+        return true;
+    }
+    return false;
 #undef ACX_BAND_K
 #undef ACX_BAND
 }
 
 }  // namespace
 
-bool launch_band_kernel(const BandLaunch &L, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2, int want_eps)
+bool launch_band_kernel(const BandLaunch &L, int m, const PairDesc *dpd, int B, int maxRows, int maxCols, int role, int write_d2, int want_eps, int arith)
 {
     switch (m) {
-#define ACX_CASE(M_) case M_: launch_band_m<M_>(L, dpd, B, maxRows, maxCols, role, write_d2, want_eps); return true;
+#define ACX_CASE(M_) case M_: return launch_band_m<M_>(L, dpd, B, maxRows, maxCols, role, write_d2, want_eps, arith);
 #ifdef ACX_FAST_BUILD   /* development builds: only the default stack size */
 #ifndef ACX_FAST_BUILD_M
 #define ACX_FAST_BUILD_M 9

@@ -897,6 +897,31 @@ static __global__ void rotpool_kernel(const float *__restrict__ pool, float *__r
     }
 }
 
+// The same pool for the opt-in f16x2 Gram (acx_serra09_params.arith = ACX_ARITH_F16X2): every bin value as TWO fp16 terms
+// x = h1 + h2 (h1 = fp16(x), h2 = fp16(x - h1): 22-23 significant bits, fp16 subnormals are kept by the matrix pipe), and per
+// (frame, r, cls) the 8 halfs [h1(b0) h1(b1) h1(b2) h2(b0) h2(b1) h2(b2) h1(b0) h1(b1)], b_j = cls + 4 ((r + j) mod 3): exactly the
+// first 8 k-slots of the COLUMN operand of v_mfma_f32_16x16x32_f16 (one 16-byte load per lane and 16-frame block); the ninth
+// slot (h1(b2)) and the row operand's arrangement [h1 h1 h1 | h1 h1 h1 | h2 h2 h2] are made from the same 16 bytes in registers.
+// Products per bin: x1 y1 + x1 y2 + x2 y1 + x2 y2 (12 of the 16 k-slots a lane has in two instructions), exact in f32, accumulated by the pipe.
+constexpr int FH = 12 * 8;         // halfs per frame of the f16 operand pool (192 bytes)
+static __global__ void rotpool_f16_kernel(const float *__restrict__ pool, _Float16 *__restrict__ fh, int64_t nframes)
+{
+    const int64_t total = nframes * 12, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {     // one (frame, r, cls) entry each
+        const int64_t f = idx / 12;
+        const int e = (int)(idx - f * 12), r = e >> 2, cls = e & 3;
+        _Float16 h1[3], h2[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float x = pool[f * NBIN + cls + 4 * ((r + j) % 3)];
+            h1[j] = (_Float16)x;
+            h2[j] = (_Float16)(x - (float)h1[j]);
+        }
+        _Float16 *o = fh + idx * 8;
+        o[0] = h1[0]; o[1] = h1[1]; o[2] = h1[2]; o[3] = h2[0]; o[4] = h2[1]; o[5] = h2[2]; o[6] = h1[0]; o[7] = h1[1];
+    }
+}
+
 // Pool decimated by the stack stride tau: frame t of the output track = frame t tau of the input
 // track (grid: x = track, y = chunks of 256 floats).
 static __global__ void decimate_kernel(const float *__restrict__ in, const int64_t *__restrict__ toff_in,
@@ -915,7 +940,7 @@ static __global__ void decimate_kernel(const float *__restrict__ in, const int64
 // can be compiled with the scheduling strategy that suits it without touching the others.
 struct BandLaunch {
     hipStream_t stream;
-    const float *frot;
+    const float *frot;              // arith 0: rotated f32 frame pool; arith 1 (f16x2): the f16 operand pool, same pointer slot
     const int64_t *toff;
     const float *normtab;
     const int64_t *noff;
@@ -926,8 +951,9 @@ struct BandLaunch {
 };
 // role 1 / 0 over B pairs of one size class; false when the stack size m has no instantiation
 // (want_eps: also evaluate and store every row's eps -- the debug entry point; the production passes skip it where they can)
+// (arith: 0 = the exact f32 Gram, 1 = the opt-in f16x2 Gram, m = 9 only; L.frot then points at the f16 operand pool)
 bool launch_band_kernel(const BandLaunch &L, int m, const struct PairDesc *dpd, int B, int maxRows, int maxCols, int role,
-                        int write_d2, int want_eps);
+                        int write_d2, int want_eps, int arith);
 
 // development builds only (scripts/ab_build.sh ablN -DACX_ABL=N): the band kernel stops behind stage N -- 1 sweep, 2 exchange +
 // row read, 3 selection, 4 eps / threshold -- so that instruction counters (rocprofv3 --pmc SQ_INSTS_*) can be read per stage
@@ -950,7 +976,7 @@ struct StampT { unsigned long long t; int base; };
 #ifndef ACX_NARROW_WAVES
 #define ACX_NARROW_WAVES 8      /* waves per SIMD of the narrowest class (m <= 9): 8 = four workgroups per CU, 6 = three */
 #endif
-template <int M, int V4 = 8>
+template <int M, int V4 = 8, int ARITH = 0>
 struct BandGeom {
     static constexpr int NRT = (BAND + M - 1 + 15) / 16;            // 16-row MFMA tiles of row frames
     static constexpr int NCT = (64 + BAND - 1 + M - 1 + 15) / 16;   // 16-col MFMA tiles of column frames
@@ -964,7 +990,9 @@ struct BandGeom {
 #ifndef ACX_MID_WAVES
 #define ACX_MID_WAVES 8         /* waves per SIMD of the middle class (rows of <= 1017 cells, m <= 9): packed slabs + ONE operand register set (SINGLE_BV) */
 #endif
-    static constexpr bool PACKED = M <= 9 && ((V4 <= 2 && ACX_NARROW_WAVES >= 8) || (V4 == 4 && ACX_MID_WAVES >= 8));
+    // (f16x2 Gram: its four-dword column operands do not fit the middle class's 64 registers -- 5 to 9 spills, 13 % slower than the
+    // exact kernel -- so that class keeps three workgroups per CU and both operand sets there)
+    static constexpr bool PACKED = M <= 9 && ((V4 <= 2 && ACX_NARROW_WAVES >= 8) || (V4 == 4 && ACX_MID_WAVES >= 8 && ARITH == 0));
     static constexpr int SP = PACKED ? BW : BW + 4;
 };
 
@@ -1208,12 +1236,12 @@ __device__ __forceinline__ void band_row_tail(float (&xr)[NV], float *smem, int 
 }
 
 // (short-row variants: 6 waves / SIMD = 3 workgroups per CU; m >= 10 needs two MFMA row tiles and is LDS-limited anyway)
-constexpr int band_waves_per_simd(int m, int v4) { return (v4 <= 2 && m <= 9) ? ACX_NARROW_WAVES : ((v4 <= 4 && m <= 9) ? ACX_MID_WAVES : 4); }
+constexpr int band_waves_per_simd(int m, int v4, int arith = 0) { return (v4 <= 2 && m <= 9) ? ACX_NARROW_WAVES : ((v4 <= 4 && m <= 9) ? (arith ? 6 : ACX_MID_WAVES) : 4); }
 // WD2: the debug entry point's variant, which also writes the band's distances to HBM (D2, query-major) -- a
 // template parameter, not a flag: as a run-time flag hipcc folds it into the per-cell store predicates and every
 // tile of the production kernel pays 24 VALU + 40 SALU instructions for stores that never happen.
-template <int M, int V4, int ROLE, bool WD2 = false>
-__global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band_kernel(const float *__restrict__ frot,
+template <int M, int V4, int ROLE, bool WD2 = false, int ARITH = 0>
+__global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4, ARITH)) void band_kernel(const float *__restrict__ frot,
                                                             const int64_t *__restrict__ toff,
                                                             const float *__restrict__ normtab,
                                                             const int64_t *__restrict__ noff,
@@ -1224,7 +1252,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
                                                             float kappa, int pct_mode, int inclusive, int oti_target, int want_eps)
 {
     constexpr bool write_d2 = WD2;
-    using G = BandGeom<M, V4>;
+    using G = BandGeom<M, V4, ARITH>;
     constexpr int role = ROLE;           // 1: rows = reference frames (column thresholds); 0: rows = query frames
     constexpr int NV = 4 * V4;           // values per lane of a complete row
     constexpr int NSTEP = NV / 8;        // tiles per wave
@@ -1265,25 +1293,47 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     const int lr = lane & 15, lk = lane >> 4;
     int c0a = lk - rota; if (c0a < 0) c0a += NBIN;
     int c0b = lk - rotb; if (c0b < 0) c0b += NBIN;
-    const int offA = (c0a >> 2) * NBIN + (c0a & 3) * 3;
-    const int offB = (c0b >> 2) * NBIN + (c0b & 3) * 3;
-    const float *fra = frot + (role ? P.fr : P.fq) * FROT + offA;
+    // ARITH 0: floats of the rotated f32 pool (FROT per frame, a triple per (r, cls)); ARITH 1: halfs of the f16 operand pool (FH per
+    // frame, 8 halfs per (r, cls) entry) -- `frot` then points at that pool.  PB = bytes per frame, offA / offB = byte offset of the
+    // lane's (r, cls) entry inside a frame.
+    constexpr unsigned PB = ARITH ? (unsigned)FH * 2u : (unsigned)FROT * 4u;
+    const unsigned offA = ARITH ? (unsigned)(((c0a >> 2) * 4 + (c0a & 3)) * 16) : (unsigned)(((c0a >> 2) * NBIN + (c0a & 3) * 3) * 4);
+    const unsigned offB = ARITH ? (unsigned)(((c0b >> 2) * 4 + (c0b & 3)) * 16) : (unsigned)(((c0b >> 2) * NBIN + (c0b & 3) * 3) * 4);
+    const char *pool_b = reinterpret_cast<const char *>(frot);
+    const char *fra = pool_b + (role ? P.fr : P.fq) * (int64_t)PB + offA;
     // column-frame operands go through a buffer descriptor: scalar base + scalar offset (the tile) + one 32-bit
     // lane offset -- no 64-bit VALU address arithmetic in the tile loop.  The descriptor starts 8 frames before
     // the track (a tile reaches back 7 frames: pool slack / the neighbouring track), no range check.
     const __amdgpu_buffer_rsrc_t rsB =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(frot + ((role ? P.fq : P.fr) - 8) * FROT), 0, -1, 0x00020000);
-    const unsigned voffB = (unsigned)(offB + lr * FROT) * 4u;     // this lane's byte offset inside a 16-frame block
-    const float *frb = frot + (role ? P.fq : P.fr) * FROT + offB;   // (short-row classes: per-lane pointer, plain global loads)
+        __builtin_amdgcn_make_buffer_rsrc((void *)(pool_b + ((role ? P.fq : P.fr) - 8) * (int64_t)PB), 0, -1, 0x00020000);
+    const unsigned voffB = offB + (unsigned)lr * PB;              // this lane's byte offset inside a 16-frame block
+    const char *frb = pool_b + (role ? P.fq : P.fr) * (int64_t)PB + offB;   // (short-row classes: per-lane pointer, plain global loads)
     typedef float f32x3 __attribute__((ext_vector_type(3)));
     typedef f32x3 f32x3_u __attribute__((aligned(4)));
+    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+    typedef u32x3 u32x3_u __attribute__((aligned(4)));
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    // row-frame operands, resident for the whole band.  ARITH 0: three floats (the k-steps of the f32 chain).  ARITH 1: the row
+    // arrangement [h1 h1 h1 | h1 h1 h1 | h2 h2 h2] of the entry's first three dwords w0 = (h1b0, h1b1), w1 = (h1b2, h2b0),
+    // w2 = (h2b1, h2b2): slots 0-7 in ah8, slot 8 in ah9 (the other slots of that second instruction are zero).
     float areg[G::NRT][3];
+    f16x8 ah8[G::NRT], ah9[G::NRT];
 #pragma unroll
     for (int ta = 0; ta < G::NRT; ++ta) {
         int f = i0 + 16 * ta + lr;
         f = f > TA - 1 ? TA - 1 : f;           // rows beyond the matrix are masked below
-        const f32x3 v = *reinterpret_cast<const f32x3_u *>(fra + (size_t)f * FROT);
-        areg[ta][0] = v.x; areg[ta][1] = v.y; areg[ta][2] = v.z;
+        if constexpr (ARITH == 0) {
+            const f32x3 v = *reinterpret_cast<const f32x3_u *>(fra + (size_t)f * PB);
+            areg[ta][0] = v.x; areg[ta][1] = v.y; areg[ta][2] = v.z;
+        } else {
+            const u32x3 w = *reinterpret_cast<const u32x3_u *>(fra + (size_t)f * PB);
+            const u32x4v a = {w.x, (w.y & 0xffffu) | (w.x << 16), (w.x >> 16) | (w.y << 16), (w.y >> 16) | (w.z << 16)};
+            const u32x4v a9 = {(w.z >> 16) | (w.y & 0xffff0000u), w.z, 0u, 0u};       // slots 8-11: h2b2 | h2b0 h2b1 h2b2
+            ah8[ta] = __builtin_bit_cast(f16x8, a);
+            ah9[ta] = __builtin_bit_cast(f16x8, a9);
+        }
     }
     float xrow[BAND];
 #pragma unroll
@@ -1296,7 +1346,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
 #endif
 
     const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= NV by dispatch
-    typedef float BvT[G::NCT][3];
+    typedef unsigned BvT[G::NCT][ARITH ? 4 : 3];       // column-frame operands of a tile: dwords per 16-frame block and lane
     typedef f32x4 AccT[G::NRT][G::NCT];
     // column-frame operands of a tile (frames 64 tile - 7 ... + BW)
     // (tb0: first 16-frame block wanted -- a wave's second and later tiles inherit their first HB
@@ -1308,20 +1358,29 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
         const int base = 64 * tile - (BAND - 1);
         if constexpr (V4 >= 8) {
             // wide rows (four tiles per wave): buffer loads, scalar tile offset + 32-bit lane offset (-1.7 % at T = 2000)
-            const unsigned so = (unsigned)((base + 8) * FROT) * 4u;             // wave-uniform byte offset of the tile
-            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+            const unsigned so = (unsigned)(base + 8) * PB;                        // wave-uniform byte offset of the tile
 #pragma unroll
             for (int tb = tb0; tb < G::NCT; ++tb) {
-                const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rsB, voffB, so + 16u * FROT * 4u * tb, 0);
-                bv[tb][0] = __uint_as_float(v.x); bv[tb][1] = __uint_as_float(v.y); bv[tb][2] = __uint_as_float(v.z);
+                if constexpr (ARITH == 0) {
+                    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rsB, voffB, so + 16u * PB * tb, 0);
+                    bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
+                } else {
+                    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB, so + 16u * PB * tb, 0);
+                    bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z; bv[tb][3] = v.w;
+                }
             }
         } else {
             // short rows (one or two tiles per wave): plain global loads measure 4 % faster on the covers80-shaped set
-            const float *p = frb + (ptrdiff_t)(base + lr) * FROT;
+            const char *p = frb + (ptrdiff_t)(base + lr) * (ptrdiff_t)PB;
 #pragma unroll
             for (int tb = tb0; tb < G::NCT; ++tb) {
-                const f32x3 v = *reinterpret_cast<const f32x3_u *>(p + 16 * FROT * tb);
-                bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
+                if constexpr (ARITH == 0) {
+                    const u32x3 v = *reinterpret_cast<const u32x3_u *>(p + 16 * PB * tb);
+                    bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
+                } else {
+                    const u32x4v v = *reinterpret_cast<const u32x4v *>(p + 16 * PB * tb);
+                    bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z; bv[tb][3] = v.w;
+                }
             }
         }
     };
@@ -1342,17 +1401,48 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
     // that no MFMA waits on its predecessor.
     auto gram = [&](const BvT &bv, AccT &acc, auto tb0_tag) {
         constexpr int tb0 = decltype(tb0_tag)::value;
+        // (ARITH 1: the zero is opaque to the compiler, so that the first MFMA of a block takes its accumulator from REGISTERS and
+        // writes them back -- with the constant 0 as srcC the destination is a fresh allocation that may land on the dying column
+        // operand, and v_mfma_f32_16x16x32_f16 then returns garbage: scripts/ubench/mfma_f16_probe.hip before its operands were
+        // kept alive)
+        float zero = 0.0f;
+        if constexpr (ARITH != 0) asm volatile("" : "+v"(zero));
 #pragma unroll
         for (int ta = 0; ta < G::NRT; ++ta)
 #pragma unroll
-            for (int tb = tb0; tb < G::NCT; ++tb) acc[ta][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int tb = tb0; tb < G::NCT; ++tb) acc[ta][tb] = f32x4{zero, zero, zero, zero};
+        if constexpr (ARITH == 0) {
 #pragma unroll
-        for (int kb = 0; kb < 3; ++kb)
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int ta = 0; ta < G::NRT; ++ta)
+#pragma unroll
+                    for (int tb = tb0; tb < G::NCT; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(bv[tb][kb]), areg[ta][kb], acc[ta][tb], 0, 0, 0);
+        } else {
+            // f16x2: slots 0-7 on one v_mfma_f32_16x16x32_f16, slot 8 (h1(b2) of the column frame = the low half of its second
+            // dword, h2(b2) of the row frame) on a second one whose other slots are zero: 2 x 16 cycles of the f16 matrix pipe --
+            // which runs BESIDE other waves' VALU work -- instead of 3 x 32 cycles of f32 MFMAs that block the SIMD.
+            // (Measured on the way, scripts/ubench/mfma_f16_probe.hip and the mid / wide classes of this kernel: the K = 16
+            // instruction v_mfma_f32_16x16x16_f16 chained behind the K = 32 one gave garbage in kernels with more than one
+            // tile per wave although the operands were right -- the same loads through f32 MFMAs are exact --, and a K = 32
+            // instruction whose destination is allocated over its SECOND source operand returns that operand's bits.  Hence:
+            // one opcode only, and the row operands stay alive to the end of the sweep.)
 #pragma unroll
             for (int ta = 0; ta < G::NRT; ++ta)
 #pragma unroll
-                for (int tb = tb0; tb < G::NCT; ++tb)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[tb][kb], areg[ta][kb], acc[ta][tb], 0, 0, 0);
+                for (int tb = tb0; tb < G::NCT; ++tb) {
+                    const u32x4v b8 = {bv[tb][0], bv[tb][1], bv[tb][2], bv[tb][3]};
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b8), ah8[ta], acc[ta][tb], 0, 0, 0);
+                }
+#pragma unroll
+            for (int ta = 0; ta < G::NRT; ++ta)
+#pragma unroll
+                for (int tb = tb0; tb < G::NCT; ++tb) {
+                    const u32x4v b9 = {bv[tb][1], bv[tb][2], 0u, 0u};                   // slots 8-11: h1b2 | h2b0 h2b1 h2b2 (x2 y1 of b2, then x2 y2)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b9), ah9[ta], acc[ta][tb], 0, 0, 0);
+                }
+        }
     };
     auto store_gram = [&](const AccT &acc, auto tb0_tag) {
         constexpr int tb0 = decltype(tb0_tag)::value;
@@ -1454,6 +1544,12 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4)) void band
             for (int a = 0; a < BAND; ++a) xv[a][st] = PADV;
         }
     });
+    if constexpr (ARITH != 0) {
+        // (the row operands outlive every MFMA that reads them: an empty statement that also takes the last tile's cells cannot
+        // be scheduled before the last Gram, so no MFMA destination can be allocated over ah8 / ah9)
+#pragma unroll
+        for (int ta = 0; ta < G::NRT; ++ta) asm volatile("" :: "v"(ah8[ta]), "v"(ah9[ta]), "v"(xv[0][NSTEP - 1]), "v"(xv[BAND - 1][0]));
+    }
     // debug / v1 consumers: +inf into the pad columns [MB, pitchD) of the band's rows
     if constexpr (write_d2) {
         const int npad = pitchD - MB;

@@ -775,8 +775,8 @@ def main():
             # the watchdog prints the line as it stands and ends the process.
             import bench_other
             line["other"] = {}
-            legs = (("serra09_covers", bench_other.serra09_covers_leg), ("simple", bench_other.simple_leg),
-                    ("earlyfusion", bench_other.earlyfusion_leg))
+            legs = (("serra09_covers", bench_other.serra09_covers_leg), ("serra09_f16x2", bench_other.serra09_f16x2_leg),
+                    ("simple", bench_other.simple_leg), ("earlyfusion", bench_other.earlyfusion_leg))
 
             def watchdog():
                 clock.stamp("watchdog: the `other` legs hang; printing the headline line without them")

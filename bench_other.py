@@ -130,6 +130,48 @@ def serra09_covers_leg(ctx, steps=5, warmup=1, cpu_pairs=192):
                                    "bit-identical to the GPU's (also 32 pairs of the length mix)" % (cpu_pairs, tcpu)}}
 
 
+def serra09_f16x2_leg(ctx, n=96, T=2000, reps=3):
+    """The opt-in f16x2 Gram of the band kernel (include/acx.h ACX_ARITH_F16X2) beside the exact one on the headline's shape:
+    all pairs of `n` i.i.d. tracks of `T` frames, both arithmetics, the same pair list -- pairs/s of each, how many scores
+    agree, and on two pairs the fraction of recurrence-plot cells that flip (acx_serra09_debug_pair in both modes).  NOT part of
+    the headline: the default and the timed region of bench.py stay on the exact arithmetic."""
+    from acoss_amd import _lib, synth
+    d = synth.rand_set(n, T=T, seed=4242)
+    ctx.upload_pool(d["frames"], d["offsets"])
+    i, j = np.triu_indices(n, 1)
+    pairs = np.ascontiguousarray(np.stack([i, j], 1).astype(np.int32))
+    res = {}
+    for ar in ("exact", "f16x2"):
+        p = _lib.serra09_params(arith=ar)
+        ctx.serra09_pairs(pairs[:512], p)
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            sc = ctx.serra09_pairs(pairs, p)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        res[ar] = (sc, len(pairs) / best)
+    diff = np.abs(res["exact"][0] - res["f16x2"][0])
+    flips = cells = 0
+    for (a, b) in ((0, 1), (2, 3)):
+        e = ctx.serra09_debug_pair(a, b, _lib.serra09_params())
+        f = ctx.serra09_debug_pair(a, b, _lib.serra09_params(arith="f16x2"))
+        Re = (e["d2"] <= e["thr_q"][:, None]) & (e["d2"] <= e["thr_r"][None, :])
+        Rf = (f["d2"] <= f["thr_q"][:, None]) & (f["d2"] <= f["thr_r"][None, :])
+        flips += int(np.sum(Re != Rf))
+        cells += Re.size
+    return {
+        "metric": "track-pairs/sec, Serra09 Qmax with the opt-in f16x2 Gram (T = %d), beside the exact arithmetic on the same pairs" % T,
+        "value": round(res["f16x2"][1], 1), "unit": "track-pairs/s", "n_gpus": 1, "steps": reps, "warmup": 1, "higher_is_better": True,
+        "dtype": "f16 x 2 terms -> f32", "data": "synthetic",
+        "config": {"workload": "%d i.i.d. tracks x %d frames (seed 4242), all %d pairs through acx_serra09_pairs, best of %d" % (n, T, len(pairs), reps)},
+        "exact_value": round(res["exact"][1], 1), "speedup_vs_exact": round(res["f16x2"][1] / res["exact"][1], 3),
+        "scores_identical_fraction": round(float(np.mean(diff == 0)), 4), "scores_within_2_fraction": round(float(np.mean(diff <= 2.0)), 5),
+        "max_score_diff": float(diff.max()), "flipped_cell_fraction": flips / float(cells), "flipped_cells": [flips, cells],
+        "note": "as accurate against f64 as the exact chain (scripts/f16x2_debug6.py: rms 4.1e-6 on d^2 in both), not the same bits: "
+                "a few cells per 10 000 change side of a threshold"}
+
+
 def simple_leg(ctx, steps=5, warmup=1, n=1536, tiles_per_step=16, cpu_pairs=64):
     """SiMPle (simple_silva.py:120-126): ordered pairs of tracks of 12 x 150-250 pooled frames through the pair grid
     (acx_grid_run: pairs enumerated on the device, f64 kernel, f32 scatter into a device buffer).  The pool holds
@@ -292,6 +334,7 @@ def main():
     from acoss_amd import _lib
     ctx = _lib.Context(0)
     print(json.dumps(serra09_covers_leg(ctx, args.steps, args.warmup)), flush=True)
+    print(json.dumps(serra09_f16x2_leg(ctx)), flush=True)
     print(json.dumps(simple_leg(ctx, args.steps, args.warmup)), flush=True)
     print(json.dumps(earlyfusion_leg(ctx, args.steps, args.warmup, cpu_pairs=args.cpu_pairs)), flush=True)
     ctx.close()

@@ -129,7 +129,21 @@ typedef struct {
     int32_t dp_start;    /* 2 or 3 */
     int32_t inclusive;   /* 1: d <= eps  0: d < eps */
     int32_t dmax;        /* 0 Qmax ('serra09')  1 Dmax ('chen17') */
+    int32_t arith;       /* ACX_ARITH_EXACT (default) or ACX_ARITH_F16X2, see below (ABI 2: new last field) */
 } acx_serra09_params;
+
+/*
+ * Arithmetic of the frame Gram behind the distance matrix (everything else is the same code in both):
+ *   ACX_ARITH_EXACT  v_mfma_f32_16x16x4_f32 chains: the f32 spec the oracle reproduces bit for bit
+ *   ACX_ARITH_F16X2  opt-in, m = 9 only: every bin value as two fp16 terms x = h1 + h2 (22-23 significant bits; the matrix pipe
+ *                    keeps fp16 subnormals), products x1 y1 + x1 y2 + x2 y1 on v_mfma_f32_16x16x32_f16 + 16x16x16_f16, which run
+ *                    beside other waves' VALU work where an f32 MFMA blocks the SIMD.  As accurate as the f32 chain against f64
+ *                    (2e-7 relative, scripts/ubench/mfma_f16_probe.hip) but NOT the same bits: scores are graded by north_star's
+ *                    tolerance (|score difference| <= 2.0, identical MAP / MR on cover sets; tests/test_gpu_serra09.py), the
+ *                    default and bench.py's headline stay exact.  Pairs beyond the band kernel (rows of more than 2041 cells)
+ *                    take the exact streaming kernels in either mode.
+ */
+enum { ACX_ARITH_EXACT = 0, ACX_ARITH_F16X2 = 1 };
 
 void acx_serra09_default_params(acx_serra09_params *p);
 

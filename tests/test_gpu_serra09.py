@@ -473,3 +473,61 @@ def test_benchmark_end_to_end_from_feature_files(tmp_path, monkeypatch):
     assert got[:4] == want[:4] and np.array_equal(got[4], want[4])
     assert np.array_equal(np.load("cache/Serra09_toy_Ds.npz")["main"] / 1.0, np.load("cache/Serra09_toy_Ds.npz")["main"])
     assert open("results_toy_Serra09.csv").read().startswith("name, MR, MRR, MDR, MAP,Top-1,Top-10,Top-100,Top-1000")
+
+
+def test_f16x2_gram_is_an_equally_accurate_different_arithmetic(ctx):
+    """The opt-in f16x2 Gram (acx_serra09_params.arith = ACX_ARITH_F16X2; Serra09(engine={"arith": "f16x2"})): two-term fp16
+    splits, all four term products, on v_mfma_f32_16x16x32_f16.  NOT bit-identical to the f32 spec -- this test pins the
+    envelope that was measured (profiles/r04_f16x2.md):
+      * squared distances within 3e-5 of the exact mode's (both sit at ~4e-6 rms from f64) in every size class and with a
+        transposition;
+      * a few cells per 10 000 change side of a threshold; >= 80 % of the scores of a covers80-shaped set identical, >= 99 % within
+        north_star's 2.0, none beyond 6.0; MR / Top-1 identical and |dMAP| <= 1e-4 on an easy AND a hard cover set;
+      * stack sizes other than 9 are refused, pairs beyond the band kernel take the exact streaming kernels in either mode."""
+    import oracle
+    from acoss_amd import _lib, synth
+    pe, pf = _lib.serra09_params(), _lib.serra09_params(arith="f16x2")
+    rng = np.random.default_rng(1)
+    for T, shift in ((80, 5), (300, 0), (600, 3), (1200, 2), (2000, 9)):
+        q = rng.random((T, 12), dtype=np.float32); q /= q.max(axis=1, keepdims=True)
+        r = np.roll(q, shift, axis=1) + 0.3 * rng.random((T, 12), dtype=np.float32); r /= r.max(axis=1, keepdims=True)
+        ctx.upload_pool(np.concatenate([q, r]), np.array([0, T, 2 * T]))
+        e, f = ctx.serra09_debug_pair(0, 1, pe), ctx.serra09_debug_pair(0, 1, pf)
+        assert e["oti"] == f["oti"]
+        assert np.max(np.abs(e["d2"].astype(np.float64) - f["d2"])) <= 3e-5, T
+        Re = (e["d2"] <= e["thr_q"][:, None]) & (e["d2"] <= e["thr_r"][None, :])
+        Rf = (f["d2"] <= f["thr_q"][:, None]) & (f["d2"] <= f["thr_r"][None, :])
+        assert np.mean(Re != Rf) <= 1e-3, (T, float(np.mean(Re != Rf)))
+        assert abs(e["score"] - f["score"]) <= 6.0
+
+    def cliques(labels):
+        cl = {}
+        for i, l in enumerate(labels):
+            cl.setdefault(l, []).append(i)
+        return list(cl.values())
+    for d, lo in ((synth.covers80_shaped(seed=100, t_range=(150, 650)), 0.99), (synth.covers80_shaped(seed=7, t_range=(300, 600), noise=1.0, segment_keep=0.5), 0.3)):
+        n = len(d["offsets"]) - 1
+        ctx.upload_pool(d["frames"], d["offsets"])
+        pairs = oracle.all_pairs(n, True).astype(np.int32)
+        se, sf = ctx.serra09_pairs(pairs, pe), ctx.serra09_pairs(pairs, pf)
+        diff = np.abs(se - sf)
+        assert np.mean(diff == 0) >= 0.80 and np.mean(diff <= 2.0) >= 0.99 and diff.max() <= 6.0, (np.mean(diff == 0), np.mean(diff <= 2.0), diff.max())
+        st = []
+        for s in (se, sf):
+            D = np.zeros((n, n), np.float32)
+            D[pairs[:, 0], pairs[:, 1]] = s
+            D += D.T
+            D = (D / np.sqrt(np.diff(d["offsets"]).astype(np.float64))[None, :]).astype(np.float32)
+            st.append(oracle.eval_statistics(D, cliques(d["labels"]), topsidx=(1, 10)))
+        assert st[0][3] >= lo and abs(st[0][3] - st[1][3]) <= 1e-4, (st[0][3], st[1][3])
+        assert abs(st[0][0] - st[1][0]) <= 0.05 and st[0][4][0] == st[1][4][0], (st[0], st[1])
+    with pytest.raises(NotImplementedError):
+        ctx.serra09_pairs(pairs[:4], _lib.serra09_params(m=7, arith="f16x2"))
+    with pytest.raises(ValueError):
+        ctx.serra09_pairs(pairs[:4], _lib.serra09_params(arith=5))
+    # a pair beyond the band kernel (rows of more than 2041 cells) runs the exact streaming kernels in both modes
+    T = 2100
+    q = rng.random((T, 12), dtype=np.float32); r = rng.random((T, 12), dtype=np.float32)
+    ctx.upload_pool(np.concatenate([q, r]), np.array([0, T, 2 * T]))
+    one = np.array([[0, 1]], np.int32)
+    assert np.array_equal(ctx.serra09_pairs(one, pe), ctx.serra09_pairs(one, pf))
