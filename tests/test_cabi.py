@@ -33,6 +33,10 @@ def test_default_params_match_reference_ctor():
     # rqa_serra09.py:31-32: oti=True, kappa=0.095, tau=1, m=9 ; essentia gammas 0.5 / 0.5
     assert (p.m, p.tau, p.oti) == (9, 1, 1) and abs(p.kappa - 0.095) < 1e-7
     assert (p.gamma_o, p.gamma_e) == (0.5, 0.5)
+    # the struct ends with `arith` (ABI 2): the default is the exact f32 Gram, and the shim's layout is the header's (13 x 4 bytes)
+    import ctypes
+    assert p.arith == 0 and ctypes.sizeof(_lib.Serra09Params) == 52 and _lib.Serra09Params.arith.offset == 48
+    assert _lib.serra09_params(arith="f16x2").arith == 1 and _lib.serra09_params().arith == 0
     assert L.acx_serra09_embed_len(2000, p) == 1991 and L.acx_serra09_embed_len(9, p) == 0
 
 
