@@ -29,7 +29,18 @@ Also in the line:
                 fan-out over max(45, cores) chunks (the reference's joblib scheme,
                 algorithm_template.py:172-177, has 45), on a bounded sample of the same workload;
                 its scores are checked bit-for-bit against the GPU's.  Timed BEFORE the GPU is
-                initialised (the worker processes are forks).
+                initialised (the worker processes are forks; the pool is closed and joined first).
+  phases_s      wall seconds of every untimed phase (pool generation, the two CPU figures, context +
+                upload, warm-up, self-check, every `other` leg, total); the same stamps go to stderr as
+                they happen.  Every untimed phase has a wall budget; a leg that overruns is reported
+                as an error string, never at the cost of the line.
+  fence         what brackets the timed region: one GPU -> hipDeviceSynchronize through libacx (the
+                process imports neither torch nor pandas: cold shared-library page-in on a fresh box
+                was what made round 3's driver run take 27 minutes); N > 1 -> dist.barrier +
+                torch.cuda.synchronize.
+  other         companion legs outside the timed region (bench_other.py): Serra09 on covers80-shaped
+                lengths, the opt-in f16x2 Gram beside the exact one, SiMPle, EarlyFusion.
+`--strong` runs the path as ONE job instead (strong scaling, the whole grid, one final all-gather).
 """
 import argparse
 import contextlib

@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """
-bench_other.py -- the other two algorithms of the path at DA-TACOS-like per-track shapes (BASELINE.json
-configs[3] and [4]; one GPU).  bench.py (the driver's contract benchmark: Serra09) calls the two legs
-below after its own timed region and carries their results in the `other` object of its JSON line;
-run on its own this file prints one JSON line per algorithm with the same fields:
+bench_other.py -- the companion legs of bench.py (one GPU): Serra09 on the track lengths real collections have
+(BASELINE.json configs[1] shape), the opt-in f16x2 Gram beside the exact one on the headline's shape, and the other two
+algorithms at DA-TACOS-like per-track shapes (configs[3] and [4]).  bench.py (the driver's contract benchmark: Serra09 on
+configs[2]) calls the legs below after its own timed region and carries their results in the `other` object of its JSON
+line; run on its own this file prints one JSON line per leg with the same fields:
 
     python bench_other.py [--steps K] [--warmup W]
 
-Per leg: throughput in track-pairs/s with inputs resident in HBM (scores land in a device buffer), the
-dominant kernel against its roofline (HIP events on the library's stream), and the CPU oracle timed on
-a bounded sample (one thread) and compared with the GPU's scores.
+Per leg: throughput in track-pairs/s with inputs resident in HBM, the dominant kernel against its roofline (HIP events on
+the library's stream), and the CPU oracle timed on a bounded sample (one thread) and compared with the GPU's scores.  No
+torch in the process: device buffers come from libacx (acx_dev_alloc).
 """
 import argparse
 import json
