@@ -120,6 +120,8 @@ struct acx_ctx {
     acx::EfSegWg *d_segw2 = nullptr;   size_t segw2_cap = 0;
     acx::EfSegWg *d_segw3 = nullptr;   size_t segw3_cap = 0;
     bool ef_rect_attr = false;
+    int ef_split_fmt = 0;                             // what d_efs holds: 0 three bf16 terms, 1 two fp16 terms of x / d_efsc[row]
+    float *d_efsc[3] = {nullptr, nullptr, nullptr};   // fmt 1: the power-of-two scale of every pool row (ef_rowscale_kernel)
     // scratch (grow-only)
     float *d_scratch = nullptr; size_t scratch_cap = 0;   // floats
     float *d_thr = nullptr;     size_t thr_cap = 0;
@@ -776,6 +778,7 @@ static int stage_idx(acx_ctx *c, const int64_t *idx, int64_t n)
 // twice); the blocks of those tracks, each padded to a multiple of 16, become the rows / columns of one dense
 // matrix.  A grid tile of 128 x 128 tracks is exactly one rectangle; an arbitrary pair list degrades to
 // rectangles whose pair table is mostly -1 (their empty workgroup tiles return at once).
+static int ef_build_splits(acx_ctx *c, int fmt);
 namespace {
 constexpr int SEG_TRACKS = 128;
 struct SegBatch {
@@ -1003,6 +1006,8 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                 const int tiles_x = (maxN + acx::EF_TILE - 1) / acx::EF_TILE, tiles_y = (maxM + acx::EF_TILE - 1) / acx::EF_TILE;
                 ProfScope ps(c, KS_EFGEMM, cells);
                 // mfcc, ssm: bf16 matrix pipe on the three-term splits; chroma (cosine, rolled by the pair's OTI): f32 MFMA
+                if (c->ef_gemm != ACX_EF_GEMM_F32 && c->ef_split_fmt != (c->ef_gemm == ACX_EF_GEMM_F16X2 ? 1 : 0))
+                    if ((rc = ef_build_splits(c, c->ef_gemm == ACX_EF_GEMM_F16X2 ? 1 : 0)) != ACX_OK) return rc;
                 if (c->ef_gemm == ACX_EF_GEMM_F32) {
                     hipLaunchKernelGGL(acx::ef_gemm_kernel, dim3(tiles_x * tiles_y, B, 3), dim3(256), 0, c->stream,
                                        c->d_ef[0], c->d_ef[1], c->d_ef[2], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
@@ -1027,28 +1032,39 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                         if (seg.wgs.size() > 0x7fffffffu || seg.wgs3.size() > 0x7fffffffu)
                             return fail(c, ACX_ERR_UNSUPPORTED, "earlyfusion: batch too large for one launch");
                         if (!c->ef_rect_attr) {
-                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel<0>),
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel<0, 0>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
-                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel<1>),
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel<1, 0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel<0, 1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel<1, 1>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
                             c->ef_rect_attr = true;
                         }
+                        const bool f16 = c->ef_gemm == ACX_EF_GEMM_F16X2;
+                        const auto rect_eucl = f16 ? &acx::ef_gemm_rect_bf16x3_kernel<0, 1> : &acx::ef_gemm_rect_bf16x3_kernel<0, 0>;
+                        const auto rect_chroma = f16 ? &acx::ef_gemm_rect_bf16x3_kernel<1, 1> : &acx::ef_gemm_rect_bf16x3_kernel<1, 0>;
                         if (!seg.wgs2.empty()) {
                             if ((rc = ensure(c, c->d_segw2, c->segw2_cap, seg.wgs2.size())) != ACX_OK) return rc;
                             ACX_HIP(c, hipMemcpyAsync(c->d_segw2, seg.wgs2.data(), sizeof(acx::EfSegWg) * seg.wgs2.size(), hipMemcpyHostToDevice, c->stream));
-                            hipLaunchKernelGGL(acx::ef_gemm_rect_bf16x3_kernel<0>, dim3((unsigned)seg.wgs2.size(), 1, 2), dim3(acx::EFR_THREADS),
+                            hipLaunchKernelGGL(rect_eucl,
+                                               dim3((unsigned)seg.wgs2.size(), 1, 2), dim3(acx::EFR_THREADS),
                                                acx::EFR_LDS_BYTES, c->stream, c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd,
-                                               c->d_rects, c->d_segw2, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1]);
+                                               c->d_rects, c->d_segw2, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1],
+                                               c->d_efsc[0], c->d_efsc[1]);
                         }
                         // chroma (cosine, the first song rolled by the pair's OTI): the same kernel on the bin-major split
                         // pool; ACX_EF_GEMM_BF16X3_CHROMA_F32 (and block shapes the split does not cover): f32 MFMAs
-                        if (c->ef_gemm == ACX_EF_GEMM_BF16X3 && c->ef_kp[2] > 0) {
+                        if ((c->ef_gemm == ACX_EF_GEMM_BF16X3 || f16) && c->ef_kp[2] > 0) {
                             if (!seg.wgs3.empty()) {
                                 if ((rc = ensure(c, c->d_segw3, c->segw3_cap, seg.wgs3.size())) != ACX_OK) return rc;
                                 ACX_HIP(c, hipMemcpyAsync(c->d_segw3, seg.wgs3.data(), sizeof(acx::EfSegWg) * seg.wgs3.size(), hipMemcpyHostToDevice, c->stream));
-                                hipLaunchKernelGGL(acx::ef_gemm_rect_bf16x3_kernel<1>, dim3((unsigned)seg.wgs3.size(), 1, 1), dim3(acx::EFR_THREADS),
+                                hipLaunchKernelGGL(rect_chroma,
+                                                   dim3((unsigned)seg.wgs3.size(), 1, 1), dim3(acx::EFR_THREADS),
                                                    acx::EFR_LDS_BYTES, c->stream, c->d_efs[2], c->d_efs[2], (const float *)nullptr, (const float *)nullptr,
-                                                   c->d_efpd, c->d_rects, c->d_segw3, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[2], c->ef_kp[2]);
+                                                   c->d_efpd, c->d_rects, c->d_segw3, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[2], c->ef_kp[2],
+                                                   c->d_efsc[2], c->d_efsc[2]);
                             }
                         } else if (!seg.wgs.empty()) {
                             if ((rc = ensure(c, c->d_segw, c->segw_cap, seg.wgs.size())) != ACX_OK) return rc;
@@ -1783,10 +1799,35 @@ static void ef_free_pool(acx_ctx *c)
     for (int k = 0; k < 3; ++k) if (c->d_ef[k]) { (void)hipFree(c->d_ef[k]); c->d_ef[k] = nullptr; }
     for (int k = 0; k < 2; ++k) if (c->d_efn[k]) { (void)hipFree(c->d_efn[k]); c->d_efn[k] = nullptr; }
     for (int k = 0; k < 3; ++k) if (c->d_efs[k]) { (void)hipFree(c->d_efs[k]); c->d_efs[k] = nullptr; }
+    for (int k = 0; k < 3; ++k) if (c->d_efsc[k]) { (void)hipFree(c->d_efsc[k]); c->d_efsc[k] = nullptr; }
     if (c->d_efmed) { (void)hipFree(c->d_efmed); c->d_efmed = nullptr; }
     if (c->d_efoff) { (void)hipFree(c->d_efoff); c->d_efoff = nullptr; }
     c->ef_ntracks = 0;
     c->ef_open = 0;
+}
+
+// (Re)build the split pools the matrix-pipe GEMMs read from the f32 features: fmt 0 = three bf16 terms, fmt 1 = two
+// fp16 terms of x / inv[row] (ACX_EF_GEMM_F16X2; inv = the row's own power-of-two scale).  The pool keeps ONE of them
+// (69 GB at DA-TACOS size): switching between the modes re-splits.
+static int ef_build_splits(acx_ctx *c, int fmt)
+{
+    const int64_t nb = c->h_efoff.empty() ? 0 : c->h_efoff.back();
+    for (int k = 0; k < 3 && nb > 0; ++k) {
+        if (c->ef_kp[k] == 0 || !c->d_efs[k]) continue;
+        if (fmt == 1) {
+            if (!c->d_efsc[k]) {
+                ACX_HIP(c, hipMalloc((void **)&c->d_efsc[k], sizeof(float) * (nb + 32)));      // (+ slack: a group of 16 scales is read at once)
+                ACX_HIP(c, hipMemsetAsync(c->d_efsc[k], 0, sizeof(float) * (nb + 32), c->stream));
+            }
+            hipLaunchKernelGGL(acx::ef_rowscale_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, c->stream, c->d_ef[k], c->d_efsc[k], nb, c->ef_dims[k]);
+        }
+        const int64_t nthr = nb * c->ef_kp[k];
+        hipLaunchKernelGGL(acx::ef_split_bf16_kernel, dim3((unsigned)std::min<int64_t>((nthr + 255) / 256, 1 << 22)), dim3(256), 0, c->stream,
+                           c->d_ef[k], c->d_efs[k], nb, c->ef_dims[k], c->ef_kp[k], k == 2 ? 1 : 0, fmt == 1 ? c->d_efsc[k] : (const float *)nullptr);
+        ACX_HIP(c, hipGetLastError());
+    }
+    c->ef_split_fmt = fmt;
+    return ACX_OK;
 }
 
 // The block features are on the device (d_ef[0..2], d_efmed): unit-norm chroma rows in place
@@ -1823,12 +1864,10 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
         if (k == 2 && dims[2] % 96 != 0) { c->ef_kp[2] = 0; continue; }
         const int64_t nel = std::max<int64_t>(1, nb) * 3 * c->ef_kp[k];
         ACX_HIP(c, hipMalloc((void **)&c->d_efs[k], sizeof(unsigned short) * nel));
-        if (nb > 0) {
-            const int64_t nthr = nb * c->ef_kp[k];
-            hipLaunchKernelGGL(acx::ef_split_bf16_kernel, dim3((unsigned)std::min<int64_t>((nthr + 255) / 256, 1 << 22)), dim3(256), 0, c->stream,
-                               c->d_ef[k], c->d_efs[k], nb, dims[k], c->ef_kp[k], k == 2 ? 1 : 0);
-            ACX_HIP(c, hipGetLastError());
-        }
+    }
+    {
+        const int rc = ef_build_splits(c, c->ef_gemm == ACX_EF_GEMM_F16X2 ? 1 : 0);
+        if (rc != ACX_OK) { ef_free_pool(c); return rc; }
     }
     ACX_HIP(c, hipStreamSynchronize(c->stream));
     return ACX_OK;
@@ -1841,7 +1880,8 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
 int acx_set_ef_gemm(acx_ctx *c, int32_t mode)
 {
     if (!c) return ACX_ERR_INVALID;
-    if (mode != ACX_EF_GEMM_BF16X3 && mode != ACX_EF_GEMM_F32 && mode != ACX_EF_GEMM_BF16X3_PAIRWISE && mode != ACX_EF_GEMM_BF16X3_CHROMA_F32)
+    if (mode != ACX_EF_GEMM_BF16X3 && mode != ACX_EF_GEMM_F32 && mode != ACX_EF_GEMM_BF16X3_PAIRWISE && mode != ACX_EF_GEMM_BF16X3_CHROMA_F32 &&
+        mode != ACX_EF_GEMM_F16X2)
         return fail(c, ACX_ERR_INVALID, "set_ef_gemm: unknown mode");
     c->ef_gemm = mode;
     return ACX_OK;

@@ -276,10 +276,37 @@ __device__ __forceinline__ unsigned ef_bf16_rne(float x)
     return u >> 16;
 }
 
+// ACX_EF_GEMM_F16X2: the power-of-two scale of every pool row (one wave per row).  inv[row] = 2^(e - 15) with
+// max |x| of the row = f 2^e, f in [0.5, 1): scale * x = x / inv lies in [2^14, 2^15) for the row's largest value, so
+// the second fp16 term of every value within 2^-17 of it is a normal number (smaller ones lose bits that are below
+// 2^-39 of the row's largest value -- nothing an f32 dot product of the row keeps either).  The scale depends on the
+// ROW alone: a track's operands, and with them a pair's score, do not depend on what else is in the pool.
+__global__ __launch_bounds__(256) void ef_rowscale_kernel(const float *__restrict__ f, float *__restrict__ inv, int64_t nblocks, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nblocks) return;
+    unsigned m = 0;
+    for (int k = lane; k < K; k += 64) {
+        const unsigned u = __float_as_uint(f[row * K + k]) & 0x7fffffffu;       // (non-negative floats order like their bits)
+        m = u > m ? u : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned v = (unsigned)__shfl_xor((int)m, o, 64);
+        m = v > m ? v : m;
+    }
+    if (lane == 0) {
+        int e = (int)(m >> 23) - 126;                                           // frexp's exponent (subnormal / zero rows: clamped below)
+        e = e < -95 ? -95 : (e > 110 ? 110 : e);
+        inv[row] = __uint_as_float((unsigned)(e - 15 + 127) << 23);
+    }
+}
+
 // (grid-stride: a launch carries at most 2^32 - 1 work-items per dimension, and a DA-TACOS-sized pool has 7.5e9
 // split values per feature -- a one-thread-per-value grid wraps silently and leaves the tail of the pool unwritten)
 __global__ __launch_bounds__(256) void ef_split_bf16_kernel(const float *__restrict__ f, unsigned short *__restrict__ out,
-                                                            int64_t nblocks, int K, int Kp, int binmajor)
+                                                            int64_t nblocks, int K, int Kp, int binmajor, const float *__restrict__ inv)
 {
     const int64_t total = nblocks * Kp, stride = (int64_t)gridDim.x * 256;
     const int G = K / 12;                                             // (binmajor: frames of a chroma block)
@@ -289,11 +316,23 @@ __global__ __launch_bounds__(256) void ef_split_bf16_kernel(const float *__restr
         // binmajor (chroma, K = 12 G): position k = G bin + frame of the split row takes value 12 frame + bin of the block
         const int ks = binmajor ? 12 * (k % G) + k / G : k;
         const float x = k < K ? f[row * K + ks] : 0.0f;
-        const unsigned h1 = ef_bf16_rne(x);
-        const float r1 = x - __uint_as_float(h1 << 16);            // exact
-        const unsigned h2 = ef_bf16_rne(r1);
-        const float r2 = r1 - __uint_as_float(h2 << 16);           // exact
-        const unsigned h3 = ef_bf16_rne(r2);
+        unsigned h1, h2, h3;
+        if (!inv) {
+            h1 = ef_bf16_rne(x);
+            const float r1 = x - __uint_as_float(h1 << 16);            // exact
+            h2 = ef_bf16_rne(r1);
+            const float r2 = r1 - __uint_as_float(h2 << 16);           // exact
+            h3 = ef_bf16_rne(r2);
+        } else {
+            // ACX_EF_GEMM_F16X2: two fp16 terms of x / inv[row] (ef_rowscale_kernel; a power of two: its reciprocal by
+            // the exponent bits); term 3 stays zero and is never staged
+            const float xs = x * __uint_as_float(0x7F000000u - __float_as_uint(inv[row]));      // exact
+            const _Float16 a = (_Float16)xs;
+            const _Float16 b = (_Float16)(xs - (float)a);              // (the remainder is exact in f32)
+            h1 = __builtin_bit_cast(unsigned short, a);
+            h2 = __builtin_bit_cast(unsigned short, b);
+            h3 = 0;
+        }
         // [block][k / 32][term][k % 32]: the three terms of a 32-k chunk are 192 contiguous bytes, so the GEMM's three
         // 64-byte reads per row and chunk share their 128-byte lines
         unsigned short *o = out + row * 3 * Kp + (int64_t)(k / EFB_BK) * (3 * EFB_BK) + (k % EFB_BK);
@@ -453,12 +492,18 @@ constexpr int EFR_LDS_BYTES = 2 * 2 * (EFR_A + EFR_B) + 8 * 16 * EFR_TP * 4;    
 __device__ unsigned long long g_ef_clk[16];          // [0] start-up, [1] k loop, [2] epilogue until the last store is issued, [3] until it is acknowledged, [15] waves
 #endif
 
-template <int CH>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// F16 = 1 (ACX_EF_GEMM_F16X2): the pool holds TWO fp16 terms of x / inv[row] (ef_split_bf16_kernel with row scales) and
+// a cell takes FOUR v_mfma_f32_16x16x32_f16 per chunk -- x2 y2, x1 y2, x2 y1, x1 y1 -- instead of six bf16 ones: 22
+// significant bits of every value instead of all 24, two thirds of the MFMAs, LDS stores and pool reads.  The epilogue
+// multiplies a product by inv[row] inv[column] (powers of two: exact): inv0 / inv1 = the row scales of split0 / split1.
+template <int CH, int F16 = 0>
 __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ef_gemm_rect_bf16x3_kernel(
     const unsigned short *__restrict__ split0, const unsigned short *__restrict__ split1, const float *__restrict__ nrm0,
     const float *__restrict__ nrm1, const EfPair *__restrict__ pd, const EfSegRect *__restrict__ rects,
     const EfSegWg *__restrict__ wgs, const EfSegGroup *__restrict__ rowg, const EfSegGroup *__restrict__ colg, const int32_t *__restrict__ pairtab,
-    float *__restrict__ scratch, int Kp0, int Kp1)
+    float *__restrict__ scratch, int Kp0, int Kp1, const float *__restrict__ inv0, const float *__restrict__ inv1)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short efr_lds[];
     unsigned short *As = efr_lds;                    // [buffer][term][row][32 k]
@@ -509,10 +554,12 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     const unsigned long long clkA_ = __builtin_readcyclecounter();     // the wave's groups and pairs are known
 #endif
     f32x4 acc[NA][NB];
+    float zero_ = 0.0f;
+    if (F16) asm volatile("v_mov_b32 %0, 0" : "=v"(zero_));     // (a register, not the inline constant: see band_kernel's note on this MFMA's destination)
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{zero_, zero_, zero_, zero_};
 
     // staging: thread -> 16-byte piece tid % 4 of rows tid / 4 and 128 + tid / 4 of A, row tid / 4 of B, every term.
     // Rows that do not exist (behind a track's last block, behind the rectangle) read pool row 0: their products only
@@ -553,6 +600,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     u32x4 st[9];                                      // pieces 0-2: A rows tid / 4, 3-5: A rows 128 + tid / 4, 6-8: B (one per term)
     auto gload_piece = [&](auto p_tag) {
         constexpr int p = decltype(p_tag)::value;
+        if (F16 && p % 3 == 2) return;                 // (the third term does not exist)
         const unsigned short *src;
         if (p >= 6) src = bp;
         else if (!CH) src = p < 3 ? ap0 : ap1;
@@ -580,6 +628,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     unsigned short *as0 = As + srow * EFB_LP + skl, *bs0 = Bs + srow * EFB_LP + skl;
     auto lstore_piece = [&](int buf, auto p_tag) {
         constexpr int p = decltype(p_tag)::value;
+        if (F16 && p % 3 == 2) return;
         unsigned short *dst = p < 3 ? as0 + buf * EFR_A + (p * EFR_ROWS) * EFB_LP
                             : (p < 6 ? as0 + buf * EFR_A + ((p - 3) * EFR_ROWS + 128) * EFB_LP : bs0 + buf * EFR_B + ((p - 6) * EFR_COLS) * EFB_LP);
         *reinterpret_cast<u32x4 *>(dst) = st[p];
@@ -600,44 +649,56 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     // operands of the first two groups of chunk k + 1 are read into registers of their own while groups 19 - 23 run, so
     // that the matrix pipe does not drain at the chunk boundary (8 waves x 15 reads after a barrier at the boundary
     // kept it idle for ~10 % of a chunk).
-    bf16x8 pa0[NA], pa2[NA], pb0, pb2;                 // prefetched: av[.][0], av[.][2], bv[0][0], bv[0][2] of the next chunk
+    constexpr int TP = F16 ? 1 : 2;                    // the term the chunk's first products take (F16: that is all of them)
+    bf16x8 pa0[NA], pa2[NA], pb0, pb2;                 // prefetched: av[.][0], av[.][TP], bv[0][0], bv[0][TP] of the next chunk
     auto prefetch = [&](int buf) {
         const unsigned short *a_ = aop + buf * EFR_A, *b_ = bop + buf * EFR_B;
-        pb2 = *reinterpret_cast<const bf16x8 *>(b_ + (2 * EFR_COLS) * EFB_LP);
+        pb2 = *reinterpret_cast<const bf16x8 *>(b_ + (TP * EFR_COLS) * EFB_LP);
 #pragma unroll
         for (int a = 0; a < NA; ++a) pa0[a] = *reinterpret_cast<const bf16x8 *>(a_ + (16 * a) * EFB_LP);
         pb0 = *reinterpret_cast<const bf16x8 *>(b_);
 #pragma unroll
-        for (int a = 0; a < NA; ++a) pa2[a] = *reinterpret_cast<const bf16x8 *>(a_ + (2 * EFR_ROWS + 16 * a) * EFB_LP);
+        for (int a = 0; a < NA; ++a) pa2[a] = *reinterpret_cast<const bf16x8 *>(a_ + (TP * EFR_ROWS + 16 * a) * EFB_LP);
     };
     auto chunk_mma = [&](int cur, auto st_tag, auto ld_tag) {
         constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
-        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};       // smallest products first, as in E1b
+        constexpr int NG = F16 ? 4 : 6;                                              // products of a cell and chunk
+        constexpr int TA[6] = {F16 ? 1 : 0, F16 ? 0 : 2, 1, 0, 1, 0}, TB[6] = {F16 ? 1 : 2, F16 ? 1 : 0, F16 ? 0 : 1, F16 ? 0 : 1, 0, 0};   // smallest products first, as in E1b
+        constexpr int LASTP = F16 ? 11 : 18;                                         // the slot of the chunk's last staging piece and its barrier
         const unsigned short *a_ = aop + cur * EFR_A, *b_ = bop + cur * EFR_B;
         bf16x8 av[NA][3], bv[2][3];
         auto rdb = [&](int e, int b, int q) { bv[e][q] = *reinterpret_cast<const bf16x8 *>(b_ + (q * EFR_COLS + 16 * b) * EFB_LP); };
 #pragma unroll
-        for (int a = 0; a < NA; ++a) { av[a][0] = pa0[a]; av[a][2] = pa2[a]; }
-        bv[0][2] = pb2; bv[0][0] = pb0;
-        rdb(0, 0, 1);
+        for (int a = 0; a < NA; ++a) { av[a][0] = pa0[a]; av[a][TP] = pa2[a]; }
+        bv[0][TP] = pb2; bv[0][0] = pb0;
+        if (!F16) {
+            rdb(0, 0, 1);
 #pragma unroll
-        for (int a = 0; a < NA; ++a) av[a][1] = *reinterpret_cast<const bf16x8 *>(a_ + (EFR_ROWS + 16 * a) * EFB_LP);
+            for (int a = 0; a < NA; ++a) av[a][1] = *reinterpret_cast<const bf16x8 *>(a_ + (EFR_ROWS + 16 * a) * EFB_LP);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
 #pragma unroll
-            for (int g = 0; g < 6; ++g) {
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
-                for (int a = 0; a < NA; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[b & 1][TB[g]], av[a][TA[g]], acc[a][b], 0, 0, 0);
-                if (g == 1 && b + 1 < NB) { rdb((b + 1) & 1, b + 1, 2); rdb((b + 1) & 1, b + 1, 0); rdb((b + 1) & 1, b + 1, 1); }
-                const int slot = 6 * b + g;
-                if (slot >= 2 && slot <= 18 && (slot & 1) == 0) {
+                for (int a = 0; a < NA; ++a) {
+                    if (F16) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bv[b & 1][TB[g]]), __builtin_bit_cast(f16x8, av[a][TA[g]]), acc[a][b], 0, 0, 0);
+                    else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[b & 1][TB[g]], av[a][TA[g]], acc[a][b], 0, 0, 0);
+                }
+                if (g == 1 && b + 1 < NB) {
+                    if (F16) { rdb((b + 1) & 1, b + 1, 1); rdb((b + 1) & 1, b + 1, 0); }
+                    else { rdb((b + 1) & 1, b + 1, 2); rdb((b + 1) & 1, b + 1, 0); rdb((b + 1) & 1, b + 1, 1); }
+                }
+                const int slot = NG * b + g;
+                // bf16x3: nine pieces behind slots 2, 4 .. 18; f16x2: its six behind slots 1, 3 .. 11
+                if (slot >= (F16 ? 1 : 2) && slot <= LASTP && (slot & 1) == (F16 ? 1 : 0)) {
                     auto piece = [&](auto p_tag) {
                         if (ST) lstore_piece(cur ^ 1, p_tag);
                         if (LD) gload_piece(p_tag);
                     };
-                    switch ((slot - 2) / 2) {
+                    const int nth = (slot - (F16 ? 1 : 2)) / 2;
+                    switch (F16 ? nth + nth / 2 : nth) {                             // (f16x2: 0 1 3 4 6 7)
                     case 0: piece(std::integral_constant<int, 0>()); break;
                     case 1: piece(std::integral_constant<int, 1>()); break;
                     case 2: piece(std::integral_constant<int, 2>()); break;
@@ -649,7 +710,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                     default: piece(std::integral_constant<int, 8>()); break;
                     }
                 }
-                if (ST && slot == 18) {
+                if (ST && slot == LASTP) {
                     __syncthreads();
                     prefetch(cur ^ 1);
                 }
@@ -706,6 +767,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     // round's first version of this epilogue: ~2 k cycles x 16 sub-tiles of a 180 k-cycle tile).
     if (!any) return;
     const float *nrm = s == 0 ? nrm0 : nrm1;
+    const float *inv = (CH || s == 0) ? inv0 : inv1;
     const int il = lr, jl = 4 * lk;                      // accumulator layout: row il, columns jl .. jl + 3 of the sub-tile
     float nx[NA];
     f32x4 ny[NB];
@@ -715,6 +777,14 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         for (int a = 0; a < NA; ++a) nx[a] = nrm[GA[a].poolrow + il];
 #pragma unroll
         for (int b = 0; b < NB; ++b) ny[b] = *reinterpret_cast<const f32x4u *>(nrm + GB[b].poolrow + jl);
+    }
+    float sx[NA];
+    f32x4 sy[NB];
+    if (F16) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) sx[a] = inv[GA[a].poolrow + il];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) sy[b] = *reinterpret_cast<const f32x4u *>(inv + GB[b].poolrow + jl);
     }
     int64_t cbase[NA][NB];                               // float offset of the sub-tile's first cell in its pair's matrix
     int cpitch[NA][NB], ctn[NA][NB];
@@ -738,9 +808,10 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     auto value = [&](int a, int b, float (&v)[4]) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            if (CH) v[reg] = 1.0f - acc[a][b][reg];
+            const float dot = F16 ? acc[a][b][reg] * (sx[a] * sy[b][reg]) : acc[a][b][reg];
+            if (CH) v[reg] = 1.0f - dot;
             else {
-                float tq = (nx[a] + ny[b][reg]) - 2.0f * acc[a][b][reg];
+                float tq = (nx[a] + ny[b][reg]) - 2.0f * dot;
                 if (tq < 0.0f) tq = 0.0f;
                 v[reg] = __builtin_sqrtf(tq);
             }

@@ -324,6 +324,14 @@ int acx_earlyfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const a
  *   ACX_EF_GEMM_F32               f32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation), one
  *                                 matrix at a time
  *   ACX_EF_GEMM_BF16X3_CHROMA_F32 the rectangles of the default, chroma by f32 MFMAs (round 3's first kernel)
+ *   ACX_EF_GEMM_F16X2 (opt-in)    the default's rectangles on TWO fp16 terms of every value (scaled per feature by the
+ *                                 power of two that puts the pool's largest |x| into (2^14, 2^15]): four fp16 MFMAs per
+ *                                 cell and 32 k instead of six bf16 ones.  A value keeps 22 of its 24 significant
+ *                                 bits, i.e. the operands carry a relative rounding of 2^-23 where the other modes
+ *                                 multiply the f32 values themselves -- a different arithmetic of the same accuracy
+ *                                 class as an f32 BLAS (whose accumulation error is larger than that); DESIGN.md
+ *                                 section 5 holds what it moves.  The split pool holds one format at a time:
+ *                                 changing between this mode and the others re-splits the pool on the next call.
  * All meet the same bound against the f64 truth (tests/test_gpu_earlyfusion.py); scores that differ between
  * them sit on a row-kappa threshold tie (profiles/r03_parity_ef.json holds the measured histogram).
  */
@@ -331,7 +339,7 @@ enum { ACX_EF_GEMM_BF16X3 = 0, ACX_EF_GEMM_F32 = 1,
        ACX_EF_GEMM_BF16X3_PAIRWISE = 2, /* mfccs / ssms in the default's arithmetic, one matrix at a time (round 2's
                                            kernel; bit-identical matrices -- kept as the cross-check of the rectangle
                                            kernel), chroma by f32 MFMAs */
-       ACX_EF_GEMM_BF16X3_CHROMA_F32 = 3 };
+       ACX_EF_GEMM_BF16X3_CHROMA_F32 = 3, ACX_EF_GEMM_F16X2 = 4 };
 int acx_set_ef_gemm(acx_ctx *ctx, int32_t mode);
 
 /*

@@ -357,6 +357,71 @@ def test_chroma_on_the_bf16_pipe(ctx):
         ctx.set_ef_gemm("bf16x3")
 
 
+def test_f16x2_gemm_mode(ctx):
+    """ACX_EF_GEMM_F16X2 (opt-in): two fp16 terms per value, four MFMAs per cell.  Matrices against the f64 truth under
+    the bounds the other modes are held to; scores of pair lists against the default's (threshold ties may move);
+    the same after the whole pool is scaled by 2^10 and 2^-10 (the per-feature scale follows the pool's range); the
+    default's bits return when the mode is switched back (the pool is re-split both ways)."""
+    rng = np.random.default_rng(46)
+    nbs = [1, 15, 16, 17, 33, 128, 129, 300, 47, 250] + [int(v) for v in rng.integers(20, 90, 30)]
+
+    def track(nb):
+        mf = rng.standard_normal((nb, 650)).astype(np.float32)
+        mf[:, :3] *= 30.0                                           # a few large coordinates, many small ones
+        ch = rng.random((nb, 480)).astype(np.float32) ** 3
+        return dict(mfccs=mf, ssms=(2 * rng.random((nb, 1225))).astype(np.float32), chromas=ch, chroma_med=rng.random(12) ** 2)
+    tracks = [track(nb) for nb in nbs]
+    n = len(tracks)
+    iu, ju = np.triu_indices(24, 1)
+    lists = [np.ascontiguousarray(np.stack([iu, ju], 1), np.int32), np.ascontiguousarray(rng.integers(0, n, (300, 2)), np.int32)]
+    try:
+        ctx.ef_upload_pool(tracks)
+        ctx.set_ef_gemm("bf16x3")
+        want = [ctx.earlyfusion_pairs(pr) for pr in lists]
+        ctx.set_ef_gemm("f16x2")
+        worst = [0.0, 0.0, 0.0]
+        for (i, j) in [(7, 8), (5, 6), (0, 7), (3, 2), (9, 7), (8, 9), (20, 30), (31, 21), (5, 5)]:
+            d = ctx.ef_debug_pair(i, j)
+            for k, s in enumerate(("mfccs", "ssms")):
+                x64, y64 = tracks[i][s].astype(np.float64), tracks[j][s].astype(np.float64)
+                scale = float(np.sum(x64 ** 2, 1).max() + np.sum(y64 ** 2, 1).max())
+                true2 = np.maximum(0, np.sum(x64 ** 2, 1)[:, None] + np.sum(y64 ** 2, 1)[None, :] - 2 * x64.dot(y64.T))
+                err = float(np.max(np.abs(d["csm"][k].astype(np.float64) ** 2 - true2))) / scale
+                worst[k] = max(worst[k], err)
+                assert err <= 4e-6, (s, err)
+            X = tracks[i]["chromas"].astype(np.float64)
+            Y = tracks[j]["chromas"].astype(np.float64)
+            X = np.roll(X.reshape(len(X), 40, 12), d["oti"], axis=2).reshape(len(X), 480)
+            X /= np.linalg.norm(X, axis=1, keepdims=True)
+            Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+            e2 = float(np.max(np.abs(d["csm"][2] - (1.0 - X @ Y.T))))
+            worst[2] = max(worst[2], e2)
+            assert e2 <= 2e-6, e2
+        print("f16x2 worst errors (d^2 / scale mfccs, ssms; chroma abs):", worst)
+        got = [ctx.earlyfusion_pairs(pr) for pr in lists]
+        for g, w in zip(got, want):
+            same = np.all(g == w, axis=1)
+            assert same.mean() >= 0.95, same.mean()
+            assert np.max(np.abs(g - w)) <= 3.0
+        # the pool scaled by powers of two: distances scale exactly, thresholds are ranks -> the mode's own scores again
+        # (mfccs / ssms planes; chroma rows are normalised anyway)
+        for f in (1024.0, 1.0 / 1024.0):
+            scaled = [dict(mfccs=t["mfccs"] * np.float32(f), ssms=t["ssms"] * np.float32(f), chromas=t["chromas"], chroma_med=t["chroma_med"])
+                      for t in tracks]
+            ctx.ef_upload_pool(scaled)
+            g2 = ctx.earlyfusion_pairs(lists[0])
+            assert np.array_equal(g2[:, :3], got[0][:, :3]), f
+        ctx.ef_upload_pool(tracks)
+        assert np.array_equal(ctx.earlyfusion_pairs(lists[0]), got[0])
+        ctx.set_ef_gemm("bf16x3")
+        assert np.array_equal(ctx.earlyfusion_pairs(lists[0]), want[0])
+        ctx.set_ef_gemm("bf16x3_pairwise")                          # (needs the bf16 pool as well)
+        pw = ctx.earlyfusion_pairs(lists[0])
+        assert np.array_equal(pw[:, :2], want[0][:, :2])
+    finally:
+        ctx.set_ef_gemm("bf16x3")
+
+
 def test_neighbourhood_sizes(ctx):
     """K (the neighbourhood of getWCSM's kernel widths) up to 16: the column means come from C itself
     (ef_colstat_kernel); beyond: the transposed matrices and the row-selection kernel.  Both against the oracle's

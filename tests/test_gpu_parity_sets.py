@@ -154,6 +154,7 @@ def test_earlyfusion_cover_set_map(ctx):
     try:
         P = grid("bf16x3")
         P32 = grid("f32")
+        P16 = grid("f16x2")
     finally:
         ctx.set_ef_gemm("bf16x3")
     rec = {"tracks": n, "works": 100, "pairs": int(len(pairs)), "noise": 4.0}
@@ -170,8 +171,12 @@ def test_earlyfusion_cover_set_map(ctx):
         st_f32 = oracle.eval_statistics(P32[e], cl, topsidx=(1, 10, 100))
         got = P[e][pairs[:, 0], pairs[:, 1]].astype(np.float64)
         got32 = P32[e][pairs[:, 0], pairs[:, 1]].astype(np.float64)
+        got16 = P16[e][pairs[:, 0], pairs[:, 1]].astype(np.float64)
+        st_f16 = oracle.eval_statistics(P16[e], cl, topsidx=(1, 10, 100))
         rec[s] = {"hip_vs_oracle": _hist(got - ref[:, e]), "f32gemm_vs_oracle": _hist(got32 - ref[:, e]),
                   "bf16x3_vs_f32gemm": _hist(got - got32),
+                  "f16x2_vs_oracle": _hist(got16 - ref[:, e]), "f16x2_vs_f64matrices": _hist(got16 - ref[:, 4 + e]),
+                  "MAP_hip_f16x2": st_f16[3], "MR_hip_f16x2": st_f16[0], "top1_hip_f16x2": float(st_f16[4][0]),
                   "oracle_vs_f64matrices": _hist(ref[:, e] - ref[:, 4 + e]), "hip_vs_f64matrices": _hist(got - ref[:, 4 + e]),
                   "MAP_oracle": st_ref[3], "MAP_hip": st_hip[3], "MAP_hip_f32gemm": st_f32[3], "MAP_f64matrices": st_64[3],
                   "MR_oracle": st_ref[0], "MR_hip": st_hip[0], "MRR_oracle": st_ref[1], "MRR_hip": st_hip[1],
@@ -190,6 +195,13 @@ def test_earlyfusion_cover_set_map(ctx):
         moved_hip = r["hip_vs_f64matrices"]["n"] - r["hip_vs_f64matrices"]["0"]
         moved_ref = r["oracle_vs_f64matrices"]["n"] - r["oracle_vs_f64matrices"]["0"]
         assert moved_hip <= moved_ref + moved_ref // 2 + EF_MOVED_SLACK, (s, moved_hip, moved_ref)
+        # the opt-in f16x2 GEMM (two fp16 terms per value, 22 significant bits): the default's bars
+        assert abs(r["MAP_hip_f16x2"] - r["MAP_oracle"]) <= EF_MAP_TOL, (s, r)
+        assert abs(r["MR_hip_f16x2"] - r["MR_oracle"]) <= 1e-2 and r["top1_hip_f16x2"] == r["top1_oracle"], (s, r)
+        h = r["f16x2_vs_oracle"]
+        assert h["max"] <= EF_TOL + 1e-6 and h["0"] >= EF_MIN_SAME * h["n"], (s, h)
+        moved_f16 = r["f16x2_vs_f64matrices"]["n"] - r["f16x2_vs_f64matrices"]["0"]
+        assert moved_f16 <= moved_ref + moved_ref // 2 + EF_MOVED_SLACK, (s, moved_f16, moved_ref)
         # the two arithmetics of the device (three-term bf16 splits / f32 MFMAs) against each other: ties only
         h = r["bf16x3_vs_f32gemm"]
         assert h["max"] <= EF_TOL + 1e-6 and h["0"] >= EF_MIN_SAME * h["n"], (s, h)
