@@ -490,12 +490,12 @@ class Context(object):
         self._check(self._L.acx_ef_pool_tracks(self._h, int(first), int(count), *[k[0] for k in keep]))
 
     def set_ef_gemm(self, mode):
-        """'bf16x3' (default: dense rectangles of pairs, all three matrices on the bf16 pipe), 'f32', 'bf16x3_pairwise'
-        (one matrix at a time: mfccs / ssms with the default's bits, chroma f32), 'bf16x3_chroma_f32' (rectangles,
-        chroma f32) or 'f16x2' (opt-in: the rectangles on two fp16 terms per value, four MFMAs per cell instead of
-        six; 22 significant bits of every operand): EarlyFusion's cross-similarity GEMMs (acx_set_ef_gemm)."""
+        """'f16x2' (= 'default': dense rectangles of pairs, all three matrices on the matrix pipe from two fp16 terms per
+        value, four MFMAs per cell), 'bf16x3' (three bf16 terms, six MFMAs: all 24 bits of every operand), 'f32',
+        'bf16x3_pairwise' (one matrix at a time: mfccs / ssms with bf16x3's bits, chroma f32) or 'bf16x3_chroma_f32'
+        (rectangles, chroma f32): EarlyFusion's cross-similarity GEMMs (acx_set_ef_gemm)."""
         self._check(self._L.acx_set_ef_gemm(self._h, {"bf16x3": 0, "f32": 1, "bf16x3_pairwise": 2,
-                                                      "bf16x3_chroma_f32": 3, "f16x2": 4}.get(mode, mode)))
+                                                      "bf16x3_chroma_f32": 3, "f16x2": 4, "default": -1}.get(mode, mode)))
 
     def set_ef_fuse(self, mode):
         """'fast' (default: reciprocal + exp2 per kernel weight) or 'exact' (the reference's operation order with IEEE

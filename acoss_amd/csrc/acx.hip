@@ -101,7 +101,7 @@ struct acx_ctx {
     int64_t *d_efoff = nullptr;
     std::vector<int64_t> h_efoff;
     int32_t ef_ntracks = 0;
-    int32_t ef_gemm = ACX_EF_GEMM_BF16X3;             // arithmetic of the two Euclidean cross-similarity GEMMs
+    int32_t ef_gemm = ACX_EF_GEMM_DEFAULT;            // arithmetic of the three cross-similarity GEMMs
     int32_t ef_fuse = ACX_EF_FUSE_FAST;               // arithmetic of getWCSM's weights and the fused matrix (acx_set_ef_fuse)
     int32_t ef_open = 0;                              // > 0: a pool of that many tracks is being filled (acx_ef_pool_begin .. _end)
     std::vector<uint8_t> ef_filled;                   // per track of the open pool: handed over by acx_ef_pool_tracks yet?
@@ -1880,6 +1880,7 @@ static int ef_finish_pool(acx_ctx *c, const int64_t *offsets, int32_t n_tracks, 
 int acx_set_ef_gemm(acx_ctx *c, int32_t mode)
 {
     if (!c) return ACX_ERR_INVALID;
+    if (mode == -1) mode = ACX_EF_GEMM_DEFAULT;
     if (mode != ACX_EF_GEMM_BF16X3 && mode != ACX_EF_GEMM_F32 && mode != ACX_EF_GEMM_BF16X3_PAIRWISE && mode != ACX_EF_GEMM_BF16X3_CHROMA_F32 &&
         mode != ACX_EF_GEMM_F16X2)
         return fail(c, ACX_ERR_INVALID, "set_ef_gemm: unknown mode");

@@ -280,8 +280,25 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
     dt = time.perf_counter() - t0
     prof = ctx.profile()
     host = buf.read(np.float32)
-    buf.free()
     timed = tiles[warmup:warmup + steps]
+    # the same tiles on three bf16 terms per value (round 3's default, all 24 bits of every operand), for comparison
+    ctx.set_ef_gemm("bf16x3")
+    try:
+        ctx.grid_run(plan["spec"], ep, 0, buf.data_ptr(), first=0, count=1)            # (re-splits the pool)
+        ctx.profile_reset()
+        t1 = time.perf_counter()
+        for s in range(warmup, warmup + steps):
+            ctx.grid_run(plan["spec"], ep, 0, buf.data_ptr(), first=s, count=1)
+        dt_b = time.perf_counter() - t1
+        prof_b = ctx.profile()
+        host_b = buf.read(np.float32)
+    finally:
+        ctx.set_ef_gemm("default")
+    buf.free()
+    used = np.zeros(len(host), bool)
+    for t in timed:
+        used[t.offset:t.offset + 4 * t.rows * t.cols] = True
+    same_modes = float(np.mean(host[used] == host_b[used]))
     allp = [p for t in timed for p in _tile_pairs(t)]
     npairs = len(allp)
     pi, pj = np.array(allp).T
@@ -310,16 +327,20 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
         "config": {"workload": "configs[4] per-track shape: pool of %d tracks of 300-500 blocks, one 128 x 128 grid tile per step "
                                "(diagonal: 8128 pairs, off-diagonal: 16 384), another tile every step, %d pairs in %d steps through "
                                "acx_grid_run (scores scattered into a device buffer)" % (n, npairs, steps)},
-        # all three cross-similarity GEMMs run on the bf16 matrix pipe from three-term splits: six bf16 products per
-        # f32-equivalent multiply-add are what the pipe executes, and what is priced against its dense peak
-        "roofline": {"bound": "mfma", "kernel": "ef_gemm_rect_bf16x3_kernel<0> (mfcc / ssm) + <1> (chroma): three-term bf16 splits, "
-                                                "256 x 128 tiles over dense rectangles of pairs",
-                     "achieved": round(6.0 * flops / ks / 1e12, 1), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": round(6.0 * flops / ks / 1e12 / BF16_MFMA_PEAK_TF, 4), "traffic": None,
-                     "flops": "executed bf16 flops = 6 x the f32-equivalent 2 (650 + 1225 + 480) nb1 nb2 per pair (SURVEY 8d)",
+        # all three cross-similarity GEMMs run on the 16-bit matrix pipe from two fp16 terms per value: four fp16 products
+        # per f32-equivalent multiply-add are what the pipe executes, and what is priced against its dense peak
+        "roofline": {"bound": "mfma", "kernel": "ef_gemm_rect_bf16x3_kernel<0, 1> (mfcc / ssm) + <1, 1> (chroma): two fp16 terms per value "
+                                                "(ACX_EF_GEMM_F16X2, the default), 256 x 128 tiles over dense rectangles of pairs",
+                     "achieved": round(4.0 * flops / ks / 1e12, 1), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(4.0 * flops / ks / 1e12 / BF16_MFMA_PEAK_TF, 4), "traffic": None,
+                     "flops": "executed fp16 flops = 4 x the f32-equivalent 2 (650 + 1225 + 480) nb1 nb2 per pair (SURVEY 8d); dense fp16 peak = dense bf16 peak",
                      "f32_equivalent_tflops": round(flops / ks / 1e12, 2), "f32_mfma_peak_tflops": F32_MFMA_PEAK_TF,
                      "kernel_ms_per_step": round(g["ms"] / steps, 3),
                      "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]}},
+        "bf16x3": {"value": round(npairs / dt_b, 1), "gemm_ms_per_step": round(prof_b["ef_gemm_kernel"]["ms"] / steps, 3),
+                   "executed_tflops": round(6.0 * flops / (prof_b["ef_gemm_kernel"]["ms"] * 1e-3) / 1e12, 1),
+                   "scores_identical_to_default_fraction": round(same_modes, 6),
+                   "note": "ACX_EF_GEMM_BF16X3 on the same tiles: three bf16 terms per value, six MFMAs per cell (round 3's default)"},
         "cpu_baseline": {"value": round(len(cp) / tcpu, 3), "unit": "track-pairs/s", "cores": 1, "kind": "port",
                          "sample": "first %d pairs of the first timed tile, numpy + C oracle, BLAS limited to one thread, %.1f s; "
                                    "%.4f of the 4 x %d scores identical to the GPU's, max |diff| %.3g"

@@ -314,32 +314,33 @@ int acx_earlyfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const a
 
 /*
  * Arithmetic of the three cross-similarity products (mfccs, ssms: get_csm, cross_recurrence.py:30-48; chromas:
- * get_csm_blocked_oti, :105-134 -- the reference's are BLAS sgemms in f32):
- *   ACX_EF_GEMM_BF16X3 (default)  three-term bf16 splits on the bf16 matrix pipe, f32 accumulation: the dropped
- *                                 terms are below one f32 rounding of the product; the pairs of a batch are laid
- *                                 out as dense rectangles (query tracks' blocks x reference tracks' blocks), so
- *                                 the 256 x 128 tiles of the GEMM are full and tracks are read once per rectangle.
- *                                 Chroma rows are kept bin-major, which turns the OTI roll into a shift of the
- *                                 row by whole 16-byte pieces (blocks of a multiple of 8 frames; others: f32)
+ * get_csm_blocked_oti, :105-134 -- the reference's are BLAS sgemms in f32).  The matrix-pipe modes lay the pairs of a
+ * batch out as dense rectangles (query tracks' blocks x reference tracks' blocks), so that the 256 x 128 tiles of the
+ * GEMM are full and a track is read once per rectangle; chroma rows are kept bin-major, which turns the OTI roll into a
+ * shift of the row by whole 16-byte pieces (blocks of a multiple of 8 frames; others: f32 MFMAs).
+ *   ACX_EF_GEMM_F16X2 (default)   every value as TWO fp16 terms of x / s, s = the power of two that puts the largest
+ *                                 |x| of the value's own ROW into [2^14, 2^15) (so a track's operands depend on the
+ *                                 track alone); four fp16 MFMAs per cell and 32 k -- x2 y2, x1 y2, x2 y1, x1 y1,
+ *                                 f32 accumulation -- and the product rescaled by s_row s_column (exact).  An
+ *                                 operand keeps 22 of its 24 significant bits: a relative rounding of 2^-23 per
+ *                                 value, below the accumulation error of any f32 sgemm over K = 480 .. 1225.
+ *   ACX_EF_GEMM_BF16X3            three-term bf16 splits (all 24 bits of every value), six bf16 MFMAs per cell and
+ *                                 32 k: the dropped terms are below one f32 rounding of the product.  1.27 x the GEMM
+ *                                 time of the default (round 3's default)
  *   ACX_EF_GEMM_F32               f32 MFMA (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation), one
  *                                 matrix at a time
- *   ACX_EF_GEMM_BF16X3_CHROMA_F32 the rectangles of the default, chroma by f32 MFMAs (round 3's first kernel)
- *   ACX_EF_GEMM_F16X2 (opt-in)    the default's rectangles on TWO fp16 terms of every value (scaled per feature by the
- *                                 power of two that puts the pool's largest |x| into (2^14, 2^15]): four fp16 MFMAs per
- *                                 cell and 32 k instead of six bf16 ones.  A value keeps 22 of its 24 significant
- *                                 bits, i.e. the operands carry a relative rounding of 2^-23 where the other modes
- *                                 multiply the f32 values themselves -- a different arithmetic of the same accuracy
- *                                 class as an f32 BLAS (whose accumulation error is larger than that); DESIGN.md
- *                                 section 5 holds what it moves.  The split pool holds one format at a time:
- *                                 changing between this mode and the others re-splits the pool on the next call.
- * All meet the same bound against the f64 truth (tests/test_gpu_earlyfusion.py); scores that differ between
- * them sit on a row-kappa threshold tie (profiles/r03_parity_ef.json holds the measured histogram).
+ *   ACX_EF_GEMM_BF16X3_CHROMA_F32 the rectangles of BF16X3, chroma by f32 MFMAs (round 3's first kernel)
+ * All meet the same bound against the f64 truth (tests/test_gpu_earlyfusion.py) and move as many scores against
+ * f64-evaluated matrices as the reference's own f32 arithmetic does (tests/test_gpu_parity_sets.py, 124 750 pairs;
+ * profiles/r04_parity_ef.json); scores that differ between them sit on a row-kappa threshold tie.  The split pool
+ * holds ONE operand format (69 GB at DA-TACOS size): changing between F16X2 and the bf16 modes re-splits the pool
+ * on the next call.  mode -1 = the default.
  */
 enum { ACX_EF_GEMM_BF16X3 = 0, ACX_EF_GEMM_F32 = 1,
-       ACX_EF_GEMM_BF16X3_PAIRWISE = 2, /* mfccs / ssms in the default's arithmetic, one matrix at a time (round 2's
+       ACX_EF_GEMM_BF16X3_PAIRWISE = 2, /* mfccs / ssms in BF16X3's arithmetic, one matrix at a time (round 2's
                                            kernel; bit-identical matrices -- kept as the cross-check of the rectangle
                                            kernel), chroma by f32 MFMAs */
-       ACX_EF_GEMM_BF16X3_CHROMA_F32 = 3, ACX_EF_GEMM_F16X2 = 4 };
+       ACX_EF_GEMM_BF16X3_CHROMA_F32 = 3, ACX_EF_GEMM_F16X2 = 4, ACX_EF_GEMM_DEFAULT = ACX_EF_GEMM_F16X2 };
 int acx_set_ef_gemm(acx_ctx *ctx, int32_t mode);
 
 /*

@@ -43,11 +43,11 @@ def check_case(ctx, c, oracle, _lib):
     ctx.ef_upload_pool(tracks)
     if len(pairs) == 0:
         return 0
-    ctx.set_ef_gemm("bf16x3")
+    ctx.set_ef_gemm("default")
     got = ctx.earlyfusion_pairs(pairs, kappa=kappa, K=K)
     ctx.set_ef_gemm("f32")
     want = ctx.earlyfusion_pairs(pairs, kappa=kappa, K=K)
-    ctx.set_ef_gemm("bf16x3")
+    ctx.set_ef_gemm("default")
     # (a track against itself has an exactly-zero diagonal in one arithmetic and rounding noise in the other; with K = 1 the
     # reference's own getWCSM divides 0 by 0 there: self pairs stay in the list, but are not compared)
     other = pairs[:, 0] != pairs[:, 1]
@@ -95,7 +95,7 @@ def run(rounds=20, seed=0, ctx=None):
         for _ in range(rounds):
             total += one_round(ctx, rng, oracle, _lib)
     finally:
-        ctx.set_ef_gemm("bf16x3")
+        ctx.set_ef_gemm("default")
         if own:
             ctx.close()
     return total

@@ -284,7 +284,7 @@ def test_rectangle_gemm_equals_pairwise_gemm(ctx):
         ctx.set_ef_gemm("bf16x3_chroma_f32")
         assert np.array_equal(ctx.earlyfusion_pairs(pr), want)
     finally:
-        ctx.set_ef_gemm("bf16x3")
+        ctx.set_ef_gemm("default")
 
 
 def test_chroma_on_the_bf16_pipe(ctx):
@@ -354,14 +354,14 @@ def test_chroma_on_the_bf16_pipe(ctx):
         ctx.set_ef_gemm("bf16x3")
         assert np.array_equal(ctx.earlyfusion_pairs(pr), want)
     finally:
-        ctx.set_ef_gemm("bf16x3")
+        ctx.set_ef_gemm("default")
 
 
 def test_f16x2_gemm_mode(ctx):
-    """ACX_EF_GEMM_F16X2 (opt-in): two fp16 terms per value, four MFMAs per cell.  Matrices against the f64 truth under
-    the bounds the other modes are held to; scores of pair lists against the default's (threshold ties may move);
-    the same after the whole pool is scaled by 2^10 and 2^-10 (the per-feature scale follows the pool's range); the
-    default's bits return when the mode is switched back (the pool is re-split both ways)."""
+    """ACX_EF_GEMM_F16X2 (the default): two fp16 terms per value, four MFMAs per cell.  Matrices against the f64 truth
+    under the bounds the other modes are held to; scores of pair lists against bf16x3's (threshold ties may move); the
+    same scores after the whole pool is scaled by 2^10 and 2^-10 (every row carries its own power-of-two scale); each
+    mode's bits return when the mode is switched back and forth (the pool is re-split both ways)."""
     rng = np.random.default_rng(46)
     nbs = [1, 15, 16, 17, 33, 128, 129, 300, 47, 250] + [int(v) for v in rng.integers(20, 90, 30)]
 
@@ -419,7 +419,7 @@ def test_f16x2_gemm_mode(ctx):
         pw = ctx.earlyfusion_pairs(lists[0])
         assert np.array_equal(pw[:, :2], want[0][:, :2])
     finally:
-        ctx.set_ef_gemm("bf16x3")
+        ctx.set_ef_gemm("default")
 
 
 def test_neighbourhood_sizes(ctx):
