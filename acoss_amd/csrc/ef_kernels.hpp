@@ -808,7 +808,8 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     auto value = [&](int a, int b, float (&v)[4]) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const float dot = F16 ? acc[a][b][reg] * (sx[a] * sy[b][reg]) : acc[a][b][reg];
+            // (two multiplications: the product of two scales may leave f32's range where the rescaled sum does not)
+            const float dot = F16 ? (acc[a][b][reg] * sx[a]) * sy[b][reg] : acc[a][b][reg];
             if (CH) v[reg] = 1.0f - dot;
             else {
                 float tq = (nx[a] + ny[b][reg]) - 2.0f * dot;
