@@ -23,7 +23,7 @@ EXPORTS = [
     "acx_abi_version", "acx_create", "acx_destroy", "acx_last_error", "acx_set_scratch_limit",
     "acx_upload_pool", "acx_serra09_default_params", "acx_serra09_pairs", "acx_serra09_debug_pair",
     "acx_serra09_embed_len", "acx_profile_enable", "acx_profile_reset", "acx_profile_count",
-    "acx_profile_get", "acx_debug_sqrt", "acx_upload_pool_f64", "acx_simple_pairs",
+    "acx_profile_get", "acx_debug_sqrt", "acx_debug_ef_sqrt", "acx_upload_pool_f64", "acx_simple_pairs",
     "acx_ef_upload_pool", "acx_earlyfusion_pairs", "acx_ef_debug_pair", "acx_sw_binary",
     "acx_chenfusion_pairs", "acx_csm_binary_sw", "acx_upload_raw_pool", "acx_download_pool",
     "acx_simple_upload_raw_pool", "acx_download_pool_f64", "acx_snf_fuse", "acx_qmax_binary",
@@ -192,6 +192,7 @@ def load():
     L.acx_profile_get.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_double), lp, lp]
     L.acx_debug_sqrt.argtypes = [vp, fp, ctypes.c_int64, fp]
+    L.acx_debug_ef_sqrt.argtypes = [vp, fp, ctypes.c_int64, fp]
     dp = ctypes.POINTER(ctypes.c_double)
     L.acx_upload_pool_f64.argtypes = [vp, dp, lp, ctypes.c_int32, ctypes.c_int32]
     L.acx_simple_upload_raw_pool.argtypes = [vp, fp, lp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -746,8 +747,9 @@ class Context(object):
             out[name.value.decode()] = dict(ms=ms.value, launches=n.value, cells=cells.value)
         return out
 
-    def debug_sqrt(self, x):
+    def debug_sqrt(self, x, ef=False):
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.empty_like(x)
-        self._check(self._L.acx_debug_sqrt(self._h, _fptr(x), x.size, _fptr(out)))
+        fn = self._L.acx_debug_ef_sqrt if ef else self._L.acx_debug_sqrt
+        self._check(fn(self._h, _fptr(x), x.size, _fptr(out)))
         return out

@@ -2855,7 +2855,10 @@ int acx_profile_get(acx_ctx *c, int idx, char *name, int name_len, double *ms, i
 }
 
 
-int acx_debug_sqrt(acx_ctx *c, const float *in, int64_t n, float *out)
+static int debug_sqrt(acx_ctx *c, const float *in, int64_t n, float *out, bool ef);
+int acx_debug_sqrt(acx_ctx *c, const float *in, int64_t n, float *out) { return debug_sqrt(c, in, n, out, false); }
+int acx_debug_ef_sqrt(acx_ctx *c, const float *in, int64_t n, float *out) { return debug_sqrt(c, in, n, out, true); }
+static int debug_sqrt(acx_ctx *c, const float *in, int64_t n, float *out, bool ef)
 {
     if (!c || !in || !out || n <= 0) return ACX_ERR_INVALID;
     ACX_HIP(c, hipSetDevice(c->device));
@@ -2863,7 +2866,8 @@ int acx_debug_sqrt(acx_ctx *c, const float *in, int64_t n, float *out)
     ACX_HIP(c, hipMalloc((void **)&d_in, sizeof(float) * n));
     ACX_HIP(c, hipMalloc((void **)&d_o, sizeof(float) * n));
     ACX_HIP(c, hipMemcpy(d_in, in, sizeof(float) * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(acx::sqrt_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, d_o, n);
+    if (ef) hipLaunchKernelGGL(acx::ef_sqrt_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, d_o, n);
+    else hipLaunchKernelGGL(acx::sqrt_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, d_o, n);
     ACX_HIP(c, hipStreamSynchronize(c->stream));
     ACX_HIP(c, hipMemcpy(out, d_o, sizeof(float) * n, hipMemcpyDeviceToHost));
     (void)hipFree(d_in);

@@ -67,6 +67,24 @@ __host__ __device__ __forceinline__ int64_t ef_jcut_off(const EfPair &P, int src
     return src < 3 ? 2 * (int64_t)P.pitchT + P.pitchC : (int64_t)P.pitchT;
 }
 
+// sqrt of a distance^2 (>= 0) for get_csm's epilogues: v_sqrt_f32 (1 ulp) and one Newton step on the fma residual --
+// the correctly rounded value except in rare halfway cases, never more than 1 ulp off (tests/test_gpu_earlyfusion.py::
+// test_epilogue_sqrt), in 9 instructions.  The compiler's IEEE expansion of sqrtf is ~20 (input scaling for denormals,
+// two integer-stepped candidates, class tests): 64 of them per lane made the rectangle GEMM's epilogue VALU-bound
+// (1 900 VALU instructions per wave = 15 k of a tile's 87 k cycles).  Zero, denormal results and inf pass through.
+__device__ __forceinline__ float ef_sqrt_nonneg(float x)
+{
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float e = __builtin_fmaf(-r, r, x);
+    const float c = __builtin_fmaf(e, 0.5f * __builtin_amdgcn_rcpf(r), r);
+    return (r > 1e-18f && r < 1e18f) ? c : r;
+}
+static __global__ void ef_sqrt_probe_kernel(const float *in, float *out, int64_t n)       // (acx_debug_ef_sqrt)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ef_sqrt_nonneg(in[i]);
+}
+
 // ---- OTI of the pair (cross_recurrence.py:75-103): argmax_s sum(roll(C1, s) * C2), f64, first max
 __global__ void ef_oti_kernel(EfPair *pd, int B, const double *__restrict__ med)
 {
@@ -111,7 +129,7 @@ __device__ __forceinline__ void ef_gemm_epilogue(const f32x4 (&acc)[NA][4], cons
                     const float nx = (i < P.M) ? nrm[boff[P.q] + i] : 0.0f, ny = (j < P.N) ? nrm[boff[P.r] + j] : 0.0f;
                     float t = (nx + ny) - 2.0f * dot;
                     if (t < 0.0f) t = 0.0f;
-                    v[reg] = __builtin_sqrtf(t);
+                    v[reg] = ef_sqrt_nonneg(t);
                 }
                 if (i < P.M && j < P.N) C[(size_t)i * P.pitchC + j] = v[reg];
             }
@@ -317,6 +335,7 @@ __global__ __launch_bounds__(256) void ef_split_bf16_kernel(const float *__restr
         const int ks = binmajor ? 12 * (k % G) + k / G : k;
         const float x = k < K ? f[row * K + ks] : 0.0f;
         unsigned h1, h2, h3;
+        const int nt = inv ? 2 : 3;                                   // terms kept per value: a row and 32-k chunk is 128 / 192 contiguous bytes
         if (!inv) {
             h1 = ef_bf16_rne(x);
             const float r1 = x - __uint_as_float(h1 << 16);            // exact
@@ -325,7 +344,7 @@ __global__ __launch_bounds__(256) void ef_split_bf16_kernel(const float *__restr
             h3 = ef_bf16_rne(r2);
         } else {
             // ACX_EF_GEMM_F16X2: two fp16 terms of x / inv[row] (ef_rowscale_kernel; a power of two: its reciprocal by
-            // the exponent bits); term 3 stays zero and is never staged
+            // the exponent bits), 128 contiguous bytes = one cache line per row and 32-k chunk
             const float xs = x * __uint_as_float(0x7F000000u - __float_as_uint(inv[row]));      // exact
             const _Float16 a = (_Float16)xs;
             const _Float16 b = (_Float16)(xs - (float)a);              // (the remainder is exact in f32)
@@ -335,8 +354,9 @@ __global__ __launch_bounds__(256) void ef_split_bf16_kernel(const float *__restr
         }
         // [block][k / 32][term][k % 32]: the three terms of a 32-k chunk are 192 contiguous bytes, so the GEMM's three
         // 64-byte reads per row and chunk share their 128-byte lines
-        unsigned short *o = out + row * 3 * Kp + (int64_t)(k / EFB_BK) * (3 * EFB_BK) + (k % EFB_BK);
-        o[0] = (unsigned short)h1; o[EFB_BK] = (unsigned short)h2; o[2 * EFB_BK] = (unsigned short)h3;
+        unsigned short *o = out + row * nt * Kp + (int64_t)(k / EFB_BK) * (nt * EFB_BK) + (k % EFB_BK);
+        o[0] = (unsigned short)h1; o[EFB_BK] = (unsigned short)h2;
+        if (!inv) o[2 * EFB_BK] = (unsigned short)h3;
     }
 }
 
@@ -522,6 +542,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     const int wr = wave >> 1, wc = wave & 1;
     const int lr = lane & 15, lk = lane >> 4;
     constexpr int NA = 4, NB = 4;
+    constexpr int NT = F16 ? 2 : 3;                  // terms of a value in the pool: a row's 32-k chunk is NT x 64 contiguous bytes
     const int gr0 = 16 * ty + NA * wr, gc0 = tx + NB * wc;
     // the wave's 4 row and 4 column groups, and the pair of every sub-tile (-1: nothing to store) -- wave-uniform.
     // Straight-line loads with clamped indices (8 group records, then 16 table entries: two latencies, not 32)
@@ -581,15 +602,15 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         };
         if (16 * ty + sg < R.ng) {
             const EfSegGroup g = rowg[R.g0 + 16 * ty + sg];
-            if (sr < g.valid) { ap0 = S + (g.poolrow + sr) * 3 * Kp; if (CH) sp0 = roll_of(g); }
+            if (sr < g.valid) { ap0 = S + (g.poolrow + sr) * NT * Kp; if (CH) sp0 = roll_of(g); }
         }
         if (16 * ty + 8 + sg < R.ng) {
             const EfSegGroup g = rowg[R.g0 + 16 * ty + 8 + sg];
-            if (sr < g.valid) { ap1 = S + (g.poolrow + sr) * 3 * Kp; if (CH) sp1 = roll_of(g); }
+            if (sr < g.valid) { ap1 = S + (g.poolrow + sr) * NT * Kp; if (CH) sp1 = roll_of(g); }
         }
         if (sg < ncg) {
             const EfSegGroup g = colg[R.h0 + tx + sg];
-            if (sr < g.valid) bp = S + (g.poolrow + sr) * 3 * Kp + sp * 8;
+            if (sr < g.valid) bp = S + (g.poolrow + sr) * NT * Kp + sp * 8;
         }
         if (!CH) { ap0 += sp * 8; ap1 += sp * 8; }
     }
@@ -606,13 +627,13 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         else if (!CH) src = p < 3 ? ap0 : ap1;
         else {                                         // [k / 32][term][k % 32]: piece q of the row sits at 96 (q / 4) + 8 (q % 4)
             const int q = p < 3 ? sp0 : sp1;
-            src = (p < 3 ? ap0 : ap1) + 96 * (q >> 2) + 8 * (q & 3);
+            src = (p < 3 ? ap0 : ap1) + (32 * NT) * (q >> 2) + 8 * (q & 3);
         }
         st[p] = *reinterpret_cast<const u32x4 *>(src + (p % 3) * EFB_BK);
     };
     auto gload_advance = [&]() {
-        bp += 3 * EFB_BK;
-        if (!CH) { ap0 += 3 * EFB_BK; ap1 += 3 * EFB_BK; }
+        bp += NT * EFB_BK;
+        if (!CH) { ap0 += NT * EFB_BK; ap1 += NT * EFB_BK; }
         else {
             sp0 += 4; sp0 = sp0 >= pieces ? sp0 - pieces : sp0;
             sp1 += 4; sp1 = sp1 >= pieces ? sp1 - pieces : sp1;
@@ -814,7 +835,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             else {
                 float tq = (nx[a] + ny[b][reg]) - 2.0f * dot;
                 if (tq < 0.0f) tq = 0.0f;
-                v[reg] = __builtin_sqrtf(tq);
+                v[reg] = ef_sqrt_nonneg(tq);
             }
         }
     };

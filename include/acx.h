@@ -525,6 +525,8 @@ int acx_profile_get(acx_ctx *ctx, int idx, char *name, int name_len,
 
 /* device-side sqrt probe used by the parity tests (must be correctly rounded) */
 int acx_debug_sqrt(acx_ctx *ctx, const float *in, int64_t n, float *out);
+/* the sqrt of the EarlyFusion distance epilogues (v_sqrt_f32 + one Newton step: within 1 ulp, almost always exact) */
+int acx_debug_ef_sqrt(acx_ctx *ctx, const float *in, int64_t n, float *out);
 
 #ifdef __cplusplus
 }

@@ -422,6 +422,28 @@ def test_f16x2_gemm_mode(ctx):
         ctx.set_ef_gemm("default")
 
 
+def test_epilogue_sqrt(ctx):
+    """The sqrt of the distance epilogues (ef_sqrt_nonneg: v_sqrt_f32 + one Newton step on the fma residual) against
+    numpy's correctly rounded one: never more than 1 ulp apart, identical on all but a sliver of the inputs; 0, tiny and
+    huge values pass through."""
+    rng = np.random.default_rng(77)
+    x = np.concatenate([rng.random(2_000_000).astype(np.float32) * 4000.0,                    # distances^2 of z-scored 650-dim rows
+                        np.exp(rng.uniform(-40, 40, 2_000_000)).astype(np.float32),
+                        np.arange(0, 70000, dtype=np.float32),
+                        np.array([0.0, 1e-45, 1e-38, 1.1754944e-38, 1e-30, 3.4e38, np.inf], np.float32)])
+    got = ctx.debug_sqrt(x, ef=True)
+    want = np.sqrt(x)
+    assert np.all(got[np.isinf(want)] == np.inf) and got[x == 0].max() == 0.0
+    fin = np.isfinite(want) & (x >= 1.1754944e-38)
+    ulp = np.abs(got[fin].view(np.int32).astype(np.int64) - want[fin].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, ulp.max()
+    frac = float(np.mean(ulp == 0))
+    print("ef_sqrt_nonneg: identical to the correctly rounded sqrt on %.6f of %d inputs" % (frac, int(fin.sum())))
+    assert frac >= 0.999, frac
+    den = (x > 0) & (x < 1.1754944e-38)                      # denormal inputs: the raw instruction's answer (flushed or not), never NaN
+    assert not np.any(np.isnan(got[den]))
+
+
 def test_neighbourhood_sizes(ctx):
     """K (the neighbourhood of getWCSM's kernel widths) up to 16: the column means come from C itself
     (ef_colstat_kernel); beyond: the transposed matrices and the row-selection kernel.  Both against the oracle's
