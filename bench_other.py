@@ -169,7 +169,7 @@ def serra09_f16x2_leg(ctx, n=96, T=2000, reps=3):
         "exact_value": round(res["exact"][1], 1), "speedup_vs_exact": round(res["f16x2"][1] / res["exact"][1], 3),
         "scores_identical_fraction": round(float(np.mean(diff == 0)), 4), "scores_within_2_fraction": round(float(np.mean(diff <= 2.0)), 5),
         "max_score_diff": float(diff.max()), "flipped_cell_fraction": flips / float(cells), "flipped_cells": [flips, cells],
-        "note": "as accurate against f64 as the exact chain (scripts/f16x2_debug6.py: rms 4.1e-6 on d^2 in both), not the same bits: "
+        "note": "as accurate against f64 as the exact chain (scripts/f16x2_accuracy.py: rms 4.1e-6 on d^2 in both), not the same bits: "
                 "a few cells per 10 000 change side of a threshold"}
 
 

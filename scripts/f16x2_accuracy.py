@@ -1,3 +1,5 @@
+"""Serra09 Gram, exact f32 chain vs the opt-in f16x2 arithmetic: both d^2 matrices of one 300-frame i.i.d. pair against
+the f64-evaluated truth (max / rms error), as cited in profiles/r04_f16x2.md.  (python scripts/f16x2_accuracy.py, on a GPU)"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")

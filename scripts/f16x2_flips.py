@@ -1,3 +1,5 @@
+"""Serra09: the fraction of recurrence cells that change side of a threshold under the opt-in f16x2 Gram (debug pairs,
+both arithmetics), per track length (profiles/r04_f16x2.md).  (python scripts/f16x2_flips.py, on a GPU)"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,3 +1,5 @@
+"""Serra09, exact chain vs the opt-in f16x2 Gram on three cover-structured sets: pairs/s, fraction of identical scores, |diff| <= 2,
+MAP / MR / Top-1 of both (the numbers of profiles/r04_f16x2.md).  (python scripts/f16x2_map.py, on a GPU)"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
