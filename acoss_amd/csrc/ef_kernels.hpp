@@ -1090,6 +1090,25 @@ __global__ __launch_bounds__(256) void ef_gemm_seg_f32_kernel(const float *__res
 // kappa == 0 handled by the host) and r_i = mean of the kw smallest; mode 1 (C^T rows):
 // only the mean (= column statistic c_j); mode 2 (F rows): only the threshold.
 // ------------------------------------------------------------------------------------
+// lane exchanges of the row statistics by DPP (no LDS round trip; __shfl_xor is a ds_bpermute_b32: ~100 cycles each, six of them
+// in a row's sum -- the neighbourhood mean cost more than the selection in front of it): xor 1 / xor 2 inside a quad, then the
+// mirrored half row / row -- the partner differs from xor 4 / xor 8, but after the quad steps every lane of a quad (of a half
+// row) holds the same partial value, so the result is the xor butterfly's.
+template <int CTRL> __device__ __forceinline__ int ef_dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float ef_dpp_f(float v) { return __int_as_float(ef_dpp_i<CTRL>(__float_as_int(v))); }
+constexpr int EF_DPP_XOR1 = 0xB1, EF_DPP_XOR2 = 0x4E, EF_DPP_HALF_MIRROR = 0x141, EF_DPP_ROW_MIRROR = 0x140;
+// sum over the wave, the same in every lane: a balanced tree (lanes 1, 2, 4, 8 apart, then the four rows as (r0 + r1) + (r2 + r3))
+__device__ __forceinline__ float ef_wave_sum_f(float s)
+{
+    s += ef_dpp_f<EF_DPP_XOR1>(s);
+    s += ef_dpp_f<EF_DPP_XOR2>(s);
+    s += ef_dpp_f<EF_DPP_HALF_MIRROR>(s);
+    s += ef_dpp_f<EF_DPP_ROW_MIRROR>(s);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 template <int NX>
 __device__ __forceinline__ float mean_k_smallest(const float (&x)[NX], int kw, float vk, int lane)
 {
@@ -1103,11 +1122,9 @@ __device__ __forceinline__ float mean_k_smallest(const float (&x)[NX], int kw, f
         acc += lt ? x[t] : 0.0f;
         cnt += lt ? 1 : 0;
     }
-    // deterministic wave sum (DPP scan order)
+    // deterministic wave sums
     const int tot = wave_sum_i(cnt);
-    float s = acc;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float s = ef_wave_sum_f(acc);
     (void)lane;
     return (s + (float)(kw - tot) * vk) / (float)kw;
 }
@@ -1278,6 +1295,11 @@ __device__ __forceinline__ float ef_fused_value_exact(float wsum) { return expf(
                                        no spills, 8 instead of 6 waves per SIMD -- the selection's chain waits on latencies: 15.3 -> 13.9 ms per 5 grid tiles */
 #endif
 constexpr int ef_rowstat_min_waves(int nq) { return (nq <= 2 && ACX_EF_ROWSTAT_WAVES > 0) ? ACX_EF_ROWSTAT_WAVES : 1; }
+#ifdef ACX_EF_ABL   /* stage ablations of the row statistics (scripts/ab_build_acx.sh ablN -DACX_EF_ABL=N): leave after stage N, the row kept alive */
+#define ACX_EF_ABL_EXIT(n_) do { if (ACX_EF_ABL == (n_)) { float k_ = 0.f; for (int e_ = 0; e_ < NX; ++e_) k_ += x[e_]; if (k_ == 1.2345e-33f) stat[0] = k_; return; } } while (0)
+#else
+#define ACX_EF_ABL_EXIT(n_) do { } while (0)
+#endif
 template <int NQ, bool FUSED, bool EXACT = false>
 __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
                                                          float *__restrict__ stat, unsigned *__restrict__ bits, int mode, int kw, int store_f)
@@ -1380,8 +1402,9 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
         }
         lane_has_data = cells > 0;
         const int cap = 8 * ((n + 255) / 256);                 // slots of a lane pair that CAN be cells in a row of n (4 per lane and 256 columns)
-        group_full = cells + __shfl_xor(cells, 1, 64) >= cap - cap / 4;
+        group_full = cells + ef_dpp_i<EF_DPP_XOR1>(cells) >= cap - cap / 4;
     }
+    ACX_EF_ABL_EXIT(1);                                  // the row (FUSED: the fused row) is in registers
     float *S = stat + P.offS + (mode >= 2 ? 3 * ef_s_stride(P) : s * ef_s_stride(P));
     // mode 0 wants two order statistics of the row: rank K - 1 (neighbourhood mean) and rank kbin - 1 (threshold).  Both
     // from one histogram when the row is long enough for the pivot filter (ef_select_pivot2), else one after the other.
@@ -1395,12 +1418,14 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
             have2 = ef_select_pivot2<NX>(x, kk - 1, kb - 1, fh_addr, cand[wave], lane, vk2, t2, lane_has_data, group_full, 0.15f);
         }
     }
+    if (!FUSED) ACX_EF_ABL_EXIT(2);                      // + both order statistics from one histogram
     if (!FUSED && mode < 2) {                          // (before the threshold: nothing of it is alive during this selection)
         const int kk = kw < n ? kw : n;
         const float vk = have2 ? vk2 : kth(x, kk - 1, n);
         const float m = mean_k_smallest(x, kk, vk, lane);
         if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
     }
+    if (!FUSED) ACX_EF_ABL_EXIT(3);                      // + neighbourhood mean
     if (FUSED || mode != 1) {
         const int kb = P.kbin;
         float t;
@@ -1453,6 +1478,7 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
                 jcut = cand_j;
             }
         }
+        ACX_EF_ABL_EXIT(4);                              // + threshold (FUSED: its selection) and the tie count
         if (lane == 0) {
             S[row] = t;
             reinterpret_cast<int *>(S)[ef_jcut_off(P, mode >= 2 ? 3 : s) + row] = jcut;
@@ -1474,9 +1500,9 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
                 }
             }
             unsigned w = nib << (4 * (lane & 7));
-            w |= __shfl_xor(w, 1, 64);
-            w |= __shfl_xor(w, 2, 64);
-            w |= __shfl_xor(w, 4, 64);
+            w |= (unsigned)ef_dpp_i<EF_DPP_XOR1>((int)w);
+            w |= (unsigned)ef_dpp_i<EF_DPP_XOR2>((int)w);
+            w |= (unsigned)ef_dpp_i<EF_DPP_HALF_MIRROR>((int)w);      // (lanes 8 k .. 8 k + 7 now hold the word; lane 8 k stores it)
             const int word = 8 * q + (lane >> 3);
             if ((lane & 7) == 0 && 32 * word < pitch)
                 bits[P.offB + ((int64_t)(mode >= 2 ? 3 : s) * P.M + row) * (pitch >> 5) + word] = w;
@@ -1655,7 +1681,7 @@ __global__ __launch_bounds__(64) void sw_kernel(const EfPair *__restrict__ pd, c
                         }
                     }
                     issue(i + SW_PF, ring[sl], tring[sl], jring[sl]);
-                    const int l1a = __shfl(U1[CPL - 1], prev, 64), l1b = __shfl(U1[CPL - 2], prev, 64), l2a = __shfl(U2[CPL - 1], prev, 64);
+                    const int l1a = lane_prev_i(U1[CPL - 1]), l1b = lane_prev_i(U1[CPL - 2]), l2a = lane_prev_i(U2[CPL - 1]);
                     int Tn[CPL];
 #pragma unroll
                     for (int e = 0; e < CPL; ++e) {
@@ -1741,7 +1767,7 @@ __global__ __launch_bounds__(64, ACX_SW_BITS_WAVES) void sw_bits_kernel(const Ef
                     bool b[CPL];
 #pragma unroll
                     for (int e = 0; e < CPL; ++e) b[e] = ((wb >> e) & 1u) != 0u;
-                    const int l1a = __shfl(U1[CPL - 1], prev, 64), l1b = __shfl(U1[CPL - 2], prev, 64), l2a = __shfl(U2[CPL - 1], prev, 64);
+                    const int l1a = lane_prev_i(U1[CPL - 1]), l1b = lane_prev_i(U1[CPL - 2]), l2a = lane_prev_i(U2[CPL - 1]);
                     int Tn[CPL];
 #pragma unroll
                     for (int e = 0; e < CPL; ++e) {
@@ -1924,7 +1950,7 @@ __global__ __launch_bounds__(64) void sw_long_kernel(const EfPair *__restrict__ 
             if (st > 0) recB = rin[0];
             for (int i = 2; i <= M - 2; ++i) {
                 load_b(i, b);
-                int l1a = __shfl(U1[CPL - 1], prev, 64), l1b = __shfl(U1[CPL - 2], prev, 64), l2a = __shfl(U2[CPL - 1], prev, 64);
+                int l1a = lane_prev_i(U1[CPL - 1]), l1b = lane_prev_i(U1[CPL - 2]), l2a = lane_prev_i(U2[CPL - 1]);
                 int2 recA = make_int2(0, 0);                    // record of row i - 1
                 if (st > 0) recA = rin[i - 1];
                 if (lane == 0) { l1a = recA.x; l1b = recA.y; l2a = recB.x; }

@@ -76,6 +76,11 @@ __device__ __forceinline__ float wave_shfl(float v, int src)
 {
     return __shfl(v, src, 64);
 }
+// The value of lane - 1 (lane 0: zero) by DPP wave_shr:1 -- the left neighbour of the alignment recursions.  __shfl(v, lane - 1)
+// is a ds_bpermute_b32: an LDS round trip in the dependency chain of every DP row.
+__device__ __forceinline__ int lane_prev_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned lane_prev_u(unsigned v) { return (unsigned)lane_prev_i((int)v); }
+__device__ __forceinline__ float lane_prev_f(float v) { return __int_as_float(lane_prev_i(__float_as_int(v))); }
 
 // ------------------------------------------------------------------------------------
 // doubling-tree window sum (DESIGN.md "arithmetic spec"; oracle tree_sum)
@@ -1751,15 +1756,15 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
     auto dp_row = [&](int i, unsigned d0, unsigned d1, float (&QA)[CPL], float (&QB)[CPL],
                       float (&PA)[EQG ? 1 : CPL], float (&PB)[EQG ? 1 : CPL]) {
         const unsigned wraw = row_bits(i, d0, d1);
-        float l1a = wave_shfl(QA[CPL - 1], prev), l1b = wave_shfl(QA[CPL - 2], prev), l2a = wave_shfl(QB[CPL - 1], prev);
+        float l1a = lane_prev_f(QA[CPL - 1]), l1b = lane_prev_f(QA[CPL - 2]), l2a = lane_prev_f(QB[CPL - 1]);
         float p1a = 0.f, p1b = 0.f, p2a = 0.f;
         if constexpr (!EQG) {
-            p1a = wave_shfl(PA[CPL - 1], prev); p1b = wave_shfl(PA[CPL - 2], prev); p2a = wave_shfl(PB[CPL - 1], prev);
+            p1a = lane_prev_f(PA[CPL - 1]); p1b = lane_prev_f(PA[CPL - 2]); p2a = lane_prev_f(PB[CPL - 1]);
         }
         if (lane == 0) { l1a = 0.f; l1b = 0.f; l2a = 0.f; p1a = 0.f; p1b = 0.f; p2a = 0.f; }
         unsigned wleft = 0u;                                    // bit e = R[i][j-1]
         if constexpr (DMAX) {
-            unsigned carry = (unsigned)__shfl((int)((wraw >> (CPL - 1)) & 1u), prev, 64);
+            unsigned carry = lane_prev_u((wraw >> (CPL - 1)) & 1u);
             if (lane == 0) carry = 0u;
             wleft = (wraw << 1) | carry;
         }
@@ -1837,8 +1842,8 @@ __global__ __launch_bounds__(64) void qmax_bits_h16_kernel(const PairDesc *__res
         const int sh = (BAND - 1) - (i & (BAND - 1));
         const unsigned w = __builtin_amdgcn_alignbit(d1, d0, bit0 + sh) & colmask;
         // neighbour lane's last registers: its columns CPL-1 / CPL-2 are the HIGH halves of registers NR-1 / NR-2
-        unsigned nA1 = (unsigned)__shfl((int)QA[NR - 1], prev, 64), nA2 = (unsigned)__shfl((int)QA[NR - 2], prev, 64);
-        unsigned nB1 = (unsigned)__shfl((int)QB[NR - 1], prev, 64);
+        unsigned nA1 = lane_prev_u(QA[NR - 1]), nA2 = lane_prev_u(QA[NR - 2]);
+        unsigned nB1 = lane_prev_u(QB[NR - 1]);
         if (lane == 0) { nA1 = 0u; nA2 = 0u; nB1 = 0u; }
         // register "-1": low half = column -1 (neighbour's high half of NR-1), high half = column NR-1 (own low half of NR-1)
         const unsigned a_m1 = __builtin_amdgcn_alignbit(QA[NR - 1], nA1, 16);
