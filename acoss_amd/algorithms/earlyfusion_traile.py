@@ -34,7 +34,16 @@ class EarlyFusion(CoverAlgorithm):
 
     def __init__(self, dataset_csv, datapath, chroma_type='hpcp', shortname='Covers80', blocksize=20,
                  mfccs_per_block=50, ssm_res=50, chromas_per_block=40, kappa=0.1, K=10, niters=5,
-                 log_times=False, device=None, nonfinite="raise"):
+                 log_times=False, device=None, nonfinite="raise", engine=None):
+        """The reference's arguments (earlyfusion_traile.py:40-56), plus: `device`, `nonfinite` ("raise" | "propagate" for
+        NaN / inf in the features), and `engine`, a dict of the library's arithmetic switches for this chain --
+        {"gemm": "f16x2" (default) | "bf16x3" | "f32" | ...} (Context.set_ef_gemm: how the three cross-similarity
+        products are evaluated; all within an f32 sgemm's accuracy) and {"fuse": "fast" (default) | "exact"}
+        (Context.set_ef_fuse: getWCSM's kernel weights by reciprocal + exp2, or in numpy's own operation order)."""
+        self._engine = dict(engine or {})
+        unknown = set(self._engine) - {"gemm", "fuse"}
+        if unknown:
+            raise ValueError("EarlyFusion: unknown engine option(s) %s" % sorted(unknown))
         self.chroma_type = chroma_type
         self.blocksize = blocksize
         self.mfccs_per_block = mfccs_per_block
@@ -89,9 +98,7 @@ class EarlyFusion(CoverAlgorithm):
         self._pool_ready = False
 
     def _context(self):
-        if self._ctx is None:
-            dev = self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0"))
-            self._ctx = _lib.Context(dev, nonfinite=getattr(self, "_nonfinite", "raise"))
+        self._fusion_context()
         if not self._pool_ready:
             feats = None
             if not self.all_block_feats:
@@ -122,6 +129,11 @@ class EarlyFusion(CoverAlgorithm):
         if getattr(self, "_ctx", None) is None:
             dev = getattr(self, "_device", None)
             self._ctx = _lib.Context(dev if dev is not None else int(os.environ.get("LOCAL_RANK", "0")), nonfinite=getattr(self, "_nonfinite", "raise"))
+            eng = getattr(self, "_engine", {})
+            if "gemm" in eng:
+                self._ctx.set_ef_gemm(eng["gemm"])
+            if "fuse" in eng:
+                self._ctx.set_ef_fuse(eng["fuse"])
         return self._ctx
 
     def do_late_fusion(self):

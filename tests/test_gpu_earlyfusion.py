@@ -224,6 +224,37 @@ def test_benchmark_end_to_end(tmp_path, monkeypatch):
     assert np.array_equal(Ds["early"], Ds["early"].T) and Ds["early"][0, 1] > 10
 
 
+def test_engine_options_of_the_class(ctx, tmp_path, monkeypatch):
+    """EarlyFusion(engine={"gemm": ..., "fuse": ...}) reaches the library's switches: the class's scores are the
+    context's in the same mode; unknown options are refused."""
+    from acoss_amd import synth
+    from acoss_amd.algorithms.earlyfusion_traile import EarlyFusion
+    tracks = synth.earlyfusion_set(6, seed=31, nb_range=(40, 90))
+    monkeypatch.chdir(tmp_path)
+    with open("ds.csv", "w") as f:
+        f.write("work_id,track_id\n")
+        for i in range(6):
+            f.write("w%d,t%d\n" % (i // 2, i))
+    pairs = np.array([[0, 1], [2, 5], [3, 4]], np.int32)
+    try:
+        for eng in ({"gemm": "bf16x3"}, {"gemm": "f32", "fuse": "exact"}, {}):
+            ef = EarlyFusion("ds.csv", "feat/", shortname="toy", engine=eng)
+            ef.set_block_features(tracks)
+            ctx.set_ef_gemm(eng.get("gemm", "default"))
+            ctx.set_ef_fuse(eng.get("fuse", "fast"))
+            ctx.ef_upload_pool(tracks)
+            want = ctx.earlyfusion_pairs(pairs)
+            for k, (i, j) in enumerate(pairs):
+                ef.similarity([(int(i), int(j))])
+                got = [ef.Ds[s][i, j] for s in ("mfccs", "ssms", "chromas", "early")]
+                assert np.array_equal(np.asarray(got, np.float32), want[k]), (eng, i, j)
+    finally:
+        ctx.set_ef_gemm("default")
+        ctx.set_ef_fuse("fast")
+    with pytest.raises(ValueError):
+        EarlyFusion("ds.csv", "feat/", shortname="toy", engine={"gem": "f32"})
+
+
 def test_rectangle_gemm_equals_pairwise_gemm(ctx):
     """The dense-rectangle GEMM (ef_gemm_rect_bf16x3_kernel; chroma by f32 MFMAs as in the one-matrix-at-a-time
     kernels: mode 'bf16x3_chroma_f32') against the one-matrix-at-a-time kernels of
@@ -288,7 +319,7 @@ def test_rectangle_gemm_equals_pairwise_gemm(ctx):
 
 
 def test_chroma_on_the_bf16_pipe(ctx):
-    """The default's chroma matrix (ef_gemm_rect_bf16x3_kernel<1>: bin-major three-term bf16 splits, the OTI roll as a
+    """The bf16x3 mode's chroma matrix (ef_gemm_rect_bf16x3_kernel<1>: bin-major three-term bf16 splits, the OTI roll as a
     shift of the staged row) against the f32-MFMA kernel and against the f64 truth: same bound for both; scores of
     whole pair lists (several tracks per tile, every roll, tracks shorter than a group, column chunks that end with
     their track) agree except on threshold ties."""
