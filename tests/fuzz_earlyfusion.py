@@ -5,7 +5,7 @@ tests/fuzz_earlyfusion.py [rounds] [seed]` on the GPU box; tests/test_gpu_earlyf
 Every round draws a pool of ragged tracks (1 .. 140 blocks, sometimes one of 520 or 1100), odd feature widths
 (mfcc / ssm widths that are not multiples of 32, chroma blocks of 8, 16 or 40 frames), random kappa / K, and a random pair
 list (duplicates, self pairs, both orders), and checks
-  * the default arithmetic (three-term bf16 splits, rectangles, bits path) against the exact-f32 one-matrix-at-a-time
+  * the default arithmetic (two fp16 terms per value, rectangles, bits path) against the exact-f32 one-matrix-at-a-time
     kernels: mfccs / ssms / chromas / early scores equal except on ties (>= 92 % identical, none further than 3.0);
   * a sample of pairs against the numpy oracle within the same bound;
   * the pair grid against the pair list.
@@ -27,6 +27,21 @@ def make_case(rng):
         return dict(mfccs=rng.standard_normal((nb, d0)).astype(np.float32), ssms=(2 * rng.random((nb, d1))).astype(np.float32),
                     chromas=(rng.random((nb, 12 * G)).astype(np.float32) ** 2), chroma_med=rng.random(12) ** 2)
     tracks = [track(nb) for nb in nbs]
+    # value ranges the per-row scales of the f16x2 operands have to follow: whole tracks scaled by up to 10^+-3, single
+    # elements 100 times their row's size, rows of zeros
+    if rng.random() < 0.3:
+        for t in tracks:
+            t["mfccs"] *= np.float32(10.0 ** rng.uniform(-3, 3))
+            t["ssms"] *= np.float32(10.0 ** rng.uniform(-3, 3))
+    if rng.random() < 0.3:
+        for t in tracks:
+            nb = t["mfccs"].shape[0]
+            for key in ("mfccs", "ssms"):
+                r = rng.integers(0, nb, 3)
+                cidx = rng.integers(0, t[key].shape[1], 3)
+                t[key][r, cidx] *= np.float32(100.0)
+            if nb > 6 and rng.random() < 0.3:
+                t["mfccs"][int(rng.integers(0, nb))] = 0.0
     K = int(rng.choice([1, 3, 10, 16, 17]))
     kappa = float(rng.choice([0.05, 0.1, 0.3]))
     m = int(rng.integers(1, 300))
