@@ -3,7 +3,8 @@ for Serra09 (coverid.py:57-70): Serra09.all_pairwise(symmetric=True) + normalize
 getEvalStatistics() on the synthetic 5 000-track x 2000-frame pool of bench.py (12 497 500 pairs), wall time
 per phase -> profiles/r03_end_to_end.json (via gpurun_out/).
 
-    python scripts/end_to_end.py [n_tracks] [frames]
+    python scripts/end_to_end.py [n_tracks] [frames | covers]        (covers: lengths uniform in 150 .. 650 pooled frames, the
+                                                                       shape of covers80 / DA-TACOS tracks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/end_to_end.py [n_tracks] [frames]
 
 The i.i.d. pool has no cover structure; every 5 consecutive tracks are labelled as one work so that the
@@ -22,7 +23,8 @@ import bench  # noqa: E402
 from acoss_amd.algorithms.rqa_serra09 import Serra09  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else bench.N_TRACKS
-T = int(sys.argv[2]) if len(sys.argv) > 2 else bench.T_FRAMES
+COVERS = len(sys.argv) > 2 and sys.argv[2] == "covers"
+T = 0 if COVERS else (int(sys.argv[2]) if len(sys.argv) > 2 else bench.T_FRAMES)
 # one process per GPU under torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK from the launcher): the classes find the
 # process group on their own (acoss_amd/dist.py); every rank keeps its own phase clock, rank 0 reports all of them
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -39,7 +41,14 @@ if world > 1 or os.environ.get("ACX_GRID_VIA_COLLECTIVE", "") not in ("", "0"):
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend)
-frames, offsets = bench.make_pool(N, T)
+if COVERS:
+    _rng = np.random.default_rng(4321)
+    _len = _rng.integers(150, 651, N)
+    offsets = np.concatenate([[0], np.cumsum(_len)]).astype(np.int64)
+    frames = _rng.random((int(offsets[-1]), 12), dtype=np.float32)
+    frames /= frames.max(axis=1, keepdims=True)
+else:
+    frames, offsets = bench.make_pool(N, T)
 labels = ["w%d" % (i // 5) for i in range(N)]
 out_dir = os.path.join(ROOT, "gpurun_out")
 os.makedirs(out_dir, exist_ok=True)
@@ -78,7 +87,13 @@ if rank == 0:
     total = sum(ph.values())
     host_phases = ph["normalize_by_length_s"] + ph["getEvalStatistics_s"]
     ap = [p["all_pairwise_s"] for p in per_rank]
-    rec = {"workload": "configs[2]: %d tracks x %d frames, Serra09 Qmax, all %d unordered pairs, %d rank(s), one MI355X each" % (N, T, pairs, world),
+    shape = "150-650 frames each (uniform: the covers80 / DA-TACOS shape; %d frames in all)" % int(offsets[-1]) if COVERS else "%d frames" % T
+    cells = None
+    if COVERS:
+        M = (np.diff(offsets) - 8).astype(np.float64)           # embedded frames (m = 9, tau = 1)
+        cells = float((M.sum() ** 2 - (M ** 2).sum()) / 2)
+    rec = {"workload": "configs[2]: %d tracks x %s, Serra09 Qmax, all %d unordered pairs, %d rank(s), one MI355X each" % (N, shape, pairs, world),
+           "gcells_per_s_all_pairwise": (round(cells / ph["all_pairwise_s"] / 1e9, 1) if cells else None),
            "n_gpus": world, "collectives": (dist.get_backend() if dist is not None else None),
            "phases_s": {k: round(v, 2) for k, v in ph.items()}, "total_s": round(total, 2),
            "phases_s_per_rank": [{k: round(v, 2) for k, v in p.items()} for p in per_rank],
