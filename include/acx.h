@@ -257,7 +257,7 @@ int acx_ef_upload_pool(acx_ctx *ctx, const float *mfccs, const float *ssms, cons
  *                       Slices may arrive in any order and may be handed over again (the last copy wins)
  *   acx_ef_pool_end     checks that EVERY track was handed over (else ACX_ERR_STATE naming the first missing
  *                       track; the pool stays open, so the missing slices can still be supplied), then the
- *                       non-finite scan, row norms, bf16 splits; the pool is usable from here on
+ *                       non-finite scan, row norms, the GEMM operands (two fp16 or three bf16 terms per value, acx_set_ef_gemm); the pool is usable from here on
  */
 int acx_ef_pool_begin(acx_ctx *ctx, const int64_t *offsets, int32_t n_tracks, const int32_t *dims);
 int acx_ef_pool_tracks(acx_ctx *ctx, int32_t first_track, int32_t count, const float *mfccs, const float *ssms,
@@ -333,7 +333,8 @@ int acx_earlyfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const a
  * All meet the same bound against the f64 truth (tests/test_gpu_earlyfusion.py) and move as many scores against
  * f64-evaluated matrices as the reference's own f32 arithmetic does (tests/test_gpu_parity_sets.py, 124 750 pairs;
  * profiles/r04_parity_ef.json); scores that differ between them sit on a row-kappa threshold tie.  The split pool
- * holds ONE operand format (69 GB at DA-TACOS size): changing between F16X2 and the bf16 modes re-splits the pool
+ * holds ONE operand format (46 GB of fp16 terms or 69 GB of bf16 terms at DA-TACOS size, in one allocation sized for the larger):
+ * changing between F16X2 and the bf16 modes re-splits the pool
  * on the next call.  mode -1 = the default.
  */
 enum { ACX_EF_GEMM_BF16X3 = 0, ACX_EF_GEMM_F32 = 1,
