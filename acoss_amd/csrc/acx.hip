@@ -691,10 +691,11 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
 #define ACX_QB(E_, D_) do { if (cl == 0) ACX_QB3(E_, D_, 8); else if (cl == 1) ACX_QB3(E_, D_, 16); else if (cl == 2) ACX_QB3(E_, D_, 32); \
                             else ACX_QBL(E_, D_); } while (0)
                     // the default penalties (0.5 / 0.5): packed 16-bit integer DP in half-units, two cells per instruction
-                    if (eqg && !dmax && p.gamma_o == 0.5f && cl < 3) {
-#define ACX_QH(C_) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<C_>), dim3(Bc), dim3(64), 0, c->stream, \
-                                      S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.dp_start)
-                        if (cl == 0) ACX_QH(8); else if (cl == 1) ACX_QH(16); else ACX_QH(32);
+                    if (eqg && p.gamma_o == 0.5f && cl < 3) {
+#define ACX_QH(C_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<C_, D_>), dim3(Bc), dim3(64), 0, c->stream, \
+                                          S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.dp_start)
+                        if (dmax) { if (cl == 0) ACX_QH(8, true); else if (cl == 1) ACX_QH(16, true); else ACX_QH(32, true); }
+                        else { if (cl == 0) ACX_QH(8, false); else if (cl == 1) ACX_QH(16, false); else ACX_QH(32, false); }
 #undef ACX_QH
                     }
                     else if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }
@@ -1575,10 +1576,11 @@ int acx_qmax_binary(acx_ctx *c, const uint8_t *R, int32_t M, int32_t N, const ac
                                        S.d_pd, c->d_bits, c->d_scratch, S.d_out, 1, params->gamma_o, params->gamma_e, params->dp_start)
 #define ACX_QB(E_, D_) do { if (cl == 0) ACX_QB3(E_, D_, 8); else if (cl == 1) ACX_QB3(E_, D_, 16); else if (cl == 2) ACX_QB3(E_, D_, 32); \
                         else ACX_QBL(E_, D_); } while (0)
-    if (eqg && !dmax && params->gamma_o == 0.5f && cl < 3) {
-        if (cl == 0) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<8>), dim3(1), dim3(64), 0, c->stream, S.d_pd, c->d_bits, S.d_out, 1, params->dp_start);
-        else if (cl == 1) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<16>), dim3(1), dim3(64), 0, c->stream, S.d_pd, c->d_bits, S.d_out, 1, params->dp_start);
-        else hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<32>), dim3(1), dim3(64), 0, c->stream, S.d_pd, c->d_bits, S.d_out, 1, params->dp_start);
+    if (eqg && params->gamma_o == 0.5f && cl < 3) {
+#define ACX_QH1(C_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<C_, D_>), dim3(1), dim3(64), 0, c->stream, S.d_pd, c->d_bits, S.d_out, 1, params->dp_start)
+        if (dmax) { if (cl == 0) ACX_QH1(8, true); else if (cl == 1) ACX_QH1(16, true); else ACX_QH1(32, true); }
+        else { if (cl == 0) ACX_QH1(8, false); else if (cl == 1) ACX_QH1(16, false); else ACX_QH1(32, false); }
+#undef ACX_QH1
     }
     else if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }
     else { if (dmax) ACX_QB(false, true); else ACX_QB(false, false); }

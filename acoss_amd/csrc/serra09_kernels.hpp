@@ -1796,13 +1796,17 @@ __global__ __launch_bounds__(64) void qmax_bits_kernel(const PairDesc *__restric
 // t = +2 (match) / -1 (gap) half-units = 3 bit - 1, the bits of both halves spread by one shift + and;
 // the clamp at 0 is the saturation of an unsigned subtract (v_pk_mad + v_pk_sub_u16 clamp).
 // Exactly the arithmetic of qmax_bits_kernel<true, false, CPL>: integers instead of exact floats.
+// DMAX (chen17, latefusion_chen.py:68; qmax_bits_kernel<true, true, CPL>): the (i-2, j-1) predecessor gains R[i-1][j] and the
+// (i-1, j-2) predecessor R[i][j-1] -- the RAW recurrence bits, + 2 half-units each (two more v_pk_mad per register) --, and a cell
+// outside the matrix or in its first two columns is forced to 0 (a per-register mask).  Dmax values stay below 2 min(M, N)
+// = 8164 half-units: int16 holds them.
 // ------------------------------------------------------------------------------------
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ i16x2 as_i16x2(unsigned v) { return __builtin_bit_cast(i16x2, v); }
 __device__ __forceinline__ unsigned as_u32(i16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
-template <int CPL>
+template <int CPL, bool DMAX = false>
 __global__ __launch_bounds__(64) void qmax_bits_h16_kernel(const PairDesc *__restrict__ pd,
                                                            const unsigned long long *__restrict__ bits,
                                                            float *__restrict__ out, int out_stride, int dp_start)
@@ -1836,11 +1840,34 @@ __global__ __launch_bounds__(64) void qmax_bits_h16_kernel(const PairDesc *__res
         }
     };
     const i16x2 three = {3, 3};
+    const i16x2 two = {2, 2};
     const u16x2 one_u = {1, 1};
+    // A lane's CPL column bits "arranged": bits [0, NR) stay, bits [NR, CPL) move to [16, 16 + NR) -- once per word and row
+    // (three instructions; nothing to do at CPL = 32), so that the bits of columns k and k + NR drop into bit 0 of the two
+    // halves of register k with one shift and one mask
+    auto arrange = [&](unsigned v) -> unsigned {
+        if constexpr (NR == 16) return v;
+        else return (v & ((1u << NR) - 1u)) | (((v >> NR) & ((1u << NR) - 1u)) << 16);
+    };
+    auto spread = [&](unsigned va, int k) -> unsigned { return (va >> k) & 0x00010001u; };     // (of an ARRANGED word)
+    const unsigned colmask_a = arrange(colmask);
+    unsigned cm[DMAX ? NR : 1];                                  // Dmax: 0xffff in the halves whose column exists and is >= 2
+    unsigned wprev = 0u;                                         // Dmax: raw recurrence bits of row i - 1
+    if constexpr (DMAX) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) cm[k] = spread(colmask_a, k) * 0xffffu;
+        unsigned p0, p1;
+        load_row(1, p0, p1);
+        wprev = arrange(__builtin_amdgcn_alignbit(p1, p0, bit0 + ((BAND - 1) - (1 & (BAND - 1)))));
+    } else cm[0] = 0u;
     // One DP row: QA = row i-1, QB = row i-2 (overwritten with row i)
     auto dp_row = [&](int i, unsigned d0, unsigned d1, unsigned (&QA)[NR], unsigned (&QB)[NR]) {
         const int sh = (BAND - 1) - (i & (BAND - 1));
-        const unsigned w = __builtin_amdgcn_alignbit(d1, d0, bit0 + sh) & colmask;
+        const unsigned wraw = __builtin_amdgcn_alignbit(d1, d0, bit0 + sh);
+        const unsigned wraw_a = arrange(wraw);
+        const unsigned w = wraw_a & colmask_a;                   // (arranged, like everything `spread` reads)
+        unsigned wleft = 0u;                                     // Dmax: bit e = R[i][j - 1]
+        if constexpr (DMAX) wleft = arrange((wraw << 1) | lane_prev_u((wraw >> (CPL - 1)) & 1u));
         // neighbour lane's last registers: its columns CPL-1 / CPL-2 are the HIGH halves of registers NR-1 / NR-2
         unsigned nA1 = lane_prev_u(QA[NR - 1]), nA2 = lane_prev_u(QA[NR - 2]);
         unsigned nB1 = lane_prev_u(QB[NR - 1]);
@@ -1852,18 +1879,22 @@ __global__ __launch_bounds__(64) void qmax_bits_h16_kernel(const PairDesc *__res
 #pragma unroll
         for (int k = NR - 1; k >= 0; --k) {
             const i16x2 c2 = as_i16x2(k >= 1 ? QA[k - 1] : a_m1);                          // (i-1, j-1)
-            const i16x2 c3 = as_i16x2(k >= 1 ? QB[k - 1] : b_m1);                          // (i-2, j-1)
-            const i16x2 c4 = as_i16x2(k >= 2 ? QA[k - 2] : (k == 1 ? a_m1 : a_m2));        // (i-1, j-2)
+            i16x2 c3 = as_i16x2(k >= 1 ? QB[k - 1] : b_m1);                                // (i-2, j-1)
+            i16x2 c4 = as_i16x2(k >= 2 ? QA[k - 2] : (k == 1 ? a_m1 : a_m2));              // (i-1, j-2)
+            if constexpr (DMAX) {
+                c3 = as_i16x2(spread(wprev, k)) * two + c3;
+                c4 = as_i16x2(spread(wleft, k)) * two + c4;
+            }
             const i16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(c2, c3), c4);
-            unsigned sp;                                     // recurrence bit of column k -> low half, of column k + NR -> high half
-            if constexpr (NR == 16) sp = (w >> k) & 0x00010001u;
-            else sp = ((w >> k) & 1u) | (((w >> (k + NR)) & 1u) << 16);
+            const unsigned sp = spread(w, k);                // recurrence bit of column k -> low half, of column k + NR -> high half
             // max(mx + 3 bit - 1, 0): multiply-add, then an unsigned saturating subtract (all values are >= 0)
             const u16x2 up = __builtin_bit_cast(u16x2, as_i16x2(sp) * three + mx);
-            const i16x2 q = __builtin_bit_cast(i16x2, __builtin_elementwise_sub_sat(up, one_u));
+            i16x2 q = __builtin_bit_cast(i16x2, __builtin_elementwise_sub_sat(up, one_u));
+            if constexpr (DMAX) q = as_i16x2(as_u32(q) & cm[k]);
             QB[k] = as_u32(q);
             best = __builtin_elementwise_max(best, q);
         }
+        if constexpr (DMAX) wprev = wraw_a;
     };
     unsigned a0, a1, b0, b1, c0, c1, d0, d1;
     load_row(2, a0, a1); load_row(3, b0, b1); load_row(4, c0, c1); load_row(5, d0, d1);

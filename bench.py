@@ -787,6 +787,7 @@ def main():
             import bench_other
             line["other"] = {}
             legs = (("serra09_covers", bench_other.serra09_covers_leg), ("serra09_f16x2", bench_other.serra09_f16x2_leg),
+                    ("chenfusion", bench_other.chenfusion_leg),
                     ("simple", bench_other.simple_leg), ("earlyfusion", bench_other.earlyfusion_leg))
 
             def watchdog():

@@ -173,6 +173,57 @@ def serra09_f16x2_leg(ctx, n=96, T=2000, reps=3):
                 "a few cells per 10 000 change side of a threshold"}
 
 
+def chenfusion_leg(ctx, steps=3, warmup=1, cpu_pairs=96):
+    """LateFusionChen's pair work (latefusion_chen.py:58-73: Qmax AND Dmax of the same cross recurrence plot) on
+    covers80-shaped lengths: `steps + warmup` sets of 164 tracks, all 13 366 pairs of a different set per step through
+    acx_chenfusion_pairs; one-core CPU figure and bit-for-bit check on a bounded sample (the C oracle, both alignments)."""
+    import oracle
+    from acoss_amd import _lib, synth
+    sets = [synth.covers80_shaped(seed=300 + s, t_range=(150, 650)) for s in range(steps + warmup)]
+    frames = np.concatenate([d["frames"] for d in sets])
+    lens = np.concatenate([np.diff(d["offsets"]) for d in sets])
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ctx.upload_pool(frames, offs)
+    params = _lib.serra09_params()
+    n = 164
+    iu, ju = np.triu_indices(n, 1)
+    base = np.stack([iu, ju], 1).astype(np.int32)
+    L = lens - 9
+    for s in range(warmup):
+        ctx.chenfusion_pairs(base + s * n, params)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    dt, cells, got0, p0 = 0.0, 0.0, None, None
+    for s in range(warmup, warmup + steps):
+        p = np.ascontiguousarray(base + s * n)
+        t0 = time.perf_counter()
+        got = ctx.chenfusion_pairs(p, params)
+        dt += time.perf_counter() - t0
+        cells += float(np.sum(L[p[:, 0]].astype(np.float64) * L[p[:, 1]]))
+        if got0 is None:
+            got0, p0 = got, p
+    prof = ctx.profile()
+    with _one_thread():
+        tc = time.perf_counter()
+        rq = oracle.serra09_pairs(frames, offs, p0[:cpu_pairs], oracle.serra09_params())
+        rd = oracle.serra09_pairs(frames, offs, p0[:cpu_pairs], oracle.serra09_params(dmax=1))
+        tcpu = time.perf_counter() - tc
+    if not (np.array_equal(rq, got0[:cpu_pairs, 0]) and np.array_equal(rd, got0[:cpu_pairs, 1])):
+        raise AssertionError("chenfusion: GPU scores differ from the CPU oracle")
+    npairs = steps * len(base)
+    return {
+        "metric": "track-pairs/sec, LateFusionChen's Qmax + Dmax on covers80-shaped lengths (164 tracks of 150-650 pooled frames, all 13 366 pairs)",
+        "value": round(npairs / dt, 1), "unit": "track-pairs/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1] shape, %d sets (seeds 300..%d), a different set per step, acx_chenfusion_pairs (both scores to the host)"
+                               % (steps + warmup, 300 + steps + warmup - 1)},
+        "gcells_per_s": round(cells / dt / 1e9, 1),
+        "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]},
+        "cpu_baseline": {"value": round(cpu_pairs / tcpu, 2), "unit": "track-pairs/s", "cores": 1, "kind": "port",
+                         "sample": "first %d pairs of the first timed set, C oracle (gcc -O3), one thread, Qmax and Dmax one after the "
+                                   "other, %.1f s; both scores bit-identical to the GPU's" % (cpu_pairs, tcpu)}}
+
+
 def simple_leg(ctx, steps=5, warmup=1, n=1536, tiles_per_step=16, cpu_pairs=64):
     """SiMPle (simple_silva.py:120-126): ordered pairs of tracks of 12 x 150-250 pooled frames through the pair grid
     (acx_grid_run: pairs enumerated on the device, f64 kernel, f32 scatter into a device buffer).  The pool holds
@@ -357,6 +408,7 @@ def main():
     ctx = _lib.Context(0)
     print(json.dumps(serra09_covers_leg(ctx, args.steps, args.warmup)), flush=True)
     print(json.dumps(serra09_f16x2_leg(ctx)), flush=True)
+    print(json.dumps(chenfusion_leg(ctx)), flush=True)
     print(json.dumps(simple_leg(ctx, args.steps, args.warmup)), flush=True)
     print(json.dumps(earlyfusion_leg(ctx, args.steps, args.warmup, cpu_pairs=args.cpu_pairs)), flush=True)
     ctx.close()
