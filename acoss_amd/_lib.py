@@ -492,7 +492,7 @@ class Context(object):
 
     def set_ef_gemm(self, mode):
         """'f16x2' (= 'default': dense rectangles of pairs, all three matrices on the matrix pipe from two fp16 terms per
-        value, four MFMAs per cell), 'bf16x3' (three bf16 terms, six MFMAs: all 24 bits of every operand), 'f32',
+        value, three MFMAs per cell), 'bf16x3' (three bf16 terms, six MFMAs: all 24 bits of every operand), 'f32',
         'bf16x3_pairwise' (one matrix at a time: mfccs / ssms with bf16x3's bits, chroma f32) or 'bf16x3_chroma_f32'
         (rectangles, chroma f32): EarlyFusion's cross-similarity GEMMs (acx_set_ef_gemm)."""
         self._check(self._L.acx_set_ef_gemm(self._h, {"bf16x3": 0, "f32": 1, "bf16x3_pairwise": 2,

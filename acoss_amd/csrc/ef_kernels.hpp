@@ -515,8 +515,9 @@ __device__ unsigned long long g_ef_clk[16];          // [0] start-up, [1] k loop
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // F16 = 1 (ACX_EF_GEMM_F16X2): the pool holds TWO fp16 terms of x / inv[row] (ef_split_bf16_kernel with row scales) and
-// a cell takes FOUR v_mfma_f32_16x16x32_f16 per chunk -- x2 y2, x1 y2, x2 y1, x1 y1 -- instead of six bf16 ones: 22
-// significant bits of every value instead of all 24, two thirds of the MFMAs, LDS stores and pool reads.  The epilogue
+// a cell takes THREE v_mfma_f32_16x16x32_f16 per chunk -- x1 y2, x2 y1, x1 y1 (x2 y2 stays below the accumulator's
+// rounding: ACX_EF_F16_PRODUCTS) -- instead of six bf16 ones: 22 significant bits of every value instead of all 24,
+// half of the MFMAs, two thirds of the LDS stores and pool reads.  The epilogue
 // multiplies a product by inv[row] inv[column] (powers of two: exact): inv0 / inv1 = the row scales of split0 / split1.
 template <int CH, int F16 = 0>
 __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ef_gemm_rect_bf16x3_kernel(
@@ -683,9 +684,17 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     };
     auto chunk_mma = [&](int cur, auto st_tag, auto ld_tag) {
         constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
-        constexpr int NG = F16 ? 4 : 6;                                              // products of a cell and chunk
-        constexpr int TA[6] = {F16 ? 1 : 0, F16 ? 0 : 2, 1, 0, 1, 0}, TB[6] = {F16 ? 1 : 2, F16 ? 1 : 0, F16 ? 0 : 1, F16 ? 0 : 1, 0, 0};   // smallest products first, as in E1b
-        constexpr int LASTP = F16 ? 11 : 18;                                         // the slot of the chunk's last staging piece and its barrier
+#ifndef ACX_EF_F16_PRODUCTS
+#define ACX_EF_F16_PRODUCTS 3      /* 3: x1 y2 + x2 y1 + x1 y1.  x2 y2 is <= 2^-22 |x y| per element -- a chunk's 32 such terms almost never reach the
+                                      accumulator's last bit: with it (4; the round's first version) the 500-track parity set gives the SAME moved-score
+                                      counts and MAPs to every printed digit, and the worst d^2 error against f64 moves from 7.5e-7 to 8.0e-7 of the
+                                      scale (bar 4e-6); without it the GEMMs take 21.5 instead of 24.7 ms per 8128 pairs */
+#endif
+        constexpr bool P3 = F16 && ACX_EF_F16_PRODUCTS == 3;
+        constexpr int NG = F16 ? (P3 ? 3 : 4) : 6;                                   // products of a cell and chunk
+        constexpr int TA[6] = {F16 ? (P3 ? 0 : 1) : 0, F16 ? (P3 ? 1 : 0) : 2, P3 ? 0 : 1, 0, 1, 0},
+                      TB[6] = {F16 ? 1 : 2, F16 ? (P3 ? 0 : 1) : 0, F16 ? 0 : 1, F16 ? 0 : 1, 0, 0};   // smallest products first, as in E1b
+        constexpr int LASTP = F16 ? (P3 ? 8 : 11) : 18;                              // the slot of the chunk's barrier (behind its last staging piece and its last operand read)
         const unsigned short *a_ = aop + cur * EFR_A, *b_ = bop + cur * EFR_B;
         bf16x8 av[NA][3], bv[2][3];
         auto rdb = [&](int e, int b, int q) { bv[e][q] = *reinterpret_cast<const bf16x8 *>(b_ + (q * EFR_COLS + 16 * b) * EFB_LP); };
@@ -713,12 +722,12 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                 }
                 const int slot = NG * b + g;
                 // bf16x3: nine pieces behind slots 2, 4 .. 18; f16x2: its six behind slots 1, 3 .. 11
-                if (slot >= (F16 ? 1 : 2) && slot <= LASTP && (slot & 1) == (F16 ? 1 : 0)) {
+                if (P3 ? (slot >= 1 && slot <= 6) : (slot >= (F16 ? 1 : 2) && slot <= LASTP && (slot & 1) == (F16 ? 1 : 0))) {
                     auto piece = [&](auto p_tag) {
                         if (ST) lstore_piece(cur ^ 1, p_tag);
                         if (LD) gload_piece(p_tag);
                     };
-                    const int nth = (slot - (F16 ? 1 : 2)) / 2;
+                    const int nth = P3 ? slot - 1 : (slot - (F16 ? 1 : 2)) / 2;
                     switch (F16 ? nth + nth / 2 : nth) {                             // (f16x2: 0 1 3 4 6 7)
                     case 0: piece(std::integral_constant<int, 0>()); break;
                     case 1: piece(std::integral_constant<int, 1>()); break;

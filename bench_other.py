@@ -378,13 +378,13 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
         "config": {"workload": "configs[4] per-track shape: pool of %d tracks of 300-500 blocks, one 128 x 128 grid tile per step "
                                "(diagonal: 8128 pairs, off-diagonal: 16 384), another tile every step, %d pairs in %d steps through "
                                "acx_grid_run (scores scattered into a device buffer)" % (n, npairs, steps)},
-        # all three cross-similarity GEMMs run on the 16-bit matrix pipe from two fp16 terms per value: four fp16 products
+        # all three cross-similarity GEMMs run on the 16-bit matrix pipe from two fp16 terms per value: three fp16 products
         # per f32-equivalent multiply-add are what the pipe executes, and what is priced against its dense peak
         "roofline": {"bound": "mfma", "kernel": "ef_gemm_rect_bf16x3_kernel<0, 1> (mfcc / ssm) + <1, 1> (chroma): two fp16 terms per value "
                                                 "(ACX_EF_GEMM_F16X2, the default), 256 x 128 tiles over dense rectangles of pairs",
-                     "achieved": round(4.0 * flops / ks / 1e12, 1), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": round(4.0 * flops / ks / 1e12 / BF16_MFMA_PEAK_TF, 4), "traffic": None,
-                     "flops": "executed fp16 flops = 4 x the f32-equivalent 2 (650 + 1225 + 480) nb1 nb2 per pair (SURVEY 8d); dense fp16 peak = dense bf16 peak",
+                     "achieved": round(3.0 * flops / ks / 1e12, 1), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(3.0 * flops / ks / 1e12 / BF16_MFMA_PEAK_TF, 4), "traffic": None,
+                     "flops": "executed fp16 flops = 3 x (x1 y2 + x2 y1 + x1 y1) the f32-equivalent 2 (650 + 1225 + 480) nb1 nb2 per pair (SURVEY 8d); dense fp16 peak = dense bf16 peak",
                      "f32_equivalent_tflops": round(flops / ks / 1e12, 2), "f32_mfma_peak_tflops": F32_MFMA_PEAK_TF,
                      "kernel_ms_per_step": round(g["ms"] / steps, 3),
                      "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]}},

@@ -320,8 +320,9 @@ int acx_earlyfusion_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const a
  * shift of the row by whole 16-byte pieces (blocks of a multiple of 8 frames; others: f32 MFMAs).
  *   ACX_EF_GEMM_F16X2 (default)   every value as TWO fp16 terms of x / s, s = the power of two that puts the largest
  *                                 |x| of the value's own ROW into [2^14, 2^15) (so a track's operands depend on the
- *                                 track alone); four fp16 MFMAs per cell and 32 k -- x2 y2, x1 y2, x2 y1, x1 y1,
- *                                 f32 accumulation -- and the product rescaled by s_row s_column (exact).  An
+ *                                 track alone); three fp16 MFMAs per cell and 32 k -- x1 y2, x2 y1, x1 y1, f32
+ *                                 accumulation; x2 y2 (<= 2^-22 |x y|) stays below the accumulator's rounding and is
+ *                                 not formed -- and the product rescaled by s_row s_column (exact).  An
  *                                 operand keeps 22 of its 24 significant bits: a relative rounding of 2^-23 per
  *                                 value, below the accumulation error of any f32 sgemm over K = 480 .. 1225.
  *   ACX_EF_GEMM_BF16X3            three-term bf16 splits (all 24 bits of every value), six bf16 MFMAs per cell and

@@ -389,7 +389,7 @@ def test_chroma_on_the_bf16_pipe(ctx):
 
 
 def test_f16x2_gemm_mode(ctx):
-    """ACX_EF_GEMM_F16X2 (the default): two fp16 terms per value, four MFMAs per cell.  Matrices against the f64 truth
+    """ACX_EF_GEMM_F16X2 (the default): two fp16 terms per value, three MFMAs per cell.  Matrices against the f64 truth
     under the bounds the other modes are held to; scores of pair lists against bf16x3's (threshold ties may move); the
     same scores after the whole pool is scaled by 2^10 and 2^-10 (every row carries its own power-of-two scale); each
     mode's bits return when the mode is switched back and forth (the pool is re-split both ways)."""
