@@ -1305,9 +1305,9 @@ __device__ __forceinline__ float ef_fused_value_exact(float wsum) { return expf(
 #endif
 constexpr int ef_rowstat_min_waves(int nq) { return (nq <= 2 && ACX_EF_ROWSTAT_WAVES > 0) ? ACX_EF_ROWSTAT_WAVES : 1; }
 #ifdef ACX_EF_ABL   /* stage ablations of the row statistics (scripts/ab_build_acx.sh ablN -DACX_EF_ABL=N): leave after stage N, the row kept alive */
-#define ACX_EF_ABL_EXIT(n_) do { if (ACX_EF_ABL == (n_)) { float k_ = 0.f; for (int e_ = 0; e_ < NX; ++e_) k_ += x[e_]; if (k_ == 1.2345e-33f) stat[0] = k_; return; } } while (0)
+#define ACX_EF_ABL_EXIT(n_, ...) do { if (ACX_EF_ABL == (n_)) { float k_ = 0.f; for (int e_ = 0; e_ < NX; ++e_) k_ += x[e_]; const float ks_[] = {__VA_ARGS__}; for (float v_ : ks_) k_ += v_; if (k_ == 1.2345e-33f) stat[0] = k_; return; } } while (0)
 #else
-#define ACX_EF_ABL_EXIT(n_) do { } while (0)
+#define ACX_EF_ABL_EXIT(n_, ...) do { } while (0)
 #endif
 template <int NQ, bool FUSED, bool EXACT = false>
 __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
         const int cap = 8 * ((n + 255) / 256);                 // slots of a lane pair that CAN be cells in a row of n (4 per lane and 256 columns)
         group_full = cells + ef_dpp_i<EF_DPP_XOR1>(cells) >= cap - cap / 4;
     }
-    ACX_EF_ABL_EXIT(1);                                  // the row (FUSED: the fused row) is in registers
+    ACX_EF_ABL_EXIT(1, 0.f);                             // the row (FUSED: the fused row) is in registers
     float *S = stat + P.offS + (mode >= 2 ? 3 * ef_s_stride(P) : s * ef_s_stride(P));
     // mode 0 wants two order statistics of the row: rank K - 1 (neighbourhood mean) and rank kbin - 1 (threshold).  Both
     // from one histogram when the row is long enough for the pivot filter (ef_select_pivot2), else one after the other.
@@ -1427,14 +1427,14 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
             have2 = ef_select_pivot2<NX>(x, kk - 1, kb - 1, fh_addr, cand[wave], lane, vk2, t2, lane_has_data, group_full, 0.15f);
         }
     }
-    if (!FUSED) ACX_EF_ABL_EXIT(2);                      // + both order statistics from one histogram
+    if (!FUSED) ACX_EF_ABL_EXIT(2, vk2, t2, have2 ? 1.f : 0.f);      // + both order statistics from one histogram
     if (!FUSED && mode < 2) {                          // (before the threshold: nothing of it is alive during this selection)
         const int kk = kw < n ? kw : n;
         const float vk = have2 ? vk2 : kth(x, kk - 1, n);
         const float m = mean_k_smallest(x, kk, vk, lane);
         if (lane == 0) S[(mode == 0 ? P.pitchT : 2 * P.pitchT) + row] = m;
     }
-    if (!FUSED) ACX_EF_ABL_EXIT(3);                      // + neighbourhood mean
+    if (!FUSED) ACX_EF_ABL_EXIT(3, vk2, t2, have2 ? 1.f : 0.f);      // + neighbourhood mean (stored by lane 0 above)
     if (FUSED || mode != 1) {
         const int kb = P.kbin;
         float t;
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
                 jcut = cand_j;
             }
         }
-        ACX_EF_ABL_EXIT(4);                              // + threshold (FUSED: its selection) and the tie count
+        ACX_EF_ABL_EXIT(4, t, (float)jcut);              // + threshold (FUSED: its selection) and the tie count
         if (lane == 0) {
             S[row] = t;
             reinterpret_cast<int *>(S)[ef_jcut_off(P, mode >= 2 ? 3 : s) + row] = jcut;
