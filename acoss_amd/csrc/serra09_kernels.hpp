@@ -1105,11 +1105,13 @@ __device__ __forceinline__ void band_row_bits(const float (&xr)[NV], const TCG (
         }
         acc &= valid;
         // NV < 32: neighbouring lanes complete a dword
+        // (the lanes that store -- every second / fourth -- take their neighbours' bits inside their quad: DPP quad_perm
+        //  [1,1,3,3] / [1,2,3,3], [2,3,3,3] instead of ds_bpermute round trips)
         if constexpr (NV == 16) {
-            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 16;
+            acc |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)acc, 0xF5, 0xf, 0xf, false) << 16;
         } else if constexpr (NV == 8) {
-            acc |= (unsigned)__shfl_down((int)acc, 1, 64) << 8;
-            acc |= (unsigned)__shfl_down((int)acc, 2, 64) << 16;
+            acc |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)acc, 0xF9, 0xf, 0xf, false) << 8;
+            acc |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)acc, 0xFE, 0xf, 0xf, false) << 16;
         }
         constexpr int LPD = 32 / NV;                                    // lanes per dword
         unsigned *rowbits = reinterpret_cast<unsigned *>(bits + P.offT + (size_t)row * P.nw);
