@@ -1112,8 +1112,9 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                 ACX_FUSESEL(dim3((maxM + 3) / 4, B, 1));             // the fused matrix: made, thresholded and binarised row by row
             }
             ProfScope ps(c, KS_EFSW, cells);
-            if (wide_cols) hipLaunchKernelGGL((acx::sw_bits_kernel<16>), dim3(B, ext_matrix ? 1 : 4), dim3(64), 0, c->stream, c->d_efpd, c->d_efbits, c->d_out, 0);
-            else hipLaunchKernelGGL((acx::sw_bits_kernel<8>), dim3(B, ext_matrix ? 1 : 4), dim3(64), 0, c->stream, c->d_efpd, c->d_efbits, c->d_out, 0);
+            // (packed 16-bit integers: rows of <= 1024 cells keep every score below 10 240 tenths)
+            if (wide_cols) hipLaunchKernelGGL((acx::sw_bits_h16_kernel<16>), dim3(B, ext_matrix ? 1 : 4), dim3(64), 0, c->stream, c->d_efpd, c->d_efbits, c->d_out, 0);
+            else hipLaunchKernelGGL((acx::sw_bits_h16_kernel<8>), dim3(B, ext_matrix ? 1 : 4), dim3(64), 0, c->stream, c->d_efpd, c->d_efbits, c->d_out, 0);
         } else {
             {
                 ProfScope ps(c, KS_EFSW, cells);

@@ -1811,6 +1811,108 @@ __global__ __launch_bounds__(64, ACX_SW_BITS_WAVES) void sw_bits_kernel(const Ef
 }
 
 // ------------------------------------------------------------------------------------
+// E4c: E4b in PACKED 16-bit integers (round 4; the pattern of qmax_bits_h16_kernel): scores are tenths, at most 10 min(M, N)
+// <= 10 240 for rows of <= 1024 cells, and U >= -7, so V = U + 7 fits the unsigned half of a register and one v_pk_* instruction
+// updates two cells.  Register k of a lane holds its columns k (low half) and k + CPL / 2 (high half): the (i-1, j-1), (i-2, j-1),
+// (i-1, j-2) predecessors of register k are registers k - 1 / k - 2 of the two previous rows (the first two stitched from the
+// left neighbour lane by DPP + one funnel shift).  With the bias, T = max(max(U) +- 10, 0) = sat_sub(max(V) + 20 bit, 17) (an
+// unsigned saturating subtract) and the new V = T + 7 bit: 11 packed instructions per two cells.  The same integers as E4b.
+// ------------------------------------------------------------------------------------
+template <int CPL>
+__global__ __launch_bounds__(64) void sw_bits_h16_kernel(const EfPair *__restrict__ pd, const unsigned *__restrict__ bits,
+                                                         float *__restrict__ out, int src_base)
+{
+    constexpr int NR = CPL / 2;
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x;
+    const EfPair P = pd[blockIdx.x];
+    const int src = src_base + blockIdx.y;
+    const int M = P.M, N = P.N, pitch = P.pitchC;
+    float result = 0.0f;
+    if (M >= 4 && N >= 4) {
+        const unsigned char *rows = reinterpret_cast<const unsigned char *>(bits + P.offB + (int64_t)src * M * (pitch >> 5));
+        const int rowbytes = pitch >> 3;
+        const int j0 = CPL * lane;
+        const bool inrow = j0 < pitch;
+        auto load = [&](int row) -> unsigned {
+            const int r = row < M ? row : M - 1;                     // (rows past the last one: a valid address, never used)
+            if (!inrow) return 0u;
+            if (CPL == 8) return rows[(size_t)r * rowbytes + lane];
+            return *reinterpret_cast<const unsigned short *>(rows + (size_t)r * rowbytes + 2 * lane);
+        };
+        // a lane's CPL bits with the upper half moved to bit 16: the bits of columns k and k + NR are bit 0 of the halves of (w >> k)
+        auto arrange = [&](unsigned v) -> unsigned { return (v & ((1u << NR) - 1u)) | (((v >> NR) & ((1u << NR) - 1u)) << 16); };
+        auto spread = [&](unsigned va, int k) -> unsigned { return (va >> k) & 0x00010001u; };
+        // columns that may hold a score (j >= 2) / that count for the maximum (j <= N - 2), as half masks per register
+        unsigned cm[NR], bm[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int ja = j0 + k, jb = j0 + k + NR;
+            cm[k] = (ja >= 2 ? 0xffffu : 0u) | (jb >= 2 ? 0xffff0000u : 0u);
+            bm[k] = ((ja >= 2 && ja <= N - 2) ? 0xffffu : 0u) | ((jb >= 2 && jb <= N - 2) ? 0xffff0000u : 0u);
+        }
+        const u16x2 seven = {7, 7}, twenty = {20, 20}, seventeen = {17, 17};
+        unsigned V1[NR], V2[NR];                                       // V = U + 7 of rows i-1, i-2
+        {
+            const unsigned w0 = arrange(load(0)), w1 = arrange(load(1));
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                V2[k] = __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, spread(w0, k)) * seven);
+                V1[k] = __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, spread(w1, k)) * seven);
+            }
+        }
+        i16x2 best = {0, 0};
+        // one row: VA = row i-1, VB = row i-2 (overwritten with row i)
+        auto dp_row = [&](unsigned wb, unsigned (&VA)[NR], unsigned (&VB)[NR]) {
+            const unsigned w = arrange(wb);
+            // the left neighbour's columns CPL-1 / CPL-2 are the HIGH halves of its registers NR-1 / NR-2 (lane 0: zeros, masked)
+            const unsigned nA1 = lane_prev_u(VA[NR - 1]), nA2 = lane_prev_u(VA[NR - 2]), nB1 = lane_prev_u(VB[NR - 1]);
+            // register "-1": low half = column -1 (the neighbour's), high half = column NR - 1 (own low half of register NR - 1)
+            const unsigned a_m1 = __builtin_amdgcn_alignbit(VA[NR - 1], nA1, 16);
+            const unsigned a_m2 = __builtin_amdgcn_alignbit(VA[NR - 2], nA2, 16);
+            const unsigned b_m1 = __builtin_amdgcn_alignbit(VB[NR - 1], nB1, 16);
+#pragma unroll
+            for (int k = NR - 1; k >= 0; --k) {
+                const u16x2 c2 = __builtin_bit_cast(u16x2, k >= 1 ? VA[k - 1] : a_m1);                          // (i-1, j-1)
+                const u16x2 c3 = __builtin_bit_cast(u16x2, k >= 1 ? VB[k - 1] : b_m1);                          // (i-2, j-1)
+                const u16x2 c4 = __builtin_bit_cast(u16x2, k >= 2 ? VA[k - 2] : (k == 1 ? a_m1 : a_m2));        // (i-1, j-2)
+                const u16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(c2, c3), c4);
+                const u16x2 sp = __builtin_bit_cast(u16x2, spread(w, k));
+                // T = max(max(U) + (bit ? 10 : -10), 0) with U = V - 7
+                const u16x2 tt = __builtin_elementwise_sub_sat(sp * twenty + mx, seventeen);
+                const unsigned t = __builtin_bit_cast(unsigned, tt) & cm[k];                                     // columns 0, 1 stay 0
+                best = __builtin_elementwise_max(best, __builtin_bit_cast(i16x2, t & bm[k]));
+                VB[k] = __builtin_bit_cast(unsigned, sp * seven + __builtin_bit_cast(u16x2, t));                 // V = T + (bit ? 7 : 0)
+            }
+        };
+        constexpr int SW_PF = 8;
+        unsigned ring[SW_PF];
+#pragma unroll
+        for (int sl = 0; sl < SW_PF; ++sl) ring[sl] = load(2 + sl);
+        for (int i0 = 2; i0 <= M - 2; i0 += SW_PF) {
+#pragma unroll
+            for (int sl = 0; sl < SW_PF; ++sl) {
+                const int i = i0 + sl;
+                if (i <= M - 2) {                            // wave-uniform
+                    const unsigned wb = ring[sl];
+                    ring[sl] = load(i + SW_PF);
+                    if (sl & 1) dp_row(wb, V2, V1); else dp_row(wb, V1, V2);      // (i0 is even and SW_PF is even: row i-1 is V1 for even sl)
+                }
+            }
+        }
+        int bh = best.x > best.y ? best.x : best.y;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int t = __shfl_xor(bh, o, 64);
+            bh = bh > t ? bh : t;
+        }
+        result = (float)bh / 10.0f;
+    }
+    if (lane == 0) out[(size_t)blockIdx.x * 4 + src] = result;
+}
+
+// ------------------------------------------------------------------------------------
 // E2 / E4 for tracks of any length (more than 1024 blocks: a row no longer fits a wave's registers).
 // Same results as the register-resident kernels, rows streamed from HBM / L2.
 // ------------------------------------------------------------------------------------
