@@ -39,7 +39,8 @@ Also in the line:
                 was what made round 3's driver run take 27 minutes); N > 1 -> dist.barrier +
                 torch.cuda.synchronize.
   other         companion legs outside the timed region (bench_other.py): Serra09 on covers80-shaped
-                lengths, the opt-in f16x2 Gram beside the exact one, SiMPle, EarlyFusion.
+                lengths, the opt-in f16x2 Gram beside the exact one, LateFusionChen's Qmax + Dmax, SiMPle,
+                EarlyFusion (its default two-term fp16 GEMMs with the three-term bf16 ones beside them).
 `--strong` runs the path as ONE job instead (strong scaling, the whole grid, one final all-gather).
 """
 import argparse
