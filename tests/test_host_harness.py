@@ -236,6 +236,10 @@ def test_earlyfusion_class_surface(tmp_path, monkeypatch):
                      ssm_res=50, chromas_per_block=40, kappa=0.1, K=10, niters=5, log_times=False)
     assert ef.name == "EarlyFusionTraile" and sorted(ef.Ds.keys()) == ["chromas", "early", "mfccs", "ssms"]
     assert ef.get_cacheprefix() == "cache/EarlyFusionTraile_toy_hpcp"
+    # the arithmetic switches of the chain: kept for the context, unknown names refused (no GPU needed for either)
+    assert EarlyFusion(csv, root, shortname="toy", engine={"gemm": "bf16x3", "fuse": "exact"})._engine == {"gemm": "bf16x3", "fuse": "exact"}
+    with pytest.raises(ValueError):
+        EarlyFusion(csv, root, shortname="toy", engine={"arith": "f16x2"})
     with pytest.raises(KeyError):
         ef.load_features(0)                       # the toy files hold neither block nor raw MFCC / beat features
     tracks = synth.earlyfusion_set(3, seed=0, nb_range=(8, 12))
