@@ -224,7 +224,16 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, ACX_SIMPLE_WAVES) void simple_kern
                 const int b = b0 + j;                               // b % L == (1 + j) % L, b % 2 == (1 + j) % 2
                 if (b < mb) {                                       // wave-uniform
                     const double w = wb[b];
-                    double prev = __shfl_up(dot, 1, 64);            // dot[a - 1][b - 1] of the neighbour lane
+                    // dot[a - 1][b - 1] of the neighbour lane: two DPP wave_shr:1 moves (lane 0, a feeder lane whose value is never
+                    // used, reads 0) -- this value is the loop-carried dependency of the sweep; as a 64-bit __shfl_up it was two
+                    // ds_bpermute_b32 round trips per step in that chain
+                    double prev;
+                    {
+                        const long long bits_ = __double_as_longlong(dot);
+                        const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(bits_ & 0xffffffffll), 0x138, 0xf, 0xf, true);
+                        const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(bits_ >> 32), 0x138, 0xf, 0xf, true);
+                        prev = __longlong_as_double(((long long)hi_ << 32) | (unsigned int)lo_);
+                    }
                     const double e = E[b - 1 + (g == 0 ? 1 : 0) + eoff];   // group 0: row 0's own value top[b]; else dot[a - 1][b - 1] of the last lane
                     double gnew = 0.0;
 #pragma unroll
