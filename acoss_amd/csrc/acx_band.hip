@@ -3,7 +3,10 @@
 // +1 % and would cost simple_kernel 26 % and ef_rowstat_kernel 20 %.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "serra09_kernels.hpp"
+#include "serra09_band2_kernels.hpp"
 
 namespace acx {
 
@@ -20,6 +23,17 @@ bool launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows,
     // (the variant that also writes D2 exists for the row pass only: the debug entry point)
 #define ACX_BAND(V4_, A_) do { if (role) ACX_BAND_K(V4_, 1, false, A_); else if (write_d2) ACX_BAND_K(V4_, 0, true, A_); else ACX_BAND_K(V4_, 0, false, A_); } while (0)
     if (arith == 0) {
+        // rows of <= 505 cells, m <= 9: the two-rows-per-wave kernel (serra09_band2_kernels.hpp); ACX_BAND2=0 keeps band_kernel<M, 2>
+        if constexpr (M <= 9) {
+            static const bool two_rows = [] { const char *e = getenv("ACX_BAND2"); return !(e && e[0] == '0'); }();
+            if (ndata <= 8 && two_rows) {
+#define ACX_BAND2_K(R_, W_) hipLaunchKernelGGL((band2_kernel<M, R_, W_>), grid, dim3(B2_THREADS), 0, L.stream, L.frot, L.normtab, dpd, \
+                                               L.scratch, L.thr, L.bits, L.pct_mode, L.inclusive, L.oti_target, want_eps)
+                if (role) ACX_BAND2_K(1, false); else if (write_d2) ACX_BAND2_K(0, true); else ACX_BAND2_K(0, false);
+#undef ACX_BAND2_K
+                return true;
+            }
+        }
         if (ndata <= 8) ACX_BAND(2, 0);
         else if (ndata <= 16) ACX_BAND(4, 0);
         else ACX_BAND(8, 0);

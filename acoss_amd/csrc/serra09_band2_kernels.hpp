@@ -1,0 +1,582 @@
+// Serra09 band kernel for SHORT rows (<= 505 cells, stack size m <= 9): two matrix rows per wave.
+//
+// Reference call site: acoss/algorithms/rqa_serra09.py:44-69 -- the pooled tracks that reach essentia's
+// ChromaCrossSimilarity per pair hold 150-650 frames on covers80 / DA-TACOS, so THIS is the shape a user
+// sees.  Same arithmetic spec and the same bits as band_kernel (serra09_kernels.hpp); what differs is who
+// does what:
+//   * a workgroup is FOUR waves and still owns a band of 8 matrix rows; a wave sweeps two CONSECUTIVE
+//     64-column tiles (the second inherits the 16-frame halo block of the first: 12 instead of 15 MFMAs,
+//     four operand loads instead of five) -- 20 KB of Gram slabs, eight workgroups per CU;
+//   * after the exchange a wave owns TWO rows: lanes 0-31 hold row 2w, lanes 32-63 row 2w + 1, 16
+//     consecutive positions per lane.  The selection's reductions, prefix scans, bin search, candidate
+//     ranking and the threshold arithmetic do not depend on how many values a lane holds -- in
+//     band_kernel<M, 2> they are 100 of the selection's 157 VALU instructions per row
+//     (profiles/r04_narrow_classes.md) -- and every one of them now serves two rows: reductions stop at
+//     the half (DPP inside the 16-lane rows, one v_permlane16_swap across them), the histogram, its scan
+//     and the candidate list exist once per half, per-half scalars are the two halves of a ballot.
+// Anything the one-pass pivot-filtered selection cannot decide for a row (fewer than k + 2 cells below the
+// pivot, more than 32 candidates, a degenerate range) is re-laid out through LDS for the whole wave and goes
+// through band_kernel's own fallbacks (wave_select_fast / wave_select_regs on 8 values per lane): same bits.
+#pragma once
+#include "serra09_kernels.hpp"
+
+namespace acx {
+
+constexpr int B2_WAVES = 4;
+constexpr int B2_THREADS = 64 * B2_WAVES;
+constexpr int B2_NV = 16;                       // positions per lane of a half-wave row
+constexpr int B2_LNP = B2_NV + 4;               // floats per owner lane in an exchange row (16 bytes of pad: conflict-free 16-byte reads)
+constexpr int B2_ROWP = 32 * B2_LNP;            // exchange row pitch (floats): 640
+constexpr int B2_BINS = 256;                    // bins of the pivot-filtered histogram: 8 per lane of a half
+constexpr int B2_LDS_FLOATS = BAND * B2_ROWP;   // 5120 floats = 20 KB = the four packed Gram slabs of the sweep
+#ifndef ACX_B2_WAVES_PER_SIMD
+#define ACX_B2_WAVES_PER_SIMD 8
+#endif
+
+// ---- reductions over the 32 lanes of a half, result in EVERY lane of the half: xor 1, xor 2 inside the quads, mirror inside 8
+// and 16 lanes (DPP, one VALU operation each), then the two 16-lane rows of the half trade places (v_permlane16_swap).
+template <typename Op>
+__device__ __forceinline__ int half_allreduce(int v, Op op)
+{
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));    // row_half_mirror
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));    // row_mirror
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);   // r[0]: rows 0 0 2 2, r[1]: rows 1 1 3 3
+    return op((int)r[0], (int)r[1]);
+}
+// inclusive prefix sum inside each half (lanes without a source add 0)
+__device__ __forceinline__ int half_incl_scan_i(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    return v;
+}
+// a per-half scalar pair as a per-lane value
+__device__ __forceinline__ int half_pick(bool upper, int lo, int hi) { return upper ? hi : lo; }
+__device__ __forceinline__ float half_pick(bool upper, float lo, float hi) { return upper ? hi : lo; }
+
+// ------------------------------------------------------------------------------------
+// Pivot-filtered one-pass selection (wave_select_pivot, serra09_kernels.hpp) for TWO rows at once: lanes 0-31 hold
+// one row, lanes 32-63 the other, NV = 16 consecutive positions per lane, pads +inf.  k (0-based rank) is the same for
+// both rows (they belong to one pair and one pass).  `hist_addr` / `cand_addr`: LDS byte addresses of the lane's OWN
+// half's zeroed B2_BINS-dword histogram and of its 32 candidate slots + 1 zeroed counter dword.
+// Returns a 2-bit mask: bit h set = half h has its order statistics k (slo) and, with want_next, k + 1 (shi) in
+// every lane of the half; a clear bit = the pass could not decide that row (the caller's fallback takes over).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pair_select_pivot(const float (&x)[B2_NV], int k, bool want_next, unsigned hist_addr, unsigned cand_addr,
+                                                      int lane, float &slo, float &shi, bool lane_has_data, bool group_full)
+{
+    constexpr int NV = B2_NV, NB = B2_BINS, BPL = NB / 32;      // 8 bins per lane in the scan
+    static_assert(BPL == 8, "two 16-byte pieces per lane");
+    const float INF = __builtin_inff();
+    const int l = lane & 31;
+    const bool upper = lane >= 32;
+    // ---- row minimum and the largest minimum of a lane whose 16 positions are all cells (unsigned patterns: +inf pads above every cell)
+    unsigned mnl = 0xFFFFFFFFu;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const unsigned b = __float_as_uint(x[t]);
+        mnl = b < mnl ? b : mnl;
+    }
+    const unsigned mnu = (unsigned)half_allreduce((int)mnl, OpMinU());
+    const int mxg = half_allreduce(group_full ? (int)mnl : (int)0x80000000, OpMaxI());
+    const float mn = __uint_as_float(mnu);
+    const float gm = __uint_as_float((unsigned)mxg);
+    const float range = gm - mn;
+    // (the same guards as wave_select_pivot; `good` is uniform inside a half)
+    const bool good = mxg >= 0 && (int)mnu >= 0 && range >= 1e-30f && range <= 1e30f && mn <= 2048.0f * range;
+    constexpr unsigned MAGIC = 0x4B000000u;            // 2^23: the bin is the low part of the binning fma's bit pattern
+    const float scale = ((float)NB - 3.0f) * __builtin_amdgcn_rcpf(range);
+    const float offm = (lane_has_data && good) ? (8388609.0f - mn * scale) : INF;
+    unsigned off[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) off[t] = __float_as_uint(__builtin_fmaf(x[t], scale, offm));
+    // ---- histogram of the cells whose bin exists: exec-masked LDS atomics, four cells per hand-written statement
+    {
+        const unsigned nb = __builtin_amdgcn_readfirstlane(MAGIC + NB);
+        const unsigned hb = hist_addr - 4u * MAGIC;                        // (mod 2^32, like the shift); per half
+        unsigned one = 1u;
+        asm volatile("" : "+v"(one));
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            unsigned long long m0, m1, m2, m3, sv;
+            unsigned a0, a1, a2, a3;
+            asm volatile("v_cmp_gt_u32_e64 %[m0], %[nb], %[q0]\n\t"
+                         "v_cmp_gt_u32_e64 %[m1], %[nb], %[q1]\n\t"
+                         "v_cmp_gt_u32_e64 %[m2], %[nb], %[q2]\n\t"
+                         "v_cmp_gt_u32_e64 %[m3], %[nb], %[q3]\n\t"
+                         "v_lshl_add_u32 %[a0], %[q0], 2, %[hb]\n\t"
+                         "v_lshl_add_u32 %[a1], %[q1], 2, %[hb]\n\t"
+                         "v_lshl_add_u32 %[a2], %[q2], 2, %[hb]\n\t"
+                         "v_lshl_add_u32 %[a3], %[q3], 2, %[hb]\n\t"
+                         "s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b64 exec, %[m0]\n\t"
+                         "ds_add_u32 %[a0], %[one]\n\t"
+                         "s_mov_b64 exec, %[m1]\n\t"
+                         "ds_add_u32 %[a1], %[one]\n\t"
+                         "s_mov_b64 exec, %[m2]\n\t"
+                         "ds_add_u32 %[a2], %[one]\n\t"
+                         "s_mov_b64 exec, %[m3]\n\t"
+                         "ds_add_u32 %[a3], %[one]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [sv] "=&s"(sv),
+                           [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+                         : [q0] "v"(off[t]), [q1] "v"(off[t + 1]), [q2] "v"(off[t + 2]), [q3] "v"(off[t + 3]),
+                           [nb] "s"(nb), [hb] "v"(hb), [one] "v"(one)
+                         : "memory");
+        }
+    }
+    wave_lds_fence();
+    // ---- scan: lane l of a half owns bins [8 l, 8 l + 8) of its half's histogram; the two 16-byte pieces in a staggered order
+    // (lanes 8 apart would otherwise meet in one bank group)
+    int lsum = 0;
+    {
+        const int rot = (l >> 3) & 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int piece = (q + rot) & 1;
+            const u32x4 h = *(const lds_u32x4 *)(hist_addr + (unsigned)(l * BPL + 4 * piece) * 4u);
+            lsum += (int)(h.x + h.y) + (int)(h.z + h.w);
+        }
+    }
+    const int incl = half_incl_scan_i(lsum);
+    const int excl = incl - lsum;
+    const int k2 = want_next ? k + 1 : k;
+    const unsigned long long mk1 = __ballot(incl > k), mk2 = __ballot(incl > k2);
+    unsigned okm = 0u;
+    // the first lane of each half whose inclusive count exceeds the rank (s_ff1: -1 when there is none)
+    int L1[2], L2[2], ex1[2], ex2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned a = (unsigned)(mk1 >> (32 * h)), b = (unsigned)(mk2 >> (32 * h));
+        L1[h] = __ffs((int)a) - 1; L2[h] = __ffs((int)b) - 1;
+        const bool have = L1[h] >= 0 && L2[h] >= 0;       // at least k + 2 cells at or below the pivot
+        if (have) okm |= 1u << h;
+        L1[h] = have ? L1[h] : 0; L2[h] = have ? L2[h] : 0;
+        ex1[h] = __builtin_amdgcn_readlane(excl, 32 * h + L1[h]);
+        ex2[h] = __builtin_amdgcn_readlane(excl, 32 * h + L2[h]);
+    }
+    // second level: lanes 0..7 of a half look at the 8 bins of lane L1, lanes 16..23 at those of lane L2
+    const int e = l & 15;
+    const bool second = l >= 16;
+    const int Lx = second ? half_pick(upper, L2[0], L2[1]) : half_pick(upper, L1[0], L1[1]);
+    const int exx = second ? half_pick(upper, ex2[0], ex2[1]) : half_pick(upper, ex1[0], ex1[1]);
+    const int kk = second ? k2 : k;
+    int c = (int)*(const lds_u32 *)(hist_addr + (unsigned)(Lx * BPL + (e & 7)) * 4u);
+    c = e < BPL ? c : 0;
+    int P = c;                                        // inclusive prefix inside each row of 16 lanes (8 of them count)
+    P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, false);
+    P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, false);
+    P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xf, 0xf, false);
+    const unsigned long long mh = __ballot(e < BPL && exx + P > kk);
+    int cum1[2], bin1[2], bin2[2], ncand[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned f1 = (unsigned)(mh >> (32 * h)) & 0xffffu, f2 = (unsigned)(mh >> (32 * h + 16)) & 0xffffu;
+        int l1 = __ffs((int)f1) - 1, l2 = __ffs((int)f2) - 1;
+        if (l1 < 0 || l2 < 0) { okm &= ~(1u << h); l1 = 0; l2 = 0; }
+        const int cnt1 = __builtin_amdgcn_readlane(c, 32 * h + l1);
+        cum1[h] = ex1[h] + __builtin_amdgcn_readlane(P, 32 * h + l1) - cnt1;
+        bin1[h] = L1[h] * BPL + l1;
+        bin2[h] = L2[h] * BPL + l2;
+        ncand[h] = cnt1;
+        if (bin2[h] != bin1[h]) ncand[h] += __builtin_amdgcn_readlane(c, 32 * h + 16 + l2);   // the bins between are empty
+        if (ncand[h] > 32) okm &= ~(1u << h);
+        if (!((okm >> h) & 1u)) { ncand[h] = 0; bin1[h] = -2; bin2[h] = -2; }                  // (matches no pattern)
+    }
+    if (okm == 0u) return 0u;
+    // ---- gather the members of [bin1, bin2] of each half into its candidate slots (order irrelevant: slots are handed out
+    // by an LDS counter; a handful of cells per row)
+    {
+        const unsigned a1 = MAGIC + (unsigned)half_pick(upper, bin1[0], bin1[1]);
+        const unsigned span = (unsigned)half_pick(upper, bin2[0] - bin1[0], bin2[1] - bin1[1]);
+        lds_u32 *counter = (lds_u32 *)(cand_addr + 32u * 4u);
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            const bool h0 = (off[t] - a1) <= span, h1 = (off[t + 1] - a1) <= span;
+            const bool h2 = (off[t + 2] - a1) <= span, h3 = (off[t + 3] - a1) <= span;
+            if (__ballot(h0 || h1 || h2 || h3) != 0ull) {       // most groups hold no member of the target bins
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool hit = u == 0 ? h0 : (u == 1 ? h1 : (u == 2 ? h2 : h3));
+                    if (hit) {
+                        const unsigned pos = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        *(__attribute__((address_space(3))) float *)(cand_addr + 4u * (pos & 31u)) = x[t + u];
+                    }
+                }
+            }
+        }
+    }
+    wave_lds_fence();
+    // ---- rank them: a lane holds one candidate of its half and reads the others as LDS broadcasts, four per 16-byte read
+    const int nc = half_pick(upper, ncand[0], ncand[1]);
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    if (l >= nc) *(lds_f32 *)(cand_addr + 4u * (unsigned)l) = INF;
+    wave_lds_fence();
+    const float mine = *(const lds_f32 *)(cand_addr + 4u * (unsigned)l);
+    int rank = 0;
+    const int ncmax = ncand[0] > ncand[1] ? ncand[0] : ncand[1];
+#pragma unroll 1
+    for (int t = 0; t < ncmax; t += 4) {
+        const f32x4 o = *(const lds_f32x4 *)(cand_addr + 4u * (unsigned)t);
+        rank += (o.x < mine || (o.x == mine && t + 0 < l)) ? 1 : 0;
+        rank += (o.y < mine || (o.y == mine && t + 1 < l)) ? 1 : 0;
+        rank += (o.z < mine || (o.z == mine && t + 2 < l)) ? 1 : 0;
+        rank += (o.w < mine || (o.w == mine && t + 3 < l)) ? 1 : 0;
+    }
+    const int want = k - half_pick(upper, cum1[0], cum1[1]);
+    const unsigned long long ms1 = __ballot(l < nc && rank == want);
+    const unsigned long long ms2 = __ballot(l < nc && rank == want + (want_next ? 1 : 0));
+    float r1[2], r2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int s1 = __ffs((int)(unsigned)(ms1 >> (32 * h))) - 1, s2 = __ffs((int)(unsigned)(ms2 >> (32 * h))) - 1;
+        if (s1 < 0 || s2 < 0) { okm &= ~(1u << h); s1 = 0; s2 = 0; }
+        r1[h] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), 32 * h + s1));
+        r2[h] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), 32 * h + s2));
+    }
+    slo = half_pick(upper, r1[0], r1[1]);
+    shi = half_pick(upper, r2[0], r2[1]);
+    wave_lds_fence();
+    return okm;
+}
+
+// ------------------------------------------------------------------------------------
+// band2_kernel: see the head of this file.  grid = (bands of 8 rows, pairs), 256 threads.
+// ------------------------------------------------------------------------------------
+template <int M, int ROLE, bool WD2 = false>
+__global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kernel(const float *__restrict__ frot,
+                                                            const float *__restrict__ normtab,
+                                                            const PairDesc *__restrict__ pd,
+                                                            float *__restrict__ scratch,
+                                                            float *__restrict__ thr,
+                                                            unsigned long long *__restrict__ bits,
+                                                            int pct_mode, int inclusive, int oti_target, int want_eps)
+{
+    static_assert(M <= 9, "one 16-row MFMA tile of row frames");
+    constexpr bool write_d2 = WD2;
+    constexpr int role = ROLE;           // 1: rows = reference frames (column thresholds); 0: rows = query frames
+    constexpr int NV = B2_NV, LNP = B2_LNP, ROWP = B2_ROWP;
+    constexpr int NSTEP = 2;             // tiles per wave
+    constexpr int NCT = (64 + BAND - 1 + M - 1 + 15) / 16;   // 16-column MFMA blocks of a tile (5)
+    constexpr int SP = 16 * NCT;         // Gram slab pitch (packed)
+    static_assert(B2_WAVES * 16 * SP <= B2_LDS_FLOATS, "the Gram slabs fit the exchange rows' LDS");
+    __shared__ __attribute__((aligned(4096))) float smem[B2_LDS_FLOATS];
+
+    const PairDesc P = pd[blockIdx.y];
+    const int MA = role ? P.Mr : P.Mq, MB = role ? P.Mq : P.Mr;
+    const int TA = role ? P.Tr : P.Tq;
+    const int i0 = blockIdx.x * BAND;
+    if (i0 >= MA) return;     // block-uniform
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool rows_are_ref = role == 1;
+    const int rota = (rows_are_ref == (oti_target == 0)) ? P.oti : 0;
+    const int rotb = (rows_are_ref == (oti_target == 0)) ? 0 : P.oti;
+    const float *nrow = normtab + (role ? P.nr : P.nq) + (int64_t)rota * (MA + NGUARD);
+    const float *ncol = normtab + (role ? P.nq : P.nr) + (int64_t)rotb * (MB + NGUARD);
+    const float INF = __builtin_inff();
+
+    // ---- MFMA operands straight from the rotated frame pool (rotpool_kernel): one 12-byte load per lane and 16-frame block
+    const int lr = lane & 15, lk = lane >> 4;
+    int c0a = lk - rota; if (c0a < 0) c0a += NBIN;
+    int c0b = lk - rotb; if (c0b < 0) c0b += NBIN;
+    constexpr unsigned PB = (unsigned)FROT * 4u;
+    const unsigned offA = (unsigned)(((c0a >> 2) * NBIN + (c0a & 3) * 3) * 4);
+    const unsigned offB = (unsigned)(((c0b >> 2) * NBIN + (c0b & 3) * 3) * 4);
+    const char *pool_b = reinterpret_cast<const char *>(frot);
+    const char *fra = pool_b + (role ? P.fr : P.fq) * (int64_t)PB + offA;
+    const char *frb = pool_b + (role ? P.fq : P.fr) * (int64_t)PB + offB;
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    typedef f32x3 f32x3_u __attribute__((aligned(4)));
+    float areg[3];
+    {
+        int f = i0 + lr;
+        f = f > TA - 1 ? TA - 1 : f;           // rows beyond the matrix get a norm of +inf below
+        const f32x3 v = *reinterpret_cast<const f32x3_u *>(fra + (size_t)f * PB);
+        areg[0] = v.x; areg[1] = v.y; areg[2] = v.z;
+    }
+    float xrow[BAND];
+#pragma unroll
+    for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : INF;
+    float *Sw = smem + wave * (16 * SP);
+    const PctPos pp = role ? P.pos_q : P.pos_r;
+
+    const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= 8 by dispatch
+    typedef float BvT[NCT][3];
+    typedef f32x4 AccT[NCT];
+    auto load_operands = [&](int tile, BvT &bv, auto tb0_tag) {
+        constexpr int tb0 = decltype(tb0_tag)::value;
+        const char *p = frb + (ptrdiff_t)(64 * tile - (BAND - 1) + lr) * (ptrdiff_t)PB;
+#pragma unroll
+        for (int tb = tb0; tb < NCT; ++tb) {
+            const f32x3 v = *reinterpret_cast<const f32x3_u *>(p + 16 * PB * tb);
+            bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
+        }
+    };
+    auto load_norms = [&](int tile, float (&yv)[BAND]) {
+        typedef float f32x4n __attribute__((ext_vector_type(4), aligned(4)));
+        const f32x4n *p = reinterpret_cast<const f32x4n *>(ncol + (64 * tile - (BAND - 1)) + lane);
+        const f32x4n v0 = p[0], v1 = p[1];
+        yv[0] = v0.x; yv[1] = v0.y; yv[2] = v0.z; yv[3] = v0.w;
+        yv[4] = v1.x; yv[5] = v1.y; yv[6] = v1.z; yv[7] = v1.w;
+    };
+    auto gram = [&](const BvT &bv, AccT &acc, auto tb0_tag) {
+        constexpr int tb0 = decltype(tb0_tag)::value;
+#pragma unroll
+        for (int tb = tb0; tb < NCT; ++tb) acc[tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int tb = tb0; tb < NCT; ++tb)
+                acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[tb][kb], areg[kb], acc[tb], 0, 0, 0);
+    };
+    auto walk = [&](const float (&sv)[M + BAND - 1], const float (&yv)[BAND], float (&dv)[BAND]) {
+#pragma unroll
+        for (int a = 0; a < BAND; ++a) {
+            const float xy = tree_sum<M>(sv + a);
+            float t3 = ROLE ? (__builtin_fmaf(-2.0f, xy, yv[a]) + xrow[a]) : (__builtin_fmaf(-2.0f, xy, xrow[a]) + yv[a]);
+            if (!(t3 > 0.0f)) t3 = 0.0f;
+            dv[a] = t3;
+        }
+    };
+    const int pitchD = P.pitchD;
+    float *D = scratch + P.offD + (size_t)i0 * pitchD;
+    float xv[BAND][NSTEP];
+
+    // ---- sweep: wave w takes tiles w cpw .. w cpw + cpw - 1 (cpw = ceil(ntiles / 4) <= 2); the other tile slots of the 8 that
+    // make a row of 512 positions are padded with +inf (tile_of)
+    constexpr int HB = NCT - 4;
+    const int cpw = (ntiles + B2_WAVES - 1) / B2_WAVES;
+    auto tile_of = [&](int st) { return st < cpw ? wave * cpw + st : B2_WAVES * cpw + wave * (NSTEP - cpw) + (st - cpw); };
+    BvT bv;
+    f32x4 halo[HB];
+    if (wave * cpw < ntiles) load_operands(wave * cpw, bv, std::integral_constant<int, 0>());
+    static_for<0, NSTEP>([&](auto st_tag) {
+        constexpr int st = decltype(st_tag)::value;
+        constexpr int tb0 = st == 0 ? 0 : HB;
+        const int tile = tile_of(st);
+        if (st < cpw && tile < ntiles) {      // wave-uniform
+            float yv[BAND];
+            load_norms(tile, yv);
+            if constexpr (st > 0) {
+#pragma unroll
+                for (int h = 0; h < HB; ++h) *reinterpret_cast<f32x4 *>(Sw + lr * SP + 16 * h + 4 * lk) = halo[h];
+            }
+            {
+                AccT acc;
+                gram(bv, acc, std::integral_constant<int, tb0>());
+                if (st + 1 < NSTEP && st + 1 < cpw && tile + 1 < ntiles)
+                    load_operands(tile + 1, bv, std::integral_constant<int, HB>());
+#pragma unroll
+                for (int tb = tb0; tb < NCT; ++tb) *reinterpret_cast<f32x4 *>(Sw + lr * SP + 16 * tb + 4 * lk) = acc[tb];
+                if constexpr (st + 1 < NSTEP) {
+#pragma unroll
+                    for (int h = 0; h < HB; ++h) halo[h] = acc[4 + h];
+                }
+            }
+            wave_lds_fence();
+            float sv[M + BAND - 1], dv[BAND];
+#pragma unroll
+            for (int u = 0; u < M + BAND - 1; ++u) sv[u] = Sw[u * SP + lane + u];
+            walk(sv, yv, dv);
+#pragma unroll
+            for (int a = 0; a < BAND; ++a) xv[a][st] = dv[a];
+            if constexpr (write_d2) {
+                const int j0 = 64 * tile - (BAND - 1) + lane;
+#pragma unroll
+                for (int a = 0; a < BAND; ++a) {
+                    const int j = j0 + a;
+                    if (i0 + a < MA && j >= 0 && j < pitchD) D[a * pitchD + j] = dv[a];
+                }
+            }
+            wave_lds_fence();
+        } else {
+#pragma unroll
+            for (int a = 0; a < BAND; ++a) xv[a][st] = INF;
+        }
+    });
+    if constexpr (write_d2) {
+        const int npad = pitchD - MB;
+        for (int idx = tid; idx < BAND * npad; idx += B2_THREADS) {
+            const int a = idx / npad, j = MB + idx - a * npad;
+            if (i0 + a < MA) D[a * pitchD + j] = INF;
+        }
+    }
+#ifdef ACX_ABL
+    { float keep_ = 0.0f;
+      for (int a = 0; a < BAND; ++a) for (int st = 0; st < NSTEP; ++st) keep_ += xv[a][st];
+      ACX_ABL_EXIT(1, keep_); }
+#endif
+    __syncthreads();     // all slabs dead -> the LDS becomes the 8 exchange rows
+    // ---- exchange: band row a in POSITION order (position p = 64 tile + lane <-> column p - 7 + a); an owner lane's 16
+    // positions are followed by 16 bytes of pad
+    {
+        const int wl = lane + 4 * (lane >> 4);
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            float *dst = smem + tile_of(st) * (4 * LNP) + wl;
+#pragma unroll
+            for (int a = 0; a < BAND; ++a) dst[a * ROWP] = xv[a][st];
+        }
+    }
+    __syncthreads();
+    // ---- wave w owns rows 2 w (lanes 0-31) and 2 w + 1 (lanes 32-63)
+    const int l = lane & 31;
+    const bool upper = lane >= 32;
+    const int myband = 2 * wave + (upper ? 1 : 0);     // band row of this lane's half
+    const int row = i0 + myband;
+    float *myrow = smem + myband * ROWP;
+    float xr[NV];
+    {
+        const float *mine = myrow + l * LNP;
+#pragma unroll
+        for (int j = 0; j < NV / 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(mine + 4 * j);
+            xr[4 * j + 0] = v.x; xr[4 * j + 1] = v.y; xr[4 * j + 2] = v.z; xr[4 * j + 3] = v.w;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the rows have left LDS: from here on they are this wave's scratch
+#ifdef ACX_ABL
+    { float keep_ = 0.0f;
+      for (int t = 0; t < NV; ++t) keep_ += xr[t];
+      ACX_ABL_EXIT(2, keep_); }
+#endif
+    if (i0 + 2 * wave >= MA) return;                              // wave-uniform: neither row exists
+    const bool need = row < MA;                                   // (the last band of a matrix with an odd number of rows)
+    const int cshift = (BAND - 1) - myband;                       // slot s of the row <-> column s - cshift
+    const int n = MB;
+    const float kf = pp.kf, fl = pp.fl, ce = pp.ce;
+    const int ilo = pp.ilo, ihi = pp.ihi, k = pp.k;
+    const bool interp = (pct_mode == 0 || pct_mode == 1);
+    const bool want_next = interp && ihi != ilo;
+    typedef __attribute__((address_space(3))) void lds_void;
+    // a half's own row as scratch: 32 candidate slots + the counter dword, then the 256-bin histogram
+    const unsigned cand_addr = (unsigned)(uintptr_t)(lds_void *)myrow;
+    const unsigned hist_addr = cand_addr + 64u * 4u;
+    const int end_valid = MB + cshift;                            // slots [cshift, end_valid) are cells
+    const bool lane_has_data = l * NV < end_valid;
+    const bool group_full = l * NV >= cshift && l * NV + NV <= end_valid;
+    float slo = 0.0f, shi = 0.0f;
+    unsigned okm = 0u;
+    const bool use_pivot = (ihi + 2) * 9 <= n;
+    if (use_pivot) {
+        // zero the counter + histogram: dwords [32, 64 + 256) of the row, 16 bytes per lane, three rounds of 32 lanes
+        float *z = myrow + 32 + 4 * l;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < 2 || l < 8) *reinterpret_cast<float4 *>(z + 128 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        wave_lds_fence();
+        okm = pair_select_pivot(xr, k, want_next, hist_addr, cand_addr, lane, slo, shi, lane_has_data, group_full);
+    }
+    // ---- rows the one-pass selection could not decide: the whole wave takes them one at a time through band_kernel's
+    // fallbacks -- the row goes back to LDS and returns as 8 values per lane of all 64 lanes
+    {
+        const unsigned long long needm = __ballot(need);
+        const unsigned needb = ((unsigned)needm & 1u) | (((unsigned)(needm >> 32) & 1u) << 1);
+        unsigned todo = needb & ~okm;
+        if (todo != 0u) {
+            // both rows of the wave are in registers: 1280 floats of scratch; a 512-aligned block of 512 floats inside it
+            // is the histogram of wave_select_fast, the rest holds the candidates and the generic selection's bins
+            const int base = wave * 2 * ROWP;
+            const int hoff = (base + 511) & ~511;
+            const int foff = (hoff - base >= 512 + 64) ? base : hoff + 512;          // >= 512 free floats
+            float *hist = smem + hoff, *aux = smem + foff;
+            const unsigned fh_addr = (unsigned)(uintptr_t)(lds_void *)hist;
+            for (int h = 0; h < 2; ++h) {
+                if (!((todo >> h) & 1u)) continue;
+                const int cs = (BAND - 1) - (2 * wave + h);
+                wave_lds_fence();
+                if ((lane >> 5) == h) {
+#pragma unroll
+                    for (int j = 0; j < NV / 4; ++j)
+                        *reinterpret_cast<float4 *>(hist + l * NV + 4 * j) = make_float4(xr[4 * j], xr[4 * j + 1], xr[4 * j + 2], xr[4 * j + 3]);
+                }
+                wave_lds_fence();
+                float x8[8];
+                {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(hist + 8 * lane), v1 = *reinterpret_cast<const float4 *>(hist + 8 * lane + 4);
+                    x8[0] = v0.x; x8[1] = v0.y; x8[2] = v0.z; x8[3] = v0.w; x8[4] = v1.x; x8[5] = v1.y; x8[6] = v1.z; x8[7] = v1.w;
+                }
+                wave_lds_fence();
+                for (int q = 0; q < 2; ++q) *reinterpret_cast<float4 *>(hist + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+                wave_lds_fence();
+                float s_lo, s_hi;
+                bool done = wave_select_fast<8, 512, 1>(x8, k, want_next, fh_addr, aux, lane, s_lo, s_hi, lane * 8 < MB + cs);
+                if (!done) {
+                    unsigned *ghist = reinterpret_cast<unsigned *>(aux) + 64;
+                    unsigned *counter = reinterpret_cast<unsigned *>(aux) + 64 + SelGeom<256>::SLOTS;
+                    const SelectResult sr = wave_select_regs<8, 256>(x8, k, ghist, aux, counter, lane, interp);
+                    s_lo = sr.value;
+                    s_hi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;
+                }
+                if ((lane >> 5) == h) { slo = s_lo; shi = s_hi; }
+            }
+            wave_lds_fence();
+        }
+    }
+    ACX_ABL_EXIT(3, slo + shi);
+    // ---- eps, the d2-domain threshold (band_row_tail's reasoning, per half) and, in the row pass, the bitmap
+    float *X = thr + P.offX;
+    float thr_row;
+    const bool weights_ok = interp && ihi == ilo + 1 && inclusive && fl >= 1.0f && (ce - kf) >= 0.00390625f && (kf - fl) >= 0.00390625f;
+    const bool easy = !want_eps && weights_ok && shi < INF && (shi - slo) > shi * 0.000244140625f;
+    if (__ballot(easy || !need) == ~0ull) {
+        thr_row = slo;
+        if (l == 0 && need) X[role ? P.pitchT + row : row] = slo;
+    } else {
+        // (rare: ties, an exact-integer position, the debug entry point -- every lane works on its own half's values)
+        const float dlo = __builtin_sqrtf(slo), dhi = __builtin_sqrtf(shi);
+        float eps = dlo;
+        if (interp && !(pct_mode == 0 && ihi == ilo)) {
+            const float d0 = __fmul_rn(dlo, __fsub_rn(ce, kf));
+            const float d1 = __fmul_rn(dhi, __fsub_rn(kf, fl));
+            eps = __fadd_rn(d0, d1);
+        }
+        if (inclusive && dlo <= eps && eps < dhi) thr_row = slo;
+        else thr_row = d2_threshold(eps, inclusive);
+        if (l == 0 && need) {
+            const int o = role ? P.pitchT + row : row;
+            X[o] = thr_row;
+            X[P.pitchT + P.pitchD + o] = eps;
+        }
+    }
+    ACX_ABL_EXIT(4, thr_row);
+    if constexpr (ROLE == 0) {
+        if (bits && need) {
+            typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+            const float *tc = X + P.pitchT + (l * NV - cshift);
+            float tcv[NV];
+#pragma unroll
+            for (int j = 0; j < NV / 4; ++j) {
+                const f32x4_u v = *reinterpret_cast<const f32x4_u *>(tc + 4 * j);
+                tcv[4 * j + 0] = v.x; tcv[4 * j + 1] = v.y; tcv[4 * j + 2] = v.z; tcv[4 * j + 3] = v.w;
+            }
+            int lo = cshift - l * NV, hi = MB + cshift - l * NV;
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > NV ? NV : hi;
+            unsigned valid = 0u;
+            if (hi > lo) valid = ((1u << (hi - lo)) - 1u) << lo;
+            unsigned acc = 0u;
+#pragma unroll
+            for (int t = NV - 1; t >= 0; --t) {
+                float mthr;
+                asm("v_min_f32 %0, %1, %2" : "=v"(mthr) : "v"(tcv[t]), "v"(thr_row));
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(xr[t]), "v"(mthr) : "vcc");
+            }
+            acc &= valid;
+            acc |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)acc, 0xF5, 0xf, 0xf, false) << 16;    // quad_perm [1,1,3,3]: the odd neighbour's 16 bits
+            unsigned *rowbits = reinterpret_cast<unsigned *>(bits + P.offT + (size_t)row * P.nw);
+            const int ndw = 2 * P.nw, d = l >> 1;
+            if ((l & 1) == 0 && d < ndw) rowbits[d] = acc;
+            for (int z = 16 + l; z < ndw; z += 32) rowbits[z] = 0u;     // (words beyond this size class: none by dispatch)
+        }
+    }
+}
+
+}  // namespace acx
