@@ -30,18 +30,20 @@ constexpr int B2_ROWP = 32 * B2_LNP;            // exchange row pitch (floats): 
 constexpr int B2_BINS = 256;                    // bins of the pivot-filtered histogram: 8 per lane of a half
 constexpr int B2_LDS_FLOATS = BAND * B2_ROWP;   // 5120 floats = 20 KB = the four packed Gram slabs of the sweep
 #ifndef ACX_B2_WAVES_PER_SIMD
-#define ACX_B2_WAVES_PER_SIMD 8
+#define ACX_B2_WAVES_PER_SIMD 6      /* 80 registers, no spills: 308 vs 276 Gcells/s at T = 450 with 8 (10-14 spilled registers) */
 #endif
 
 // ---- reductions over the 32 lanes of a half, result in EVERY lane of the half: xor 1, xor 2 inside the quads, mirror inside 8
 // and 16 lanes (DPP, one VALU operation each), then the two 16-lane rows of the half trade places (v_permlane16_swap).
 template <typename Op>
-__device__ __forceinline__ int half_allreduce(int v, Op op)
+__device__ __forceinline__ int half_allreduce(int v, int idn, Op op)
 {
-    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
-    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
-    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));    // row_half_mirror
-    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));    // row_mirror
+    // (`idn` = the operation's identity as the DPP "old" value: every lane has a source here, so it is never used -- but with it
+    // hipcc folds the move into the operation, v_min_u32_dpp instead of v_mov + v_mov_dpp + v_min)
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x141, 0xf, 0xf, false));    // row_half_mirror
+    v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x140, 0xf, 0xf, false));    // row_mirror
     const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);   // r[0]: rows 0 0 2 2, r[1]: rows 1 1 3 3
     return op((int)r[0], (int)r[1]);
 }
@@ -82,8 +84,8 @@ __device__ __forceinline__ unsigned pair_select_pivot(const float (&x)[B2_NV], i
         const unsigned b = __float_as_uint(x[t]);
         mnl = b < mnl ? b : mnl;
     }
-    const unsigned mnu = (unsigned)half_allreduce((int)mnl, OpMinU());
-    const int mxg = half_allreduce(group_full ? (int)mnl : (int)0x80000000, OpMaxI());
+    const unsigned mnu = (unsigned)half_allreduce((int)mnl, -1, OpMinU());
+    const int mxg = half_allreduce(group_full ? (int)mnl : (int)0x80000000, (int)0x80000000, OpMaxI());
     const float mn = __uint_as_float(mnu);
     const float gm = __uint_as_float((unsigned)mxg);
     const float range = gm - mn;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
     }
     float xrow[BAND];
 #pragma unroll
-    for (int a = 0; a < BAND; ++a) xrow[a] = (i0 + a < MA) ? nrow[i0 + a] : INF;
+    for (int a = 0; a < BAND; ++a) xrow[a] = nrow[i0 + a];      // (rows past the matrix: the table's +inf guard entries -> +inf cells)
     float *Sw = smem + wave * (16 * SP);
     const PctPos pp = role ? P.pos_q : P.pos_r;
 
