@@ -64,19 +64,47 @@ __device__ __forceinline__ float half_pick(bool upper, float lo, float hi) { ret
 // ------------------------------------------------------------------------------------
 // Pivot-filtered one-pass selection (wave_select_pivot, serra09_kernels.hpp) for TWO rows at once: lanes 0-31 hold
 // one row, lanes 32-63 the other, NV = 16 consecutive positions per lane, pads +inf.  k (0-based rank) is the same for
-// both rows (they belong to one pair and one pass).  `hist_addr` / `cand_addr`: LDS byte addresses of the lane's OWN
-// half's zeroed B2_BINS-dword histogram and of its 32 candidate slots + 1 zeroed counter dword.
-// Returns a 2-bit mask: bit h set = half h has its order statistics k (slo) and, with want_next, k + 1 (shi) in
-// every lane of the half; a clear bit = the pass could not decide that row (the caller's fallback takes over).
+// both rows (they belong to one pair and one pass).
+//
+// The two halves work like two independent 32-lane groups that talk through LDS "mailboxes" in their own row's area
+// (`mb_addr`: LDS byte address of the half's 64 zeroed mailbox dwords, followed by its zeroed B2_BINS-dword histogram) --
+// no per-half scalars, no v_readlane / v_cndmask glue:
+//   1. histogram of the cells at or below the pivot (exec-masked ds_add_u32, as wave_select_pivot);
+//   2. prefix scan of the lanes' 8-bin sums inside the half; the lane whose range holds rank k (k + 1) posts {lane + 1,
+//      exclusive count}; lanes 0-7 (16-23) of the half read lane L1's (L2's) 8 bins, scan them inside their DPP row and the
+//      lane whose bin holds the rank posts {bin, cells below the bin, cells in the bin};
+//   3. the two order statistics WITHOUT gathering candidates: rank k + 1 lies in a later bin than rank k (five rows of
+//      six at 0.4 cells per bin) => s_k is the LARGEST cell of bin1 and s_(k+1) the SMALLEST of bin2; both in one bin that
+//      holds exactly two cells => its smallest and its largest.  So the cells of bin1 post their maximum, those of bin2
+//      their minimum (exec-masked ds_max_u32 on the patterns / their complements; a handful of lanes), and s_k = min, s_(k+1)
+//      = max of the two posted values in either case;
+//   4. a bin with three or more cells around the rank (heavy ties, one row in sixteen on i.i.d. data): its <= 32 members are
+//      gathered through an LDS counter and ranked directly, as wave_select_pivot does.
+// Returns in every lane whether ITS half has both order statistics (slo, shi; shi = slo without want_next); a half
+// that has not goes to the caller's fallback.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned pair_select_pivot(const float (&x)[B2_NV], int k, bool want_next, unsigned hist_addr, unsigned cand_addr,
-                                                      int lane, float &slo, float &shi, bool lane_has_data, bool group_full)
+struct B2Mail {            // dword offsets inside a half's mailbox area
+    static constexpr int CAND = 0;      // 32 candidate slots (step 4)
+    static constexpr int COUNTER = 32;  // their counter
+    static constexpr int E = 34;        // [34] max pattern of bin1's cells, [35] max complemented pattern of bin2's cells
+    static constexpr int OWN = 36;      // [36, 37] {L1 + 1, excl}, [38, 39] {L2 + 1, excl}
+    static constexpr int BIN = 40;      // [40..42] {bin1, below1, count1}, [44..46] {bin2, below2, count2}
+    static constexpr int RES = 48;      // [48] s_k, [49] s_(k+1) of step 4
+    static constexpr int HIST = 64;
+};
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+
+__device__ __forceinline__ bool pair_select_pivot(const float (&x)[B2_NV], int k, bool want_next, unsigned mb_addr, int lane,
+                                                  float &slo, float &shi, bool lane_has_data, bool group_full)
 {
     constexpr int NV = B2_NV, NB = B2_BINS, BPL = NB / 32;      // 8 bins per lane in the scan
     static_assert(BPL == 8, "two 16-byte pieces per lane");
     const float INF = __builtin_inff();
     const int l = lane & 31;
-    const bool upper = lane >= 32;
+    const unsigned hist_addr = mb_addr + 4u * B2Mail::HIST;
     // ---- row minimum and the largest minimum of a lane whose 16 positions are all cells (unsigned patterns: +inf pads above every cell)
     unsigned mnl = 0xFFFFFFFFu;
 #pragma unroll
@@ -94,10 +122,10 @@ __device__ __forceinline__ unsigned pair_select_pivot(const float (&x)[B2_NV], i
     constexpr unsigned MAGIC = 0x4B000000u;            // 2^23: the bin is the low part of the binning fma's bit pattern
     const float scale = ((float)NB - 3.0f) * __builtin_amdgcn_rcpf(range);
     const float offm = (lane_has_data && good) ? (8388609.0f - mn * scale) : INF;
-    unsigned off[NV];
+    unsigned pat[NV];
 #pragma unroll
-    for (int t = 0; t < NV; ++t) off[t] = __float_as_uint(__builtin_fmaf(x[t], scale, offm));
-    // ---- histogram of the cells whose bin exists: exec-masked LDS atomics, four cells per hand-written statement
+    for (int t = 0; t < NV; ++t) pat[t] = __float_as_uint(__builtin_fmaf(x[t], scale, offm));
+    // ---- 1. histogram of the cells whose bin exists: exec-masked LDS atomics, four cells per hand-written statement
     {
         const unsigned nb = __builtin_amdgcn_readfirstlane(MAGIC + NB);
         const unsigned hb = hist_addr - 4u * MAGIC;                        // (mod 2^32, like the shift); per half
@@ -127,14 +155,14 @@ __device__ __forceinline__ unsigned pair_select_pivot(const float (&x)[B2_NV], i
                          "s_mov_b64 exec, %[sv]"
                          : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [sv] "=&s"(sv),
                            [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
-                         : [q0] "v"(off[t]), [q1] "v"(off[t + 1]), [q2] "v"(off[t + 2]), [q3] "v"(off[t + 3]),
+                         : [q0] "v"(pat[t]), [q1] "v"(pat[t + 1]), [q2] "v"(pat[t + 2]), [q3] "v"(pat[t + 3]),
                            [nb] "s"(nb), [hb] "v"(hb), [one] "v"(one)
                          : "memory");
         }
     }
     wave_lds_fence();
-    // ---- scan: lane l of a half owns bins [8 l, 8 l + 8) of its half's histogram; the two 16-byte pieces in a staggered order
-    // (lanes 8 apart would otherwise meet in one bank group)
+    // ---- 2. scan: lane l of a half owns bins [8 l, 8 l + 8) of its half's histogram; the two 16-byte pieces in a staggered
+    // order (lanes 8 apart would otherwise meet in one bank group)
     int lsum = 0;
     {
         const int rot = (l >> 3) & 1;
@@ -148,104 +176,105 @@ __device__ __forceinline__ unsigned pair_select_pivot(const float (&x)[B2_NV], i
     const int incl = half_incl_scan_i(lsum);
     const int excl = incl - lsum;
     const int k2 = want_next ? k + 1 : k;
-    const unsigned long long mk1 = __ballot(incl > k), mk2 = __ballot(incl > k2);
-    unsigned okm = 0u;
-    // the first lane of each half whose inclusive count exceeds the rank (s_ff1: -1 when there is none)
-    int L1[2], L2[2], ex1[2], ex2[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const unsigned a = (unsigned)(mk1 >> (32 * h)), b = (unsigned)(mk2 >> (32 * h));
-        L1[h] = __ffs((int)a) - 1; L2[h] = __ffs((int)b) - 1;
-        const bool have = L1[h] >= 0 && L2[h] >= 0;       // at least k + 2 cells at or below the pivot
-        if (have) okm |= 1u << h;
-        L1[h] = have ? L1[h] : 0; L2[h] = have ? L2[h] : 0;
-        ex1[h] = __builtin_amdgcn_readlane(excl, 32 * h + L1[h]);
-        ex2[h] = __builtin_amdgcn_readlane(excl, 32 * h + L2[h]);
-    }
+    // the lane whose bins hold the rank posts itself (at most one per half and rank; none: fewer than k + 2 cells below the pivot)
+    if (excl <= k && k < incl) *(lds_u32x2 *)(mb_addr + 4u * B2Mail::OWN) = u32x2{(unsigned)l + 1u, (unsigned)excl};
+    if (excl <= k2 && k2 < incl) *(lds_u32x2 *)(mb_addr + 4u * (B2Mail::OWN + 2)) = u32x2{(unsigned)l + 1u, (unsigned)excl};
+    wave_lds_fence();
     // second level: lanes 0..7 of a half look at the 8 bins of lane L1, lanes 16..23 at those of lane L2
     const int e = l & 15;
-    const bool second = l >= 16;
-    const int Lx = second ? half_pick(upper, L2[0], L2[1]) : half_pick(upper, L1[0], L1[1]);
-    const int exx = second ? half_pick(upper, ex2[0], ex2[1]) : half_pick(upper, ex1[0], ex1[1]);
+    const bool second = (l & 16) != 0;
+    const u32x2 own = *(const lds_u32x2 *)(mb_addr + 4u * B2Mail::OWN + (second ? 8u : 0u));
+    const int Lx = (int)own.x - 1, exx = (int)own.y;                  // (Lx = -1: nobody posted; the read below then hits the mailbox area)
     const int kk = second ? k2 : k;
-    int c = (int)*(const lds_u32 *)(hist_addr + (unsigned)(Lx * BPL + (e & 7)) * 4u);
+    int c = (int)*(const lds_u32 *)(hist_addr + (unsigned)(Lx * (BPL * 4) + (e & 7) * 4));
     c = e < BPL ? c : 0;
     int P = c;                                        // inclusive prefix inside each row of 16 lanes (8 of them count)
     P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, false);
     P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, false);
     P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xf, 0xf, false);
-    const unsigned long long mh = __ballot(e < BPL && exx + P > kk);
-    int cum1[2], bin1[2], bin2[2], ncand[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const unsigned f1 = (unsigned)(mh >> (32 * h)) & 0xffffu, f2 = (unsigned)(mh >> (32 * h + 16)) & 0xffffu;
-        int l1 = __ffs((int)f1) - 1, l2 = __ffs((int)f2) - 1;
-        if (l1 < 0 || l2 < 0) { okm &= ~(1u << h); l1 = 0; l2 = 0; }
-        const int cnt1 = __builtin_amdgcn_readlane(c, 32 * h + l1);
-        cum1[h] = ex1[h] + __builtin_amdgcn_readlane(P, 32 * h + l1) - cnt1;
-        bin1[h] = L1[h] * BPL + l1;
-        bin2[h] = L2[h] * BPL + l2;
-        ncand[h] = cnt1;
-        if (bin2[h] != bin1[h]) ncand[h] += __builtin_amdgcn_readlane(c, 32 * h + 16 + l2);   // the bins between are empty
-        if (ncand[h] > 32) okm &= ~(1u << h);
-        if (!((okm >> h) & 1u)) { ncand[h] = 0; bin1[h] = -2; bin2[h] = -2; }                  // (matches no pattern)
-    }
-    if (okm == 0u) return 0u;
-    // ---- gather the members of [bin1, bin2] of each half into its candidate slots (order irrelevant: slots are handed out
-    // by an LDS counter; a handful of cells per row)
     {
-        const unsigned a1 = MAGIC + (unsigned)half_pick(upper, bin1[0], bin1[1]);
-        const unsigned span = (unsigned)half_pick(upper, bin2[0] - bin1[0], bin2[1] - bin1[1]);
-        lds_u32 *counter = (lds_u32 *)(cand_addr + 32u * 4u);
+        const int below = exx + P - c;                // cells below this lane's bin
+        if (e < BPL && Lx >= 0 && below <= kk && kk < below + c) {
+            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+            typedef __attribute__((address_space(3))) u32x3 lds_u32x3;
+            *(lds_u32x3 *)(mb_addr + 4u * B2Mail::BIN + (second ? 16u : 0u)) = u32x3{(unsigned)(Lx * BPL + e), (unsigned)below, (unsigned)c};
+        }
+    }
+    wave_lds_fence();
+    const u32x4 r1 = *(const lds_u32x4 *)(mb_addr + 4u * B2Mail::BIN), r2 = *(const lds_u32x4 *)(mb_addr + 4u * (B2Mail::BIN + 4));
+    const int bin1 = (int)r1.x, below1 = (int)r1.y, cnt1 = (int)r1.z, bin2 = (int)r2.x, cnt2 = (int)r2.z;
+    const bool found = good && cnt1 != 0 && cnt2 != 0;               // (zeroed mailbox: nobody posted)
+    // ---- 3. the largest cell of bin1, the smallest of bin2 (complemented: the mailbox is zeroed, both are ds_max_u32)
+    const unsigned a1 = found ? MAGIC + (unsigned)bin1 : 0u, a2 = found ? MAGIC + (unsigned)bin2 : 0u;    // (0 matches no pattern)
+    {
+        lds_u32 *e1 = (lds_u32 *)(mb_addr + 4u * B2Mail::E), *e2 = (lds_u32 *)(mb_addr + 4u * (B2Mail::E + 1));
 #pragma unroll
         for (int t = 0; t < NV; t += 4) {
-            const bool h0 = (off[t] - a1) <= span, h1 = (off[t + 1] - a1) <= span;
-            const bool h2 = (off[t + 2] - a1) <= span, h3 = (off[t + 3] - a1) <= span;
-            if (__ballot(h0 || h1 || h2 || h3) != 0ull) {       // most groups hold no member of the target bins
+            bool h1[4], h2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { h1[u] = pat[t + u] == a1; h2[u] = pat[t + u] == a2; }
+            if (__ballot(h1[0] || h1[1] || h1[2] || h1[3] || h2[0] || h2[1] || h2[2] || h2[3]) != 0ull) {     // most groups hold no member
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const bool hit = u == 0 ? h0 : (u == 1 ? h1 : (u == 2 ? h2 : h3));
-                    if (hit) {
-                        const unsigned pos = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        *(__attribute__((address_space(3))) float *)(cand_addr + 4u * (pos & 31u)) = x[t + u];
-                    }
+                    if (h1[u]) __hip_atomic_fetch_max(e1, __float_as_uint(x[t + u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (h2[u]) __hip_atomic_fetch_max(e2, ~__float_as_uint(x[t + u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
     }
     wave_lds_fence();
-    // ---- rank them: a lane holds one candidate of its half and reads the others as LDS broadcasts, four per 16-byte read
-    const int nc = half_pick(upper, ncand[0], ncand[1]);
-    typedef __attribute__((address_space(3))) float lds_f32;
-    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-    if (l >= nc) *(lds_f32 *)(cand_addr + 4u * (unsigned)l) = INF;
-    wave_lds_fence();
-    const float mine = *(const lds_f32 *)(cand_addr + 4u * (unsigned)l);
-    int rank = 0;
-    const int ncmax = ncand[0] > ncand[1] ? ncand[0] : ncand[1];
-#pragma unroll 1
-    for (int t = 0; t < ncmax; t += 4) {
-        const f32x4 o = *(const lds_f32x4 *)(cand_addr + 4u * (unsigned)t);
-        rank += (o.x < mine || (o.x == mine && t + 0 < l)) ? 1 : 0;
-        rank += (o.y < mine || (o.y == mine && t + 1 < l)) ? 1 : 0;
-        rank += (o.z < mine || (o.z == mine && t + 2 < l)) ? 1 : 0;
-        rank += (o.w < mine || (o.w == mine && t + 3 < l)) ? 1 : 0;
+    const u32x2 ev = *(const lds_u32x2 *)(mb_addr + 4u * B2Mail::E);
+    const unsigned E1 = ev.x, E2 = ~ev.y;
+    bool ok;
+    if (want_next) {
+        ok = found && (bin1 != bin2 || cnt1 == 2);
+        slo = __uint_as_float(E1 < E2 ? E1 : E2);
+        shi = __uint_as_float(E1 < E2 ? E2 : E1);
+    } else {
+        const int p = k - below1;                     // position of rank k inside its bin
+        ok = found && (p == 0 || p == cnt1 - 1);
+        slo = __uint_as_float(p == 0 ? E2 : E1);
+        shi = slo;
     }
-    const int want = k - half_pick(upper, cum1[0], cum1[1]);
-    const unsigned long long ms1 = __ballot(l < nc && rank == want);
-    const unsigned long long ms2 = __ballot(l < nc && rank == want + (want_next ? 1 : 0));
-    float r1[2], r2[2];
+    // ---- 4. three or more cells in the bin around the rank: gather the members of [bin1, bin2] (<= 32) and rank them
+    const int ncand = (bin2 != bin1) ? cnt1 + cnt2 : cnt1;            // (the bins between are empty)
+    const bool crowded = found && !ok && ncand <= 32;
+    if (__ballot(crowded) != 0ull) {
+        const unsigned cand_addr = mb_addr + 4u * B2Mail::CAND;
+        lds_u32 *counter = (lds_u32 *)(mb_addr + 4u * B2Mail::COUNTER);
+        const unsigned g1 = crowded ? a1 : 0u, span = (unsigned)(bin2 - bin1);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        int s1 = __ffs((int)(unsigned)(ms1 >> (32 * h))) - 1, s2 = __ffs((int)(unsigned)(ms2 >> (32 * h))) - 1;
-        if (s1 < 0 || s2 < 0) { okm &= ~(1u << h); s1 = 0; s2 = 0; }
-        r1[h] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), 32 * h + s1));
-        r2[h] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), 32 * h + s2));
+        for (int t = 0; t < NV; ++t) {
+            if ((pat[t] - g1) <= span) {
+                const unsigned pos = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                *(lds_f32 *)(cand_addr + 4u * (pos & 31u)) = x[t];
+            }
+        }
+        wave_lds_fence();
+        const int nc = crowded ? ncand : 0;
+        if (l >= nc) *(lds_f32 *)(cand_addr + 4u * (unsigned)l) = INF;
+        wave_lds_fence();
+        const float mine = *(const lds_f32 *)(cand_addr + 4u * (unsigned)l);
+        int rank = 0;
+        for (int t = 0; __ballot(t < nc) != 0ull; t += 4) {
+            const f32x4 o = *(const lds_f32x4 *)(cand_addr + 4u * (unsigned)t);
+            rank += (o.x < mine || (o.x == mine && t + 0 < l)) ? 1 : 0;
+            rank += (o.y < mine || (o.y == mine && t + 1 < l)) ? 1 : 0;
+            rank += (o.z < mine || (o.z == mine && t + 2 < l)) ? 1 : 0;
+            rank += (o.w < mine || (o.w == mine && t + 3 < l)) ? 1 : 0;
+        }
+        const int want = k - below1;
+        if (l < nc && rank == want) *(lds_f32 *)(mb_addr + 4u * B2Mail::RES) = mine;
+        if (l < nc && rank == want + (want_next ? 1 : 0)) *(lds_f32 *)(mb_addr + 4u * (B2Mail::RES + 1)) = mine;
+        wave_lds_fence();
+        if (crowded) {
+            const u32x2 rr = *(const lds_u32x2 *)(mb_addr + 4u * B2Mail::RES);
+            slo = __uint_as_float(rr.x); shi = __uint_as_float(rr.y);
+            ok = true;          // (ranks want and want + 1 exist among the nc = count of [bin1, bin2] members)
+        }
     }
-    slo = half_pick(upper, r1[0], r1[1]);
-    shi = half_pick(upper, r2[0], r2[1]);
     wave_lds_fence();
-    return okm;
+    return ok;
 }
 
 // ------------------------------------------------------------------------------------
@@ -266,9 +295,9 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
     constexpr int NV = B2_NV, LNP = B2_LNP, ROWP = B2_ROWP;
     constexpr int NSTEP = 2;             // tiles per wave
     constexpr int NCT = (64 + BAND - 1 + M - 1 + 15) / 16;   // 16-column MFMA blocks of a tile (5)
-    constexpr int SP = 16 * NCT;         // Gram slab pitch (packed)
-    static_assert(B2_WAVES * 16 * SP <= B2_LDS_FLOATS, "the Gram slabs fit the exchange rows' LDS");
-    __shared__ __attribute__((aligned(4096))) float smem[B2_LDS_FLOATS];
+    constexpr int SP = 16 * NCT + 4;     // Gram slab pitch: 84 % 32 = 20 keeps the 16-byte tile stores conflict-free
+    constexpr int LDS_FLOATS = B2_WAVES * 16 * SP > B2_LDS_FLOATS ? B2_WAVES * 16 * SP : B2_LDS_FLOATS;     // 21.5 KB: six workgroups per CU
+    __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
 
     const PairDesc P = pd[blockIdx.y];
     const int MA = role ? P.Mr : P.Mq, MB = role ? P.Mq : P.Mr;
@@ -458,9 +487,8 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
     const bool interp = (pct_mode == 0 || pct_mode == 1);
     const bool want_next = interp && ihi != ilo;
     typedef __attribute__((address_space(3))) void lds_void;
-    // a half's own row as scratch: 32 candidate slots + the counter dword, then the 256-bin histogram
-    const unsigned cand_addr = (unsigned)(uintptr_t)(lds_void *)myrow;
-    const unsigned hist_addr = cand_addr + 64u * 4u;
+    // a half's own row as scratch: 64 mailbox dwords, then the 256-bin histogram (B2Mail)
+    const unsigned mb_addr = (unsigned)(uintptr_t)(lds_void *)myrow;
     const int end_valid = MB + cshift;                            // slots [cshift, end_valid) are cells
     const bool lane_has_data = l * NV < end_valid;
     const bool group_full = l * NV >= cshift && l * NV + NV <= end_valid;
@@ -468,13 +496,15 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
     unsigned okm = 0u;
     const bool use_pivot = (ihi + 2) * 9 <= n;
     if (use_pivot) {
-        // zero the counter + histogram: dwords [32, 64 + 256) of the row, 16 bytes per lane, three rounds of 32 lanes
+        // zero the mailboxes + histogram: dwords [32, 64 + 256) of the row, 16 bytes per lane, three rounds of 32 lanes
         float *z = myrow + 32 + 4 * l;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             if (q < 2 || l < 8) *reinterpret_cast<float4 *>(z + 128 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         wave_lds_fence();
-        okm = pair_select_pivot(xr, k, want_next, hist_addr, cand_addr, lane, slo, shi, lane_has_data, group_full);
+        const bool ok = pair_select_pivot(xr, k, want_next, mb_addr, lane, slo, shi, lane_has_data, group_full);
+        const unsigned long long om = __ballot(ok);
+        okm = ((unsigned)om & 1u) | (((unsigned)(om >> 32) & 1u) << 1);
     }
     // ---- rows the one-pass selection could not decide: the whole wave takes them one at a time through band_kernel's
     // fallbacks -- the row goes back to LDS and returns as 8 values per lane of all 64 lanes
