@@ -32,8 +32,9 @@ EXPORTS = [
     "acx_set_ef_gemm", "acx_hip_versions",
     "acx_dev_alloc", "acx_dev_free", "acx_dev_read", "acx_dev_sync",
     "acx_comm_id", "acx_comm_init", "acx_comm_destroy", "acx_grid_allgather", "acx_pair_grid_ranks", "acx_set_ef_fuse",
+    "acx_device_info",
 ]
-ABI_VERSION = 2           # include/acx.h ACX_ABI_VERSION this shim was written against
+ABI_VERSION = 3           # include/acx.h ACX_ABI_VERSION this shim was written against
 COMM_ID_BYTES = 128
 
 ALGO_SERRA09, ALGO_CHENFUSION, ALGO_SIMPLE, ALGO_EARLYFUSION = 0, 1, 2, 3
@@ -162,6 +163,7 @@ def load():
     L.acx_dev_read.argtypes = [vp, vp, vp, ctypes.c_int64]
     L.acx_dev_sync.argtypes = [vp]
     L.acx_comm_id.argtypes = [vp]
+    L.acx_device_info.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.acx_comm_init.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32]
     L.acx_comm_destroy.argtypes = [vp]
     L.acx_grid_allgather.argtypes = [vp, vp, vp, ctypes.c_int64]
@@ -291,6 +293,16 @@ def grid_scatter(lengths, spec, gathered, rank_stride, planes, mirror, first=0, 
                             int(count), ptrs, n, int(bool(mirror)))
     if rc != ACX_OK:
         raise ValueError("acx_grid_scatter: bad argument")
+
+
+def device_info(device=0):
+    """{"pci_bus_id", "name", "visible_devices"} of HIP device `device` of this process (acx_device_info): what bench.py gathers per rank."""
+    L = load()
+    pci, name, vis = ctypes.create_string_buffer(64), ctypes.create_string_buffer(256), ctypes.c_int(0)
+    rc = L.acx_device_info(int(device), pci, 64, name, 256, ctypes.byref(vis))
+    if rc != 0:
+        raise AcxError("acx_device_info(%d) failed (%d): no such HIP device" % (device, rc))
+    return {"pci_bus_id": pci.value.decode(), "name": name.value.decode(), "visible_devices": int(vis.value)}
 
 
 def comm_id():

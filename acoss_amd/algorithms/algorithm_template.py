@@ -16,7 +16,7 @@ Differences from the reference, all deliberate:
   * the distance matrices are saved as <prefix>_Ds.npz (no deepdish/h5py offline);
   * device-backed subclasses (those with a _grid() method) never build the pair list at all:
     libacx enumerates the N x N grid itself in cost-balanced tiles (acx_pair_grid; under
-    torch.distributed, one process per GPU, acx_grid_run + ONE all-gather of the tile scores,
+    torch.distributed, one process per GPU, acx_grid_run + ONE gather of the tile scores to rank 0,
     scattered into the matrices by rank 0).  User subclasses that implement similarity()
     themselves keep the reference's chunked pair-list loop (sharded by pair count over the ranks).
   * under torch.distributed rank 0 owns the result: it alone holds the filled matrices, writes
@@ -230,7 +230,7 @@ class CoverAlgorithm(object):
     def _all_pairwise_grid(self, symmetric):
         """Device-backed classes: `self._grid()` -> (context with the pool uploaded, ACX_ALGO_*, params
         struct, similarity types in plane order).  One GPU: acx_pair_grid straight into the memmaps.
-        N GPUs: every rank runs its tiles into a device buffer, one all-gather, rank 0 scatters."""
+        N GPUs: every rank runs its tiles into a device buffer, one gather to rank 0, rank 0 scatters."""
         ctx, algo, params, keys = self._grid()
         planes = [self.Ds[k] for k in keys]
         rank, ws = _dist.world()

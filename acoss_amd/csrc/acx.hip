@@ -2697,24 +2697,33 @@ bool rccl_load()
 {
     if (g_rccl.handle) return true;
     std::vector<std::string> cand;
-    if (const char *e = getenv("ACX_RCCL_LIB")) cand.push_back(e);
     void *h = nullptr;
-    for (const char *n : {"librccl.so", "librccl.so.1"})                 // a copy this process already holds
-        if (!h && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) g_rccl.path = std::string(n) + " (already loaded)";
-    if (!h) {
-        Dl_info info;
-        if (dladdr((void *)hipGetDeviceCount, &info) && info.dli_fname) {       // next to the HIP runtime in use
-            std::string d(info.dli_fname);
-            const size_t k = d.rfind('/');
-            if (k != std::string::npos) { cand.push_back(d.substr(0, k) + "/librccl.so"); cand.push_back(d.substr(0, k) + "/librccl.so.1"); }
+    const char *forced = getenv("ACX_RCCL_LIB");          // an explicit choice is the ONLY candidate: a wrong path fails loudly
+    if (forced && forced[0]) {
+        cand.push_back(forced);
+    } else {
+        for (const char *n : {"librccl.so", "librccl.so.1"})                 // a copy this process already holds
+            if (!h && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) g_rccl.path = std::string(n) + " (already loaded)";
+        if (!h) {
+            Dl_info info;
+            if (dladdr((void *)hipGetDeviceCount, &info) && info.dli_fname) {       // next to the HIP runtime in use
+                std::string d(info.dli_fname);
+                const size_t k = d.rfind('/');
+                if (k != std::string::npos) { cand.push_back(d.substr(0, k) + "/librccl.so"); cand.push_back(d.substr(0, k) + "/librccl.so.1"); }
+            }
+            cand.push_back("librccl.so.1");
+            cand.push_back("librccl.so");
+            cand.push_back("/opt/rocm/lib/librccl.so");
         }
-        cand.push_back("librccl.so.1");
-        cand.push_back("librccl.so");
-        cand.push_back("/opt/rocm/lib/librccl.so");
-        for (const std::string &p : cand)
-            if ((h = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL))) { g_rccl.path = p; break; }
     }
-    if (!h) { g_rccl.error = std::string("librccl.so not found (set ACX_RCCL_LIB): ") + (dlerror() ? dlerror() : ""); return false; }
+    std::string why;
+    for (const std::string &p : cand) {
+        if (h) break;
+        if ((h = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL))) { g_rccl.path = p; break; }
+        const char *e = dlerror();                          // (one call: dlerror() clears the message it returns)
+        if (e) why = e;
+    }
+    if (!h) { g_rccl.error = std::string("librccl.so not found (set ACX_RCCL_LIB): ") + why; return false; }
 #define ACX_SYM(F_) g_rccl.F_ = reinterpret_cast<decltype(g_rccl.F_)>(dlsym(h, "nccl" #F_)); \
     if (!g_rccl.F_) { g_rccl.error = "librccl (" + g_rccl.path + ") lacks nccl" #F_; dlclose(h); return false; }
     ACX_SYM(GetUniqueId) ACX_SYM(CommInitRank) ACX_SYM(AllGather) ACX_SYM(CommDestroy) ACX_SYM(GetErrorString)
@@ -2790,6 +2799,12 @@ int acx_grid_allgather(acx_ctx *c, const float *d_local, float *d_gathered, int6
 // `_all_pairwise_grid` for a host without Python (reference: algorithm_template.py:168-192).
 int acx_pair_grid_ranks(acx_ctx *c, const acx_grid_spec *spec_in, const void *params, float *const *D, int64_t ld, int32_t mirror)
 {
+    // A COLLECTIVE: what can differ between the ranks (rank 0's planes, a rank's pool, its device memory, its kernels) must
+    // not make one rank return while the others wait in the all-gather.  Only checks that come out the same on every rank
+    // return early; everything else becomes this rank's STATUS, which travels with the exchanges: one float per rank ahead
+    // of the tiles (a rank that cannot even allocate its buffers is seen by all before anybody starts) and one appended to
+    // every rank's score buffer (a rank whose kernels failed).  Any non-zero status fails the call on EVERY rank and rank 0
+    // scatters nothing.
     if (!c) return ACX_ERR_INVALID;
     if (!c->comm) return fail(c, ACX_ERR_STATE, "pair_grid_ranks: no communicator (acx_comm_init)");
     if (!spec_in || !params) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: bad argument");
@@ -2797,41 +2812,100 @@ int acx_pair_grid_ranks(acx_ctx *c, const acx_grid_spec *spec_in, const void *pa
     spec.world = c->comm_world;
     if (!acx::grid_spec_ok(&spec)) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: bad grid spec");
     const int w = acx::grid_planes(spec.algo);
+    const int world = spec.world;
+    ACX_HIP(c, hipSetDevice(c->device));
+    float *d_st = nullptr;                                      // [0] this rank's status, [1 .. world] everybody's
+    ACX_HIP(c, hipMalloc((void **)&d_st, sizeof(float) * (size_t)(world + 1)));
+    int st = ACX_OK;
+    std::string why;
+    auto local_fail = [&](int code, const std::string &msg) { if (st == ACX_OK) { st = code; why = msg; } };
     if (c->comm_rank == 0) {
-        if (!D) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: rank 0 needs the planes");
-        for (int e = 0; e < w; ++e) if (!D[e]) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: null plane");
+        if (!D) local_fail(ACX_ERR_INVALID, "pair_grid_ranks: rank 0 needs the planes");
+        else for (int e = 0; e < w; ++e) if (!D[e]) local_fail(ACX_ERR_INVALID, "pair_grid_ranks: null plane");
     }
     std::vector<int64_t> len;
-    int rc = pool_lengths(c, spec.algo, len);
-    if (rc != ACX_OK) return rc;
-    if (c->comm_rank == 0 && ld < (int64_t)len.size()) return fail(c, ACX_ERR_INVALID, "pair_grid_ranks: leading dimension smaller than the number of tracks");
+    {
+        const int rl = pool_lengths(c, spec.algo, len);
+        if (rl != ACX_OK) local_fail(rl, acx_last_error(c));
+    }
+    if (st == ACX_OK && c->comm_rank == 0 && ld < (int64_t)len.size())
+        local_fail(ACX_ERR_INVALID, "pair_grid_ranks: leading dimension smaller than the number of tracks");
     std::vector<acx_grid_tile> tiles;
     std::vector<int64_t> fl;
     std::vector<double> co;
-    acx::grid_plan(len.data(), (int)len.size(), spec, tiles, fl, co);
     int64_t stride = 1;
-    for (int r = 0; r < spec.world; ++r) stride = std::max(stride, fl[r]);
-    ACX_HIP(c, hipSetDevice(c->device));
     float *d_local = nullptr, *d_all = nullptr;
-    ACX_HIP(c, hipMalloc((void **)&d_local, sizeof(float) * (size_t)stride));
-    if (hipMalloc((void **)&d_all, sizeof(float) * (size_t)stride * spec.world) != hipSuccess) {
-        (void)hipFree(d_local);
-        return fail(c, ACX_ERR_NOMEM, "pair_grid_ranks: the gathered score buffers do not fit the device");
+    if (st == ACX_OK) {
+        acx::grid_plan(len.data(), (int)len.size(), spec, tiles, fl, co);
+        for (int r = 0; r < world; ++r) stride = std::max(stride, fl[r]);
+        // (+ 1: the status float behind the tiles)
+        if (hipMalloc((void **)&d_local, sizeof(float) * (size_t)(stride + 1)) != hipSuccess ||
+            hipMalloc((void **)&d_all, sizeof(float) * (size_t)(stride + 1) * world) != hipSuccess) {
+            (void)hipGetLastError();
+            local_fail(ACX_ERR_NOMEM, "pair_grid_ranks: the gathered score buffers do not fit the device");
+        }
     }
-    (void)hipMemsetAsync(d_local, 0, sizeof(float) * (size_t)stride, c->stream);
-    rc = acx_grid_run(c, &spec, params, c->comm_rank, 0, -1, d_local);
-    // (every rank reaches the collective even if its own tiles failed: the others must not be left waiting)
-    const int rg = acx_grid_allgather(c, d_local, d_all, stride);
-    if (rc == ACX_OK) rc = rg;
-    if (rc == ACX_OK && c->comm_rank == 0) {
-        std::vector<float> h((size_t)stride * spec.world);
+    auto release = [&]() { if (d_local) (void)hipFree(d_local); if (d_all) (void)hipFree(d_all); (void)hipFree(d_st); };
+    // every rank's status, before any rank starts its tiles
+    std::vector<float> hst((size_t)world + 1, 0.0f);
+    auto exchange_status = [&](int mine) -> int {                // returns the first failing rank, -1 if none, -2 on a HIP / RCCL error
+        const float f = (float)mine;
+        if (hipMemcpy(d_st, &f, sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -2;      // (nothing is pending on the stream)
+        if (acx_grid_allgather(c, d_st, d_st + 1, 1) != ACX_OK) return -2;
+        if (hipMemcpy(hst.data(), d_st + 1, sizeof(float) * (size_t)world, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+        for (int r = 0; r < world; ++r) if (hst[r] != 0.0f) return r;
+        return -1;
+    };
+    auto fail_all = [&](int bad_rank) -> int {
+        release();
+        if (bad_rank == -2) return fail(c, ACX_ERR_HIP, "pair_grid_ranks: the status exchange failed");
+        if (st != ACX_OK) return fail(c, st, why);
+        return fail(c, (int)hst[bad_rank], "pair_grid_ranks: rank " + std::to_string(bad_rank) + " failed (its own context holds the message)");
+    };
+    int bad = exchange_status(st);
+    if (bad != -1) return fail_all(bad);
+    (void)hipMemsetAsync(d_local, 0, sizeof(float) * (size_t)(stride + 1), c->stream);
+    const int rc = acx_grid_run(c, &spec, params, c->comm_rank, 0, -1, d_local);
+    if (rc != ACX_OK) { st = rc; why = acx_last_error(c); }
+    {
+        const float f = (float)st;
+        // (acx_grid_run returns with its stream drained, the memset included: a plain copy cannot race it)
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(d_local + stride, &f, sizeof(float), hipMemcpyHostToDevice) != hipSuccess) (void)hipGetLastError();
+    }
+    // (a rank whose tiles failed still joins: the others must not be left waiting, and they learn about it from the status float)
+    const int rg = acx_grid_allgather(c, d_local, d_all, stride + 1);
+    if (rg != ACX_OK) { release(); return rg; }
+    if (hipMemcpy2D(hst.data(), sizeof(float), d_all + stride, sizeof(float) * (size_t)(stride + 1), sizeof(float), (size_t)world,
+                    hipMemcpyDeviceToHost) != hipSuccess) return fail_all(-2);
+    bad = -1;
+    for (int r = 0; r < world; ++r) if (hst[r] != 0.0f) { bad = r; break; }
+    if (bad != -1) return fail_all(bad);
+    int out = ACX_OK;
+    if (c->comm_rank == 0) {
+        std::vector<float> h((size_t)(stride + 1) * world);
         const hipError_t e = hipMemcpy(h.data(), d_all, sizeof(float) * h.size(), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(c, ACX_ERR_HIP, std::string("pair_grid_ranks: ") + hipGetErrorString(e));
-        else acx::grid_scatter(tiles, spec, h.data(), stride, 0, -1, D, ld, mirror);
+        if (e != hipSuccess) out = fail(c, ACX_ERR_HIP, std::string("pair_grid_ranks: ") + hipGetErrorString(e));
+        else acx::grid_scatter(tiles, spec, h.data(), stride + 1, 0, -1, D, ld, mirror);
     }
-    (void)hipFree(d_local);
-    (void)hipFree(d_all);
-    return rc;
+    release();
+    return out;
+}
+
+// The device a context would run on, for hosts that have to PROVE which GPU each of their ranks holds (bench.py's `ranks`
+// array): PCI bus id ("0000:c1:00.0"), marketing name, gcn arch, and how many devices this process can see.
+int acx_device_info(int device, char *pci_bus_id, int pci_len, char *name, int name_len, int *visible)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ACX_ERR_HIP;
+    if (visible) *visible = n;
+    if (device < 0 || device >= n) return ACX_ERR_INVALID;
+    if (pci_bus_id && pci_len > 0 && hipDeviceGetPCIBusId(pci_bus_id, pci_len, device) != hipSuccess) return ACX_ERR_HIP;
+    if (name && name_len > 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ACX_ERR_HIP;
+        snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    return ACX_OK;
 }
 
 int acx_profile_enable(acx_ctx *c, int on)

@@ -3,13 +3,13 @@ Multi-GPU execution of the pair grid: one process per GPU under torch.distribute
 "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).  Pairs are independent; the grid is
 cut into B x B track tiles that libacx deals to the ranks by cost (acx_grid_plan), every rank
 writes the scores of its tiles into ONE dense device buffer (acx_grid_run), and the only exchange
-on the path is ONE all-gather of those buffers -- device to device under
+on the path is ONE gather of those buffers to rank 0 -- device to device under
 RCCL, no host staging.  Rank 0 then scatters the tiles into the N x N matrices.
 """
 import numpy as np
 
 __all__ = ["world", "bind_device", "barrier", "broadcast_object", "on_root", "any_rank", "shard_bounds", "gather_scores",
-           "gather_tiles"]
+           "gather_tiles", "gather_tiles_device", "exchange_kind"]
 
 # The GPU this process works on (set by bind_device).  Under "nccl" EVERY collective needs a device:
 # torch picks torch.cuda.current_device() for dist.barrier() and for the tensors behind
@@ -138,27 +138,47 @@ def any_rank(flag):
     return bool(int(t.item()))
 
 
-def gather_tiles(local, stride):
-    """All-gather of the per-rank tile-score buffers: `local` is a torch tensor of `stride` float32
-    (on the rank's GPU under nccl).  Rank 0 -- the owner of the result -- gets the gathered
-    (world * stride,) float32 numpy array, every other rank None (no device-to-host copy there: at
-    N = 15 000 that would be 450 MB per rank for nothing).  Under nccl the collective runs on the
-    device buffers themselves; under gloo (CPU tests, ranks sharing one GPU) the buffer is moved to
-    the host first."""
+def exchange_kind():
+    """"gather" (default: ONE gather of the per-rank buffers to rank 0, the owner of the result -- only rank 0 holds
+    world x stride floats) or "allgather" (ACX_GRID_EXCHANGE=allgather: every rank receives every buffer, rounds 1-4)."""
+    import os
+    return "allgather" if os.environ.get("ACX_GRID_EXCHANGE", "") == "allgather" else "gather"
+
+
+def gather_tiles_device(local, stride):
+    """The one exchange of the path on the DEVICE buffers (nccl = RCCL over xGMI): rank 0 gets a (world * stride,)
+    float32 tensor on its GPU, rank r's buffer at r * stride; every other rank None.  `local`: this rank's `stride`
+    float32 (what acx_grid_run filled).  Under gloo (CPU tests, ranks sharing one GPU) the buffers travel through
+    host memory and the result is a CPU tensor."""
     import torch
     import torch.distributed as dist
     rank, ws = world()
     assert local.dtype == torch.float32 and local.numel() == stride
     if single():
-        return local.cpu().numpy()
-    if dist.get_backend() == "nccl":
-        out = torch.empty(ws * stride, dtype=torch.float32, device=local.device)
-        dist.all_gather_into_tensor(out, local)
-        return out.cpu().numpy() if rank == 0 else None
-    loc = local.cpu()
-    outs = [torch.empty_like(loc) for _ in range(ws)]
-    dist.all_gather(outs, loc)
-    return torch.cat(outs).numpy() if rank == 0 else None
+        return local
+    nccl = dist.get_backend() == "nccl"
+    loc = local if nccl else local.cpu()
+    if exchange_kind() == "allgather":
+        out = torch.empty(ws * stride, dtype=torch.float32, device=loc.device)
+        if nccl:
+            dist.all_gather_into_tensor(out, loc)
+        else:
+            dist.all_gather(list(out.view(ws, stride).unbind(0)), loc)
+        return out if rank == 0 else None
+    # reference: the joblib workers' results come back to the one parent process (algorithm_template.py:172-191)
+    out = torch.empty(ws * stride, dtype=torch.float32, device=loc.device) if rank == 0 else None
+    dist.gather(loc, gather_list=list(out.view(ws, stride).unbind(0)) if rank == 0 else None, dst=0)
+    return out
+
+
+def gather_tiles(local, stride):
+    """Gather of the per-rank tile-score buffers: `local` is a torch tensor of `stride` float32
+    (on the rank's GPU under nccl).  Rank 0 -- the owner of the result -- gets the gathered
+    (world * stride,) float32 numpy array, every other rank None (no device-to-host copy and, since
+    round 5, no world x stride allocation there: at N = 15 000 EarlyFusion that was 1.8 GB per rank for
+    nothing)."""
+    out = gather_tiles_device(local, stride)
+    return out.cpu().numpy() if out is not None else None
 
 
 # ---- pair-LIST sharding: the CPU loop of user subclasses that implement similarity() themselves

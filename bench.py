@@ -152,6 +152,8 @@ T_FRAMES = 2000
 N_TRACKS = 5000
 TILE = 64
 TILES_PER_STEP = 2             # per rank: 2 x 64 x 64 = 8192 pairs per GPU per step
+# the sub-grid of the N > 1 run's `strong` leg: 1280 tracks = 210 tiles = 818 560 pairs (~1 s per rank at 8 GPUs, ~8 s at one)
+STRONG_LEG_TRACKS = int(os.environ.get("ACX_BENCH_STRONG_TRACKS", "1280"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = f32 vector rate
 M_STACK = 9
@@ -344,6 +346,61 @@ def derive_bound(real_bound):
     return max(units, key=units.get) if units else None
 
 
+def rank_identity(rank, local_rank, device_index):
+    """What one rank says about the GPU it holds (libacx acx_device_info: no torch needed): gathered into the line's
+    `ranks` array so that a multi-GPU figure proves which devices produced it."""
+    import socket
+    from acoss_amd import _lib
+    info = {"rank": rank, "local_rank": local_rank, "device_index": device_index, "host": socket.gethostname(),
+            "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES")}
+    try:
+        info.update(_lib.device_info(device_index))
+    except Exception as e:                      # noqa: BLE001 -- reported, and treated as "cannot prove its device" below
+        info.update({"pci_bus_id": None, "name": None, "visible_devices": 0, "error": "%s: %s" % (type(e).__name__, e)})
+    return info
+
+
+def gather_identities(info, collective, dist, backend, local_rank):
+    if not collective:
+        return [info]
+    box = [None] * dist.get_world_size()
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(local_rank)
+    dist.all_gather_object(box, info)
+    return box
+
+
+def shared_device_reason(infos, backend, world):
+    """One line naming the ranks that hold the SAME GPU (same host, same PCI bus id), or a rank that cannot name its GPU;
+    None when every rank has a device of its own.  Enforced for RCCL worlds (one communicator rank per device; a figure
+    from ranks sharing a GPU is not a multi-GPU figure) and, ACX_BENCH_REQUIRE_DISTINCT=1, for any backend -- the gloo
+    development mode deliberately shares devices and says so in `collectives`."""
+    if world < 2 or not (backend == "nccl" or os.environ.get("ACX_BENCH_REQUIRE_DISTINCT") == "1"):
+        return None
+    seen = {}
+    for i in infos:
+        if not i.get("pci_bus_id"):
+            return "bench: rank %d cannot name its GPU (%s): no multi-GPU figure without proof of the devices" % (i["rank"], i.get("error"))
+        key = (i["host"], i["pci_bus_id"])
+        if key in seen:
+            return ("bench: ranks %d and %d hold the same GPU (%s on %s; %d rank(s), rank %d sees %d device(s), HIP_VISIBLE_DEVICES=%s): "
+                    "one rank per GPU or no multi-GPU figure" % (seen[key], i["rank"], i["pci_bus_id"], i["host"], world, i["rank"],
+                                                                  i["visible_devices"], i["HIP_VISIBLE_DEVICES"]))
+        seen[key] = i["rank"]
+    return None
+
+
+def rccl_version(collective, backend):
+    if not (collective and backend == "nccl"):
+        return None
+    try:
+        import torch
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                           # noqa: BLE001
+        return None
+
+
 def init_torch(clock, local_rank, world, backend, collective):
     with clock.phase("import_torch"):
         import torch
@@ -365,38 +422,26 @@ def init_torch(clock, local_rank, world, backend, collective):
     return torch, dist, local_rank
 
 
-def run_strong(args, clock, out, rank, world, local_rank):
-    """`--strong`: the WHOLE pair grid of the pool (5 000 tracks: 12 497 500 pairs) once, split over the N ranks the
-    way all_pairwise splits it (algorithm_template.py:168-192 in the reference; here acx_grid_plan's cost-balanced
-    deal, acoss_amd/algorithms/algorithm_template.py:_all_pairwise_grid): every rank runs ALL its tiles into one device
-    buffer (acx_grid_run), then the ONE collective of the path -- all_gather_into_tensor of the real per-rank buffers --
-    and rank 0 scatters + mirrors the tiles into the N x N float32 memmap (acx_grid_scatter).  Strong scaling: total
-    work fixed.  `value` = pairs / (kernels + gather), max over ranks; `strong.value_incl_scatter` adds the device-to-
-    host copy and rank 0's scatter, the only serial part.  Reports plan imbalance, gather ms / bytes, scatter s."""
+def strong_core(ctx, params, lengths, tile, rank, world, local_rank, collective, backend, torch, dist, clock, warmup, label):
+    """One whole pair grid as ONE job over the ranks, the way all_pairwise splits it (algorithm_template.py:168-192 in the
+    reference; acoss_amd/algorithms/algorithm_template.py:_all_pairwise_grid here): acx_grid_plan's cost-balanced deal, every
+    rank runs ALL its tiles into one device buffer (acx_grid_run), the ONE exchange of the path on the real per-rank buffers
+    (acoss_amd.dist.gather_tiles_device: a gather to rank 0 over RCCL; ACX_GRID_EXCHANGE=allgather for the all-gather of
+    rounds 1-4), rank 0 copies the result to the host, scatters + mirrors it into an N x N float32 matrix (acx_grid_scatter)
+    and checks 256 sampled cells against the pair-LIST path.  The pool must already be in the context; `lengths` may be a
+    prefix of it (the sub-grid leg of the default run)."""
     import tempfile
     from acoss_amd import _lib
-    with clock.phase("pool_gen"):
-        frames, offsets = make_pool(args.tracks, args.frames)
-    backend = os.environ.get("ACX_BENCH_BACKEND", "nccl")
-    collective = world > 1 or os.environ.get("ACX_BENCH_FORCE_COLLECTIVE") == "1"
-    torch = dist = None
-    if collective:
-        torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
-        dev = torch.device("cuda", local_rank)
-    with clock.phase("context_and_upload"):
-        ctx = _lib.Context(local_rank)
-        ctx.upload_pool(frames, offsets)
-    params = _lib.serra09_params()
-    lengths = np.full(args.tracks, args.frames, np.int64)
-    plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=world, tile=args.tile, want_tiles=True)
+    from acoss_amd import dist as adist
+    n = len(lengths)
+    plan = _lib.grid_plan(lengths, _lib.ALGO_SERRA09, True, world=world, tile=tile, want_tiles=True)
     spec = plan["spec"]
     stride = int(max(1, plan["floats_per_rank"].max()))
     if collective:
+        dev = torch.device("cuda", local_rank)
         local = torch.zeros(stride, dtype=torch.float32, device=dev)
-        gathered = torch.empty(world * stride, dtype=torch.float32, device=dev)
     else:                                                        # one rank, no collective: no torch in the process
         local = ctx.dev_alloc(4 * stride)
-        gathered = None
     n_mine = sum(1 for t in plan["tiles"] if t.rank == rank)
 
     def fence():
@@ -406,49 +451,44 @@ def run_strong(args, clock, out, rank, world, local_rank):
         else:
             ctx.dev_sync()
 
-    with clock.phase("warmup"):
-        for _ in range(max(1, args.warmup)):                     # arena, code objects, clocks: the rank's first tile(s)
-            ctx.grid_run(spec, params, rank, local.data_ptr(), first=0, count=min(2, n_mine))
-        # (acx_grid_run zeroes the slice it fills: the warm-up's scores are overwritten by the timed pass)
+    if warmup:
+        with clock.phase(label + "_warmup"):
+            for _ in range(warmup):                              # arena, code objects, clocks: the rank's first tile(s)
+                ctx.grid_run(spec, params, rank, local.data_ptr(), first=0, count=min(2, n_mine))
+            # (acx_grid_run zeroes the slice it fills: the warm-up's scores are overwritten by the timed pass)
     ctx.profile_enable(True)
     ctx.profile_reset()
     fence()
-    clock.stamp("timed region (whole grid) ...")
+    clock.stamp("%s: timed region (whole grid of %d tracks) ..." % (label, n))
     t0 = time.perf_counter()
     ctx.grid_run(spec, params, rank, local.data_ptr())           # all tiles of this rank; returns after its stream drained
     t_compute = time.perf_counter() - t0
     tg0 = time.perf_counter()
-    host_gather = None
+    gathered = None
     if collective:
+        gathered = adist.gather_tiles_device(local, stride)     # rank 0: (world * stride,) on its GPU (nccl) / the host (gloo)
         if backend == "nccl":
-            dist.all_gather_into_tensor(gathered, local)
             torch.cuda.synchronize()
-        else:                                                    # development: ranks sharing a GPU, gather through the host
-            loc = local.cpu()
-            outs = [torch.empty_like(loc) for _ in range(world)]
-            dist.all_gather(outs, loc)
-            host_gather = torch.cat(outs).numpy()
     t_gather = time.perf_counter() - tg0
     fence()
     elapsed = time.perf_counter() - t0
-    clock.stamp("timed region: %.2f s (kernels %.2f s, gather %.4f s)" % (elapsed, t_compute, t_gather))
+    clock.stamp("%s: timed region %.2f s (kernels %.2f s, exchange %.4f s)" % (label, elapsed, t_compute, t_gather))
     prof = ctx.profile()
-    # ---- the serial tail: rank 0 brings the gathered buffers to the host and scatters them into the memmap
+    # ---- the serial tail: rank 0 brings the gathered buffers to the host and scatters them into the matrix
     t_d2h = t_scatter = None
     check = None
     if rank == 0:
         ts0 = time.perf_counter()
-        if host_gather is None:
-            host_gather = gathered.cpu().numpy() if collective else local.read(np.float32, stride)
+        host_gather = gathered.cpu().numpy() if collective else local.read(np.float32, stride)
         t_d2h = time.perf_counter() - ts0
         tmp = tempfile.mkdtemp(prefix="acx_strong_")
-        D = np.lib.format.open_memmap(os.path.join(tmp, "D.npy"), mode="w+", dtype=np.float32, shape=(args.tracks, args.tracks))
+        D = np.lib.format.open_memmap(os.path.join(tmp, "D.npy"), mode="w+", dtype=np.float32, shape=(n, n))
         ts1 = time.perf_counter()
         _lib.grid_scatter(lengths, spec, host_gather, stride, [D], mirror=True)
         t_scatter = time.perf_counter() - ts1
         # the matrix against the pair-LIST path of the library on sampled pairs (and its own transpose)
         rng = np.random.default_rng(5)
-        smp = rng.integers(0, args.tracks, (512, 2))
+        smp = rng.integers(0, n, (512, 2))
         smp = np.sort(smp[smp[:, 0] != smp[:, 1]][:256], axis=1)       # (i < j): the triangle all_pairwise computes
         smp = np.ascontiguousarray(smp.astype(np.int32))
         got = ctx.serra09_pairs(smp, params)
@@ -456,7 +496,7 @@ def run_strong(args, clock, out, rank, world, local_rank):
                  "matrix_equals_pair_list": bool(np.array_equal(D[smp[:, 0], smp[:, 1]], got)),
                  "cells_equal": int(np.sum(D[smp[:, 0], smp[:, 1]] == got)),
                  "symmetric": bool(np.array_equal(D[smp[:, 0], smp[:, 1]], D[smp[:, 1], smp[:, 0]])),
-                 "nonzero_fraction_offdiag": float(np.count_nonzero(D) / max(1, args.tracks * (args.tracks - 1)))}
+                 "nonzero_fraction_offdiag": float(np.count_nonzero(D) / max(1, n * (n - 1)))}
         del D
         try:
             os.remove(os.path.join(tmp, "D.npy"))
@@ -465,7 +505,7 @@ def run_strong(args, clock, out, rank, world, local_rank):
             pass
     per_rank = [t_compute]
     if collective:
-        cdev = dev if backend == "nccl" else torch.device("cpu")
+        cdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -473,38 +513,77 @@ def run_strong(args, clock, out, rank, world, local_rank):
         outs = [torch.zeros_like(tc) for _ in range(world)]
         dist.all_gather(outs, tc)
         per_rank = [float(o.item()) for o in outs]
+    if not collective:
+        local.free()
+    pairs = n * (n - 1) // 2
+    kname, kst = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    exchange = None
+    if collective:
+        exchange = "%s over %s" % ("all_gather_into_tensor" if adist.exchange_kind() == "allgather" else "gather to rank 0 (torch.distributed.gather)",
+                                   "RCCL, device to device" if backend == "nccl" else "gloo through host memory (development: ranks may share a GPU)")
+    res = {"tracks": n, "pairs": pairs, "elapsed_s": elapsed, "spec_tile": int(spec.tile),
+           "strong": {"tracks": n, "pairs": pairs, "value": round(pairs / elapsed, 1),
+                      "kernels_s_per_rank": [round(t, 3) for t in per_rank],
+                      "plan_imbalance_max_over_mean": round(max(per_rank) / (sum(per_rank) / len(per_rank)), 4),
+                      "plan_cost_per_rank": [float(c) for c in plan["cost_per_rank"]],
+                      "tiles": int(plan["n_tiles"]), "tile": int(spec.tile), "exchange": exchange,
+                      "gather_ms": round(1e3 * t_gather, 3), "gather_bytes": int(world * stride * 4),
+                      "gather_bytes_per_rank": int(stride * 4),
+                      "dominant_kernel": kname, "dominant_kernel_ms": round(kst["ms"], 1)}}
     if rank == 0:
-        pairs = args.tracks * (args.tracks - 1) // 2
-        kname, kst = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        res["strong"].update({"d2h_s": round(t_d2h, 3), "scatter_mirror_s": round(t_scatter, 3),
+                              "value_incl_scatter": round(pairs / (elapsed + t_d2h + t_scatter), 1), "check": check})
+    return res
+
+
+def run_strong(args, clock, out, rank, world, local_rank):
+    """`--strong`: the WHOLE pair grid of the pool (5 000 tracks: 12 497 500 pairs) once, split over the N ranks
+    (strong_core).  Strong scaling: total work fixed.  `value` = pairs / (kernels + exchange), max over ranks;
+    `strong.value_incl_scatter` adds the device-to-host copy and rank 0's scatter, the only serial part.  Reports the
+    per-rank devices, plan imbalance, exchange ms / bytes, scatter s."""
+    from acoss_amd import _lib
+    with clock.phase("pool_gen"):
+        frames, offsets = make_pool(args.tracks, args.frames)
+    backend = os.environ.get("ACX_BENCH_BACKEND", "nccl")
+    collective = world > 1 or os.environ.get("ACX_BENCH_FORCE_COLLECTIVE") == "1"
+    torch = dist = None
+    if collective:
+        torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
+    infos = gather_identities(rank_identity(rank, local_rank, local_rank), collective, dist, backend, local_rank)
+    why = shared_device_reason(infos, backend, world)
+    if why:
+        if rank == 0:
+            print(why, file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    with clock.phase("context_and_upload"):
+        ctx = _lib.Context(local_rank)
+        ctx.upload_pool(frames, offsets)
+    params = _lib.serra09_params()
+    lengths = np.full(args.tracks, args.frames, np.int64)
+    res = strong_core(ctx, params, lengths, args.tile, rank, world, local_rank, collective, backend, torch, dist, clock,
+                      max(1, args.warmup), "strong")
+    if rank == 0:
+        pairs, elapsed = res["pairs"], res["elapsed_s"]
         line = {
             "metric": "track-pairs/sec on N x N Serra09 Qmax (HPCP, T=%d)" % args.frames,
             "value": round(pairs / elapsed, 1), "unit": "track-pairs/s", "n_gpus": world,
             "ranks_seen": dist.get_world_size() if collective else 1, "collectives": (backend if collective else None),
+            "rccl_version": rccl_version(collective, backend), "ranks": infos,
             "steps": 1, "warmup": max(1, args.warmup), "ms_per_step": round(1e3 * elapsed, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2] as ONE job: synthetic %d tracks x %d-frame HPCP (seed 1234), Serra09 Qmax, the whole "
                                    "%d x %d upper-triangle grid (%d pairs) in %d x %d tiles dealt to %d rank(s) by cost; every rank "
-                                   "runs all its tiles, ONE all-gather of the per-rank score buffers, rank 0 scatters"
-                                   % (args.tracks, args.frames, args.tracks, args.tracks, pairs, spec.tile, spec.tile, world),
+                                   "runs all its tiles, ONE exchange of the per-rank score buffers, rank 0 scatters"
+                                   % (args.tracks, args.frames, args.tracks, args.tracks, pairs, res["spec_tile"], res["spec_tile"], world),
                        "pairs": pairs, "frames_per_track": args.frames, "pool_tracks": args.tracks,
                        "parallelism": "pair-grid tiles over %d GPU(s), strong scaling" % world},
-            "strong": {
-                "kernels_s_per_rank": [round(t, 3) for t in per_rank],
-                "plan_imbalance_max_over_mean": round(max(per_rank) / (sum(per_rank) / len(per_rank)), 4),
-                "plan_cost_per_rank": [float(c) for c in plan["cost_per_rank"]],
-                "tiles": int(plan["n_tiles"]), "tile": int(spec.tile),
-                "gather_ms": round(1e3 * t_gather, 3), "gather_bytes": int(world * stride * 4),
-                "gather_bytes_per_rank": int(stride * 4),
-                "d2h_s": round(t_d2h, 3), "scatter_mirror_s": round(t_scatter, 3),
-                "value_incl_scatter": round(pairs / (elapsed + t_d2h + t_scatter), 1),
-                "check": check,
-                "dominant_kernel": kname, "dominant_kernel_ms": round(kst["ms"], 1)},
+            "strong": res["strong"],
             "phases_s": clock.phases,
         }
         print(json.dumps(line), file=out, flush=True)
     ctx.close()
     if collective:
-        fence()
+        dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 
@@ -620,6 +699,13 @@ def main():
     if collective:
         torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
         dev = torch.device("cuda", local_rank)
+    # which GPU does every rank hold?  Gathered BEFORE any measurement; two RCCL ranks on one device end the run here
+    infos = gather_identities(rank_identity(rank, local_rank, local_rank), collective, dist, backend, local_rank)
+    why = shared_device_reason(infos, backend, world)
+    if why:
+        if rank == 0:
+            print(why, file=sys.stderr, flush=True)
+        raise SystemExit(3)
 
     with clock.phase("context_and_upload"):
         ctx = _lib.Context(local_rank)
@@ -687,6 +773,31 @@ def main():
         total_pairs = my_pairs
     ranks_seen = dist.get_world_size() if collective else 1        # what the collective actually spanned
     prof = ctx.profile()
+    my_kernels_s = sum(v["ms"] for v in prof.values()) / 1e3
+    if collective:
+        box = [None] * world
+        dist.all_gather_object(box, (rank, round(my_kernels_s, 4), round(my_pairs)))
+        for r, ks, pp_ in box:
+            infos[r]["kernels_s"] = ks
+            infos[r]["pairs"] = int(pp_)
+    else:
+        infos[0]["kernels_s"] = round(my_kernels_s, 4)
+        infos[0]["pairs"] = int(round(my_pairs))
+    # ---- N > 1 (or a forced one-rank world): the path as ONE job on a sub-grid of the same pool -- the real plan, the real
+    # per-rank buffers through the ONE exchange, rank 0's device-to-host copy + scatter + mirror, the matrix checked against
+    # the pair-list path.  Outside the timed region above; reported under `strong` in the same line.
+    strong = None
+    if collective and not os.environ.get("ACX_BENCH_NO_STRONG_LEG"):
+        n_sub = min(args.tracks, STRONG_LEG_TRACKS)
+        with clock.phase("strong_leg"):
+            # (acx_grid_run plans over the WHOLE pool of the context: the sub-grid gets a pool of its own, the first n_sub tracks)
+            ctx.upload_pool(frames[:int(offsets[n_sub])], offsets[:n_sub + 1])
+            strong = strong_core(ctx, params, np.full(n_sub, T_FRAMES, np.int64), TILE, rank, world, local_rank, collective, backend,
+                                 torch, dist, clock, 0, "strong_leg")["strong"]
+            strong["pool"] = "the first %d tracks of the run's pool, uploaded as a pool of their own" % n_sub
+            if world == 1:
+                ctx.upload_pool(frames, offsets)        # (the self-check and the companion legs below want the run's pool back)
+        ctx.profile_enable(False)
 
     if rank == 0:
         value = total_pairs / elapsed
@@ -757,7 +868,8 @@ def main():
                     raise SystemExit("bench: GPU scores differ from the CPU oracle on the sampled pairs")
         line = {
             "metric": "track-pairs/sec on N x N Serra09 Qmax (HPCP, T=2000)",
-            "value": round(value, 1), "unit": "track-pairs/s", "n_gpus": world, "ranks_seen": ranks_seen, "collectives": (backend if collective else None), "steps": args.steps,
+            "value": round(value, 1), "unit": "track-pairs/s", "n_gpus": world, "ranks_seen": ranks_seen, "collectives": (backend if collective else None),
+            "rccl_version": rccl_version(collective, backend), "ranks": infos, "strong": strong, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",

@@ -28,7 +28,9 @@ extern "C" {
 /* 2 (round 4): + acx_dev_alloc / _free / _read / _sync, acx_comm_id / _init / _destroy, acx_grid_allgather,
  *              acx_pair_grid_ranks; acx_ef_pool_end fails on tracks never handed over; uploads reject non-finite input
  *              (since the round-3 library, which still said 1).  The ctypes shim refuses a library of another version. */
-#define ACX_ABI_VERSION 2
+/* 3 (round 5): + acx_device_info; acx_pair_grid_ranks carries a per-rank status through its exchanges (a failing rank fails the call
+ *              on every rank instead of leaving the others in the all-gather); ACX_RCCL_LIB, when set, is the only librccl tried. */
+#define ACX_ABI_VERSION 3
 
 enum {
     ACX_OK = 0,
@@ -56,6 +58,11 @@ int acx_abi_version(void);
  * that also holds PyTorch-ROCm runs on the runtime torch bundles (this image: built against 7.2, runs on 7.0 --
  * same major, recorded, no warning). */
 int acx_hip_versions(int *build, int *runtime);
+/* Which GPU is HIP device `device` of this process: PCI bus id ("0000:c1:00.0"), "name (gcn arch)", and the number of
+ * devices the process can see (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES applied).  bench.py gathers one of these per
+ * rank and refuses to report a multi-GPU figure when two ranks hold the same device.  No reference counterpart
+ * (joblib workers share one host, algorithm_template.py:172-177). */
+int acx_device_info(int device, char *pci_bus_id, int pci_len, char *name, int name_len, int *visible);
 /* Upper bound (bytes) for the per-batch device scratch; 0 restores the default: env ACX_SCRATCH_GB, else 40 % of
  * device memory for the Serra09 batches and min(40 %, 36 GB) for the EarlyFusion arena (what one 128 x 128 grid tile
  * of 300-500-block tracks needs; larger arenas only cost allocation time). */

@@ -1,6 +1,6 @@
 """Development aid: the Serra09 chain on the short-row workloads (i.i.d. T = 450 / 250, covers80-shaped 150-650), several repetitions,
 best and median rate + the band kernels' share.  Pick the build with ACX_LIB=build_ab/libacx_<name>.so / ACX_BAND2=0|1.
-usage: ab_narrow.py [reps]"""
+usage: ab_narrow.py [reps] [prof]      (prof: also read the library's per-kernel event clocks -- they cost 10-20 % of a short call)"""
 import sys
 import time
 import zlib
@@ -11,6 +11,7 @@ sys.path.insert(0, ".")
 from acoss_amd import _lib, synth  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+prof = len(sys.argv) > 2
 ctx = _lib.Context(0)
 
 
@@ -22,14 +23,14 @@ def run(label, d):
     L = (np.diff(d["offsets"]) - 9).astype(np.float64)
     cells = float(np.sum(L[i] * L[j]))
     ctx.serra09_pairs(pairs[:64])
-    ctx.profile_enable(True)
+    ctx.profile_enable(prof)
     ts, band = [], []
     for _ in range(reps):
         ctx.profile_reset()
         t0 = time.time()
         out = ctx.serra09_pairs(pairs)
         ts.append(time.time() - t0)
-        pr = ctx.profile()
+        pr = ctx.profile() if prof else {}
         band.append(sum(v["ms"] for k, v in pr.items() if "band" in k))
     ts = np.array(ts)
     print("%-22s pairs=%d  best %.1f / median %.1f Gcells/s  (%.0f k pairs/s best)  band kernels %.3f ms (best)  crc %08x" % (

@@ -23,7 +23,7 @@ def test_header_and_library_agree():
     for s in declared:
         assert hasattr(L, s), "libacx.so does not export %s" % s
     assert sorted(_lib.EXPORTS) == declared
-    assert L.acx_abi_version() == _lib.ABI_VERSION == 2
+    assert L.acx_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_default_params_match_reference_ctor():
@@ -38,6 +38,25 @@ def test_default_params_match_reference_ctor():
     assert p.arith == 0 and ctypes.sizeof(_lib.Serra09Params) == 52 and _lib.Serra09Params.arith.offset == 48
     assert _lib.serra09_params(arith="f16x2").arith == 1 and _lib.serra09_params().arith == 0
     assert L.acx_serra09_embed_len(2000, p) == 1991 and L.acx_serra09_embed_len(9, p) == 0
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """with no librccl to open, acx_comm_id must return ACX_ERR_UNSUPPORTED (the message used to be built from two
+    dlerror() calls, the second of which returns NULL).  ACX_RCCL_LIB names the ONLY candidate, so a wrong path is that case."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from acoss_amd import _lib\n"
+            "L = _lib.load()\n"
+            "buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)\n"
+            "rc = L.acx_comm_id(buf)\n"
+            "msg = L.acx_last_error(None)\n"
+            "print('rc', rc, msg)\n"
+            "sys.exit(0 if rc == -6 and b'librccl' in msg else 1)\n" % ROOT)
+    env = dict(os.environ, ACX_RCCL_LIB="/nonexistent/librccl.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
 
 
 def test_no_silent_cpu_fallback():

@@ -319,6 +319,10 @@ def test_bench_strong_nccl_world_of_one():
     assert s["check"]["nonzero_fraction_offdiag"] == 1.0
     assert s["gather_bytes"] >= 4 * line["config"]["pairs"] and s["gather_ms"] > 0
     assert "phases_s" in line and line["value"] > 0
+    # the line proves its device: PCI bus id + name of the GPU the rank holds, RCCL's version
+    (r0,) = line["ranks"]
+    assert r0["rank"] == 0 and len(r0["pci_bus_id"]) >= 7 and "gfx950" in r0["name"] and r0["visible_devices"] >= 1
+    assert line["rccl_version"] and "gather to rank 0" in s["exchange"]
 
 
 def test_bench_strong_gloo_world_of_two():
@@ -333,6 +337,61 @@ def test_bench_strong_gloo_world_of_two():
     assert s["gather_bytes"] == 2 * s["gather_bytes_per_rank"]
     c = s["plan_cost_per_rank"]
     assert max(c) / (sum(c) / 2) < 1.1                                # the deal balances the modelled cost
+    assert [r["rank"] for r in line["ranks"]] == [0, 1] and all(r["pci_bus_id"] for r in line["ranks"])
+
+
+def _bench_default(env_extra, nproc, extra_args=(), expect_rc=0):
+    """The driver's command (`bench.py --gpus N --steps K --warmup W`, weak scaling) as a child process on a small pool."""
+    import json
+    import os
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("ACX_BENCH_STRONG_TRACKS", "192")
+    args = ["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--tracks", "640", "--no-cpu", "--no-other"] + list(extra_args)
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    else:
+        env.update(MASTER_PORT=str(_free_port()))
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert (r.returncode == 0) == (expect_rc == 0), (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    if expect_rc != 0:
+        return r
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_default_line_proves_its_ranks_and_carries_the_real_exchange():
+    """the DEFAULT (weak) bench line of an N > 1 run names every rank's GPU (PCI bus id, device name, visible
+    devices, its kernel seconds) and carries a `strong` object from a sub-grid run as ONE job -- the real plan, ONE exchange of the
+    real per-rank buffers, rank-0 scatter, the matrix checked against the pair-list path.  Here: a one-rank RCCL world
+    (ACX_BENCH_FORCE_COLLECTIVE=1) and two gloo ranks sharing the GPU."""
+    line = _bench_default({"ACX_BENCH_FORCE_COLLECTIVE": "1"}, 1)
+    assert line["scaling"] == "weak" and line["collectives"] == "nccl" and line["rccl_version"]
+    (r0,) = line["ranks"]
+    assert len(r0["pci_bus_id"]) >= 7 and r0["kernels_s"] > 0 and r0["pairs"] == 2 * 8192
+    s = line["strong"]
+    assert s["tracks"] == 192 and s["pairs"] == 192 * 191 // 2 and s["check"]["matrix_equals_pair_list"] and s["check"]["symmetric"]
+    assert s["gather_ms"] > 0 and s["gather_bytes"] >= 4 * s["pairs"] and s["scatter_mirror_s"] >= 0
+    line = _bench_default({"ACX_BENCH_BACKEND": "gloo"}, 2)
+    assert line["n_gpus"] == 2 and [r["rank"] for r in line["ranks"]] == [0, 1] and line["collectives"] == "gloo"
+    assert line["ranks"][0]["pci_bus_id"] == line["ranks"][1]["pci_bus_id"]          # (development mode: the ranks share the box's GPU)
+    s = line["strong"]
+    assert len(s["kernels_s_per_rank"]) == 2 and s["check"]["matrix_equals_pair_list"], s
+    # one rank without a collective: still says which GPU it ran on, no strong leg
+    line = _bench_default({}, 1)
+    assert line["strong"] is None and len(line["ranks"]) == 1 and line["ranks"][0]["pci_bus_id"]
+
+
+def test_bench_refuses_ranks_that_share_a_gpu():
+    """Two ranks on ONE device are not a two-GPU figure: under RCCL semantics (here claimed for a gloo world by
+    ACX_BENCH_REQUIRE_DISTINCT=1 -- a 1-GPU box cannot hold two RCCL ranks) the run ends non-zero with a one-line reason and
+    prints no JSON line."""
+    r = _bench_default({"ACX_BENCH_BACKEND": "gloo", "ACX_BENCH_REQUIRE_DISTINCT": "1"}, 2, expect_rc=3)
+    assert "hold the same GPU" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_rccl_inside_libacx_world_of_one():
