@@ -28,6 +28,17 @@ F64_VALU_PEAK_TF = 78.6        # f64 vector FMA peak (half the f32 rate)
 BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 matrix peak (no sparsity)
 
 
+def _ref_ratio(key):
+    """The oracle's per-pair speed relative to the REFERENCE's own numpy code, measured once in the authoring container
+    (scripts/ref_vs_oracle_timing.py -> profiles/r05_ref_vs_oracle.json: the reference never travels to the GPU box)."""
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "r05_ref_vs_oracle.json")))[key]["oracle_speed_over_reference"]
+        return ("; this port runs at %.2f x the per-pair, one-thread speed of the reference's own numpy code (profiles/r05_ref_vs_oracle.json, "
+                "taken in the authoring container)" % r)
+    except Exception:                               # noqa: BLE001
+        return ""
+
+
 def _one_thread():
     try:
         from threadpoolctl import threadpool_limits
@@ -304,7 +315,7 @@ def simple_leg(ctx, steps=5, warmup=1, n=1536, tiles_per_step=16, cpu_pairs=64):
                      "survey_8d_model_tflops_240_per_cell": round(240.0 * cells / ks / 1e12, 2)},
         "cpu_baseline": {"value": round(len(cp) / tcpu, 2), "unit": "track-pairs/s", "cores": 1, "kind": "port",
                          "sample": "first %d pairs of the first timed tile, numpy oracle, BLAS limited to one thread; max relative |diff| vs the "
-                                   "GPU's f32 scores %.1e" % (len(cp), err)}}
+                                   "GPU's f32 scores %.1e%s" % (len(cp), err, _ref_ratio("simple"))}}
 
 
 def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
@@ -373,7 +384,7 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
     return {
         "metric": "track-pairs/sec, EarlyFusion per-pair chain (3 CSMs, 4 x binarise + Smith-Waterman, kernel fusion) at 300-500 blocks",
         "value": round(npairs / dt, 1), "unit": "track-pairs/s", "n_gpus": 1, "steps": steps,
-        "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "dtype": "f32",
+        "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "dtype": "f16x2 -> f32",
         "data": "synthetic",
         "config": {"workload": "configs[4] per-track shape: pool of %d tracks of 300-500 blocks, one 128 x 128 grid tile per step "
                                "(diagonal: 8128 pairs, off-diagonal: 16 384), another tile every step, %d pairs in %d steps through "
@@ -394,8 +405,8 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
                    "note": "ACX_EF_GEMM_BF16X3 on the same tiles: three bf16 terms per value, six MFMAs per cell (round 3's default)"},
         "cpu_baseline": {"value": round(len(cp) / tcpu, 3), "unit": "track-pairs/s", "cores": 1, "kind": "port",
                          "sample": "first %d pairs of the first timed tile, numpy + C oracle, BLAS limited to one thread, %.1f s; "
-                                   "%.4f of the 4 x %d scores identical to the GPU's, max |diff| %.3g"
-                                   % (len(cp), tcpu, same, len(cp), diff)}}
+                                   "%.4f of the 4 x %d scores identical to the GPU's, max |diff| %.3g%s"
+                                   % (len(cp), tcpu, same, len(cp), diff, _ref_ratio("earlyfusion"))}}
 
 
 def main():
