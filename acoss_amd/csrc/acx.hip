@@ -22,6 +22,7 @@
 #include "snf_kernels.hpp"
 #include "simple_kernels.hpp"
 #include "ef_kernels.hpp"
+#include "ef_rowstat2_kernels.hpp"
 #include "ef_prep_kernels.hpp"
 #include "grid.hpp"
 
@@ -1099,7 +1100,13 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                                  else hipLaunchKernelGGL((acx::sw_kernel<8>), grid_, dim3(64), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, c->d_out, src_); } while (0)
         {
             ProfScope ps(c, KS_EFSTAT, cells);
-            ACX_ROWSTAT(dim3(rows_g, B, nfeat), 0);
+            // rows of <= 512 cells: two rows per wave (ef_rowstat2_kernels.hpp; ACX_EF_ROWSTAT2=0 keeps the one-row kernel)
+            static const bool two_rows = [] { const char *e = getenv("ACX_EF_ROWSTAT2"); return !(e && e[0] == '0'); }();
+            if (two_rows && !long_rows && maxN <= 512)
+                hipLaunchKernelGGL(acx::ef_rowstat2_kernel, dim3((maxM + 7) / 8, B, nfeat), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr,
+                                   c->d_efbits, p.K);
+            else
+                ACX_ROWSTAT(dim3(rows_g, B, nfeat), 0);
             if (!ext_matrix) {
                 if (keep_ct) ACX_ROWSTAT(dim3(rows_g, B, 3), 1);
                 else if (p.K <= 10) hipLaunchKernelGGL((acx::ef_colstat_kernel<10>), dim3((maxN + 63) / 64, B, 3), dim3(256), 0, c->stream, c->d_efpd, c->d_scratch, c->d_thr, p.K);

@@ -1232,6 +1232,46 @@ __device__ __forceinline__ bool ef_select_pivot2(const float (&x)[NV], int k1, i
     const int cum1 = ex1 + __builtin_amdgcn_readlane(Pp, l1) - cnt1, cum2 = ex2 + __builtin_amdgcn_readlane(Pp, l2) - cnt2;
     const int bin1 = L1 * BPL + l1, bin2 = L2 * BPL + (l2 - 16);
     if (cnt1 > 64 || cnt2 > 64) return false;
+    // Round 5: most of the time no member has to be gathered at all.  The rank sits at position p = k - cum of its bin of cnt cells:
+    // p == 0 -> the bin's SMALLEST cell, p == cnt - 1 -> its LARGEST (at ~0.4 cells per bin the bin holds one or two cells nine
+    // times in ten).  The cells of the two target bins post their minimum / maximum with exec-masked LDS atomics on four dwords
+    // (a handful of lanes; unsigned patterns order like the non-negative values) -- no candidate list, no ranking loop, no
+    // readlane picks: ~70 of the kernel's 390 VALU instructions per row.
+    {
+        const int p1 = k1 - cum1, p2 = k2 - cum2;
+        if ((p1 == 0 || p1 == cnt1 - 1) && (p2 == 0 || p2 == cnt2 - 1)) {
+            lds_u32 *ext = (lds_u32 *)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)cand;     // [0] min1 [1] max1 [2] min2 [3] max2
+            if (lane < 4) ext[lane] = (lane & 1) ? 0u : 0xFFFFFFFFu;
+            wave_lds_fence();
+            const unsigned a1 = MAGIC + (unsigned)bin1, a2 = MAGIC + (unsigned)bin2;
+#pragma unroll
+            for (int t = 0; t < NV; t += 4) {
+                bool h1[4], h2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { h1[u] = off[t + u] == a1; h2[u] = off[t + u] == a2; }
+                if (__ballot(h1[0] || h1[1] || h1[2] || h1[3] || h2[0] || h2[1] || h2[2] || h2[3]) != 0ull) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned xb = __float_as_uint(x[t + u]);
+                        if (h1[u]) {
+                            __hip_atomic_fetch_min(ext + 0, xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_max(ext + 1, xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        if (h2[u]) {
+                            __hip_atomic_fetch_min(ext + 2, xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_max(ext + 3, xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
+            wave_lds_fence();
+            const u32x4 ev = *(const lds_u32x4 *)ext;
+            wave_lds_fence();
+            v1 = __uint_as_float(p1 == 0 ? ev.x : ev.y);
+            v2 = __uint_as_float(p2 == 0 ? ev.z : ev.w);
+            return true;
+        }
+    }
     // the members of one bin, gathered and ranked (LDS broadcasts); value of rank `want` among them
     auto resolve = [&](int bin, int ncand, int want, float &out) -> bool {
         const unsigned a1 = MAGIC + (unsigned)bin;
@@ -1309,19 +1349,21 @@ constexpr int ef_rowstat_min_waves(int nq) { return (nq <= 2 && ACX_EF_ROWSTAT_W
 #else
 #define ACX_EF_ABL_EXIT(n_, ...) do { } while (0)
 #endif
-template <int NQ, bool FUSED, bool EXACT = false>
-__global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
-                                                         float *__restrict__ stat, unsigned *__restrict__ bits, int mode, int kw, int store_f)
+constexpr int EF_ROW_GB = 512;       // bins of the generic fallback (small: LDS per workgroup decides how many rows a CU works on)
+// Everything the row statistics do once a wave holds ONE row in registers (x[4 q + e] = column 256 q + 4 lane + e, +inf behind the
+// row): both order statistics, the neighbourhood mean, the threshold with its tie column, the binarised row.  `fhist` (256 zeroable
+// dwords, 1 KB aligned), `hist`, `cand` (64 floats), `counter`: the wave's own LDS scratch.  Shared by ef_rowstat_kernel (one row per
+// wave) and by the fallback of ef_rowstat2_kernel (a row its two-rows-per-wave pass could not decide).
+template <int NQ, bool FUSED>
+__device__ __forceinline__ void ef_row_finish(const float (&x)[4 * NQ], const EfPair &P, int s, int mode, int kw, int n, int pitch, int row,
+                                              float *__restrict__ stat, unsigned *__restrict__ bits, unsigned *fhist_w, unsigned *hist_w,
+                                              float *cand_w, unsigned *counter_w, int lane)
 {
-    constexpr int NX = 4 * NQ;                        // values per lane
-    __shared__ __attribute__((aligned(4096))) unsigned fhist[4][256];      // one-pass selection (wave_select_fast)
-    constexpr int GB = 512;                           // bins of the generic fallback (small: LDS per workgroup decides how many rows a CU works on)
-    __shared__ __attribute__((aligned(16))) unsigned hist[4][SelGeom<GB>::SLOTS];   // generic fallback
-    __shared__ __attribute__((aligned(16))) float cand[4][64];
-    __shared__ unsigned counter[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NX = 4 * NQ;
+    constexpr int GB = EF_ROW_GB;
+    const float INF = __builtin_inff();
     typedef __attribute__((address_space(3))) void lds_void;
-    const unsigned fh_addr = (unsigned)(uintptr_t)(lds_void *)(&fhist[wave][0]);
+    const unsigned fh_addr = (unsigned)(uintptr_t)(lds_void *)fhist_w;
     // k-th smallest (0-based) of the row: one histogram pass, generic narrowing when that cannot decide
     // Small ranks (the row-kappa threshold sits at rank ~ 0.1 n, the neighbourhood mean at rank 9) first try the
     // pivot-filtered pass of the band kernel (wave_select_pivot): only the cells below a pivot near the 0.2 quantile
@@ -1329,77 +1371,19 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
     // round 3: 69 % of this kernel's LDS cycles were bank / same-address conflicts of the unfiltered atomics); the
     // filtered pass issues an eighth of them.  It gives up (too few cells below the pivot, ties, short rows) and the
     // unfiltered pass takes over: all paths are exact.
-    bool lane_has_data = false, group_full = false;        // set once the row is loaded (below)
+    bool lane_has_data = false, group_full = false;        // set below
     auto kth = [&](const float (&xx)[NX], int k, int n_) -> float {
-        *reinterpret_cast<uint4 *>(&fhist[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(fhist_w + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_fence();
         float lo, hi;
         if ((k + 2) * 6 <= n_) {
-            if (wave_select_pivot<NX, 256, 2>(xx, k, false, fh_addr, cand[wave], lane, lo, hi, lane_has_data, group_full, 0.15f)) return lo;
-            *reinterpret_cast<uint4 *>(&fhist[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+            if (wave_select_pivot<NX, 256, 2>(xx, k, false, fh_addr, cand_w, lane, lo, hi, lane_has_data, group_full, 0.15f)) return lo;
+            *reinterpret_cast<uint4 *>(fhist_w + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
             wave_lds_fence();
         }
-        if (wave_select_fast<NX, 256>(xx, k, false, fh_addr, cand[wave], lane, lo, hi)) return lo;
-        return wave_select_regs<NX, GB>(xx, k, hist[wave], cand[wave], &counter[wave], lane, false).value;
+        if (wave_select_fast<NX, 256>(xx, k, false, fh_addr, cand_w, lane, lo, hi)) return lo;
+        return wave_select_regs<NX, GB>(xx, k, hist_w, cand_w, counter_w, lane, false).value;
     };
-    const EfPair P = pd[blockIdx.y];
-    const int s = blockIdx.z;                         // feature (mode 2: always 0)
-    const int nrows = mode == 1 ? P.N : P.M;
-    const int n = mode == 1 ? P.M : P.N;              // row length
-    const int pitch = mode == 1 ? P.pitchT : P.pitchC;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= nrows) return;
-    float x[NX];
-    const float INF = __builtin_inff();
-    if constexpr (!FUSED) {
-        const int64_t base = mode == 0 ? ef_c_off(P, s) : (mode == 1 ? ef_ct_off(P, s) : ef_f_off(P));
-        const float *v = scratch + base + (size_t)row * pitch;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int j = 256 * q + 4 * lane;
-            float4 t = make_float4(INF, INF, INF, INF);
-            if (j < pitch) t = *reinterpret_cast<const float4 *>(v + j);
-            x[4 * q + 0] = (j + 0 < n) ? t.x : INF;
-            x[4 * q + 1] = (j + 1 < n) ? t.y : INF;
-            x[4 * q + 2] = (j + 2 < n) ? t.z : INF;
-            x[4 * q + 3] = (j + 3 < n) ? t.w : INF;
-        }
-    } else {
-        // FUSED: the row of the fused matrix, F_ij = exp(-(W0 + W1 + W2)) with getWCSM's weights (ef_wcsm_weight, the
-        // arithmetic of ef_fuse_kernel to the operation), made in the registers the selection works on: the matrix is
-        // binarised without a trip to memory
-        float wsum[NX];
-#pragma unroll
-        for (int e = 0; e < NX; ++e) wsum[e] = 0.0f;
-#pragma unroll
-        for (int sf = 0; sf < 3; ++sf) {
-            const float *Sf = stat + P.offS + sf * ef_s_stride(P);
-            const float ri = Sf[P.pitchT + row];
-            const float *cj = Sf + 2 * P.pitchT;
-            const float *cv = scratch + ef_c_off(P, sf) + (size_t)row * pitch;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int j = 256 * q + 4 * lane;
-                float4 cc = make_float4(0.f, 0.f, 0.f, 0.f), vv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j < pitch) { cc = *reinterpret_cast<const float4 *>(cj + j); vv = *reinterpret_cast<const float4 *>(cv + j); }
-                const float c4[4] = {cc.x, cc.y, cc.z, cc.w}, v4[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wsum[4 * q + e] += EXACT ? ef_wcsm_weight_exact(ri, c4[e], v4[e]) : ef_wcsm_weight(ri, c4[e], v4[e]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int j = 256 * q + 4 * lane;
-            float f4[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f4[e] = EXACT ? ef_fused_value_exact(wsum[4 * q + e]) : ef_fused_value(wsum[4 * q + e]);
-                x[4 * q + e] = (j + e < n) ? f4[e] : INF;
-            }
-            if (store_f && j < pitch)                                      // (the debug entry point hands the matrix out)
-                *reinterpret_cast<float4 *>(scratch + ef_f_off(P) + (size_t)row * pitch + j) = make_float4(f4[0], f4[1], f4[2], f4[3]);
-        }
-    }
     {   // which lanes / lane pairs hold cells: a pair of lanes (16 slots) takes part in the pivot estimate when at
         // least three quarters of the slots it can have in a row of this length are cells (a pair with few cells has a large
         // minimum: a pivot that filters nothing)
@@ -1422,9 +1406,9 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
     if (!FUSED && mode == 0) {
         const int kk = kw < n ? kw : n, kb = P.kbin;
         if (kb > kk && kb < n && (kb + 1) * 6 <= n) {
-            *reinterpret_cast<uint4 *>(&fhist[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(fhist_w + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
             wave_lds_fence();
-            have2 = ef_select_pivot2<NX>(x, kk - 1, kb - 1, fh_addr, cand[wave], lane, vk2, t2, lane_has_data, group_full, 0.15f);
+            have2 = ef_select_pivot2<NX>(x, kk - 1, kb - 1, fh_addr, cand_w, lane, vk2, t2, lane_has_data, group_full, 0.15f);
         }
     }
     if (!FUSED) ACX_EF_ABL_EXIT(2, vk2, t2, have2 ? 1.f : 0.f);      // + both order statistics from one histogram
@@ -1517,6 +1501,77 @@ __global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kern
                 bits[P.offB + ((int64_t)(mode >= 2 ? 3 : s) * P.M + row) * (pitch >> 5) + word] = w;
         }
     }
+}
+
+template <int NQ, bool FUSED, bool EXACT = false>
+__global__ __launch_bounds__(256, ef_rowstat_min_waves(NQ)) void ef_rowstat_kernel(const EfPair *__restrict__ pd, float *__restrict__ scratch,
+                                                         float *__restrict__ stat, unsigned *__restrict__ bits, int mode, int kw, int store_f)
+{
+    constexpr int NX = 4 * NQ;                        // values per lane
+    __shared__ __attribute__((aligned(4096))) unsigned fhist[4][256];      // one-pass selection (wave_select_fast)
+    __shared__ __attribute__((aligned(16))) unsigned hist[4][SelGeom<EF_ROW_GB>::SLOTS];   // generic fallback
+    __shared__ __attribute__((aligned(16))) float cand[4][64];
+    __shared__ unsigned counter[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const EfPair P = pd[blockIdx.y];
+    const int s = blockIdx.z;                         // feature (mode 2: always 0)
+    const int nrows = mode == 1 ? P.N : P.M;
+    const int n = mode == 1 ? P.M : P.N;              // row length
+    const int pitch = mode == 1 ? P.pitchT : P.pitchC;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= nrows) return;
+    float x[NX];
+    const float INF = __builtin_inff();
+    if constexpr (!FUSED) {
+        const int64_t base = mode == 0 ? ef_c_off(P, s) : (mode == 1 ? ef_ct_off(P, s) : ef_f_off(P));
+        const float *v = scratch + base + (size_t)row * pitch;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int j = 256 * q + 4 * lane;
+            float4 t = make_float4(INF, INF, INF, INF);
+            if (j < pitch) t = *reinterpret_cast<const float4 *>(v + j);
+            x[4 * q + 0] = (j + 0 < n) ? t.x : INF;
+            x[4 * q + 1] = (j + 1 < n) ? t.y : INF;
+            x[4 * q + 2] = (j + 2 < n) ? t.z : INF;
+            x[4 * q + 3] = (j + 3 < n) ? t.w : INF;
+        }
+    } else {
+        // FUSED: the row of the fused matrix, F_ij = exp(-(W0 + W1 + W2)) with getWCSM's weights (ef_wcsm_weight, the
+        // arithmetic of ef_fuse_kernel to the operation), made in the registers the selection works on: the matrix is
+        // binarised without a trip to memory
+        float wsum[NX];
+#pragma unroll
+        for (int e = 0; e < NX; ++e) wsum[e] = 0.0f;
+#pragma unroll
+        for (int sf = 0; sf < 3; ++sf) {
+            const float *Sf = stat + P.offS + sf * ef_s_stride(P);
+            const float ri = Sf[P.pitchT + row];
+            const float *cj = Sf + 2 * P.pitchT;
+            const float *cv = scratch + ef_c_off(P, sf) + (size_t)row * pitch;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int j = 256 * q + 4 * lane;
+                float4 cc = make_float4(0.f, 0.f, 0.f, 0.f), vv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < pitch) { cc = *reinterpret_cast<const float4 *>(cj + j); vv = *reinterpret_cast<const float4 *>(cv + j); }
+                const float c4[4] = {cc.x, cc.y, cc.z, cc.w}, v4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wsum[4 * q + e] += EXACT ? ef_wcsm_weight_exact(ri, c4[e], v4[e]) : ef_wcsm_weight(ri, c4[e], v4[e]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int j = 256 * q + 4 * lane;
+            float f4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f4[e] = EXACT ? ef_fused_value_exact(wsum[4 * q + e]) : ef_fused_value(wsum[4 * q + e]);
+                x[4 * q + e] = (j + e < n) ? f4[e] : INF;
+            }
+            if (store_f && j < pitch)                                      // (the debug entry point hands the matrix out)
+                *reinterpret_cast<float4 *>(scratch + ef_f_off(P) + (size_t)row * pitch + j) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+        }
+    }
+    ef_row_finish<NQ, FUSED>(x, P, s, mode, kw, n, pitch, row, stat, bits, fhist[wave], hist[wave], cand[wave], &counter[wave], lane);
 }
 
 // ------------------------------------------------------------------------------------

@@ -736,6 +736,43 @@ __device__ __forceinline__ bool wave_select_pivot(const float (&x)[NV], int k, b
         if (bin2 != bin1) ncand += __builtin_amdgcn_readlane(c, l2);    // the bins between are empty
     }
     if (ncand > 64) return false;
+    // ---- Round 5: the two order statistics WITHOUT gathering candidates, five rows in six.  Rank k + 1 in a LATER bin than rank k:
+    // s_k is the LARGEST cell of bin1 (every cell of bin1 ranks at or below k) and s_(k+1) the SMALLEST of bin2; both ranks in one
+    // bin of exactly two cells: its smallest and its largest.  The cells of bin1 post their maximum, those of bin2 their minimum
+    // (complemented: both slots start at 0 and take ds_max_u32; unsigned patterns order like the non-negative values) under exec
+    // masks a handful of lanes wide -- no candidate list, no ranking loop, no readlane picks.  Same values as the gather below:
+    // they ARE the cells of rank k and k + 1.
+#ifdef ACX_MINMAX_SHORTCUT      /* development A/B (scripts/ab_build.sh mm -DACX_MINMAX_SHORTCUT).  A MEASURED NEGATIVE with one row per wave: 92.0 vs 93.7 k
+                                   pairs/s at T = 2000, 420 vs 424 k at T = 900 -- the per-wave scalars of the gather below cost SALU slots that overlap the
+                                   other waves' VALU work, the extrema pass costs 64 vector compares and two LDS round trips (profiles/r05_wide_class.md);
+                                   band2_kernel and ef_rowstat2_kernel, where a half cannot keep scalars, are where it pays */
+    if (want_next && (bin2 != bin1 || cnt1 == 2)) {
+        lds_u32 *ext = (lds_u32 *)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)cand;
+        if (lane < 2) ext[lane] = 0u;
+        wave_lds_fence();
+        const unsigned a1 = MAGIC + (unsigned)bin1, a2 = MAGIC + (unsigned)bin2;
+#pragma unroll
+        for (int t = 0; t < NV; t += 4) {
+            bool h1[4], h2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { h1[u] = off[t + u] == a1; h2[u] = off[t + u] == a2; }
+            if (__ballot(h1[0] || h1[1] || h1[2] || h1[3] || h2[0] || h2[1] || h2[2] || h2[3]) != 0ull) {       // most groups hold no member
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned xb = __float_as_uint(x[t + u]);
+                    if (h1[u]) __hip_atomic_fetch_max(ext + 0, xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (h2[u]) __hip_atomic_fetch_max(ext + 1, ~xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        wave_lds_fence();
+        const unsigned e1 = ext[0], e2 = ~ext[1];
+        wave_lds_fence();
+        slo = __uint_as_float(e1 < e2 ? e1 : e2);
+        shi = __uint_as_float(e1 < e2 ? e2 : e1);
+        return true;
+    }
+#endif
     // ---- gather the members of [bin1, bin2]
     // (the slots hold MAGIC + bin; pads and the lanes that stayed out of the histogram hold patterns no bin matches)
     const unsigned a1 = MAGIC + (unsigned)bin1;

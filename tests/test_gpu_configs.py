@@ -229,23 +229,27 @@ def test_simple_dataset_scale_15000(ctx):
 
 def test_earlyfusion_scale_1200(ctx):
     """BASELINE configs[4] per-track shape at a pool that no longer fits any cache (1 200 tracks of
-    300-500 blocks: 4.5 GB of block features): 30 000 random pairs; 6 against the oracle (scores
-    within +-2 tenths-exact units like the chain tests), the rest through oracle-free properties."""
+    300-500 blocks: 4.5 GB of block features): 30 000 random pairs; 256 of them against the oracle on a process pool
+    (identical scores but for a handful of row-kappa tie movers, capped at 3.0 -- tests/test_gpu_parity_sets.py says
+    what the cap means; the |dscore| histogram is recorded), the rest through oracle-free properties."""
     import oracle
     from acoss_amd import synth
     tracks = synth.earlyfusion_set(1200, seed=77, nb_range=(300, 500))
     ctx.ef_upload_pool(tracks)
     rng = np.random.default_rng(3)
     pairs = rng.integers(0, 1200, (30000, 2)).astype(np.int32)
+    # (the first 256 pairs stay among 40 tracks: only those travel to the oracle's worker processes)
+    sub = rng.choice(1200, 40, replace=False)
+    pairs[:300] = sub[rng.integers(0, 40, (300, 2))]
     pairs = pairs[pairs[:, 0] != pairs[:, 1]]
     sc = ctx.earlyfusion_pairs(pairs)
     assert sc.shape == (len(pairs), 4) and np.all(np.isfinite(sc)) and np.all(sc >= 0.0)
     assert np.all(np.abs(sc * 10 - np.round(sc * 10)) < 1e-3)         # Smith-Waterman scores are tenths
-    for k in range(6):
-        i, j = pairs[k]
-        o = oracle.earlyfusion_pair(tracks[i], tracks[j], kappa=0.1, K=10)[0]
-        want = np.array([o[s] for s in ("mfccs", "ssms", "chromas", "early")])
-        assert np.all(np.abs(sc[k] - want) <= 3.0), (sc[k], want)       # (tests/test_gpu_parity_sets.py: what the cap means)
+    from tests.test_gpu_parity_sets import ef_oracle_on_pairs, _hist
+    want = ef_oracle_on_pairs({int(t): tracks[int(t)] for t in sub}, pairs[:256])
+    hist = {s: _hist(sc[:256, e] - want[:, e]) for e, s in enumerate(("mfccs", "ssms", "chromas", "early"))}
+    assert float(np.max(np.abs(sc[:256] - want))) <= 3.0, hist
+    assert all(h["0"] >= 0.98 * h["n"] for h in hist.values()), hist
     again = ctx.earlyfusion_pairs(pairs[:500][::-1].copy())
     assert np.array_equal(again, sc[:500][::-1])
-    _record("earlyfusion_1200", {"tracks": 1200, "pairs_run": int(len(pairs)), "oracle_checked": 6})
+    _record("earlyfusion_1200", {"tracks": 1200, "pairs_run": int(len(pairs)), "oracle_checked": 256, "dscore_histograms_vs_oracle": hist})
