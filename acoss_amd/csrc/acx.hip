@@ -569,31 +569,33 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             pd.push_back(d);
         }
         const int B = (int)pd.size();
-        // Pairs are processed in size classes PER PASS: a pass whose rows hold <= 505 / 1017 / 2041 cells runs the band
-        // kernel with 8 / 16 / 32 values per lane.  The row pass (and the alignment sweep behind it) has rows of Mr cells,
-        // the column pass rows of Mq cells, so a pair carries two classes (cr, cq) and the batch is sorted by the key
-        // 3 cr + cq: the row pass and the sweep take the three keys of one cr in ONE launch, the column pass one launch per
-        // key -- a short track paired with a long one no longer drags BOTH passes through the wider kernel (round 4;
-        // before, both passes were dispatched on the longer side).  Key 9: a side beyond 2041 cells (or m > 16), the
-        // streaming kernels.  `perm[k]` = position in the batch of sorted pair k.
+        // Pairs are processed in size classes PER PASS: a pass whose rows hold <= 505 / 761 / 1017 / 2041 cells runs the band
+        // kernel that fits (band2_kernel with 16 / 24 positions per lane of a half-wave row, band_kernel with 16 / 32 values per
+        // lane).  The row pass (and the alignment sweep behind it) has rows of Mr cells, the column pass rows of Mq cells, so a
+        // pair carries two classes (cr, cq) and the batch is sorted by the key NC cr + cq: the row pass and the sweep take the NC
+        // keys of one cr in ONE launch, the column pass one launch per key -- a short track paired with a long one does not drag
+        // BOTH passes through the wider kernel.  Key NC * NC: a side beyond 2041 cells (or m > 16), the streaming kernels.
+        // `perm[k]` = position in the batch of sorted pair k.
+        constexpr int NC = 4;
         std::vector<int> &perm = S.perm;
         perm.resize(B);
-        int key_begin[11];
+        int key_begin[NC * NC + 2];
         {
             auto cls1 = [&](int M) {
                 const int nd = (M + acx::BAND - 1 + 63) / 64;
-                return nd <= 8 ? 0 : (nd <= 16 ? 1 : (nd <= 32 ? 2 : 3));
+                return nd <= 8 ? 0 : (nd <= 12 ? 1 : (nd <= 16 ? 2 : (nd <= 32 ? 3 : 4)));
             };
             auto key_of = [&](const PairDesc &d) {
                 const int cr = cls1(d.Mr), cq = cls1(d.Mq);
-                return (!band_ok || cr == 3 || cq == 3) ? 9 : 3 * cr + cq;
+                return (!band_ok || cr == NC || cq == NC) ? NC * NC : NC * cr + cq;
             };
-            int cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            int cnt[NC * NC + 1];
+            for (int kk = 0; kk <= NC * NC; ++kk) cnt[kk] = 0;
             for (const PairDesc &d : pd) cnt[key_of(d)]++;
             key_begin[0] = 0;
-            for (int kk = 0; kk < 10; ++kk) key_begin[kk + 1] = key_begin[kk] + cnt[kk];
-            int fill[10];
-            for (int kk = 0; kk < 10; ++kk) fill[kk] = key_begin[kk];
+            for (int kk = 0; kk <= NC * NC; ++kk) key_begin[kk + 1] = key_begin[kk] + cnt[kk];
+            int fill[NC * NC + 1];
+            for (int kk = 0; kk <= NC * NC; ++kk) fill[kk] = key_begin[kk];
             std::vector<PairDesc> &sorted = S.sorted;
             sorted.resize(B);
             for (int k2 = 0; k2 < B; ++k2) {
@@ -603,10 +605,12 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             }
             pd.swap(sorted);
         }
-        // row-pass classes (keys 3 cr .. 3 cr + 2) + the long class, as [begin, end) ranges
-        const int cls_begin[5] = {key_begin[0], key_begin[3], key_begin[6], key_begin[9], B};
-        if (cls_begin[3] > 0 && (rc = ensure_normtab(c, p)) != ACX_OK) return rc;
-        if (cls_begin[3] > 0 && p.arith == ACX_ARITH_F16X2 && (rc = ensure_f16pool(c)) != ACX_OK) return rc;
+        // row-pass classes (keys NC cr .. NC cr + NC - 1) + the long class, as [begin, end) ranges
+        int cls_begin[NC + 2];
+        for (int cl = 0; cl <= NC; ++cl) cls_begin[cl] = key_begin[NC * cl];
+        cls_begin[NC + 1] = B;
+        if (cls_begin[NC] > 0 && (rc = ensure_normtab(c, p)) != ACX_OK) return rc;
+        if (cls_begin[NC] > 0 && p.arith == ACX_ARITH_F16X2 && (rc = ensure_f16pool(c)) != ACX_OK) return rc;
         // (the band kernel reads its column thresholds 16 bytes at a time without a bounds check, up to
         // 64 x 32 floats behind a pair's column-threshold row: the arena carries that much slack)
         if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)std::max<int64_t>(used, 1))) != ACX_OK) return rc;
@@ -629,7 +633,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             hipLaunchKernelGGL(acx::oti_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream,
                                S.d_pd, B, c->d_gch, p.oti, p.oti_target, c->d_toff, c->d_noff);
         }
-        for (int cl = 0; cl < 4; ++cl) {
+        for (int cl = 0; cl <= NC; ++cl) {
             const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
             if (Bc <= 0) continue;
             int cMq = 0, cMr = 0;
@@ -638,11 +642,11 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                 cMq = std::max(cMq, pd[k2].Mq); cMr = std::max(cMr, pd[k2].Mr);
                 ccells += (int64_t)pd[k2].Mq * pd[k2].Mr;
             }
-            if (cl < 3) {
+            if (cl < NC) {
                 bool ok = true;
                 // K1' role 1: rows = reference frames (Mq cells each) -> column thresholds; one launch per (cr, cq) key
-                for (int cq = 0; cq < 3; ++cq) {
-                    const int q0 = key_begin[3 * cl + cq], Bq = key_begin[3 * cl + cq + 1] - q0;
+                for (int cq = 0; cq < NC; ++cq) {
+                    const int q0 = key_begin[NC * cl + cq], Bq = key_begin[NC * cl + cq + 1] - q0;
                     if (Bq <= 0) continue;
                     int qMq = 0, qMr = 0;
                     int64_t qcells = 0;
@@ -680,23 +684,23 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             // both == 0: Qmax or Dmax as p.dmax says; both == 1: out[2k] = Qmax, out[2k+1] = Dmax
             const bool eqg = p.gamma_o == p.gamma_e;
             ProfScope ps(c, KS_QMAX, cells);
-            // one launch per size class: a lane owns 8 / 16 / 32 columns of rows up to 505 / 1017 / 2041 cells
+            // one launch per size class: a lane owns 8 / 16 / 16 / 32 columns of rows up to 505 / 761 / 1017 / 2041 cells
             auto sweep = [&](bool dmax, float *dst) {
-                for (int cl = 0; cl < 4; ++cl) {
+                for (int cl = 0; cl <= NC; ++cl) {
                     const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
                     if (Bc <= 0) continue;
 #define ACX_QB3(E_, D_, C_) hipLaunchKernelGGL((acx::qmax_bits_kernel<E_, D_, C_>), dim3(Bc), dim3(64), 0, c->stream, \
                                                S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.gamma_o, p.gamma_e, p.dp_start)
 #define ACX_QBL(E_, D_) hipLaunchKernelGGL((acx::qmax_bits_long_kernel<E_, D_>), dim3(Bc), dim3(64), 0, c->stream, \
                                            S.d_pd + b0, c->d_bits, c->d_scratch, dst + (size_t)b0 * w, w, p.gamma_o, p.gamma_e, p.dp_start)
-#define ACX_QB(E_, D_) do { if (cl == 0) ACX_QB3(E_, D_, 8); else if (cl == 1) ACX_QB3(E_, D_, 16); else if (cl == 2) ACX_QB3(E_, D_, 32); \
+#define ACX_QB(E_, D_) do { if (cl == 0) ACX_QB3(E_, D_, 8); else if (cl <= 2) ACX_QB3(E_, D_, 16); else if (cl == 3) ACX_QB3(E_, D_, 32); \
                             else ACX_QBL(E_, D_); } while (0)
                     // the default penalties (0.5 / 0.5): packed 16-bit integer DP in half-units, two cells per instruction
-                    if (eqg && p.gamma_o == 0.5f && cl < 3) {
+                    if (eqg && p.gamma_o == 0.5f && cl < NC) {
 #define ACX_QH(C_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<C_, D_>), dim3(Bc), dim3(64), 0, c->stream, \
                                           S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.dp_start)
-                        if (dmax) { if (cl == 0) ACX_QH(8, true); else if (cl == 1) ACX_QH(16, true); else ACX_QH(32, true); }
-                        else { if (cl == 0) ACX_QH(8, false); else if (cl == 1) ACX_QH(16, false); else ACX_QH(32, false); }
+                        if (dmax) { if (cl == 0) ACX_QH(8, true); else if (cl <= 2) ACX_QH(16, true); else ACX_QH(32, true); }
+                        else { if (cl == 0) ACX_QH(8, false); else if (cl <= 2) ACX_QH(16, false); else ACX_QH(32, false); }
 #undef ACX_QH
                     }
                     else if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }

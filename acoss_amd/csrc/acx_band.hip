@@ -26,13 +26,15 @@ bool launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows,
         // rows of <= 505 cells, m <= 9: the two-rows-per-wave kernel (serra09_band2_kernels.hpp); ACX_BAND2=0 keeps band_kernel<M, 2>
         if constexpr (M <= 9) {
             static const bool two_rows = [] { const char *e = getenv("ACX_BAND2"); return !(e && e[0] == '0'); }();
-            if (ndata <= 8 && two_rows) {
-#define ACX_BAND2_K(R_, W_) hipLaunchKernelGGL((band2_kernel<M, R_, W_>), grid, dim3(B2_THREADS), 0, L.stream, L.frot, L.normtab, dpd, \
-                                               L.scratch, L.thr, L.bits, L.pct_mode, L.inclusive, L.oti_target, want_eps)
-                if (role) ACX_BAND2_K(1, false); else if (write_d2) ACX_BAND2_K(0, true); else ACX_BAND2_K(0, false);
+            // (a second class of it, 24 positions per lane: rows of <= 761 cells -- ACX_BAND2=1 keeps that one on band_kernel<M, 4>)
+            static const bool mid_two_rows = [] { const char *e = getenv("ACX_BAND2"); return !(e && (e[0] == '0' || e[0] == '1')); }();
+#define ACX_BAND2_K(R_, W_, NV_) hipLaunchKernelGGL((band2_kernel<M, R_, W_, NV_>), grid, dim3(B2_THREADS), 0, L.stream, L.frot, L.normtab, dpd, \
+                                                    L.scratch, L.thr, L.bits, L.pct_mode, L.inclusive, L.oti_target, want_eps)
+#define ACX_BAND2(NV_) do { if (role) ACX_BAND2_K(1, false, NV_); else if (write_d2) ACX_BAND2_K(0, true, NV_); else ACX_BAND2_K(0, false, NV_); } while (0)
+            if (ndata <= 8 && two_rows) { ACX_BAND2(B2_NV); return true; }
+            if (ndata > 8 && ndata <= 12 && two_rows && mid_two_rows) { ACX_BAND2(B2_NV_MID); return true; }
+#undef ACX_BAND2
 #undef ACX_BAND2_K
-                return true;
-            }
         }
         if (ndata <= 8) ACX_BAND(2, 0);
         else if (ndata <= 16) ACX_BAND(4, 0);

@@ -24,14 +24,24 @@ namespace acx {
 
 constexpr int B2_WAVES = 4;
 constexpr int B2_THREADS = 64 * B2_WAVES;
-constexpr int B2_NV = 16;                       // positions per lane of a half-wave row
-constexpr int B2_LNP = B2_NV + 4;               // floats per owner lane in an exchange row (16 bytes of pad: conflict-free 16-byte reads)
-constexpr int B2_ROWP = 32 * B2_LNP;            // exchange row pitch (floats): 640
+constexpr int B2_NV = 16;                       // positions per lane of a half-wave row: rows of <= 505 cells (8 tiles) ...
+constexpr int B2_NV_MID = 24;                   // ... and, the second class, 24: rows of <= 761 cells (12 tiles) -- every covers80 / DA-TACOS length
 constexpr int B2_BINS = 256;                    // bins of the pivot-filtered histogram: 8 per lane of a half
-constexpr int B2_LDS_FLOATS = BAND * B2_ROWP;   // 5120 floats = 20 KB = the four packed Gram slabs of the sweep
+// geometry of an exchange row by positions per lane: NV + 4 floats per owner lane (16 bytes of pad: conflict-free 16-byte reads at
+// lane pitches of 20 and 28 floats alike -- 4 x an odd number), 32 owner lanes
+template <int NV> struct B2Geom {
+    static_assert(NV == 16 || NV == 24, "16 or 24 positions per lane");
+    static constexpr int LNP = NV + 4;
+    static constexpr int ROWP = 32 * LNP;       // 640 / 896 floats
+    static constexpr int NSTEP = NV / 8;        // tiles per wave of the sweep
+};
 #ifndef ACX_B2_WAVES_PER_SIMD
-#define ACX_B2_WAVES_PER_SIMD 6      /* 80 registers, no spills: 308 vs 276 Gcells/s at T = 450 with 8 (10-14 spilled registers) */
+#define ACX_B2_WAVES_PER_SIMD 7      /* 72 registers, 0-4 spilled; eight (64 registers) spill 10-14: 276 vs 308 (six) vs 332 (seven) Gcells/s at T = 450 */
 #endif
+#ifndef ACX_B2_MID_WAVES_PER_SIMD
+#define ACX_B2_MID_WAVES_PER_SIMD 5  /* the 24-position class: 96 registers, 28.7 KB of exchange rows */
+#endif
+constexpr int b2_waves_per_simd(int nv) { return nv == 16 ? ACX_B2_WAVES_PER_SIMD : ACX_B2_MID_WAVES_PER_SIMD; }
 
 // ---- reductions over the 32 lanes of a half, result in EVERY lane of the half: xor 1, xor 2 inside the quads, mirror inside 8
 // and 16 lanes (DPP, one VALU operation each), then the two 16-lane rows of the half trade places (v_permlane16_swap).
@@ -63,7 +73,7 @@ __device__ __forceinline__ float half_pick(bool upper, float lo, float hi) { ret
 
 // ------------------------------------------------------------------------------------
 // Pivot-filtered one-pass selection (wave_select_pivot, serra09_kernels.hpp) for TWO rows at once: lanes 0-31 hold
-// one row, lanes 32-63 the other, NV = 16 consecutive positions per lane, pads +inf.  k (0-based rank) is the same for
+// one row, lanes 32-63 the other, NV consecutive positions per lane, pads +inf.  k (0-based rank) is the same for
 // both rows (they belong to one pair and one pass).
 //
 // The two halves work like two independent 32-lane groups that talk through LDS "mailboxes" in their own row's area
@@ -97,10 +107,12 @@ typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 
-__device__ __forceinline__ bool pair_select_pivot(const float (&x)[B2_NV], int k, bool want_next, unsigned mb_addr, int lane,
+template <int NV>
+__device__ __forceinline__ bool pair_select_pivot(const float (&x)[NV], int k, bool want_next, unsigned mb_addr, int lane,
                                                   float &slo, float &shi, bool lane_has_data, bool group_full)
 {
-    constexpr int NV = B2_NV, NB = B2_BINS, BPL = NB / 32;      // 8 bins per lane in the scan
+    constexpr int NB = B2_BINS, BPL = NB / 32;      // 8 bins per lane in the scan
+    static_assert(NV % 4 == 0, "atomics and the extrema pass go in groups of 4");
     static_assert(BPL == 8, "two 16-byte pieces per lane");
     const float INF = __builtin_inff();
     const int l = lane & 31;
@@ -280,8 +292,8 @@ __device__ __forceinline__ bool pair_select_pivot(const float (&x)[B2_NV], int k
 // ------------------------------------------------------------------------------------
 // band2_kernel: see the head of this file.  grid = (bands of 8 rows, pairs), 256 threads.
 // ------------------------------------------------------------------------------------
-template <int M, int ROLE, bool WD2 = false>
-__global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kernel(const float *__restrict__ frot,
+template <int M, int ROLE, bool WD2 = false, int NVT = B2_NV>
+__global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kernel(const float *__restrict__ frot,
                                                             const float *__restrict__ normtab,
                                                             const PairDesc *__restrict__ pd,
                                                             float *__restrict__ scratch,
@@ -292,11 +304,12 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
     static_assert(M <= 9, "one 16-row MFMA tile of row frames");
     constexpr bool write_d2 = WD2;
     constexpr int role = ROLE;           // 1: rows = reference frames (column thresholds); 0: rows = query frames
-    constexpr int NV = B2_NV, LNP = B2_LNP, ROWP = B2_ROWP;
-    constexpr int NSTEP = 2;             // tiles per wave
+    constexpr int NV = NVT, LNP = B2Geom<NV>::LNP, ROWP = B2Geom<NV>::ROWP;
+    constexpr int NSTEP = B2Geom<NV>::NSTEP;       // tiles per wave: 2 (rows of <= 505 cells) or 3 (<= 761)
+    constexpr int B2_LDS_FLOATS = BAND * ROWP;     // the 8 exchange rows: 20 / 28 KB
     constexpr int NCT = (64 + BAND - 1 + M - 1 + 15) / 16;   // 16-column MFMA blocks of a tile (5)
     constexpr int SP = 16 * NCT + 4;     // Gram slab pitch: 84 % 32 = 20 keeps the 16-byte tile stores conflict-free
-    constexpr int LDS_FLOATS = B2_WAVES * 16 * SP > B2_LDS_FLOATS ? B2_WAVES * 16 * SP : B2_LDS_FLOATS;     // 21.5 KB: six workgroups per CU
+    constexpr int LDS_FLOATS = B2_WAVES * 16 * SP > B2_LDS_FLOATS ? B2_WAVES * 16 * SP : B2_LDS_FLOATS;     // NV = 16: 21.5 KB of Gram slabs, six workgroups per CU; NV = 24: 28 KB of exchange rows, five
     __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
 
     const PairDesc P = pd[blockIdx.y];
@@ -338,17 +351,36 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
     float *Sw = smem + wave * (16 * SP);
     const PctPos pp = role ? P.pos_q : P.pos_r;
 
-    const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= 8 by dispatch
+    const int ntiles = (MB + BAND - 1 + 63) / 64;      // <= 4 NSTEP (8 / 12) by dispatch
     typedef float BvT[NCT][3];
     typedef f32x4 AccT[NCT];
+#ifndef ACX_B2_BUFFER_LOADS
+#define ACX_B2_BUFFER_LOADS 1      /* +0.5-1 % over plain global loads with their 64-bit VALU address arithmetic (profiles/r05_narrow_classes.md) */
+#endif
+#if ACX_B2_BUFFER_LOADS
+    // the column-frame operands through a buffer descriptor: scalar tile offset + one 32-bit lane offset, no VALU address arithmetic per tile
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(pool_b + ((role ? P.fq : P.fr) - 8) * (int64_t)PB), 0, -1, 0x00020000);
+    const unsigned voffB = offB + (unsigned)lr * PB;
+#endif
     auto load_operands = [&](int tile, BvT &bv, auto tb0_tag) {
         constexpr int tb0 = decltype(tb0_tag)::value;
+#if ACX_B2_BUFFER_LOADS
+        typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+        const unsigned so = (unsigned)(64 * tile - (BAND - 1) + 8) * PB;
+#pragma unroll
+        for (int tb = tb0; tb < NCT; ++tb) {
+            const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rsB, voffB, so + 16u * PB * tb, 0);
+            bv[tb][0] = __uint_as_float(v.x); bv[tb][1] = __uint_as_float(v.y); bv[tb][2] = __uint_as_float(v.z);
+        }
+#else
         const char *p = frb + (ptrdiff_t)(64 * tile - (BAND - 1) + lr) * (ptrdiff_t)PB;
 #pragma unroll
         for (int tb = tb0; tb < NCT; ++tb) {
             const f32x3 v = *reinterpret_cast<const f32x3_u *>(p + 16 * PB * tb);
             bv[tb][0] = v.x; bv[tb][1] = v.y; bv[tb][2] = v.z;
         }
+#endif
     };
     auto load_norms = [&](int tile, float (&yv)[BAND]) {
         typedef float f32x4n __attribute__((ext_vector_type(4), aligned(4)));
@@ -381,7 +413,7 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
     float xv[BAND][NSTEP];
 
     // ---- sweep: wave w takes tiles w cpw .. w cpw + cpw - 1 (cpw = ceil(ntiles / 4) <= 2); the other tile slots of the 8 that
-    // make a row of 512 positions are padded with +inf (tile_of)
+    // make a row of 32 NV positions are padded with +inf (tile_of)
     constexpr int HB = NCT - 4;
     const int cpw = (ntiles + B2_WAVES - 1) / B2_WAVES;
     auto tile_of = [&](int st) { return st < cpw ? wave * cpw + st : B2_WAVES * cpw + wave * (NSTEP - cpw) + (st - cpw); };
@@ -448,10 +480,13 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
     // ---- exchange: band row a in POSITION order (position p = 64 tile + lane <-> column p - 7 + a); an owner lane's 16
     // positions are followed by 16 bytes of pad
     {
-        const int wl = lane + 4 * (lane >> 4);
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
-            float *dst = smem + tile_of(st) * (4 * LNP) + wl;
+            // position p = 64 tile + lane belongs to owner lane p / NV, slot p % NV
+            int off;
+            if constexpr (NV == 16) off = tile_of(st) * (4 * LNP) + lane + 4 * (lane >> 4);
+            else { const int pp_ = 64 * tile_of(st) + lane, ow = pp_ / NV; off = pp_ + 4 * ow; }
+            float *dst = smem + off;
 #pragma unroll
             for (int a = 0; a < BAND; ++a) dst[a * ROWP] = xv[a][st];
         }
@@ -513,12 +548,14 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
         const unsigned needb = ((unsigned)needm & 1u) | (((unsigned)(needm >> 32) & 1u) << 1);
         unsigned todo = needb & ~okm;
         if (todo != 0u) {
-            // both rows of the wave are in registers: 1280 floats of scratch; a 512-aligned block of 512 floats inside it
+            // both rows of the wave are in registers: 2 ROWP floats of scratch; a 512-aligned block of 512 floats inside it
             // is the histogram of wave_select_fast, the rest holds the candidates and the generic selection's bins
             const int base = wave * 2 * ROWP;
             const int hoff = (base + 511) & ~511;
-            const int foff = (hoff - base >= 512 + 64) ? base : hoff + 512;          // >= 512 free floats
-            float *hist = smem + hoff, *aux = smem + foff;
+            float *hist = smem + hoff, *aux = smem + hoff + 512;                     // (hoff <= base + 256: both fit the two rows)
+            float *relay = smem + base;                                              // the row in position order: 32 NV floats
+            constexpr int NV8 = NV / 2;                                              // values per lane of the whole wave
+            static_assert(2 * ROWP >= 256 + 512 + 512 && 2 * ROWP >= 32 * NV, "fallback scratch fits the wave's two rows");
             const unsigned fh_addr = (unsigned)(uintptr_t)(lds_void *)hist;
             for (int h = 0; h < 2; ++h) {
                 if (!((todo >> h) & 1u)) continue;
@@ -527,23 +564,24 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
                 if ((lane >> 5) == h) {
 #pragma unroll
                     for (int j = 0; j < NV / 4; ++j)
-                        *reinterpret_cast<float4 *>(hist + l * NV + 4 * j) = make_float4(xr[4 * j], xr[4 * j + 1], xr[4 * j + 2], xr[4 * j + 3]);
+                        *reinterpret_cast<float4 *>(relay + l * NV + 4 * j) = make_float4(xr[4 * j], xr[4 * j + 1], xr[4 * j + 2], xr[4 * j + 3]);
                 }
                 wave_lds_fence();
-                float x8[8];
-                {
-                    const float4 v0 = *reinterpret_cast<const float4 *>(hist + 8 * lane), v1 = *reinterpret_cast<const float4 *>(hist + 8 * lane + 4);
-                    x8[0] = v0.x; x8[1] = v0.y; x8[2] = v0.z; x8[3] = v0.w; x8[4] = v1.x; x8[5] = v1.y; x8[6] = v1.z; x8[7] = v1.w;
+                float x8[NV8];
+#pragma unroll
+                for (int j = 0; j < NV8 / 4; ++j) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(relay + NV8 * lane + 4 * j);
+                    x8[4 * j] = v0.x; x8[4 * j + 1] = v0.y; x8[4 * j + 2] = v0.z; x8[4 * j + 3] = v0.w;
                 }
                 wave_lds_fence();
                 for (int q = 0; q < 2; ++q) *reinterpret_cast<float4 *>(hist + 256 * q + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
                 wave_lds_fence();
                 float s_lo, s_hi;
-                bool done = wave_select_fast<8, 512, 1>(x8, k, want_next, fh_addr, aux, lane, s_lo, s_hi, lane * 8 < MB + cs);
+                bool done = wave_select_fast<NV8, 512, 1>(x8, k, want_next, fh_addr, aux, lane, s_lo, s_hi, lane * NV8 < MB + cs);
                 if (!done) {
                     unsigned *ghist = reinterpret_cast<unsigned *>(aux) + 64;
                     unsigned *counter = reinterpret_cast<unsigned *>(aux) + 64 + SelGeom<256>::SLOTS;
-                    const SelectResult sr = wave_select_regs<8, 256>(x8, k, ghist, aux, counter, lane, interp);
+                    const SelectResult sr = wave_select_regs<NV8, 256>(x8, k, ghist, aux, counter, lane, interp);
                     s_lo = sr.value;
                     s_hi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;
                 }
@@ -593,7 +631,7 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
             lo = lo < 0 ? 0 : lo;
             hi = hi > NV ? NV : hi;
             unsigned valid = 0u;
-            if (hi > lo) valid = ((1u << (hi - lo)) - 1u) << lo;
+            if (hi > lo) valid = ((1u << (hi - lo)) - 1u) << lo;      // (hi - lo <= NV < 32)
             unsigned acc = 0u;
 #pragma unroll
             for (int t = NV - 1; t >= 0; --t) {
@@ -602,11 +640,22 @@ __global__ __launch_bounds__(B2_THREADS, ACX_B2_WAVES_PER_SIMD) void band2_kerne
                 asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(xr[t]), "v"(mthr) : "vcc");
             }
             acc &= valid;
-            acc |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)acc, 0xF5, 0xf, 0xf, false) << 16;    // quad_perm [1,1,3,3]: the odd neighbour's 16 bits
             unsigned *rowbits = reinterpret_cast<unsigned *>(bits + P.offT + (size_t)row * P.nw);
-            const int ndw = 2 * P.nw, d = l >> 1;
-            if ((l & 1) == 0 && d < ndw) rowbits[d] = acc;
-            for (int z = 16 + l; z < ndw; z += 32) rowbits[z] = 0u;     // (words beyond this size class: none by dispatch)
+            const int ndw = 2 * P.nw;
+            if constexpr (NV == 16) {
+                acc |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)acc, 0xF5, 0xf, 0xf, false) << 16;    // quad_perm [1,1,3,3]: the odd neighbour's 16 bits
+                const int d = l >> 1;
+                if ((l & 1) == 0 && d < ndw) rowbits[d] = acc;
+            } else {
+                // 24 bits per lane: a quad of lanes makes three dwords -- lane j of the quad stores dword j = its own bits from 8 j on,
+                // topped up with the next lane's (quad_perm [1,2,3,3]); lane 3 stores nothing
+                const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)acc, 0xF9, 0xf, 0xf, false);
+                const int j = l & 3;
+                const unsigned dwv = (acc >> (8 * j)) | (nxt << (24 - 8 * j));
+                const int d = 3 * (l >> 2) + j;
+                if (j < 3 && d < ndw) rowbits[d] = dwv;
+            }
+            for (int z = NV + l; z < ndw; z += 32) rowbits[z] = 0u;     // (words beyond this size class: none by dispatch)
         }
     }
 }

@@ -172,7 +172,7 @@ def kernel_source_sha16():
     """Hash of the Serra09 kernel sources (scripts/summarise_profile.py stamps the committed counter records with it)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("serra09_kernels.hpp", "acx_band.hip", "Makefile"):
+    for f in ("serra09_kernels.hpp", "serra09_band2_kernels.hpp", "acx_band.hip", "Makefile"):
         with open(os.path.join(ROOT, "acoss_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

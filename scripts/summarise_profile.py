@@ -21,7 +21,7 @@ def kernel_source_sha16():
     """Hash of the Serra09 kernel sources: bench.py reports the committed counters only for the build they were
     taken on (same function in bench.py)."""
     h = hashlib.sha256()
-    for f in ("serra09_kernels.hpp", "acx_band.hip", "Makefile"):
+    for f in ("serra09_kernels.hpp", "serra09_band2_kernels.hpp", "acx_band.hip", "Makefile"):
         with open(os.path.join(ROOT, "acoss_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
