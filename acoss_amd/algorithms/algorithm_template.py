@@ -84,8 +84,9 @@ class CoverAlgorithm(object):
         LOCAL_RANK's): under a process group, torch's collectives are bound to THAT device before the first of them
         runs (the clique-table broadcast can precede the first kernel).  A second, different device in one process is
         refused right here, in the constructor, on the rank that asked for it -- not in the middle of all_pairwise
-        with the other ranks already waiting in a collective.  Without a process group nothing happens (and torch is
-        not imported)."""
+        with the other ranks already waiting in a collective.  Without a process group nothing happens: no device is
+        bound, no collective runs (dist.single() does import torch.distributed when torch is installed -- that creates no
+        process group and touches no GPU)."""
         dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
         if not _dist.single():
             try:

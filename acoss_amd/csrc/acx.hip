@@ -365,10 +365,39 @@ int ensure_tau(acx_ctx *c, int tau)
 }
 
 // The f16 operand pool of the opt-in f16x2 Gram (192 B per frame of the ACTIVE pool): built on first use, dropped with the pool.
+// largest |x| of a float array as a bit pattern (|x| patterns order like the values)
+static __global__ void absmax_kernel(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out)
+{
+    unsigned m = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(v[i]) & 0x7fffffffu);
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 int ensure_f16pool(acx_ctx *c)
 {
     if (c->d_fh) return ACX_OK;
     const int64_t total = c->h_off[c->n_tracks];
+    // The two-term fp16 split x = h1 + h2 carries 22 bits only while h1 is a NORMAL fp16 and finite: features above 65504 would
+    // become inf (NaN distances), features far below 1 lose their second term to fp16's subnormal range -- and the embedded
+    // norms, made from the exact f32 values, would no longer match the Gram.  HPCP / CREMA frames are normalised to a
+    // maximum of 1; a pool whose largest value lies outside [2^-8, 2^15] is refused (rescale it, or use ACX_ARITH_EXACT).
+    if (total > 0) {
+        unsigned *d_m = nullptr, h_m = 0u;
+        ACX_HIP(c, hipMalloc((void **)&d_m, sizeof(unsigned)));
+        ACX_HIP(c, hipMemsetAsync(d_m, 0, sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<int64_t>((total * acx::NBIN + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                           c->d_frames, total * acx::NBIN, d_m);
+        ACX_HIP(c, hipMemcpyAsync(&h_m, d_m, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        ACX_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(d_m);
+        float mx;
+        memcpy(&mx, &h_m, sizeof(mx));
+        if (!(mx >= 0.00390625f && mx <= 32768.0f))
+            return fail(c, ACX_ERR_UNSUPPORTED, "serra09: arith = f16x2 needs features whose largest magnitude lies in [2^-8, 2^15] (this pool: " +
+                                                    std::to_string(mx) + "): rescale the pool or use the exact arithmetic");
+    }
     const size_t halfs = (size_t)(std::max<int64_t>(1, total) + 2 * POOL_SLACK) * acx::FH;
     const hipError_t e = hipMalloc((void **)&c->d_fh, sizeof(_Float16) * halfs);
     if (e != hipSuccess) { c->d_fh = nullptr; return fail(c, ACX_ERR_NOMEM, std::string("serra09: the f16 operand pool does not fit the device: ") + hipGetErrorString(e)); }

@@ -29,7 +29,8 @@ def _forced():
 
 
 def single():
-    """True when no collective is needed: no process group, or one rank and not forced through the collectives."""
+    """True when no collective is needed: no process group, or one rank and not forced through the collectives.
+    (Imports torch.distributed when torch is installed -- importing it creates no process group and touches no GPU.)"""
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():

@@ -39,6 +39,30 @@ def _ref_ratio(key):
         return ""
 
 
+def other_source_sha16():
+    """Hash of the kernel sources the companion legs run (scripts/make_traffic_other.py stamps its record with it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("serra09_kernels.hpp", "serra09_band2_kernels.hpp", "acx_band.hip", "ef_kernels.hpp", "ef_rowstat2_kernels.hpp", "simple_kernels.hpp", "Makefile"):
+        with open(os.path.join(ROOT, "acoss_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _traffic(leg):
+    """(HBM bytes per launch of the leg's dominant kernel family, where it comes from) from profiles/pmc_traffic_other.json --
+    counters of a SEPARATE rocprofv3 --pmc run, reported only for the kernel sources of this build; else (None, why)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_other.json")))
+    except Exception:                               # noqa: BLE001
+        return None, "no profiles/pmc_traffic_other.json"
+    if tj.get("kernel_source_sha16") != other_source_sha16():
+        return None, "profiles/pmc_traffic_other.json was taken on other kernel sources: not reported"
+    if leg not in tj:
+        return None, "no record for this leg"
+    return tj[leg]["hbm_bytes_per_launch"], "profiles/pmc_traffic_other.json (%s; mean over the launches of the kernel family)" % tj.get("source")
+
+
 def _one_thread():
     try:
         from threadpoolctl import threadpool_limits
@@ -91,8 +115,10 @@ def serra09_covers_leg(ctx, steps=5, warmup=1, cpu_pairs=192):
 
     for s in range(warmup):
         ctx.serra09_pairs(base + s * n, params)
-    ctx.profile_enable(True)
-    ctx.profile_reset()
+    # The timed steps run WITHOUT the library's per-kernel event clocks (two hipEventRecord around every launch: a call of
+    # 13 366 short pairs is ~9 ms of kernels in ~10 launches, the clocks cost it 3-8 %); the kernel times of the roofline
+    # come from a second, untimed pass over the same steps with the clocks on.
+    ctx.profile_enable(False)
     dt, cells, got0 = 0.0, 0.0, None
     for s in range(warmup, warmup + steps):
         p = np.ascontiguousarray(base + s * n)
@@ -102,7 +128,12 @@ def serra09_covers_leg(ctx, steps=5, warmup=1, cpu_pairs=192):
         cells += cells_of(p)
         if got0 is None:
             got0, p0 = got, p
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for s in range(warmup, warmup + steps):
+        ctx.serra09_pairs(np.ascontiguousarray(base + s * n), params)
     prof = ctx.profile()
+    ctx.profile_enable(False)
     npairs = steps * len(base)
     # the length mix: all pairs of its 328 tracks, twice (first call untimed)
     m0 = (steps + warmup) * n
@@ -134,7 +165,8 @@ def serra09_covers_leg(ctx, steps=5, warmup=1, cpu_pairs=192):
                        "value": round(len(pm) / dtm, 1), "gcells_per_s": round(cells_of(pm) / dtm / 1e9, 1)},
         "roofline": {"bound": "valu (selection: per-row latency chain) + f32 mfma", "kernel": kname,
                      "achieved": round(kbytes / (kst["ms"] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(kbytes / (kst["ms"] * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                     "frac": round(kbytes / (kst["ms"] * 1e-3) / 1e9 / 8000.0, 4), "traffic": _traffic("serra09_covers")[0],
+                     "traffic_source": _traffic("serra09_covers")[1],
                      "model": "same 4 B per cell and launch byte model as the headline's band_kernel (a throughput proxy)",
                      "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]}},
         "cpu_baseline": {"value": round(cpu_pairs / tcpu, 2), "unit": "track-pairs/s", "cores": 1, "kind": "port",
@@ -202,8 +234,7 @@ def chenfusion_leg(ctx, steps=3, warmup=1, cpu_pairs=96):
     L = lens - 9
     for s in range(warmup):
         ctx.chenfusion_pairs(base + s * n, params)
-    ctx.profile_enable(True)
-    ctx.profile_reset()
+    ctx.profile_enable(False)                    # (timed without the event clocks, kernel times from a second pass: serra09_covers_leg)
     dt, cells, got0, p0 = 0.0, 0.0, None, None
     for s in range(warmup, warmup + steps):
         p = np.ascontiguousarray(base + s * n)
@@ -213,7 +244,12 @@ def chenfusion_leg(ctx, steps=3, warmup=1, cpu_pairs=96):
         cells += float(np.sum(L[p[:, 0]].astype(np.float64) * L[p[:, 1]]))
         if got0 is None:
             got0, p0 = got, p
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for s in range(warmup, warmup + steps):
+        ctx.chenfusion_pairs(np.ascontiguousarray(base + s * n), params)
     prof = ctx.profile()
+    ctx.profile_enable(False)
     with _one_thread():
         tc = time.perf_counter()
         rq = oracle.serra09_pairs(frames, offs, p0[:cpu_pairs], oracle.serra09_params())
@@ -304,7 +340,7 @@ def simple_leg(ctx, steps=5, warmup=1, n=1536, tiles_per_step=16, cpu_pairs=64):
                                % (n, tiles_per_step, int(npairs))},
         "roofline": {"bound": "valu-f64 issue (~ 0.6 - 0.7 busy) next to the LDS permutes of the sliding dot product (0.46 busy); not the scalar cache: one second track for every pair runs at the same rate (scripts/simple_probe2.py)", "kernel": "simple_kernel",
                      "achieved": round(executed / ks / 1e12, 2), "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": round(executed / ks / 1e12 / F64_VALU_PEAK_TF, 4), "traffic": None,
+                     "frac": round(executed / ks / 1e12 / F64_VALU_PEAK_TF, 4), "traffic": _traffic("simple")[0], "traffic_source": _traffic("simple")[1],
                      "kernel_ms_per_step": round(kms, 3), "executed_flop_per_cell": round(30.0 * 64.0 / 54.0, 2),
                      "frac_executed_35_6_flop_per_cell": round(executed / ks / 1e12 / F64_VALU_PEAK_TF, 4),
                      "frac_reference_stomp_54_flop_per_cell": round(54.0 * cells / ks / 1e12 / F64_VALU_PEAK_TF, 4),
@@ -394,7 +430,7 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
         "roofline": {"bound": "mfma", "kernel": "ef_gemm_rect_bf16x3_kernel<0, 1> (mfcc / ssm) + <1, 1> (chroma): two fp16 terms per value "
                                                 "(ACX_EF_GEMM_F16X2, the default), 256 x 128 tiles over dense rectangles of pairs",
                      "achieved": round(3.0 * flops / ks / 1e12, 1), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": round(3.0 * flops / ks / 1e12 / BF16_MFMA_PEAK_TF, 4), "traffic": None,
+                     "frac": round(3.0 * flops / ks / 1e12 / BF16_MFMA_PEAK_TF, 4), "traffic": _traffic("earlyfusion")[0], "traffic_source": _traffic("earlyfusion")[1],
                      "flops": "executed fp16 flops = 3 x (x1 y2 + x2 y1 + x1 y1) the f32-equivalent 2 (650 + 1225 + 480) nb1 nb2 per pair (SURVEY 8d); dense fp16 peak = dense bf16 peak",
                      "f32_equivalent_tflops": round(flops / ks / 1e12, 2), "f32_mfma_peak_tflops": F32_MFMA_PEAK_TF,
                      "kernel_ms_per_step": round(g["ms"] / steps, 3),

@@ -148,7 +148,9 @@ typedef struct {
  *                    (2e-7 relative, scripts/ubench/mfma_f16_probe.hip) but NOT the same bits: scores are graded by north_star's
  *                    tolerance (|score difference| <= 2.0, identical MAP / MR on cover sets; tests/test_gpu_serra09.py), the
  *                    default and bench.py's headline stay exact.  Pairs beyond the band kernel (rows of more than 2041 cells)
- *                    take the exact streaming kernels in either mode.
+ *                    take the exact streaming kernels in either mode.  INPUT RANGE: the split keeps its 22 bits only while the
+ *                    first term is a normal, finite fp16 -- a pool whose largest magnitude lies outside [2^-8, 2^15] is
+ *                    refused with ACX_ERR_UNSUPPORTED (HPCP / CREMA frames are normalised to a maximum of 1).
  */
 enum { ACX_ARITH_EXACT = 0, ACX_ARITH_F16X2 = 1 };
 

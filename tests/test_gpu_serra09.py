@@ -523,6 +523,14 @@ def test_f16x2_gram_is_an_equally_accurate_different_arithmetic(ctx):
         assert abs(st[0][0] - st[1][0]) <= 0.05 and st[0][4][0] == st[1][4][0], (st[0], st[1])
     with pytest.raises(NotImplementedError):
         ctx.serra09_pairs(pairs[:4], _lib.serra09_params(m=7, arith="f16x2"))
+    #  features the two-term fp16 split cannot carry -- beyond fp16's range, or so small that the second term falls
+    # into its subnormals -- are refused in this mode, and computed as ever in the exact one
+    for factor in (2.0 ** 17, 2.0 ** -13):               # (powers of two: the exact chain is invariant to the bit)
+        ctx.upload_pool(d["frames"] * np.float32(factor), d["offsets"])
+        with pytest.raises(NotImplementedError):
+            ctx.serra09_pairs(pairs[:4], pf)
+        assert np.array_equal(ctx.serra09_pairs(pairs[:64], pe), se[:64])          # (distances scale, ranks and scores do not)
+    ctx.upload_pool(d["frames"], d["offsets"])
     with pytest.raises(ValueError):
         ctx.serra09_pairs(pairs[:4], _lib.serra09_params(arith=5))
     # a pair beyond the band kernel (rows of more than 2041 cells) runs the exact streaming kernels in both modes
