@@ -402,6 +402,10 @@ def rccl_version(collective, backend):
 
 
 def init_torch(clock, local_rank, world, backend, collective):
+    # a forced one-rank world must still EXECUTE the exchange (torch.distributed.gather over RCCL), not return its own buffer:
+    # acoss_amd.dist treats a world of one as "no collective needed" unless this is set
+    if world == 1:
+        os.environ["ACX_GRID_VIA_COLLECTIVE"] = "1"
     with clock.phase("import_torch"):
         import torch
         import torch.distributed as dist

@@ -190,7 +190,7 @@ print("ok", _lib.HIP_VERSIONS)
 def test_nccl_world_of_one(tmp_path):
     """RCCL on the code path, as far as a 1-GPU box allows: a process group of ONE rank under the "nccl" backend,
     and ACX_GRID_VIA_COLLECTIVE=1 so that the classes take the multi-rank route anyway -- device binding, tile
-    buffer on the GPU, all_gather_into_tensor over RCCL on that buffer, rank-0 scatter, the clique-table and
+    buffer on the GPU, torch.distributed.gather over RCCL on that buffer (the exchange of the path), rank-0 scatter, the clique-table and
     statistics broadcasts (broadcast_object_list with an explicit device), barrier(device_ids=...), any_rank's
     all-reduce.  Matrices and statistics must equal the plain single-process run."""
     code = r"""
