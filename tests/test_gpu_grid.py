@@ -439,6 +439,19 @@ ctx.pair_grid_ranks(_lib.ALGO_CHENFUSION, True, p, [q, dm], mirror=True)
 q1, d1 = np.zeros((n, n), np.float32), np.zeros((n, n), np.float32)
 ctx.pair_grid(_lib.ALGO_CHENFUSION, True, p, [q1, d1], mirror=True)
 assert np.array_equal(q, q1) and np.array_equal(dm, d1) and np.array_equal(q, want)
+# (ADVICE r04) a rank whose own checks fail must still take part in the exchanges and come back with the error -- here the one
+# rank there is: the planes of an algorithm with two of them handed over as one (a null plane), a leading dimension smaller than
+# the pool, and, after them, a good call again (nothing was left half-done inside the communicator)
+import ctypes
+L, h = ctx._L, ctx._h
+spec = _lib.GridSpec(_lib.ALGO_CHENFUSION, 1, 0, 1)
+arr = (ctypes.c_void_p * 2)(q.ctypes.data, None)
+assert L.acx_pair_grid_ranks(h, ctypes.byref(spec), ctypes.byref(p), arr, n, 1) == -1 and b"null plane" in L.acx_last_error(h)
+arr = (ctypes.c_void_p * 2)(q.ctypes.data, dm.ctypes.data)
+assert L.acx_pair_grid_ranks(h, ctypes.byref(spec), ctypes.byref(p), arr, n - 1, 1) == -1 and b"leading dimension" in L.acx_last_error(h)
+got3 = np.zeros((n, n), np.float32)
+ctx.pair_grid_ranks(_lib.ALGO_SERRA09, True, p, [got3], mirror=True)
+assert np.array_equal(got3, want)
 ctx.comm_destroy()
 ctx.close()
 assert "torch" not in sys.modules
