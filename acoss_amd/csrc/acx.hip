@@ -598,21 +598,21 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             pd.push_back(d);
         }
         const int B = (int)pd.size();
-        // Pairs are processed in size classes PER PASS: a pass whose rows hold <= 505 / 761 / 1017 / 2041 cells runs the band
-        // kernel that fits (band2_kernel with 16 / 24 positions per lane of a half-wave row, band_kernel with 16 / 32 values per
-        // lane).  The row pass (and the alignment sweep behind it) has rows of Mr cells, the column pass rows of Mq cells, so a
+        // Pairs are processed in size classes PER PASS: a pass whose rows hold <= 249 / 505 / 761 / 1017 / 2041 cells runs the band
+        // kernel that fits (band2_kernel with four rows per wave, two rows per wave at 16 / 24 positions per lane, band_kernel with
+        // 16 / 32 values per lane).  The row pass (and the alignment sweep behind it) has rows of Mr cells, the column pass rows of Mq cells, so a
         // pair carries two classes (cr, cq) and the batch is sorted by the key NC cr + cq: the row pass and the sweep take the NC
         // keys of one cr in ONE launch, the column pass one launch per key -- a short track paired with a long one does not drag
         // BOTH passes through the wider kernel.  Key NC * NC: a side beyond 2041 cells (or m > 16), the streaming kernels.
         // `perm[k]` = position in the batch of sorted pair k.
-        constexpr int NC = 4;
+        constexpr int NC = 5;
         std::vector<int> &perm = S.perm;
         perm.resize(B);
         int key_begin[NC * NC + 2];
         {
             auto cls1 = [&](int M) {
                 const int nd = (M + acx::BAND - 1 + 63) / 64;
-                return nd <= 8 ? 0 : (nd <= 12 ? 1 : (nd <= 16 ? 2 : (nd <= 32 ? 3 : 4)));
+                return nd <= 4 ? 0 : (nd <= 8 ? 1 : (nd <= 12 ? 2 : (nd <= 16 ? 3 : (nd <= 32 ? 4 : 5))));
             };
             auto key_of = [&](const PairDesc &d) {
                 const int cr = cls1(d.Mr), cq = cls1(d.Mq);
@@ -713,7 +713,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             // both == 0: Qmax or Dmax as p.dmax says; both == 1: out[2k] = Qmax, out[2k+1] = Dmax
             const bool eqg = p.gamma_o == p.gamma_e;
             ProfScope ps(c, KS_QMAX, cells);
-            // one launch per size class: a lane owns 8 / 16 / 16 / 32 columns of rows up to 505 / 761 / 1017 / 2041 cells
+            // one launch per size class: a lane owns 8 / 8 / 16 / 16 / 32 columns of rows up to 249 / 505 / 761 / 1017 / 2041 cells
             auto sweep = [&](bool dmax, float *dst) {
                 for (int cl = 0; cl <= NC; ++cl) {
                     const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
@@ -722,14 +722,14 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                                                S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.gamma_o, p.gamma_e, p.dp_start)
 #define ACX_QBL(E_, D_) hipLaunchKernelGGL((acx::qmax_bits_long_kernel<E_, D_>), dim3(Bc), dim3(64), 0, c->stream, \
                                            S.d_pd + b0, c->d_bits, c->d_scratch, dst + (size_t)b0 * w, w, p.gamma_o, p.gamma_e, p.dp_start)
-#define ACX_QB(E_, D_) do { if (cl == 0) ACX_QB3(E_, D_, 8); else if (cl <= 2) ACX_QB3(E_, D_, 16); else if (cl == 3) ACX_QB3(E_, D_, 32); \
+#define ACX_QB(E_, D_) do { if (cl <= 1) ACX_QB3(E_, D_, 8); else if (cl <= 3) ACX_QB3(E_, D_, 16); else if (cl == 4) ACX_QB3(E_, D_, 32); \
                             else ACX_QBL(E_, D_); } while (0)
                     // the default penalties (0.5 / 0.5): packed 16-bit integer DP in half-units, two cells per instruction
                     if (eqg && p.gamma_o == 0.5f && cl < NC) {
 #define ACX_QH(C_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<C_, D_>), dim3(Bc), dim3(64), 0, c->stream, \
                                           S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.dp_start)
-                        if (dmax) { if (cl == 0) ACX_QH(8, true); else if (cl <= 2) ACX_QH(16, true); else ACX_QH(32, true); }
-                        else { if (cl == 0) ACX_QH(8, false); else if (cl <= 2) ACX_QH(16, false); else ACX_QH(32, false); }
+                        if (dmax) { if (cl <= 1) ACX_QH(8, true); else if (cl <= 3) ACX_QH(16, true); else ACX_QH(32, true); }
+                        else { if (cl <= 1) ACX_QH(8, false); else if (cl <= 3) ACX_QH(16, false); else ACX_QH(32, false); }
 #undef ACX_QH
                     }
                     else if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }

@@ -28,11 +28,14 @@ bool launch_band_m(const BandLaunch &L, const PairDesc *dpd, int B, int maxRows,
             static const bool two_rows = [] { const char *e = getenv("ACX_BAND2"); return !(e && e[0] == '0'); }();
             // (a second class of it, 24 positions per lane: rows of <= 761 cells -- ACX_BAND2=1 keeps that one on band_kernel<M, 4>)
             static const bool mid_two_rows = [] { const char *e = getenv("ACX_BAND2"); return !(e && (e[0] == '0' || e[0] == '1')); }();
-#define ACX_BAND2_K(R_, W_, NV_) hipLaunchKernelGGL((band2_kernel<M, R_, W_, NV_>), grid, dim3(B2_THREADS), 0, L.stream, L.frot, L.normtab, dpd, \
-                                                    L.scratch, L.thr, L.bits, L.pct_mode, L.inclusive, L.oti_target, want_eps)
-#define ACX_BAND2(NV_) do { if (role) ACX_BAND2_K(1, false, NV_); else if (write_d2) ACX_BAND2_K(0, true, NV_); else ACX_BAND2_K(0, false, NV_); } while (0)
-            if (ndata <= 8 && two_rows) { ACX_BAND2(B2_NV); return true; }
-            if (ndata > 8 && ndata <= 12 && two_rows && mid_two_rows) { ACX_BAND2(B2_NV_MID); return true; }
+#define ACX_BAND2_K(R_, W_, NV_, GL_) hipLaunchKernelGGL((band2_kernel<M, R_, W_, NV_, GL_>), grid, dim3(64 * B2Geom<NV_, GL_>::WAVES), 0, L.stream, L.frot, L.normtab, \
+                                                         dpd, L.scratch, L.thr, L.bits, L.pct_mode, L.inclusive, L.oti_target, want_eps)
+#define ACX_BAND2(NV_, GL_) do { if (role) ACX_BAND2_K(1, false, NV_, GL_); else if (write_d2) ACX_BAND2_K(0, true, NV_, GL_); else ACX_BAND2_K(0, false, NV_, GL_); } while (0)
+            // (rows of <= 249 cells: FOUR rows per wave -- ACX_BAND2=2 keeps them on the two-row kernel)
+            static const bool four_rows = [] { const char *e = getenv("ACX_BAND2"); return !(e && (e[0] == '0' || e[0] == '1' || e[0] == '2')); }();
+            if (ndata <= 4 && two_rows && four_rows) { ACX_BAND2(B2_NV, 16); return true; }
+            if (ndata <= 8 && two_rows) { ACX_BAND2(B2_NV, 32); return true; }
+            if (ndata > 8 && ndata <= 12 && two_rows && mid_two_rows) { ACX_BAND2(B2_NV_MID, 32); return true; }
 #undef ACX_BAND2
 #undef ACX_BAND2_K
         }

@@ -29,11 +29,16 @@ constexpr int B2_NV_MID = 24;                   // ... and, the second class, 24
 constexpr int B2_BINS = 256;                    // bins of the pivot-filtered histogram: 8 per lane of a half
 // geometry of an exchange row by positions per lane: NV + 4 floats per owner lane (16 bytes of pad: conflict-free 16-byte reads at
 // lane pitches of 20 and 28 floats alike -- 4 x an odd number), 32 owner lanes
-template <int NV> struct B2Geom {
+// GL = lanes that hold one row after the exchange: 32 (two rows per wave) or, for rows of <= 249 cells, 16 (FOUR rows per wave)
+template <int NV, int GL = 32> struct B2Geom {
     static_assert(NV == 16 || NV == 24, "16 or 24 positions per lane");
+    static_assert(GL == 32 || (GL == 16 && NV == 16), "half-wave rows, or quarter-wave rows of 256 positions");
+    static constexpr int RPW = 64 / GL;         // rows per wave
+    static constexpr int WAVES = BAND / RPW;    // waves of a workgroup: 4 / 2
     static constexpr int LNP = NV + 4;
-    static constexpr int ROWP = 32 * LNP;       // 640 / 896 floats
-    static constexpr int NSTEP = NV / 8;        // tiles per wave of the sweep
+    static constexpr int ROWP = GL * LNP;       // 640 / 896 / 320 floats
+    static constexpr int NSTEP = NV * GL / 64 / WAVES;     // tiles per wave of the sweep: 2 / 3 / 2
+    static constexpr int BINS = GL == 32 ? 256 : 128;      // 8 bins per lane of a row's group either way
 };
 #ifndef ACX_B2_WAVES_PER_SIMD
 #define ACX_B2_WAVES_PER_SIMD 7      /* 72 registers, 0-4 spilled; eight (64 registers) spill 10-14: 276 vs 308 (six) vs 332 (seven) Gcells/s at T = 450 */
@@ -42,9 +47,12 @@ template <int NV> struct B2Geom {
 #define ACX_B2_MID_WAVES_PER_SIMD 5  /* the 24-position class: 96 registers, 28.7 KB of exchange rows */
 #endif
 constexpr int b2_waves_per_simd(int nv) { return nv == 16 ? ACX_B2_WAVES_PER_SIMD : ACX_B2_MID_WAVES_PER_SIMD; }
+constexpr int b2_threads(int gl) { return 64 * (BAND / (64 / gl)); }          // 256 (two rows per wave) / 128 (four)
 
 // ---- reductions over the 32 lanes of a half, result in EVERY lane of the half: xor 1, xor 2 inside the quads, mirror inside 8
 // and 16 lanes (DPP, one VALU operation each), then the two 16-lane rows of the half trade places (v_permlane16_swap).
+template <int GL, typename Op>
+__device__ __forceinline__ int group_allreduce(int v, int idn, Op op);
 template <typename Op>
 __device__ __forceinline__ int half_allreduce(int v, int idn, Op op)
 {
@@ -57,6 +65,19 @@ __device__ __forceinline__ int half_allreduce(int v, int idn, Op op)
     const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);   // r[0]: rows 0 0 2 2, r[1]: rows 1 1 3 3
     return op((int)r[0], (int)r[1]);
 }
+// the same over the GL lanes that hold one row: a half (above), or one 16-lane DPP row (no exchange between rows needed)
+template <int GL, typename Op>
+__device__ __forceinline__ int group_allreduce(int v, int idn, Op op)
+{
+    if constexpr (GL == 32) return half_allreduce(v, idn, op);
+    else {
+        v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0xB1, 0xf, 0xf, false));
+        v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x4E, 0xf, 0xf, false));
+        v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x141, 0xf, 0xf, false));
+        v = op(v, __builtin_amdgcn_update_dpp(idn, v, 0x140, 0xf, 0xf, false));
+        return v;
+    }
+}
 // inclusive prefix sum inside each half (lanes without a source add 0)
 __device__ __forceinline__ int half_incl_scan_i(int v)
 {
@@ -66,6 +87,18 @@ __device__ __forceinline__ int half_incl_scan_i(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
     return v;
+}
+template <int GL>
+__device__ __forceinline__ int group_incl_scan_i(int v)
+{
+    if constexpr (GL == 32) return half_incl_scan_i(v);
+    else {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+        return v;
+    }
 }
 // a per-half scalar pair as a per-lane value
 __device__ __forceinline__ int half_pick(bool upper, int lo, int hi) { return upper ? hi : lo; }
@@ -107,15 +140,15 @@ typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 
-template <int NV>
+template <int NV, int GL = 32>
 __device__ __forceinline__ bool pair_select_pivot(const float (&x)[NV], int k, bool want_next, unsigned mb_addr, int lane,
                                                   float &slo, float &shi, bool lane_has_data, bool group_full)
 {
-    constexpr int NB = B2_BINS, BPL = NB / 32;      // 8 bins per lane in the scan
+    constexpr int NB = B2Geom<NV, GL>::BINS, BPL = NB / GL;      // 8 bins per lane in the scan
     static_assert(NV % 4 == 0, "atomics and the extrema pass go in groups of 4");
     static_assert(BPL == 8, "two 16-byte pieces per lane");
     const float INF = __builtin_inff();
-    const int l = lane & 31;
+    const int l = lane & (GL - 1);
     const unsigned hist_addr = mb_addr + 4u * B2Mail::HIST;
     // ---- row minimum and the largest minimum of a lane whose 16 positions are all cells (unsigned patterns: +inf pads above every cell)
     unsigned mnl = 0xFFFFFFFFu;
@@ -124,8 +157,8 @@ __device__ __forceinline__ bool pair_select_pivot(const float (&x)[NV], int k, b
         const unsigned b = __float_as_uint(x[t]);
         mnl = b < mnl ? b : mnl;
     }
-    const unsigned mnu = (unsigned)half_allreduce((int)mnl, -1, OpMinU());
-    const int mxg = half_allreduce(group_full ? (int)mnl : (int)0x80000000, (int)0x80000000, OpMaxI());
+    const unsigned mnu = (unsigned)group_allreduce<GL>((int)mnl, -1, OpMinU());
+    const int mxg = group_allreduce<GL>(group_full ? (int)mnl : (int)0x80000000, (int)0x80000000, OpMaxI());
     const float mn = __uint_as_float(mnu);
     const float gm = __uint_as_float((unsigned)mxg);
     const float range = gm - mn;
@@ -185,25 +218,32 @@ __device__ __forceinline__ bool pair_select_pivot(const float (&x)[NV], int k, b
             lsum += (int)(h.x + h.y) + (int)(h.z + h.w);
         }
     }
-    const int incl = half_incl_scan_i(lsum);
+    const int incl = group_incl_scan_i<GL>(lsum);
     const int excl = incl - lsum;
     const int k2 = want_next ? k + 1 : k;
     // the lane whose bins hold the rank posts itself (at most one per half and rank; none: fewer than k + 2 cells below the pivot)
     if (excl <= k && k < incl) *(lds_u32x2 *)(mb_addr + 4u * B2Mail::OWN) = u32x2{(unsigned)l + 1u, (unsigned)excl};
     if (excl <= k2 && k2 < incl) *(lds_u32x2 *)(mb_addr + 4u * (B2Mail::OWN + 2)) = u32x2{(unsigned)l + 1u, (unsigned)excl};
     wave_lds_fence();
-    // second level: lanes 0..7 of a half look at the 8 bins of lane L1, lanes 16..23 at those of lane L2
-    const int e = l & 15;
-    const bool second = (l & 16) != 0;
+    // second level: lanes 0..7 of a half look at the 8 bins of lane L1, lanes 16..23 at those of lane L2 (quarter-wave rows:
+    // lanes 0..7 and 8..15 of the group)
+    const int e = l & (GL / 2 - 1);
+    const bool second = (l & (GL / 2)) != 0;
     const u32x2 own = *(const lds_u32x2 *)(mb_addr + 4u * B2Mail::OWN + (second ? 8u : 0u));
     const int Lx = (int)own.x - 1, exx = (int)own.y;                  // (Lx = -1: nobody posted; the read below then hits the mailbox area)
     const int kk = second ? k2 : k;
     int c = (int)*(const lds_u32 *)(hist_addr + (unsigned)(Lx * (BPL * 4) + (e & 7) * 4));
     c = e < BPL ? c : 0;
-    int P = c;                                        // inclusive prefix inside each row of 16 lanes (8 of them count)
-    P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, false);
-    P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, false);
-    P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xf, 0xf, false);
+    int P = c;                                        // inclusive prefix over the 8 bins
+    if constexpr (GL == 32) {                         // (they sit at the start of a 16-lane DPP row: plain row shifts)
+        P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, false);
+        P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, false);
+        P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xf, 0xf, false);
+    } else {                                          // (two groups of 8 share a DPP row: the second must not see the first)
+        int t_ = __builtin_amdgcn_update_dpp(0, P, 0x111, 0xf, 0xf, false); P += e >= 1 ? t_ : 0;
+        t_ = __builtin_amdgcn_update_dpp(0, P, 0x112, 0xf, 0xf, false); P += e >= 2 ? t_ : 0;
+        t_ = __builtin_amdgcn_update_dpp(0, P, 0x114, 0xf, 0xf, false); P += e >= 4 ? t_ : 0;
+    }
     {
         const int below = exx + P - c;                // cells below this lane's bin
         if (e < BPL && Lx >= 0 && below <= kk && kk < below + c) {
@@ -250,7 +290,7 @@ __device__ __forceinline__ bool pair_select_pivot(const float (&x)[NV], int k, b
     }
     // ---- 4. three or more cells in the bin around the rank: gather the members of [bin1, bin2] (<= 32) and rank them
     const int ncand = (bin2 != bin1) ? cnt1 + cnt2 : cnt1;            // (the bins between are empty)
-    const bool crowded = found && !ok && ncand <= 32;
+    const bool crowded = found && !ok && ncand <= GL;
     if (__ballot(crowded) != 0ull) {
         const unsigned cand_addr = mb_addr + 4u * B2Mail::CAND;
         lds_u32 *counter = (lds_u32 *)(mb_addr + 4u * B2Mail::COUNTER);
@@ -259,7 +299,7 @@ __device__ __forceinline__ bool pair_select_pivot(const float (&x)[NV], int k, b
         for (int t = 0; t < NV; ++t) {
             if ((pat[t] - g1) <= span) {
                 const unsigned pos = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                *(lds_f32 *)(cand_addr + 4u * (pos & 31u)) = x[t];
+                *(lds_f32 *)(cand_addr + 4u * (pos & (unsigned)(GL - 1))) = x[t];
             }
         }
         wave_lds_fence();
@@ -292,8 +332,8 @@ __device__ __forceinline__ bool pair_select_pivot(const float (&x)[NV], int k, b
 // ------------------------------------------------------------------------------------
 // band2_kernel: see the head of this file.  grid = (bands of 8 rows, pairs), 256 threads.
 // ------------------------------------------------------------------------------------
-template <int M, int ROLE, bool WD2 = false, int NVT = B2_NV>
-__global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kernel(const float *__restrict__ frot,
+template <int M, int ROLE, bool WD2 = false, int NVT = B2_NV, int GLT = 32>
+__global__ __launch_bounds__(b2_threads(GLT), b2_waves_per_simd(NVT)) void band2_kernel(const float *__restrict__ frot,
                                                             const float *__restrict__ normtab,
                                                             const PairDesc *__restrict__ pd,
                                                             float *__restrict__ scratch,
@@ -304,12 +344,14 @@ __global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kern
     static_assert(M <= 9, "one 16-row MFMA tile of row frames");
     constexpr bool write_d2 = WD2;
     constexpr int role = ROLE;           // 1: rows = reference frames (column thresholds); 0: rows = query frames
-    constexpr int NV = NVT, LNP = B2Geom<NV>::LNP, ROWP = B2Geom<NV>::ROWP;
-    constexpr int NSTEP = B2Geom<NV>::NSTEP;       // tiles per wave: 2 (rows of <= 505 cells) or 3 (<= 761)
-    constexpr int B2_LDS_FLOATS = BAND * ROWP;     // the 8 exchange rows: 20 / 28 KB
+    constexpr int NV = NVT, GL = GLT;
+    using BG = B2Geom<NV, GL>;
+    constexpr int LNP = BG::LNP, ROWP = BG::ROWP, RPW = BG::RPW, WAVES = BG::WAVES;
+    constexpr int NSTEP = BG::NSTEP;               // tiles per wave: 2 (rows of <= 249 / 505 cells) or 3 (<= 761)
+    constexpr int B2_LDS_FLOATS = BAND * ROWP;     // the 8 exchange rows: 10 / 20 / 28 KB
     constexpr int NCT = (64 + BAND - 1 + M - 1 + 15) / 16;   // 16-column MFMA blocks of a tile (5)
     constexpr int SP = 16 * NCT + 4;     // Gram slab pitch: 84 % 32 = 20 keeps the 16-byte tile stores conflict-free
-    constexpr int LDS_FLOATS = B2_WAVES * 16 * SP > B2_LDS_FLOATS ? B2_WAVES * 16 * SP : B2_LDS_FLOATS;     // NV = 16: 21.5 KB of Gram slabs, six workgroups per CU; NV = 24: 28 KB of exchange rows, five
+    constexpr int LDS_FLOATS = WAVES * 16 * SP > B2_LDS_FLOATS ? WAVES * 16 * SP : B2_LDS_FLOATS;     // NV = 16: 21.5 KB of Gram slabs, six workgroups per CU; NV = 24: 28 KB of exchange rows, five
     __shared__ __attribute__((aligned(4096))) float smem[LDS_FLOATS];
 
     const PairDesc P = pd[blockIdx.y];
@@ -415,8 +457,8 @@ __global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kern
     // ---- sweep: wave w takes tiles w cpw .. w cpw + cpw - 1 (cpw = ceil(ntiles / 4) <= 2); the other tile slots of the 8 that
     // make a row of 32 NV positions are padded with +inf (tile_of)
     constexpr int HB = NCT - 4;
-    const int cpw = (ntiles + B2_WAVES - 1) / B2_WAVES;
-    auto tile_of = [&](int st) { return st < cpw ? wave * cpw + st : B2_WAVES * cpw + wave * (NSTEP - cpw) + (st - cpw); };
+    const int cpw = (ntiles + WAVES - 1) / WAVES;
+    auto tile_of = [&](int st) { return st < cpw ? wave * cpw + st : WAVES * cpw + wave * (NSTEP - cpw) + (st - cpw); };
     BvT bv;
     f32x4 halo[HB];
     if (wave * cpw < ntiles) load_operands(wave * cpw, bv, std::integral_constant<int, 0>());
@@ -466,7 +508,7 @@ __global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kern
     });
     if constexpr (write_d2) {
         const int npad = pitchD - MB;
-        for (int idx = tid; idx < BAND * npad; idx += B2_THREADS) {
+        for (int idx = tid; idx < BAND * npad; idx += 64 * WAVES) {
             const int a = idx / npad, j = MB + idx - a * npad;
             if (i0 + a < MA) D[a * pitchD + j] = INF;
         }
@@ -493,9 +535,9 @@ __global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kern
     }
     __syncthreads();
     // ---- wave w owns rows 2 w (lanes 0-31) and 2 w + 1 (lanes 32-63)
-    const int l = lane & 31;
-    const bool upper = lane >= 32;
-    const int myband = 2 * wave + (upper ? 1 : 0);     // band row of this lane's half
+    const int l = lane & (GL - 1);
+    const int grp = lane / GL;                         // which of the wave's RPW rows this lane works on
+    const int myband = RPW * wave + grp;               // band row of this lane's group
     const int row = i0 + myband;
     float *myrow = smem + myband * ROWP;
     float xr[NV];
@@ -513,7 +555,7 @@ __global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kern
       for (int t = 0; t < NV; ++t) keep_ += xr[t];
       ACX_ABL_EXIT(2, keep_); }
 #endif
-    if (i0 + 2 * wave >= MA) return;                              // wave-uniform: neither row exists
+    if (i0 + RPW * wave >= MA) return;                            // wave-uniform: none of the wave's rows exists
     const bool need = row < MA;                                   // (the last band of a matrix with an odd number of rows)
     const int cshift = (BAND - 1) - myband;                       // slot s of the row <-> column s - cshift
     const int n = MB;
@@ -535,33 +577,36 @@ __global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kern
         float *z = myrow + 32 + 4 * l;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            if (q < 2 || l < 8) *reinterpret_cast<float4 *>(z + 128 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < 2 || l < 8) *reinterpret_cast<float4 *>(z + 4 * GL * q) = make_float4(0.f, 0.f, 0.f, 0.f);      // [32, 64 + BINS)
         wave_lds_fence();
-        const bool ok = pair_select_pivot(xr, k, want_next, mb_addr, lane, slo, shi, lane_has_data, group_full);
+        const bool ok = pair_select_pivot<NV, GL>(xr, k, want_next, mb_addr, lane, slo, shi, lane_has_data, group_full);
         const unsigned long long om = __ballot(ok);
-        okm = ((unsigned)om & 1u) | (((unsigned)(om >> 32) & 1u) << 1);
+#pragma unroll
+        for (int g = 0; g < RPW; ++g) okm |= (unsigned)((om >> (GL * g)) & 1ull) << g;
     }
     // ---- rows the one-pass selection could not decide: the whole wave takes them one at a time through band_kernel's
     // fallbacks -- the row goes back to LDS and returns as 8 values per lane of all 64 lanes
     {
         const unsigned long long needm = __ballot(need);
-        const unsigned needb = ((unsigned)needm & 1u) | (((unsigned)(needm >> 32) & 1u) << 1);
+        unsigned needb = 0u;
+#pragma unroll
+        for (int g = 0; g < RPW; ++g) needb |= (unsigned)((needm >> (GL * g)) & 1ull) << g;
         unsigned todo = needb & ~okm;
         if (todo != 0u) {
             // both rows of the wave are in registers: 2 ROWP floats of scratch; a 512-aligned block of 512 floats inside it
             // is the histogram of wave_select_fast, the rest holds the candidates and the generic selection's bins
-            const int base = wave * 2 * ROWP;
+            const int base = wave * RPW * ROWP;
             const int hoff = (base + 511) & ~511;
             float *hist = smem + hoff, *aux = smem + hoff + 512;                     // (hoff <= base + 256: both fit the two rows)
             float *relay = smem + base;                                              // the row in position order: 32 NV floats
-            constexpr int NV8 = NV / 2;                                              // values per lane of the whole wave
-            static_assert(2 * ROWP >= 256 + 512 + 512 && 2 * ROWP >= 32 * NV, "fallback scratch fits the wave's two rows");
+            constexpr int NV8 = NV * GL / 64;                                        // values per lane of the whole wave
+            static_assert(RPW * ROWP >= 256 + 512 + 512 && RPW * ROWP >= GL * NV, "fallback scratch fits the wave's rows");
             const unsigned fh_addr = (unsigned)(uintptr_t)(lds_void *)hist;
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < RPW; ++h) {
                 if (!((todo >> h) & 1u)) continue;
-                const int cs = (BAND - 1) - (2 * wave + h);
+                const int cs = (BAND - 1) - (RPW * wave + h);
                 wave_lds_fence();
-                if ((lane >> 5) == h) {
+                if (grp == h) {
 #pragma unroll
                     for (int j = 0; j < NV / 4; ++j)
                         *reinterpret_cast<float4 *>(relay + l * NV + 4 * j) = make_float4(xr[4 * j], xr[4 * j + 1], xr[4 * j + 2], xr[4 * j + 3]);
@@ -585,7 +630,7 @@ __global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kern
                     s_lo = sr.value;
                     s_hi = (interp && ihi != ilo && sr.cnt_le <= ihi) ? sr.next : sr.value;
                 }
-                if ((lane >> 5) == h) { slo = s_lo; shi = s_hi; }
+                if (grp == h) { slo = s_lo; shi = s_hi; }
             }
             wave_lds_fence();
         }
@@ -655,7 +700,7 @@ __global__ __launch_bounds__(B2_THREADS, b2_waves_per_simd(NVT)) void band2_kern
                 const int d = 3 * (l >> 2) + j;
                 if (j < 3 && d < ndw) rowbits[d] = dwv;
             }
-            for (int z = NV + l; z < ndw; z += 32) rowbits[z] = 0u;     // (words beyond this size class: none by dispatch)
+            for (int z = NV * GL / 32 + l; z < ndw; z += GL) rowbits[z] = 0u;     // (words beyond this size class: none by dispatch)
         }
     }
 }
