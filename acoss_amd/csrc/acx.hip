@@ -728,8 +728,15 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                     if (eqg && p.gamma_o == 0.5f && cl < NC) {
 #define ACX_QH(C_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<C_, D_>), dim3(Bc), dim3(64), 0, c->stream, \
                                           S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.dp_start)
-                        if (dmax) { if (cl <= 1) ACX_QH(8, true); else if (cl <= 3) ACX_QH(16, true); else ACX_QH(32, true); }
+                        // rows of <= 249 / 505 cells: four / two pairs per wave (qmax_bits_h16_multi_kernel; ACX_QMAX_MULTI=0: one wave per pair)
+                        static const bool multi = [] { const char *e = getenv("ACX_QMAX_MULTI"); return !(e && e[0] == '0'); }();
+#define ACX_QM(G_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_multi_kernel<G_, D_>), dim3((Bc + 64 / G_ - 1) / (64 / G_)), dim3(64), 0, c->stream, \
+                                          S.d_pd + b0, Bc, c->d_bits, dst + (size_t)b0 * w, w, p.dp_start)
+                        if (multi && cl == 0) { if (dmax) ACX_QM(16, true); else ACX_QM(16, false); }
+                        else if (multi && cl == 1) { if (dmax) ACX_QM(32, true); else ACX_QM(32, false); }
+                        else if (dmax) { if (cl <= 1) ACX_QH(8, true); else if (cl <= 3) ACX_QH(16, true); else ACX_QH(32, true); }
                         else { if (cl <= 1) ACX_QH(8, false); else if (cl <= 3) ACX_QH(16, false); else ACX_QH(32, false); }
+#undef ACX_QM
 #undef ACX_QH
                     }
                     else if (eqg) { if (dmax) ACX_QB(true, true); else ACX_QB(true, false); }

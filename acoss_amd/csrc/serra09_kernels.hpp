@@ -1952,6 +1952,128 @@ __global__ __launch_bounds__(64) void qmax_bits_h16_kernel(const PairDesc *__res
     if (lane == 0) out[(size_t)blockIdx.x * out_stride] = 0.5f * (float)bh;
 }
 
+// ------------------------------------------------------------------------------------
+// K3d (round 5): the packed-16-bit Qmax / Dmax of K3c for SEVERAL SHORT pairs per wave.  One wave per pair gives a pair of <= 505
+// (249) columns 64 lanes of 8 columns: of the 45 instructions of a row 17 do not depend on the columns a lane owns -- and a covers80
+// / DA-TACOS call spends 12 % of its time here.  GLQ = 32 (16) lanes own one pair, 16 columns each, so a wave walks the rows of 2 (4)
+// pairs at once: 73 instructions per row for all of them.  Same integers as K3c (and as qmax_bits_kernel<true, DMAX, .>): the
+// recursion of a pair never looks beyond its own lanes (the neighbour value of a group's first lane is 0, like lane 0's in K3c), a
+// pair that runs out of rows before its neighbours idles on zero bits (its cells only decay: no new maximum).
+// grid = ceil(B / (64 / GLQ)) waves; pairs of one size class, sorted or not.
+// ------------------------------------------------------------------------------------
+template <int GLQ, bool DMAX = false>
+__global__ __launch_bounds__(64) void qmax_bits_h16_multi_kernel(const PairDesc *__restrict__ pd, int B,
+                                                                 const unsigned long long *__restrict__ bits,
+                                                                 float *__restrict__ out, int out_stride, int dp_start)
+{
+    constexpr int CPL = 16, NR = CPL / 2, PPW = 64 / GLQ;
+    static_assert(GLQ == 16 || GLQ == 32, "two or four pairs per wave");
+    const int lane = threadIdx.x, l = lane & (GLQ - 1);
+    const int pair = blockIdx.x * PPW + lane / GLQ;
+    const bool valid = pair < B;
+    const PairDesc *P = pd + (valid ? pair : B - 1);
+    int Me = valid ? P->Mq : 0, Ne = P->Mr;
+    if (dp_start == 3) { Me -= 1; Ne -= 1; }
+    const int ndw = 2 * P->nw;
+    const unsigned *rows = reinterpret_cast<const unsigned *>(bits + P->offT);
+    unsigned colmask = 0u;
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+        const int j = CPL * l + e;
+        if (j >= 2 && j < Ne) colmask |= (1u << e);
+    }
+    unsigned Q1[NR], Q2[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { Q1[k] = 0u; Q2[k] = 0u; }
+    i16x2 best = {0, 0};
+    const int dw0 = (CPL * l) >> 5, bit0 = (CPL * l) & 31;
+    const bool has0 = dw0 < ndw, has1 = dw0 + 1 < ndw;
+    auto load_row = [&](int i, unsigned &d0, unsigned &d1) {
+        d0 = 0u; d1 = 0u;
+        if (i < Me) {
+            const unsigned *r = rows + (size_t)i * ndw;
+            if (has0) d0 = r[dw0];
+            if (has1) d1 = r[dw0 + 1];
+        }
+    };
+    const i16x2 three = {3, 3};
+    const i16x2 two = {2, 2};
+    const u16x2 one_u = {1, 1};
+    auto arrange = [&](unsigned v) -> unsigned { return (v & ((1u << NR) - 1u)) | (((v >> NR) & ((1u << NR) - 1u)) << 16); };
+    auto spread = [&](unsigned va, int k) -> unsigned { return (va >> k) & 0x00010001u; };
+    const unsigned colmask_a = arrange(colmask);
+    unsigned cm[DMAX ? NR : 1];
+    unsigned wprev = 0u;
+    if constexpr (DMAX) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) cm[k] = spread(colmask_a, k) * 0xffffu;
+        unsigned p0, p1;
+        load_row(1, p0, p1);
+        wprev = arrange(__builtin_amdgcn_alignbit(p1, p0, bit0 + ((BAND - 1) - (1 & (BAND - 1)))));
+    } else cm[0] = 0u;
+    const bool first = l == 0;                        // the first lane of a pair's group has no left neighbour
+    auto dp_row = [&](int i, unsigned d0, unsigned d1, unsigned (&QA)[NR], unsigned (&QB)[NR]) {
+        const int sh = (BAND - 1) - (i & (BAND - 1));
+        const unsigned wraw = __builtin_amdgcn_alignbit(d1, d0, bit0 + sh);        // (bit0 + sh <= 16 + 7)
+        const unsigned wraw_a = arrange(wraw);
+        const unsigned w = wraw_a & colmask_a;
+        unsigned wleft = 0u;
+        if constexpr (DMAX) {
+            unsigned carry = lane_prev_u((wraw >> (CPL - 1)) & 1u);
+            carry = first ? 0u : carry;
+            wleft = arrange((wraw << 1) | carry);
+        }
+        unsigned nA1 = lane_prev_u(QA[NR - 1]), nA2 = lane_prev_u(QA[NR - 2]);
+        unsigned nB1 = lane_prev_u(QB[NR - 1]);
+        if (first) { nA1 = 0u; nA2 = 0u; nB1 = 0u; }
+        const unsigned a_m1 = __builtin_amdgcn_alignbit(QA[NR - 1], nA1, 16);
+        const unsigned a_m2 = __builtin_amdgcn_alignbit(QA[NR - 2], nA2, 16);
+        const unsigned b_m1 = __builtin_amdgcn_alignbit(QB[NR - 1], nB1, 16);
+        // (Dmax: a pair that has run out of rows must not take the bits of its LAST row as "row i - 1" of the idle steps behind it --
+        // they would lift the first idle row above 0; found by tests/fuzz_serra09.py on a 3-row matrix beside longer ones)
+        const unsigned wp = (DMAX && i < Me) ? wprev : 0u;
+#pragma unroll
+        for (int k = NR - 1; k >= 0; --k) {
+            const i16x2 c2 = as_i16x2(k >= 1 ? QA[k - 1] : a_m1);
+            i16x2 c3 = as_i16x2(k >= 1 ? QB[k - 1] : b_m1);
+            i16x2 c4 = as_i16x2(k >= 2 ? QA[k - 2] : (k == 1 ? a_m1 : a_m2));
+            if constexpr (DMAX) {
+                c3 = as_i16x2(spread(wp, k)) * two + c3;
+                c4 = as_i16x2(spread(wleft, k)) * two + c4;
+            }
+            const i16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(c2, c3), c4);
+            const unsigned sp = spread(w, k);
+            const u16x2 up = __builtin_bit_cast(u16x2, as_i16x2(sp) * three + mx);
+            i16x2 q = __builtin_bit_cast(i16x2, __builtin_elementwise_sub_sat(up, one_u));
+            if constexpr (DMAX) q = as_i16x2(as_u32(q) & cm[k]);
+            QB[k] = as_u32(q);
+            best = __builtin_elementwise_max(best, q);
+        }
+        if constexpr (DMAX) wprev = wraw_a;
+    };
+    // the longest pair of the wave sets the number of row steps
+    int Mmax = Me;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(Mmax, o, 64); Mmax = Mmax > t ? Mmax : t; }
+    Mmax = __builtin_amdgcn_readfirstlane(Mmax);
+    unsigned a0, a1, b0, b1, c0, c1, d0, d1;
+    load_row(2, a0, a1); load_row(3, b0, b1); load_row(4, c0, c1); load_row(5, d0, d1);
+    for (int i = 2; i < Mmax; i += 4) {
+        unsigned n0, n1;
+        if (i < Mmax) { load_row(i + 4, n0, n1); dp_row(i, a0, a1, Q1, Q2); a0 = n0; a1 = n1; }
+        if (i + 1 < Mmax) { load_row(i + 5, n0, n1); dp_row(i + 1, b0, b1, Q2, Q1); b0 = n0; b1 = n1; }
+        if (i + 2 < Mmax) { load_row(i + 6, n0, n1); dp_row(i + 2, c0, c1, Q1, Q2); c0 = n0; c1 = n1; }
+        if (i + 3 < Mmax) { load_row(i + 7, n0, n1); dp_row(i + 3, d0, d1, Q2, Q1); d0 = n0; d1 = n1; }
+    }
+    int bh = best.x > best.y ? best.x : best.y;
+#pragma unroll
+    for (int o = GLQ / 2; o >= 1; o >>= 1) {
+        const int t = __shfl_xor(bh, o, 64);
+        bh = bh > t ? bh : t;
+    }
+    if (l == 0 && valid) out[(size_t)pair * out_stride] = 0.5f * (float)bh;
+}
+
 static __global__ void sqrt_probe_kernel(const float *in, float *out, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

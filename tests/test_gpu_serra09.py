@@ -404,6 +404,30 @@ def test_self_pairs_score_full_diagonal(ctx):
     assert np.array_equal(got, np.array([T - 9 - 2 for T in lens], np.float32)), got
 
 
+def test_pairs_of_very_different_sizes_share_a_wave(ctx):
+    """Round 5: the alignment of SHORT pairs runs two / four pairs to a wave (qmax_bits_h16_multi_kernel), the band kernels two /
+    four rows to a wave.  A pair that runs out of rows idles beside its longer neighbours -- and must not pick anything up while it
+    does (the fuzz aid found Dmax lifting the first idle row of a 3-row matrix from its last real row's bits).  Tiny and ordinary
+    tracks mixed, every ordered pair, Qmax and Dmax, both start rows: bit-identical to the oracle."""
+    import oracle
+    from acoss_amd import _lib, synth
+    rng = np.random.default_rng(998)
+    lens = [146, 86, 7, 147, 146, 52, 12, 240, 11, 230, 300, 13]
+    tracks = [synth._frame_max_normalise(rng.random((T, 12))) for T in lens]
+    frames, offsets = synth.pack(tracks)
+    ctx.upload_pool(frames, offsets)
+    i, j = np.nonzero(~np.eye(len(lens), dtype=bool))
+    pairs = np.stack([i, j], 1).astype(np.int32)
+    for kw in (dict(m=4, kappa=1.0, pct_mode=2, inclusive=0, dp_start=3, oti=False, dmax=1), dict(m=4, kappa=0.3, dmax=1),
+               dict(m=4, kappa=0.3, dmax=0), dict(m=9, dmax=1), dict(m=1, kappa=0.02, pct_mode=3, oti_target=1, dmax=1)):
+        ok = np.array([min(lens[a], lens[b]) > kw["m"] + 1 for a, b in pairs])
+        got = ctx.serra09_pairs(pairs[ok], _lib.serra09_params(**kw))
+        ref = oracle.serra09_pairs(frames, offsets, pairs[ok], oracle.serra09_params(**kw))
+        assert np.array_equal(got, ref), (kw, pairs[ok][got != ref][:5], got[got != ref][:5], ref[got != ref][:5])
+    both = ctx.chenfusion_pairs(pairs[ok], _lib.serra09_params(m=1, kappa=0.02, pct_mode=3, oti_target=1))
+    assert np.array_equal(both[:, 1], ref)
+
+
 def test_batching_is_invisible(ctx):
     """A tiny scratch limit forces many batches; results must not change."""
     from acoss_amd import synth
