@@ -1,32 +1,29 @@
-// Serra09 band kernel for SHORT rows (<= 505 cells, stack size m <= 9): two matrix rows per wave.
+// Serra09 band kernel for SHORT rows (<= 761 cells, stack size m <= 9): two -- for rows of <= 249 cells four -- matrix rows per wave.
 //
 // Reference call site: acoss/algorithms/rqa_serra09.py:44-69 -- the pooled tracks that reach essentia's
 // ChromaCrossSimilarity per pair hold 150-650 frames on covers80 / DA-TACOS, so THIS is the shape a user
 // sees.  Same arithmetic spec and the same bits as band_kernel (serra09_kernels.hpp); what differs is who
-// does what:
-//   * a workgroup is FOUR waves and still owns a band of 8 matrix rows; a wave sweeps two CONSECUTIVE
-//     64-column tiles (the second inherits the 16-frame halo block of the first: 12 instead of 15 MFMAs,
-//     four operand loads instead of five) -- 20 KB of Gram slabs, eight workgroups per CU;
-//   * after the exchange a wave owns TWO rows: lanes 0-31 hold row 2w, lanes 32-63 row 2w + 1, 16
-//     consecutive positions per lane.  The selection's reductions, prefix scans, bin search, candidate
-//     ranking and the threshold arithmetic do not depend on how many values a lane holds -- in
-//     band_kernel<M, 2> they are 100 of the selection's 157 VALU instructions per row
-//     (profiles/r04_narrow_classes.md) -- and every one of them now serves two rows: reductions stop at
-//     the half (DPP inside the 16-lane rows, one v_permlane16_swap across them), the histogram, its scan
-//     and the candidate list exist once per half, per-half scalars are the two halves of a ballot.
-// Anything the one-pass pivot-filtered selection cannot decide for a row (fewer than k + 2 cells below the
-// pivot, more than 32 candidates, a degenerate range) is re-laid out through LDS for the whole wave and goes
-// through band_kernel's own fallbacks (wave_select_fast / wave_select_regs on 8 values per lane): same bits.
+// does what (measurements: profiles/r05_narrow_classes.md):
+//   * a workgroup is FOUR (two) waves and still owns a band of 8 matrix rows; a wave sweeps two or three CONSECUTIVE
+//     64-column tiles (each inherits the 16-frame halo block of the one before: 12 instead of 15 MFMAs, four operand loads
+//     instead of five);
+//   * after the exchange a wave owns TWO (four) rows: GL = 32 (16) lanes hold one row, NV = 16 or 24 consecutive positions per
+//     lane.  The selection's reductions, prefix scans, bin search, ranking and the threshold arithmetic do not depend on
+//     how many values a lane holds -- in band_kernel<M, 2> they are 100 of the selection's 157 VALU instructions per row -- and
+//     every one of them now serves all the rows of the wave: reductions stop at the group (DPP inside the 16-lane rows, one
+//     v_permlane16_swap across the two rows of a half), the histogram, its scan and the candidates exist once per group, and the
+//     groups talk through LDS mailboxes in their own exchange rows instead of through scalars;
+//   * the two order statistics are the largest / smallest cell of their histogram bins (pair_select_pivot), no candidate list.
+// A row the one-pass selection cannot decide (fewer than k + 2 cells below the pivot, a degenerate range, a large kappa) is
+// re-laid out through LDS for the whole wave and goes through band_kernel's own fallbacks (wave_select_fast / wave_select_regs):
+// same bits.
 #pragma once
 #include "serra09_kernels.hpp"
 
 namespace acx {
 
-constexpr int B2_WAVES = 4;
-constexpr int B2_THREADS = 64 * B2_WAVES;
 constexpr int B2_NV = 16;                       // positions per lane of a half-wave row: rows of <= 505 cells (8 tiles) ...
 constexpr int B2_NV_MID = 24;                   // ... and, the second class, 24: rows of <= 761 cells (12 tiles) -- every covers80 / DA-TACOS length
-constexpr int B2_BINS = 256;                    // bins of the pivot-filtered histogram: 8 per lane of a half
 // geometry of an exchange row by positions per lane: NV + 4 floats per owner lane (16 bytes of pad: conflict-free 16-byte reads at
 // lane pitches of 20 and 28 floats alike -- 4 x an odd number), 32 owner lanes
 // GL = lanes that hold one row after the exchange: 32 (two rows per wave) or, for rows of <= 249 cells, 16 (FOUR rows per wave)
@@ -100,9 +97,6 @@ __device__ __forceinline__ int group_incl_scan_i(int v)
         return v;
     }
 }
-// a per-half scalar pair as a per-lane value
-__device__ __forceinline__ int half_pick(bool upper, int lo, int hi) { return upper ? hi : lo; }
-__device__ __forceinline__ float half_pick(bool upper, float lo, float hi) { return upper ? hi : lo; }
 
 // ------------------------------------------------------------------------------------
 // Pivot-filtered one-pass selection (wave_select_pivot, serra09_kernels.hpp) for TWO rows at once: lanes 0-31 hold
@@ -110,7 +104,7 @@ __device__ __forceinline__ float half_pick(bool upper, float lo, float hi) { ret
 // both rows (they belong to one pair and one pass).
 //
 // The two halves work like two independent 32-lane groups that talk through LDS "mailboxes" in their own row's area
-// (`mb_addr`: LDS byte address of the half's 64 zeroed mailbox dwords, followed by its zeroed B2_BINS-dword histogram) --
+// (`mb_addr`: LDS byte address of the half's 64 zeroed mailbox dwords, followed by its zeroed B2Geom::BINS-dword histogram) --
 // no per-half scalars, no v_readlane / v_cndmask glue:
 //   1. histogram of the cells at or below the pivot (exec-masked ds_add_u32, as wave_select_pivot);
 //   2. prefix scan of the lanes' 8-bin sums inside the half; the lane whose range holds rank k (k + 1) posts {lane + 1,
