@@ -411,8 +411,9 @@ def init_torch(clock, local_rank, world, backend, collective):
         import torch.distributed as dist
         torch.set_num_threads(HOST_THREADS)
     with clock.phase("gpu_init"):
-        if backend != "nccl":
-            local_rank = local_rank % max(1, torch.cuda.device_count())
+        # (a launcher may hand every rank ONE visible device, HIP_VISIBLE_DEVICES = its own: LOCAL_RANK is then not a device index.
+        #  Whether two ranks ended up on one GPU is decided from the PCI bus ids, shared_device_reason, not assumed here)
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         if collective:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -553,7 +554,7 @@ def run_strong(args, clock, out, rank, world, local_rank):
     torch = dist = None
     if collective:
         torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
-    infos = gather_identities(rank_identity(rank, local_rank, local_rank), collective, dist, backend, local_rank)
+    infos = gather_identities(rank_identity(rank, int(os.environ.get("LOCAL_RANK", "0")), local_rank), collective, dist, backend, local_rank)
     why = shared_device_reason(infos, backend, world)
     if why:
         if rank == 0:
@@ -704,7 +705,7 @@ def main():
         torch, dist, local_rank = init_torch(clock, local_rank, world, backend, collective)
         dev = torch.device("cuda", local_rank)
     # which GPU does every rank hold?  Gathered BEFORE any measurement; two RCCL ranks on one device end the run here
-    infos = gather_identities(rank_identity(rank, local_rank, local_rank), collective, dist, backend, local_rank)
+    infos = gather_identities(rank_identity(rank, int(os.environ.get("LOCAL_RANK", "0")), local_rank), collective, dist, backend, local_rank)
     why = shared_device_reason(infos, backend, world)
     if why:
         if rank == 0:
