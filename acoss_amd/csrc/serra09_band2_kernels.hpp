@@ -136,7 +136,7 @@ typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 
 template <int NV, int GL = 32>
 __device__ __forceinline__ bool pair_select_pivot(const float (&x)[NV], int k, bool want_next, unsigned mb_addr, int lane,
-                                                  float &slo, float &shi, bool lane_has_data, bool group_full)
+                                                  float &slo, float &shi, bool lane_has_data, bool group_full, bool fine_pivot)
 {
     constexpr int NB = B2Geom<NV, GL>::BINS, BPL = NB / GL;      // 8 bins per lane in the scan
     static_assert(NV % 4 == 0, "atomics and the extrema pass go in groups of 4");
@@ -144,15 +144,21 @@ __device__ __forceinline__ bool pair_select_pivot(const float (&x)[NV], int k, b
     const float INF = __builtin_inff();
     const int l = lane & (GL - 1);
     const unsigned hist_addr = mb_addr + 4u * B2Mail::HIST;
-    // ---- row minimum and the largest minimum of a lane whose 16 positions are all cells (unsigned patterns: +inf pads above every cell)
-    unsigned mnl = 0xFFFFFFFFu;
+    // ---- row minimum and the pivot: the largest minimum of a lane whose NV positions are all cells (unsigned patterns: +inf pads
+    // above every cell).  A SHORT row has few such lanes -- 8 of them leave 12 % of the row below the pivot where the rank needs
+    // 9.5 % + 2 cells --: `fine_pivot` (wave-uniform) takes the largest minimum of a HALF lane instead, twice the groups of half
+    // the size: 30 % of a row of 142 cells.  Any pivot gives the same order statistics; it only decides how often the row is sent on.
+    unsigned mna = 0xFFFFFFFFu, mnb = 0xFFFFFFFFu;
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-        const unsigned b = __float_as_uint(x[t]);
-        mnl = b < mnl ? b : mnl;
+    for (int t = 0; t < NV / 2; ++t) {
+        const unsigned a = __float_as_uint(x[t]), b = __float_as_uint(x[NV / 2 + t]);
+        mna = a < mna ? a : mna;
+        mnb = b < mnb ? b : mnb;
     }
+    const unsigned mnl = mna < mnb ? mna : mnb;
+    const unsigned pvl = fine_pivot ? (mna < mnb ? mnb : mna) : mnl;
     const unsigned mnu = (unsigned)group_allreduce<GL>((int)mnl, -1, OpMinU());
-    const int mxg = group_allreduce<GL>(group_full ? (int)mnl : (int)0x80000000, (int)0x80000000, OpMaxI());
+    const int mxg = group_allreduce<GL>(group_full ? (int)pvl : (int)0x80000000, (int)0x80000000, OpMaxI());
     const float mn = __uint_as_float(mnu);
     const float gm = __uint_as_float((unsigned)mxg);
     const float range = gm - mn;
@@ -565,7 +571,12 @@ __global__ __launch_bounds__(b2_threads(GLT), b2_waves_per_simd(NVT)) void band2
     const bool group_full = l * NV >= cshift && l * NV + NV <= end_valid;
     float slo = 0.0f, shi = 0.0f;
     unsigned okm = 0u;
-    const bool use_pivot = (ihi + 2) * 9 <= n;
+#ifndef ACX_B2_FINE_BELOW
+#define ACX_B2_FINE_BELOW 9       /* rows of fewer than 9 (rank + 2) cells -- under ~186 at kappa = 0.095 -- take the half-lane pivot (pair_select_pivot):
+                                     i.i.d. tracks of 150 frames 115 -> 165 Gcells/s, of 100 frames 72 -> 100; from 200 frames on no difference at 9 / 12 / 16 */
+#endif
+    const bool fine_pivot = (ihi + 2) * ACX_B2_FINE_BELOW > n;
+    const bool use_pivot = (ihi + 2) * (fine_pivot ? 5 : 9) <= n;
     if (use_pivot) {
         // zero the mailboxes + histogram: dwords [32, 64 + 256) of the row, 16 bytes per lane, three rounds of 32 lanes
         float *z = myrow + 32 + 4 * l;
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(b2_threads(GLT), b2_waves_per_simd(NVT)) void band2
         for (int q = 0; q < 3; ++q)
             if (q < 2 || l < 8) *reinterpret_cast<float4 *>(z + 4 * GL * q) = make_float4(0.f, 0.f, 0.f, 0.f);      // [32, 64 + BINS)
         wave_lds_fence();
-        const bool ok = pair_select_pivot<NV, GL>(xr, k, want_next, mb_addr, lane, slo, shi, lane_has_data, group_full);
+        const bool ok = pair_select_pivot<NV, GL>(xr, k, want_next, mb_addr, lane, slo, shi, lane_has_data, group_full, fine_pivot);
         const unsigned long long om = __ballot(ok);
 #pragma unroll
         for (int g = 0; g < RPW; ++g) okm |= (unsigned)((om >> (GL * g)) & 1ull) << g;
