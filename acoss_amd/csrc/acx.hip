@@ -56,7 +56,9 @@ struct Serra09Slot {
     int64_t *h_idx = nullptr; size_t hidx_cap = 0;   // pinned: destinations of the batch's scores (grid runs)
     int64_t *d_idx = nullptr; size_t didx_cap = 0;
     hipEvent_t done = nullptr;
+    hipEvent_t cls_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // a size class's recurrence bitmap is complete
     bool busy = false;
+    bool on_q = false;                               // its alignment sweeps run on the context's second stream
     int B = 0, w = 1;
     int64_t k0 = 0;
 };
@@ -66,6 +68,9 @@ struct Serra09Slot {
 struct acx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t qstream = nullptr;                   // Serra09's alignment sweeps (run_serra09): beside the next band kernels
+    hipStream_t qstream2 = nullptr;                  // ... and the second alignment (Dmax) of LateFusionChen beside the first
+    hipEvent_t q2_done = nullptr;
     std::string err;
     // pool as uploaded (d_frames0 / d_toff0 / h_off0) and the ACTIVE pool: the upload decimated by the
     // stack stride tau of the last Serra09 call (tau == 1: the same buffers)
@@ -190,14 +195,14 @@ hipEvent_t get_event(acx_ctx *c)
 }
 
 struct ProfScope {
-    acx_ctx *c; int stat; int64_t cells; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(acx_ctx *c_, int stat_, int64_t cells_) : c(c_), stat(stat_), cells(cells_)
+    acx_ctx *c; int stat; int64_t cells; hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    ProfScope(acx_ctx *c_, int stat_, int64_t cells_, hipStream_t st_ = nullptr) : c(c_), stat(stat_), cells(cells_), st(st_ ? st_ : c_->stream)
     {
-        if (c->prof) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+        if (c->prof) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, st); }
     }
     ~ProfScope()
     {
-        if (c->prof) { (void)hipEventRecord(b, c->stream); c->pending.push_back({a, b, stat, cells}); }
+        if (c->prof) { (void)hipEventRecord(b, st); c->pending.push_back({a, b, stat, cells}); }
     }
 };
 
@@ -654,6 +659,37 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             S.h_cap = (size_t)2 * B;
         }
         ACX_HIP(c, hipMemcpyAsync(S.d_pd, pd.data(), sizeof(PairDesc) * B, hipMemcpyHostToDevice, c->stream));
+        if (dd) {     // destinations of the batch's scores (staged here: the scatter may run on the second stream)
+            if ((size_t)B > S.hidx_cap) {
+                if (S.h_idx) ACX_HIP(c, hipHostFree(S.h_idx));
+                S.h_idx = nullptr; S.hidx_cap = 0;
+                ACX_HIP(c, hipHostMalloc((void **)&S.h_idx, sizeof(int64_t) * (size_t)B, hipHostMallocDefault));
+                S.hidx_cap = (size_t)B;
+            }
+            if ((rc = ensure(c, S.d_idx, S.didx_cap, (size_t)B)) != ACX_OK) return rc;
+            for (int k2 = 0; k2 < B; ++k2) S.h_idx[k2] = dd->idx[k0 + perm[k2]];
+            ACX_HIP(c, hipMemcpyAsync(S.d_idx, S.h_idx, sizeof(int64_t) * B, hipMemcpyHostToDevice, c->stream));
+        }
+        // The alignment sweeps are one wave per pair (or per two / four pairs) walking ~45 dependent packed instructions per matrix
+        // row: a launch of a few thousand waves is bound by that chain's latency, not by the SIMDs (covers80-shaped call: four
+        // launches, 1.16 of 8.8 ms; T = 2000: 0.92 ms per 2016 pairs at 2 waves per SIMD).  They go to a SECOND stream: the sweep of
+        // size class cl starts when that class's bitmap is complete (cls_ev) and runs beside the band kernels of the next classes
+        // and of the NEXT batch, whose row pass -- the writer of the shared bitmap arena -- waits for this batch's sweeps (S.done).
+        // Not for batches with long pairs (their sweep's strip records live in the shared scratch), the debug entry point, or while
+        // the per-kernel event clocks are on (acx_profile_enable: a kernel's time is then its time ALONE, not beside another launch).
+        static const bool q_overlap = [] { const char *e = getenv("ACX_QMAX_STREAM"); return !(e && e[0] == '0'); }();
+        const bool use_q = q_overlap && !dbg && !c->prof && cls_begin[NC + 1] == cls_begin[NC];
+        if (use_q && !c->qstream) ACX_HIP(c, hipStreamCreateWithFlags(&c->qstream, hipStreamNonBlocking));
+        if (use_q && both && !c->qstream2) {
+            ACX_HIP(c, hipStreamCreateWithFlags(&c->qstream2, hipStreamNonBlocking));
+            ACX_HIP(c, hipEventCreateWithFlags(&c->q2_done, hipEventDisableTiming));
+        }
+        hipStream_t qs = use_q ? c->qstream : c->stream;
+        if (use_q)
+            for (int cl = 0; cl < NC; ++cl)
+                if (!S.cls_ev[cl]) ACX_HIP(c, hipEventCreateWithFlags(&S.cls_ev[cl], hipEventDisableTiming));
+        Serra09Slot &Sprev = c->slot[(batch & 1) ^ 1];
+        bool bits_free = !(Sprev.busy && Sprev.on_q);     // false: the previous batch's sweeps may still be reading the bitmap arena
 
         int64_t cells = 0;
         for (const PairDesc &d : pd) cells += (int64_t)d.Mq * d.Mr;
@@ -662,7 +698,9 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             hipLaunchKernelGGL(acx::oti_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream,
                                S.d_pd, B, c->d_gch, p.oti, p.oti_target, c->d_toff, c->d_noff);
         }
+        int64_t cls_cells[NC + 1];
         for (int cl = 0; cl <= NC; ++cl) {
+            cls_cells[cl] = 0;
             const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
             if (Bc <= 0) continue;
             int cMq = 0, cMr = 0;
@@ -671,6 +709,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                 cMq = std::max(cMq, pd[k2].Mq); cMr = std::max(cMr, pd[k2].Mr);
                 ccells += (int64_t)pd[k2].Mq * pd[k2].Mr;
             }
+            cls_cells[cl] = ccells;
             if (cl < NC) {
                 bool ok = true;
                 // K1' role 1: rows = reference frames (Mq cells each) -> column thresholds; one launch per (cr, cq) key
@@ -686,12 +725,15 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                     ProfScope ps(c, KS_BAND, qcells);
                     ok = ok && launch_band(c, p.m, S.d_pd + q0, Bq, qMr, qMq, p, 1, 0, dbg ? 1 : 0);
                 }
+                if (!bits_free) { ACX_HIP(c, hipStreamWaitEvent(c->stream, Sprev.done, 0)); bits_free = true; }
                 {   // K1' role 0: rows = query frames (Mr cells each) -> row thresholds + recurrence bitmap (needs role 1)
                     ProfScope ps(c, KS_BAND, ccells);
                     ok = ok && launch_band(c, p.m, S.d_pd + b0, Bc, cMq, cMr, p, 0, dbg ? 1 : 0, dbg ? 1 : 0);
                 }
+                if (use_q) ACX_HIP(c, hipEventRecord(S.cls_ev[cl], c->stream));
                 if (!ok) return fail(c, ACX_ERR_UNSUPPORTED, "serra09: this build of libacx has no band kernel for the requested m");
             } else {
+                if (!bits_free) { ACX_HIP(c, hipStreamWaitEvent(c->stream, Sprev.done, 0)); bits_free = true; }
                 {   // L1: D2 and D2^T
                     const int tiles_x = (cMr + acx::LT - 1) / acx::LT, tiles_y = (cMq + acx::LT - 1) / acx::LT;
                     ProfScope ps(c, KS_CSM, ccells);
@@ -712,25 +754,26 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
         {   // K3: one sweep per requested alignment over the SAME recurrence bitmap:
             // both == 0: Qmax or Dmax as p.dmax says; both == 1: out[2k] = Qmax, out[2k+1] = Dmax
             const bool eqg = p.gamma_o == p.gamma_e;
-            ProfScope ps(c, KS_QMAX, cells);
             // one launch per size class: a lane owns 8 / 8 / 16 / 16 / 32 columns of rows up to 249 / 505 / 761 / 1017 / 2041 cells
-            auto sweep = [&](bool dmax, float *dst) {
+            auto sweep = [&](bool dmax, float *dst, hipStream_t qs) {
                 for (int cl = 0; cl <= NC; ++cl) {
                     const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
                     if (Bc <= 0) continue;
-#define ACX_QB3(E_, D_, C_) hipLaunchKernelGGL((acx::qmax_bits_kernel<E_, D_, C_>), dim3(Bc), dim3(64), 0, c->stream, \
+                    if (use_q) (void)hipStreamWaitEvent(qs, S.cls_ev[cl], 0);
+                    ProfScope ps(c, KS_QMAX, cls_cells[cl], qs);      // (its first event stands behind the wait)
+#define ACX_QB3(E_, D_, C_) hipLaunchKernelGGL((acx::qmax_bits_kernel<E_, D_, C_>), dim3(Bc), dim3(64), 0, qs, \
                                                S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.gamma_o, p.gamma_e, p.dp_start)
-#define ACX_QBL(E_, D_) hipLaunchKernelGGL((acx::qmax_bits_long_kernel<E_, D_>), dim3(Bc), dim3(64), 0, c->stream, \
+#define ACX_QBL(E_, D_) hipLaunchKernelGGL((acx::qmax_bits_long_kernel<E_, D_>), dim3(Bc), dim3(64), 0, qs, \
                                            S.d_pd + b0, c->d_bits, c->d_scratch, dst + (size_t)b0 * w, w, p.gamma_o, p.gamma_e, p.dp_start)
 #define ACX_QB(E_, D_) do { if (cl <= 1) ACX_QB3(E_, D_, 8); else if (cl <= 3) ACX_QB3(E_, D_, 16); else if (cl == 4) ACX_QB3(E_, D_, 32); \
                             else ACX_QBL(E_, D_); } while (0)
                     // the default penalties (0.5 / 0.5): packed 16-bit integer DP in half-units, two cells per instruction
                     if (eqg && p.gamma_o == 0.5f && cl < NC) {
-#define ACX_QH(C_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<C_, D_>), dim3(Bc), dim3(64), 0, c->stream, \
+#define ACX_QH(C_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_kernel<C_, D_>), dim3(Bc), dim3(64), 0, qs, \
                                           S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.dp_start)
                         // rows of <= 249 / 505 cells: four / two pairs per wave (qmax_bits_h16_multi_kernel; ACX_QMAX_MULTI=0: one wave per pair)
                         static const bool multi = [] { const char *e = getenv("ACX_QMAX_MULTI"); return !(e && e[0] == '0'); }();
-#define ACX_QM(G_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_multi_kernel<G_, D_>), dim3((Bc + 64 / G_ - 1) / (64 / G_)), dim3(64), 0, c->stream, \
+#define ACX_QM(G_, D_) hipLaunchKernelGGL((acx::qmax_bits_h16_multi_kernel<G_, D_>), dim3((Bc + 64 / G_ - 1) / (64 / G_)), dim3(64), 0, qs, \
                                           S.d_pd + b0, Bc, c->d_bits, dst + (size_t)b0 * w, w, p.dp_start)
                         if (multi && cl == 0) { if (dmax) ACX_QM(16, true); else ACX_QM(16, false); }
                         else if (multi && cl == 1) { if (dmax) ACX_QM(32, true); else ACX_QM(32, false); }
@@ -746,28 +789,24 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
 #undef ACX_QB3
                 }
             };
-            if (both) { sweep(false, S.d_out); sweep(true, S.d_out + 1); }
-            else sweep(p.dmax != 0, S.d_out);
+            if (both && use_q) {      // the two alignments of a pair read the same bitmap and write different halves of d_out: side by side
+                sweep(false, S.d_out, qs);
+                sweep(true, S.d_out + 1, c->qstream2);
+                ACX_HIP(c, hipEventRecord(c->q2_done, c->qstream2));
+                ACX_HIP(c, hipStreamWaitEvent(qs, c->q2_done, 0));
+            } else if (both) { sweep(false, S.d_out, qs); sweep(true, S.d_out + 1, qs); }
+            else sweep(p.dmax != 0, S.d_out, qs);
         }
         ACX_HIP(c, hipGetLastError());
         if (dd) {
-            if ((size_t)B > S.hidx_cap) {
-                if (S.h_idx) ACX_HIP(c, hipHostFree(S.h_idx));
-                S.h_idx = nullptr; S.hidx_cap = 0;
-                ACX_HIP(c, hipHostMalloc((void **)&S.h_idx, sizeof(int64_t) * (size_t)B, hipHostMallocDefault));
-                S.hidx_cap = (size_t)B;
-            }
-            if ((rc = ensure(c, S.d_idx, S.didx_cap, (size_t)B)) != ACX_OK) return rc;
-            for (int k2 = 0; k2 < B; ++k2) S.h_idx[k2] = dd->idx[k0 + perm[k2]];
-            ACX_HIP(c, hipMemcpyAsync(S.d_idx, S.h_idx, sizeof(int64_t) * B, hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(scatter_scores_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(scatter_scores_kernel, dim3((B + 255) / 256), dim3(256), 0, qs,
                                S.d_out, S.d_idx, dd->base, B, w);
             ACX_HIP(c, hipGetLastError());
         } else {
-            ACX_HIP(c, hipMemcpyAsync(S.h_out, S.d_out, sizeof(float) * B * w, hipMemcpyDeviceToHost, c->stream));
+            ACX_HIP(c, hipMemcpyAsync(S.h_out, S.d_out, sizeof(float) * B * w, hipMemcpyDeviceToHost, qs));
         }
-        ACX_HIP(c, hipEventRecord(S.done, c->stream));
-        S.busy = true; S.B = B; S.w = w; S.k0 = k0;
+        ACX_HIP(c, hipEventRecord(S.done, qs));
+        S.busy = true; S.on_q = use_q; S.B = B; S.w = w; S.k0 = k0;
 
         if (dbg && B >= 1) {
             if ((rc = collect_slot(c, S, out)) != ACX_OK) return rc;
@@ -1317,6 +1356,8 @@ void acx_destroy(acx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->qstream) (void)hipStreamSynchronize(c->qstream);
+    if (c->qstream2) (void)hipStreamSynchronize(c->qstream2);
     comm_release(c);
     for (void *b : c->dev_bufs) (void)hipFree(b);
     c->dev_bufs.clear();
@@ -1332,6 +1373,8 @@ void acx_destroy(acx_ctx *c)
         if (sl.h_idx) (void)hipHostFree(sl.h_idx);
         if (sl.d_idx) (void)hipFree(sl.d_idx);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        for (hipEvent_t ev : sl.cls_ev)
+            if (ev) (void)hipEventDestroy(ev);
     }
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_nf) (void)hipFree(c->d_nf);
@@ -1355,6 +1398,9 @@ void acx_destroy(acx_ctx *c)
     if (c->d_segw) (void)hipFree(c->d_segw);
     if (c->d_segw2) (void)hipFree(c->d_segw2);
     if (c->d_segw3) (void)hipFree(c->d_segw3);
+    if (c->qstream) (void)hipStreamDestroy(c->qstream);
+    if (c->qstream2) (void)hipStreamDestroy(c->qstream2);
+    if (c->q2_done) (void)hipEventDestroy(c->q2_done);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -54,5 +54,12 @@ int main()
         run<512, 11008>("512 threads, 43 KB LDS", 18, 44850, w, d);
         run<64, 1376>("64 threads, 5.4 KB LDS", 18, 44850, w, d);
     }
+    // Where do the waves of a SMALL launch go?  One-wave workgroups with a long dependent chain: if the time does not grow until the
+    // grid exceeds 1024 (one wave per SIMD) they are spread over the chip; if it is already several times the one-wave time at a few
+    // hundred, the dispatcher packs them onto few CUs and a latency-bound kernel (the alignment sweeps) becomes issue-bound there.
+    printf("\nplacement of one-wave workgroups (20000 dependent FMAs each):\n");
+    const int grids[] = {1, 64, 256, 512, 752, 1024, 2048, 4096, 8192};
+    for (int g : grids) run<64, 64>("64 threads, 256 B LDS", g, 1, 20000, d);
+    for (int g : grids) run<256, 64>("256 threads, 256 B LDS", (g + 3) / 4, 1, 20000, d);
     return 0;
 }
