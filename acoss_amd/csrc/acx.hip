@@ -4,6 +4,8 @@
 // and drives the kernels of serra09_kernels.hpp over batches of track pairs.  No torch, no
 // CPU fallback: if the device or a launch fails the call returns an error code.
 #include <hip/hip_runtime.h>
+
+#include <chrono>
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types and prototypes only: librccl is dlopen()ed when a communicator is asked for (acx_comm_init)
 
@@ -981,6 +983,7 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
     if (!(p.kappa >= 0.0)) return fail(c, ACX_ERR_INVALID, "earlyfusion: kappa must be >= 0");
     if (p.K < 1) return fail(c, ACX_ERR_INVALID, "earlyfusion: K must be >= 1");
     ACX_HIP(c, hipSetDevice(c->device));
+    const double t_call = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     int64_t limit = c->scratch_limit;
     if (limit <= 0) {
         const char *env = getenv("ACX_SCRATCH_GB");
@@ -1023,16 +1026,32 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             batch_floats = std::min<int64_t>(limit_floats, (int64_t)(total / nb * 1.02) + ((int64_t)1 << 22));
         }
     }
-    std::vector<EfPair> pd;
-    SegBatch seg;
+    // One batch on the host: its pair descriptors and -- for the rectangle GEMM -- the dense rectangles its pairs are laid out in.
+    // Built for batch b + 1 WHILE the device works on batch b (two of these; the copies to the device are staged before they
+    // return): ~1 ms per 16 384 pairs that the device used to wait for between batches.
+    struct HostBatch {
+        std::vector<EfPair> pd;
+        SegBatch seg;
+        int64_t k_begin = 0, k_end = 0, used = 0, used_s = 0, used_b = 0, cells = 0;
+        int maxM = 0, maxN = 0;
+    };
+    HostBatch hbs[2];
     std::vector<int32_t> qslot, rslot;
     int rc;
-    int64_t k0 = 0;
-    while (k0 < K) {
+    const bool rect_gemm = !ext_matrix && c->ef_gemm != ACX_EF_GEMM_F32 && c->ef_gemm != ACX_EF_GEMM_BF16X3_PAIRWISE;
+    // development aid (ACX_EF_HOST_TIMING=1): where the HOST's time of a call goes -- descriptors, rectangles, enqueue, waiting for the device
+    static const bool host_timing = [] { const char *e = getenv("ACX_EF_HOST_TIMING"); return e && e[0] == '1'; }();
+    double ht[5] = {0, 0, 0, 0, 0};
+    int nbatches = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    ht[4] = now() - t_call;
+    auto prepare = [&](HostBatch &hb, int64_t k_from) -> int {
+        const double t_a = now();
+        std::vector<EfPair> &pd = hb.pd;
         pd.clear();
         int64_t used = 0, used_s = 0, used_b = 0, cells = 0;
         int maxM = 0, maxN = 0;
-        int64_t k = k0;
+        int64_t k = k_from;
         for (; k < K && pd.size() < 65535; ++k) {
             EfPair d;
             if (ext_matrix) {
@@ -1069,7 +1088,25 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             cells += (int64_t)d.M * d.N;
             pd.push_back(d);
         }
+        hb.k_begin = k_from; hb.k_end = k;
+        hb.used = used; hb.used_s = used_s; hb.used_b = used_b; hb.cells = cells; hb.maxM = maxM; hb.maxN = maxN;
+        const double t_r = now();
+        ht[0] += t_r - t_a;
+        // the pairs of the batch laid out as dense rectangles (ef_gemm_rect_bf16x3_kernel)
+        if (rect_gemm) ef_build_rects(pd, c->h_efoff, c->ef_ntracks, hb.seg, qslot, rslot);
+        ht[1] += now() - t_r;
+        return ACX_OK;
+    };
+    if ((rc = prepare(hbs[0], 0)) != ACX_OK) return rc;
+    for (int bi = 0; hbs[bi & 1].k_begin < K; ++bi) {
+        HostBatch &hb = hbs[bi & 1];
+        std::vector<EfPair> &pd = hb.pd;
+        SegBatch &seg = hb.seg;
+        const int64_t k0 = hb.k_begin, k = hb.k_end, used = hb.used, used_s = hb.used_s, used_b = hb.used_b, cells = hb.cells;
+        const int maxM = hb.maxM, maxN = hb.maxN;
+        ++nbatches;
         const int B = (int)pd.size();
+        const double t_b = now();
         if ((rc = ensure(c, c->d_scratch, c->scratch_cap, (size_t)used)) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_thr, c->thr_cap, (size_t)used_s)) != ACX_OK) return rc;
         if ((rc = ensure(c, c->d_efbits, c->efbits_cap, (size_t)used_b)) != ACX_OK) return rc;
@@ -1099,8 +1136,6 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                                            c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efoff, c->d_efpd,
                                            c->d_scratch, c->ef_kp[0], c->ef_kp[1], tiles_x);
                     } else {
-                        // the pairs of the batch laid out as dense rectangles (ef_gemm_rect_bf16x3_kernel)
-                        ef_build_rects(pd, c->h_efoff, c->ef_ntracks, seg, qslot, rslot);
                         if ((rc = ensure(c, c->d_segr, c->segr_cap, seg.rowg.size())) != ACX_OK) return rc;
                         if ((rc = ensure(c, c->d_segc, c->segc_cap, seg.colg.size())) != ACX_OK) return rc;
                         if ((rc = ensure(c, c->d_rects, c->rects_cap, seg.rects.size())) != ACX_OK) return rc;
@@ -1229,8 +1264,18 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
         } else {
             ACX_HIP(c, hipMemcpyAsync(out + 4 * k0, c->d_out, sizeof(float) * 4 * B, hipMemcpyDeviceToHost, c->stream));
         }
+        const double t_s = now();
+        ht[2] += t_s - t_b;
+        // the next batch's descriptors and rectangles, while the device works on this one
+        HostBatch &nx = hbs[(bi & 1) ^ 1];
+        nx.k_begin = K;
+        int rc_next = ACX_OK;
+        if (k < K && !ext_matrix) rc_next = prepare(nx, k);
+        const double t_w = now();
         ACX_HIP(c, hipStreamSynchronize(c->stream));
+        ht[3] += now() - t_w;
         drain_profile(c);
+        if (rc_next != ACX_OK) return rc_next;
         if (dbg && B >= 1) {
             EfPair d;
             ACX_HIP(c, hipMemcpy(&d, c->d_efpd, sizeof(EfPair), hipMemcpyDeviceToHost));
@@ -1244,13 +1289,15 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
                                        c->d_scratch + d.offC + (int64_t)3 * d.M * d.pitchC + (int64_t)3 * d.ctN * d.pitchT,
                                        sizeof(float) * d.pitchC, sizeof(float) * d.N, d.M, hipMemcpyDeviceToHost));
         }
-        k0 = k;
         if (ext_matrix) break;
     }
 #undef ACX_ROWSTAT
 #undef ACX_FUSESEL
 #undef ACX_FUSESEL_K
 #undef ACX_SW
+    if (host_timing)
+        fprintf(stderr, "[acx ef host] %lld pairs in %d batches, %.1f ms: preamble %.1f, descriptors %.1f, rectangles %.1f, enqueue %.1f, waiting for the device %.1f\n",
+                (long long)K, nbatches, 1e3 * (now() - t_call), 1e3 * ht[4], 1e3 * ht[0], 1e3 * ht[1], 1e3 * ht[2], 1e3 * ht[3]);
     return ACX_OK;
 }
 
