@@ -13,7 +13,7 @@ Differences from the reference, all deliberate:
     hours at N = 15 000) and uses a STABLE argsort so that ties have one defined order;
   * cleanup_memmap really removes the memmap files (the reference calls rmtree on a file
     and always fails);
-  * the distance matrices are saved as <prefix>_Ds.npz (no deepdish/h5py offline);
+  * the distance matrices are saved as <prefix>_Ds.h5 (libhdf5 / h5py) and, when small or when no HDF5 library exists, <prefix>_Ds.npz;
   * device-backed subclasses (those with a _grid() method) never build the pair list at all:
     libacx enumerates the N x N grid itself in cost-balanced tiles (acx_pair_grid; under
     torch.distributed, one process per GPU, acx_grid_run + ONE gather of the tile scores to rank 0,
@@ -208,8 +208,22 @@ class CoverAlgorithm(object):
         if _dist.any_rank(not self.cliques):
             self.get_all_clique_ids()
         if rank == 0:
+            self._save_results_cache(npz, h5)
+
+    # a result set up to this size is cached in BOTH formats (the .npz needs no HDF5 library to read back); above it only in
+    # the reference's own -- at 15 000 tracks a second copy costs seconds per plane inside all_pairwise
+    NPZ_CACHE_BELOW = 256 << 20
+
+    def _save_results_cache(self, npz, h5):
+        """The reference's dd.io.save("<prefix>_Ds.h5", self.Ds) (algorithm_template.py:192): <prefix>_Ds.h5 when an HDF5
+        backend exists, <prefix>_Ds.npz when none does or the matrices are small; `all_pairwise(precomputed=True)` reads
+        whichever is there (a stale .npz of an earlier, smaller run is removed so that it cannot shadow the new .h5)."""
+        wrote_h5 = save_matrices_h5(h5, self.Ds)
+        total = sum(int(np.asarray(self.Ds[s]).nbytes) for s in self.Ds)
+        if not wrote_h5 or total <= self.NPZ_CACHE_BELOW:
             np.savez(npz, **{s: np.asarray(self.Ds[s]) for s in self.Ds})
-            save_matrices_h5(h5, self.Ds)                      # also in the reference's own format when h5py exists
+        elif os.path.exists(npz):
+            os.remove(npz)
 
     def _joblib_fanout(self, chunks, n_cores):
         """User subclasses with their own CPU `similarity()` (README "how to add an algorithm"): `parallel=1` fans the 45

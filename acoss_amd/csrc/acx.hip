@@ -2750,25 +2750,37 @@ int acx_pair_grid(acx_ctx *c, const acx_grid_spec *spec, const void *params, flo
         (void)hipFree(d);
         return fail(c, ACX_ERR_NOMEM, "pair_grid: cannot allocate the pinned staging slice");
     }
+    // development aid (ACX_GRID_TIMING=1): the host's seconds in the three steps of a slice
+    static const bool grid_timing = [] { const char *e = getenv("ACX_GRID_TIMING"); return e && e[0] == '1'; }();
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tg[3] = {0, 0, 0};
+    int nslices = 0;
     for (size_t a = 0; a < tiles.size() && rc == ACX_OK;) {
         int64_t fl = 0;
         size_t b = a;
         while (b < tiles.size() && (b == a || fl + (int64_t)tiles[b].rows * tiles[b].cols * w <= SLICE)) { fl += (int64_t)tiles[b].rows * tiles[b].cols * w; ++b; }
         // grid_run writes tile t at d_scores + t.offset: rebase so that the slice starts at d[0]
+        const double t_0 = now();
         rc = acx_grid_run(c, spec, params, 0, (int64_t)a, (int64_t)(b - a), d - tiles[a].offset);
+        const double t_1 = now();
         if (rc == ACX_OK) {
             const hipError_t e = hipMemcpy(h, d, sizeof(float) * (size_t)fl, hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = fail(c, ACX_ERR_HIP, std::string("pair_grid: ") + hipGetErrorString(e));
         }
+        const double t_2 = now();
         if (rc == ACX_OK) {
             std::vector<acx_grid_tile> part(tiles.begin() + a, tiles.begin() + b);
             for (acx_grid_tile &t : part) t.offset -= tiles[a].offset;
             acx::grid_scatter(part, *spec, h, 0, 0, -1, D, ld, mirror);
         }
+        tg[0] += t_1 - t_0; tg[1] += t_2 - t_1; tg[2] += now() - t_2;
+        ++nslices;
         a = b;
     }
     (void)hipFree(d);
     (void)hipHostFree(h);
+    if (grid_timing)
+        fprintf(stderr, "[acx pair_grid] %d slice(s): device %.2f s, copy to the host %.2f s, scatter + mirror %.2f s\n", nslices, tg[0], tg[1], tg[2]);
     return rc;
 }
 

@@ -95,17 +95,24 @@ def save_track(path, feats, fmt="npz"):
     np.savez(stem + ".npz", **flat)
 
 
+# matrices above this size go to the cache uncompressed: zlib makes ~40 MB/s of float scores and saves a fifth of the file --
+# 24 s per 15 000 x 15 000 plane, six planes for EarlyFusion, inside all_pairwise (measured: scripts/end_to_end*.py)
+H5_COMPRESS_BELOW = 64 << 20
+
+
 def save_matrices_h5(path, Ds):
     """{name: (N, N) array} -> one HDF5 file with a dataset per name -- what the reference's
     dd.io.save("<prefix>_Ds.h5", self.Ds) leaves on disk (algorithm_template.py:192; deepdish stores
-    arrays of more than 300 elements as chunked, shuffled, zlib-compressed CArrays).  Returns False when no
-    HDF5 backend exists (the .npz cache is always written)."""
+    arrays of more than 300 elements as chunked, shuffled, compressed CArrays; here zlib up to 64 MB per
+    matrix, plain chunks above -- either reads back through dd.io.load / load_matrices_h5).  Returns False when no
+    HDF5 backend exists (the caller then writes the .npz cache)."""
     backend = hdf5_backend()
     if backend is None:
         return False
     if backend == "libhdf5":
         from . import hdf5
-        hdf5.write_tree(path, {k: np.asarray(v) for k, v in Ds.items()}, compress=1)
+        big = any(np.asarray(v).nbytes > H5_COMPRESS_BELOW for v in Ds.values())
+        hdf5.write_tree(path, {k: np.asarray(v) for k, v in Ds.items()}, compress=0 if big else 1)
         return True
     import h5py
     with h5py.File(path, "w") as f:

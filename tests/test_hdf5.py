@@ -56,7 +56,7 @@ def test_reads_files_written_by_pytables():
         assert D[k].dtype == e["Ds/" + k].dtype and np.array_equal(D[k], e["Ds/" + k])
 
 
-def test_written_files_are_real_hdf5(tmp_path):
+def test_written_files_are_real_hdf5(tmp_path, monkeypatch):
     hdf5 = _need_lib()
     from acoss_amd import featurestore as fs
     rng = np.random.default_rng(1)
@@ -67,6 +67,14 @@ def test_written_files_are_real_hdf5(tmp_path):
     assert sorted(back) == sorted(Ds)
     for k in Ds:
         assert back[k].dtype == Ds[k].dtype and np.array_equal(back[k], Ds[k])
+    # matrices above the compression limit are stored in plain chunks (zlib makes ~40 MB/s of float scores) and read back the same
+    monkeypatch.setattr(fs, "H5_COMPRESS_BELOW", 1000)
+    p2 = str(tmp_path / "Y_Ds.h5")
+    assert fs.save_matrices_h5(p2, Ds) is True
+    back2 = fs.load_matrices_h5(p2)
+    for k in Ds:
+        assert back2[k].dtype == Ds[k].dtype and np.array_equal(back2[k], Ds[k])
+    assert os.path.getsize(p2) >= sum(v.nbytes for v in Ds.values())
     feats = {"hpcp": rng.random((77, 12)).astype(np.float32), "mfcc_htk": rng.standard_normal((13, 77)).astype(np.float32),
              "madmom_features": {"onsets": np.arange(0, 70, 7, dtype=np.int64)}, "label": "W_9", "track_id": "P_9_2", "duration": 12.5}
     fs.save_track(str(tmp_path / "w/t.h5"), feats, fmt="h5")

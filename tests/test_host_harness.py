@@ -379,6 +379,17 @@ def test_hdf5_feature_store_and_cache_branch(tmp_path, monkeypatch):
     again = Toy(csv, name="Toy", datapath=root, shortname="h5")
     again.all_pairwise(symmetric=True, precomputed=True)
     assert np.array_equal(np.array(again.Ds["main"]), want)
+    # a LARGE result set is cached in the reference's format only, and a stale .npz of an earlier run does not survive it
+    np.savez("cache/Toy_h5_Ds.npz", main=np.zeros_like(want))
+    monkeypatch.setattr(Toy, "NPZ_CACHE_BELOW", 8)
+    big = Toy(csv, name="Toy", datapath=root, shortname="h5")
+    big.all_pairwise(symmetric=True)
+    assert not os.path.exists("cache/Toy_h5_Ds.npz")
+    assert np.array_equal(_FakeH5.store["cache/Toy_h5_Ds.h5"]["main"], want)
+    open("cache/Toy_h5_Ds.h5", "wb").close()
+    third = Toy(csv, name="Toy", datapath=root, shortname="h5")
+    third.all_pairwise(symmetric=True, precomputed=True)
+    assert np.array_equal(np.array(third.Ds["main"]), want)
     # without h5py the HDF5 branch fails loudly and names the converter
     monkeypatch.setitem(sys.modules, "h5py", None)
     with pytest.raises(IOError):
