@@ -444,6 +444,36 @@ def test_batching_is_invisible(ctx):
     assert np.array_equal(a, oracle.serra09_pairs(d["frames"], d["offsets"], pairs))
 
 
+def test_batches_of_mixed_lengths_keep_their_scores(ctx):
+    """Many batches of pairs from several size classes, one and two alignments per pair: the alignment sweeps of a batch run on the
+    context's second stream beside the band kernels of the NEXT batch, whose row pass rewrites the shared bitmap arena -- the scores
+    must be those of the one-batch run (and the oracle's on a sample), in any order of completion."""
+    from acoss_amd import synth, _lib
+    oracle = _oracle()
+    rng = np.random.default_rng(77)
+    lens = [int(v) for v in rng.integers(40, 700, 26)] + [150, 260, 520, 780]
+    tracks = [synth._frame_max_normalise(rng.random((T, 12))) for T in lens]
+    frames = np.concatenate(tracks).astype(np.float32)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    n = len(lens)
+    ctx.upload_pool(frames, offsets)
+    pairs = oracle.all_pairs(n, True).astype(np.int32)
+    pairs = pairs[rng.permutation(len(pairs))]
+    one = ctx.serra09_pairs(pairs)
+    two = ctx.chenfusion_pairs(pairs)
+    assert np.array_equal(two[:, 0], one)
+    ctx.set_scratch_limit(1 << 20)                          # the 435 pairs in ~10 batches
+    try:
+        for rep in range(3):
+            assert np.array_equal(ctx.serra09_pairs(pairs), one), rep
+            assert np.array_equal(ctx.chenfusion_pairs(pairs), two), rep
+    finally:
+        ctx.set_scratch_limit(0)
+    sample = pairs[:48]
+    assert np.array_equal(one[:48], oracle.serra09_pairs(frames, offsets, sample))
+    assert np.array_equal(two[:48, 1], oracle.serra09_pairs(frames, offsets, sample, oracle.serra09_params(dmax=True)))
+
+
 def test_error_behaviour(ctx):
     from acoss_amd import synth, _lib
     rng = np.random.default_rng(1)
