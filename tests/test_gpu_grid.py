@@ -340,7 +340,7 @@ def test_bench_strong_gloo_world_of_two():
     assert [r["rank"] for r in line["ranks"]] == [0, 1] and all(r["pci_bus_id"] for r in line["ranks"])
 
 
-def _bench_default(env_extra, nproc, extra_args=(), expect_rc=0):
+def _bench_default(env_extra, nproc, extra_args=(), expect_rc=0, with_other=False):
     """The driver's command (`bench.py --gpus N --steps K --warmup W`, weak scaling) as a child process on a small pool."""
     import json
     import os
@@ -348,7 +348,7 @@ def _bench_default(env_extra, nproc, extra_args=(), expect_rc=0):
     env.update(env_extra)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("ACX_BENCH_STRONG_TRACKS", "192")
-    args = ["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--tracks", "640", "--no-cpu", "--no-other"] + list(extra_args)
+    args = ["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--tracks", "640", "--no-cpu"] + ([] if with_other else ["--no-other"]) + list(extra_args)
     if nproc > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
@@ -381,9 +381,15 @@ def test_bench_default_line_proves_its_ranks_and_carries_the_real_exchange():
     assert line["ranks"][0]["pci_bus_id"] == line["ranks"][1]["pci_bus_id"]          # (development mode: the ranks share the box's GPU)
     s = line["strong"]
     assert len(s["kernels_s_per_rank"]) == 2 and s["check"]["matrix_equals_pair_list"], s
-    # one rank without a collective: still says which GPU it ran on, no strong leg
+    # one rank without a collective: still says which GPU it ran on; the profiler passes' form of the command (--no-other) has no sub-grid leg
     line = _bench_default({}, 1)
     assert line["strong"] is None and len(line["ranks"]) == 1 and line["ranks"][0]["pci_bus_id"]
+    # ... the full default run does: the whole (sub-)grid as one job, copy to the host, scatter + mirror, checked against the pair list
+    line = _bench_default({}, 1, with_other=True)
+    s = line["strong"]
+    assert line["collectives"] is None and s["exchange"] is None and s["tracks"] == 192 and s["pairs"] == 192 * 191 // 2
+    assert s["check"]["matrix_equals_pair_list"] and s["check"]["symmetric"] and s["value_incl_scatter"] > 0
+    assert set(line["other"]) >= {"serra09_covers", "simple", "earlyfusion"}
 
 
 def test_bench_refuses_ranks_that_share_a_gpu():
