@@ -239,6 +239,34 @@ def test_bench_starts_its_own_ranks():
     assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
 
 
+def test_bench_rank_identity_rule():
+    """bench.shared_device_reason: what ends an N > 1 run before any measurement.  RCCL worlds need one GPU per rank -- the same
+    (host, PCI bus id) twice, or a rank that cannot name its device, is refused with one line that names the ranks; different
+    hosts may repeat a bus id; the gloo development mode shares GPUs on purpose unless ACX_BENCH_REQUIRE_DISTINCT=1."""
+    sys.path.insert(0, ROOT)
+    import bench
+    def info(rank, host, bus):
+        return {"rank": rank, "local_rank": rank, "device_index": 0, "host": host, "pci_bus_id": bus, "name": "AMD Instinct MI355X",
+                "visible_devices": 1, "HIP_VISIBLE_DEVICES": str(rank), "error": None if bus else "RuntimeError: no device"}
+    eight = [info(r, "node0", "0000:%02x:00.0" % (0x10 + 0x10 * r)) for r in range(8)]
+    assert bench.shared_device_reason(eight, "nccl", 8) is None
+    two_hosts = [info(0, "node0", "0000:26:00.0"), info(1, "node1", "0000:26:00.0")]
+    assert bench.shared_device_reason(two_hosts, "nccl", 2) is None
+    shared = [info(0, "node0", "0000:26:00.0"), info(1, "node0", "0000:46:00.0"), info(2, "node0", "0000:26:00.0")]
+    why = bench.shared_device_reason(shared, "nccl", 3)
+    assert why and "ranks 0 and 2" in why and "0000:26:00.0" in why and "\n" not in why
+    assert bench.shared_device_reason(shared, "gloo", 3) is None
+    os.environ["ACX_BENCH_REQUIRE_DISTINCT"] = "1"
+    try:
+        assert "ranks 0 and 2" in bench.shared_device_reason(shared, "gloo", 3)
+    finally:
+        del os.environ["ACX_BENCH_REQUIRE_DISTINCT"]
+    nameless = [info(0, "node0", "0000:26:00.0"), info(1, "node0", None)]
+    why = bench.shared_device_reason(nameless, "nccl", 2)
+    assert why and "rank 1 cannot name its GPU" in why
+    assert bench.shared_device_reason(nameless[:1], "nccl", 1) is None          # a world of one has nothing to share
+
+
 def test_grid_plan_is_cost_balanced_on_ragged_lengths():
     """acx_grid_plan on ragged track lengths (cost ~ len_i * len_j varies 100 x): the dealt cost of
     the fullest rank is within 2 % of the mean; every pair belongs to exactly one tile."""
