@@ -181,8 +181,11 @@ def _dataset(wd, name, n, nworks):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("kind,sym", [("toy", True), ("toy", False), ("grid", True), ("grid", False), ("labels", True)])
-def test_two_ranks_equal_one(tmp_path, kind, sym):
+@pytest.mark.parametrize("kind,sym,ws", [("toy", True, 2), ("toy", False, 2), ("grid", True, 2), ("grid", False, 2), ("labels", True, 2),
+                                         ("grid", True, 8), ("grid", False, 3), ("toy", True, 3)])
+def test_two_ranks_equal_one(tmp_path, kind, sym, ws):
+    """(and three, and eight -- the node size the scaling bench runs at: the plan, the gather to rank 0 and the scatter with
+    ranks whose tile counts differ)"""
     import torch.multiprocessing as mp
     wd = str(tmp_path)
     _dataset(wd, "toy.csv", 11, 4)
@@ -200,10 +203,10 @@ def test_two_ranks_equal_one(tmp_path, kind, sym):
     for stale in ("results_t_Toy.csv", "results_g_Dev.csv", "results_l_Toy.csv"):
         if os.path.exists(os.path.join(wd, stale)):
             os.remove(os.path.join(wd, stale))
-    mp.spawn(_worker, args=(2, _free_port(), wd, sym, out, kind), nprocs=2, join=True)
+    mp.spawn(_worker, args=(ws, _free_port(), wd, sym, out, kind), nprocs=ws, join=True)
     D0 = np.load(os.path.join(out, "D_rank0.npy"))
     assert np.array_equal(D0, single), "rank 0 differs from the single-process result"
-    for r in range(2):
+    for r in range(ws):
         assert np.array_equal(np.load(os.path.join(out, "S_rank%d.npy" % r)), np.array(sstats[:4])), "statistics differ on rank %d" % r
     # rank 0 alone wrote the results file: one header, one row
     res = [f for f in os.listdir(wd) if f.startswith("results_")]
