@@ -653,7 +653,12 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         if (F16 && p % 3 == 2) return;
         unsigned short *dst = p < 3 ? as0 + buf * EFR_A + (p * EFR_ROWS) * EFB_LP
                             : (p < 6 ? as0 + buf * EFR_A + ((p - 3) * EFR_ROWS + 128) * EFB_LP : bs0 + buf * EFR_B + ((p - 6) * EFR_COLS) * EFB_LP);
+#ifdef ACX_EF_NO_LSTORE   /* ablation build (scripts/ab_build_acx.sh nolst -DACX_EF_NO_LSTORE; WRONG matrices): what the k loop costs without its ds_write pass --
+                             the ceiling of staging by LDS-DMA (global_load_lds_dwordx4), profiles/r05_ef.md (b) */
+        { const u32x4 keep_ = st[p]; unsigned short *const d_ = dst; asm volatile("" :: "v"(keep_), "v"(d_)); }
+#else
         *reinterpret_cast<u32x4 *>(dst) = st[p];
+#endif
     };
     auto for9 = [&](auto &&f) {
         f(std::integral_constant<int, 0>()); f(std::integral_constant<int, 1>()); f(std::integral_constant<int, 2>());
