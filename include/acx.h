@@ -525,7 +525,10 @@ int acx_dev_sync(acx_ctx *ctx);
 /* ---- measurement -------------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on the library's own stream around
- * every launch (bench.py's roofline leg).  Off by default. */
+ * every launch (bench.py's roofline leg).  Off by default.  While it is on, every
+ * kernel runs on that one stream: the Serra09 alignment sweeps, which otherwise run
+ * on a second stream beside the next band kernels, are timed alone, not beside
+ * another launch -- a call is a few percent slower with the clocks on than without. */
 int acx_profile_enable(acx_ctx *ctx, int on);
 int acx_profile_reset(acx_ctx *ctx);
 int acx_profile_count(const acx_ctx *ctx);
