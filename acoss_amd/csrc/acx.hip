@@ -757,11 +757,12 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
             // both == 0: Qmax or Dmax as p.dmax says; both == 1: out[2k] = Qmax, out[2k+1] = Dmax
             const bool eqg = p.gamma_o == p.gamma_e;
             // one launch per size class: a lane owns 8 / 8 / 16 / 16 / 32 columns of rows up to 249 / 505 / 761 / 1017 / 2041 cells
+            hipError_t wait_err = hipSuccess;            // (a failed cross-stream wait would let a sweep read an unfinished bitmap: reported, not ignored)
             auto sweep = [&](bool dmax, float *dst, hipStream_t qs) {
                 for (int cl = 0; cl <= NC; ++cl) {
                     const int b0 = cls_begin[cl], Bc = cls_begin[cl + 1] - b0;
                     if (Bc <= 0) continue;
-                    if (use_q) (void)hipStreamWaitEvent(qs, S.cls_ev[cl], 0);
+                    if (use_q) { const hipError_t e_ = hipStreamWaitEvent(qs, S.cls_ev[cl], 0); if (e_ != hipSuccess) wait_err = e_; }
                     ProfScope ps(c, KS_QMAX, cls_cells[cl], qs);      // (its first event stands behind the wait)
 #define ACX_QB3(E_, D_, C_) hipLaunchKernelGGL((acx::qmax_bits_kernel<E_, D_, C_>), dim3(Bc), dim3(64), 0, qs, \
                                                S.d_pd + b0, c->d_bits, dst + (size_t)b0 * w, w, p.gamma_o, p.gamma_e, p.dp_start)
@@ -798,6 +799,7 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
                 ACX_HIP(c, hipStreamWaitEvent(qs, c->q2_done, 0));
             } else if (both) { sweep(false, S.d_out, qs); sweep(true, S.d_out + 1, qs); }
             else sweep(p.dmax != 0, S.d_out, qs);
+            ACX_HIP(c, wait_err);
         }
         ACX_HIP(c, hipGetLastError());
         if (dd) {
