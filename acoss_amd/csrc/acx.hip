@@ -542,9 +542,55 @@ static __global__ void grid_pairs_kernel(const TileDev *__restrict__ tiles, int 
     }
 }
 
+// A call that fails half way must not leave work in flight behind its error code: every stream the chain uses is drained
+// (the next call's row pass writes the bitmap arena the old sweeps may still be reading) and no slot stays marked busy
+// with results nobody will collect.  The reference fails the whole chunk of pairs (algorithm_template.py:174-177); so does this.
+void quiesce(acx_ctx *c)
+{
+    (void)hipStreamSynchronize(c->stream);
+    if (c->qstream) (void)hipStreamSynchronize(c->qstream);
+    if (c->qstream2) (void)hipStreamSynchronize(c->qstream2);
+    for (Serra09Slot &sl : c->slot) sl.busy = false;
+    (void)hipGetLastError();
+    drain_profile(c);
+}
+
+// The WHOLE pair list is checked before the first launch: indices, tracks shorter than the stack, pairs that cannot fit the
+// scratch limit on their own.  (The batch loop below used to find these when it reached them -- with earlier batches in flight.)
+int validate_serra09_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params &p, bool dbg, int64_t limit_floats)
+{
+    const bool band_ok = p.m <= acx::MAX_M;
+    for (int64_t k = 0; k < K; ++k) {
+        const int qi = pairs[2 * k], ri = pairs[2 * k + 1];
+        if (qi < 0 || ri < 0 || qi >= c->n_tracks || ri >= c->n_tracks)
+            return fail(c, ACX_ERR_INVALID, "serra09: track index out of range in pair " + std::to_string(k));
+        const int Mq = embed_len((int)(c->h_off[qi + 1] - c->h_off[qi]), p), Mr = embed_len((int)(c->h_off[ri + 1] - c->h_off[ri]), p);
+        if (Mq <= 0 || Mr <= 0)
+            return fail(c, ACX_ERR_SHORT, "serra09: track shorter than the delay-embedding stack (pair " + std::to_string(k) + ")");
+        const bool is_long = !band_ok || (std::max(Mq, Mr) + acx::BAND - 1 + 63) / 64 > 32;
+        const int64_t pitchD = round_up(Mr, 64), pitchT = round_up(Mq, 64), nw = (Mr + acx::BAND - 1 + 63) / 64;
+        const int64_t needD = (dbg || is_long) ? (int64_t)Mq * pitchD : 0;
+        const int64_t needL = is_long ? (int64_t)Mr * pitchT + 8 * (int64_t)Mq : 0;
+        if (needD + needL + 2 * (int64_t)Mq * nw > limit_floats)
+            return fail(c, ACX_ERR_NOMEM, "serra09: pair " + std::to_string(k) + " does not fit the scratch limit");
+    }
+    return ACX_OK;
+}
+
+int run_serra09_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params &p_in, float *out,
+                     const DebugOut *dbg, bool both, const DevDst *dd);
+
 // Runs the chain over `K` pairs in scratch-sized batches.
 int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params &p_in, float *out,
                 const DebugOut *dbg, bool both = false, const DevDst *dd = nullptr)
+{
+    const int rc = run_serra09_impl(c, pairs, K, p_in, out, dbg, both, dd);
+    if (rc != ACX_OK) quiesce(c);                // (c->err keeps the first failure's text)
+    return rc;
+}
+
+int run_serra09_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_params &p_in, float *out,
+                     const DebugOut *dbg, bool both, const DevDst *dd)
 {
     if (!c->d_frames0) return fail(c, ACX_ERR_STATE, "serra09: feature pool not uploaded (acx_upload_pool)");
     if (c->dim != acx::NBIN) return fail(c, ACX_ERR_INVALID, "serra09: pool dim must be 12");
@@ -557,9 +603,11 @@ int run_serra09(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serra09_p
     const int64_t limit_floats = scratch_limit_bytes(c) / 4;
     const bool band_ok = p.m <= acx::MAX_M;      // larger stacks: every pair takes the long-track kernels
     const int w = both ? 2 : 1;
+    if ((rc = validate_serra09_pairs(c, pairs, K, p, dbg != nullptr, limit_floats)) != ACX_OK) return rc;
     for (int s = 0; s < 2; ++s) {
         if (!c->slot[s].done) ACX_HIP(c, hipEventCreateWithFlags(&c->slot[s].done, hipEventDisableTiming));
-        c->slot[s].busy = false;
+        // (a slot is never marked free without its work being waited for: a failed call drains the streams, quiesce())
+        if (c->slot[s].busy) { ACX_HIP(c, hipEventSynchronize(c->slot[s].done)); c->slot[s].busy = false; }
     }
 
     int64_t k0 = 0;
@@ -976,15 +1024,36 @@ void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_
 }
 }  // namespace
 
+static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, float *out, const EfDebug *dbg,
+                       const float *ext_matrix, int extM, int extN, const DevDst *dd);
+
 // `dd` (grid runs): the four scores of pair k go to dd->base[dd->idx[k] .. + 4) on the DEVICE instead of out[4 k ..].
 int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, float *out, const EfDebug *dbg,
            const float *ext_matrix, int extM, int extN, const DevDst *dd = nullptr)
+{
+    const int rc = run_ef_impl(c, pairs, K, p, out, dbg, ext_matrix, extM, extN, dd);
+    if (rc != ACX_OK) quiesce(c);                // nothing of a failed call stays in flight behind its error code
+    return rc;
+}
+
+static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, float *out, const EfDebug *dbg,
+                       const float *ext_matrix, int extM, int extN, const DevDst *dd)
 {
     using acx::EfPair;
     if (!ext_matrix && (!c->d_ef[0] || c->ef_open)) return fail(c, ACX_ERR_STATE, "earlyfusion: block-feature pool not uploaded (acx_ef_upload_pool)");
     if (!(p.kappa >= 0.0)) return fail(c, ACX_ERR_INVALID, "earlyfusion: kappa must be >= 0");
     if (p.K < 1) return fail(c, ACX_ERR_INVALID, "earlyfusion: K must be >= 1");
     ACX_HIP(c, hipSetDevice(c->device));
+    // the WHOLE pair list is checked before the first launch (indices, tracks without blocks): a bad pair behind the
+    // first batch fails the call before any batch has run, as the reference fails a chunk (algorithm_template.py:174-177)
+    if (!ext_matrix)
+        for (int64_t k = 0; k < K; ++k) {
+            const int32_t q = pairs[2 * k], r = pairs[2 * k + 1];
+            if (q < 0 || r < 0 || q >= c->ef_ntracks || r >= c->ef_ntracks)
+                return fail(c, ACX_ERR_INVALID, "earlyfusion: track index out of range in pair " + std::to_string(k));
+            if (c->h_efoff[q + 1] - c->h_efoff[q] < 1 || c->h_efoff[r + 1] - c->h_efoff[r] < 1)
+                return fail(c, ACX_ERR_SHORT, "earlyfusion: track without blocks (pair " + std::to_string(k) + ")");
+        }
     const double t_call = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     int64_t limit = c->scratch_limit;
     if (limit <= 0) {
@@ -1011,6 +1080,12 @@ int run_ef(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params &p, 
             if (c->h_efoff[q + 1] - c->h_efoff[q] > acx::EF_MAXNB || c->h_efoff[r + 1] - c->h_efoff[r] > acx::EF_MAXNB) bits_path = false;
         }
     const bool keep_f = !bits_path || (dbg && dbg->fused);
+    if (!ext_matrix)                              // (the last of the up-front checks: a pair that cannot fit the scratch limit on its own)
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t M = c->h_efoff[pairs[2 * k] + 1] - c->h_efoff[pairs[2 * k]], N = c->h_efoff[pairs[2 * k + 1] + 1] - c->h_efoff[pairs[2 * k + 1]];
+            if ((keep_f ? 4 : 3) * M * round_up((int)N, 64) + (keep_ct ? 3 * N * round_up((int)M, 64) : 0) > limit_floats)
+                return fail(c, ACX_ERR_NOMEM, "earlyfusion: pair " + std::to_string(k) + " does not fit the scratch limit");
+        }
     // Batches of EQUAL size: a list that needs 1.3 limits runs as 0.65 + 0.65, not 1.0 + 0.3 (the last kernels of a batch
     // run on a draining device; a small trailing batch pays that for little work -- a 128 x 128 grid tile of 400-block
     // tracks is 16 384 pairs = 31 GB of matrices)

@@ -9,7 +9,7 @@ RCCL, no host staging.  Rank 0 then scatters the tiles into the N x N matrices.
 import numpy as np
 
 __all__ = ["world", "bind_device", "barrier", "broadcast_object", "on_root", "any_rank", "shard_bounds", "gather_scores",
-           "gather_tiles", "gather_tiles_device", "exchange_kind"]
+           "gather_tiles", "gather_tiles_device", "exchange_kind", "exchange_in_use"]
 
 # The GPU this process works on (set by bind_device).  Under "nccl" EVERY collective needs a device:
 # torch picks torch.cuda.current_device() for dist.barrier() and for the tensors behind
@@ -146,6 +146,43 @@ def exchange_kind():
     return "allgather" if os.environ.get("ACX_GRID_EXCHANGE", "") == "allgather" else "gather"
 
 
+# The default exchange -- torch.distributed.gather into unbind() views of ONE tensor on rank 0 -- is grouped send / recv inside
+# ProcessGroupNCCL; whether a given torch / RCCL pair accepts it is found out ONCE per process group, on a few floats, before the
+# score buffers go through it: every rank sends (rank + 1) x 4, rank 0 checks what arrived, the verdict is agreed through
+# any_rank() (an all-reduce), and a gather that raised or returned the wrong values turns the exchange into the all-gather of
+# rounds 1-4 on EVERY rank.  (An exception out of argument checking is raised on all ranks alike: nobody is left inside it.)
+_GATHER_OK = {}
+
+
+def _gather_probe():
+    import torch
+    import torch.distributed as dist
+    rank, ws = world()
+    key = (dist.get_backend(), ws)
+    if key in _GATHER_OK:
+        return _GATHER_OK[key]
+    dev = _collective_device() if _is_nccl() else torch.device("cpu")
+    bad = False
+    try:
+        mine = torch.full((4,), float(rank + 1), dtype=torch.float32, device=dev)
+        out = torch.zeros(ws * 4, dtype=torch.float32, device=dev) if rank == 0 else None
+        dist.gather(mine, gather_list=list(out.view(ws, 4).unbind(0)) if rank == 0 else None, dst=0)
+        if rank == 0:
+            want = torch.arange(1, ws + 1, dtype=torch.float32).repeat_interleave(4)
+            bad = not torch.equal(out.cpu(), want)
+    except Exception:                                 # noqa: BLE001 -- any refusal means: use the other collective
+        bad = True
+    _GATHER_OK[key] = not any_rank(bad)
+    return _GATHER_OK[key]
+
+
+def exchange_in_use():
+    """The exchange gather_tiles_device performs in this process group: exchange_kind(), unless the probe of the gather failed."""
+    if single():
+        return exchange_kind()
+    return "gather" if exchange_kind() == "gather" and _gather_probe() else "allgather"
+
+
 def gather_tiles_device(local, stride):
     """The one exchange of the path on the DEVICE buffers (nccl = RCCL over xGMI): rank 0 gets a (world * stride,)
     float32 tensor on its GPU, rank r's buffer at r * stride; every other rank None.  `local`: this rank's `stride`
@@ -159,7 +196,7 @@ def gather_tiles_device(local, stride):
         return local
     nccl = dist.get_backend() == "nccl"
     loc = local if nccl else local.cpu()
-    if exchange_kind() == "allgather":
+    if exchange_in_use() == "allgather":
         out = torch.empty(ws * stride, dtype=torch.float32, device=loc.device)
         if nccl:
             dist.all_gather_into_tensor(out, loc)

@@ -464,8 +464,7 @@ def strong_core(ctx, params, lengths, tile, rank, world, local_rank, collective,
             for _ in range(warmup):                              # arena, code objects, clocks: the rank's first tile(s)
                 ctx.grid_run(spec, params, rank, local.data_ptr(), first=0, count=min(2, n_mine))
             # (acx_grid_run zeroes the slice it fills: the warm-up's scores are overwritten by the timed pass)
-    ctx.profile_enable(True)
-    ctx.profile_reset()
+    ctx.profile_enable(False)                                    # the product path: no per-kernel event clocks, sweeps on their own streams
     fence()
     clock.stamp("%s: timed region (whole grid of %d tracks) ..." % (label, n))
     t0 = time.perf_counter()
@@ -481,7 +480,6 @@ def strong_core(ctx, params, lengths, tile, rank, world, local_rank, collective,
     fence()
     elapsed = time.perf_counter() - t0
     clock.stamp("%s: timed region %.2f s (kernels %.2f s, exchange %.4f s)" % (label, elapsed, t_compute, t_gather))
-    prof = ctx.profile()
     # ---- the serial tail: rank 0 brings the gathered buffers to the host and scatters them into the matrix
     t_d2h = t_scatter = None
     check = None
@@ -524,10 +522,9 @@ def strong_core(ctx, params, lengths, tile, rank, world, local_rank, collective,
     if not collective:
         local.free()
     pairs = n * (n - 1) // 2
-    kname, kst = max(prof.items(), key=lambda kv: kv[1]["ms"])
     exchange = None
     if collective:
-        exchange = "%s over %s" % ("all_gather_into_tensor" if adist.exchange_kind() == "allgather" else "gather to rank 0 (torch.distributed.gather)",
+        exchange = "%s over %s" % ("all_gather_into_tensor" if adist.exchange_in_use() == "allgather" else "gather to rank 0 (torch.distributed.gather)",
                                    "RCCL, device to device" if backend == "nccl" else "gloo through host memory (development: ranks may share a GPU)")
     res = {"tracks": n, "pairs": pairs, "elapsed_s": elapsed, "spec_tile": int(spec.tile),
            "strong": {"tracks": n, "pairs": pairs, "value": round(pairs / elapsed, 1),
@@ -537,7 +534,7 @@ def strong_core(ctx, params, lengths, tile, rank, world, local_rank, collective,
                       "tiles": int(plan["n_tiles"]), "tile": int(spec.tile), "exchange": exchange,
                       "gather_ms": round(1e3 * t_gather, 3), "gather_bytes": int(world * stride * 4),
                       "gather_bytes_per_rank": int(stride * 4),
-                      "dominant_kernel": kname, "dominant_kernel_ms": round(kst["ms"], 1)}}
+                      "kernel_clocks": "off (the product path: alignment sweeps on their own streams beside the next band kernels)"}}
     if rank == 0:
         res["strong"].update({"d2h_s": round(t_d2h, 3), "scatter_mirror_s": round(t_scatter, 3),
                               "value_incl_scatter": round(pairs / (elapsed + t_d2h + t_scatter), 1), "check": check})
@@ -721,27 +718,27 @@ def main():
     params = _lib.serra09_params()
     slice_floats = max(sum(t.rows * t.cols for t in mine[k:k + TILES_PER_STEP]) for k in range(0, nslices * TILES_PER_STEP, TILES_PER_STEP))
     if collective:
+        from acoss_amd import dist as adist
+        adist.bind_device(local_rank)
         local = torch.zeros(slice_floats, dtype=torch.float32, device=dev)
-        gathered = torch.zeros(world * slice_floats, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
     else:
         local = ctx.dev_alloc(4 * slice_floats)
-        gathered = None
         ctx.dev_sync()
     pairs_per_step = []
 
-    def step(s):
+    def step(s, exchange=True):
         k, tiles = slice_of(s)
         # acx_grid_run writes tile t at d_scores + t.offset: rebase so that the slice starts at local[0]
         ctx.grid_run(spec, params, rank, local.data_ptr() - 4 * tiles[0].offset, first=k, count=TILES_PER_STEP)
-        if collective:                              # the one collective of the path, device to device
+        if collective and exchange:
+            # the one exchange of the path, the library's own (acoss_amd.dist.gather_tiles_device: what
+            # CoverAlgorithm.all_pairwise calls -- a gather to rank 0, device to device under RCCL; or the all-gather
+            # of rounds 1-4 under ACX_GRID_EXCHANGE=allgather / when the probe of the gather failed)
+            adist.gather_tiles_device(local, slice_floats)
             if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, local)
                 # the next step's kernels (libacx's own stream) overwrite `local`: the host waits for the collective
                 torch.cuda.current_stream().synchronize()
-            else:
-                outs = [torch.empty(slice_floats) for _ in range(world)]
-                dist.all_gather(outs, local.cpu())
         return sum((t.rows * (t.rows - 1)) // 2 if t.diagonal else t.rows * t.cols for t in tiles)
 
     def fence():
@@ -757,8 +754,10 @@ def main():
     with clock.phase("warmup"):
         for s in range(args.warmup):
             step(s)
-    ctx.profile_enable(True)
-    ctx.profile_reset()
+    # The timed region runs the PRODUCT path: the per-kernel event clocks stay off (with them on the library keeps its
+    # alignment sweeps on the band kernels' stream, acx.hip run_serra09).  The per-kernel figures of the roofline object
+    # come from a second pass over the same steps' tiles behind the timed region, clocks on (as bench_other.py's legs do).
+    ctx.profile_enable(False)
     fence()
     clock.stamp("timed region ...")
     t0 = time.perf_counter()
@@ -780,7 +779,17 @@ def main():
     else:
         total_pairs = my_pairs
     ranks_seen = dist.get_world_size() if collective else 1        # what the collective actually spanned
-    prof = ctx.profile()
+    with clock.phase("kernel_clock_pass"):
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        fence()
+        tk0 = time.perf_counter()
+        for s in range(args.warmup, args.warmup + args.steps):
+            step(s, exchange=False)
+        fence()
+        clocked_elapsed = time.perf_counter() - tk0
+        prof = ctx.profile()
+        ctx.profile_enable(False)
     my_kernels_s = sum(v["ms"] for v in prof.values()) / 1e3
     if collective:
         box = [None] * world
@@ -868,6 +877,12 @@ def main():
                                            "product) but sweep the matrix twice (column pass, row pass)"},
                     "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": algo_bytes,
                     "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+                    "kernel_clock_pass": {"what": "avg_launch_ms / kernels_ms_per_step: HIP events around every launch on the library's "
+                                                  "stream, taken in a SECOND pass over the same steps' tiles behind the timed region (the "
+                                                  "clocks serialise the alignment sweeps onto the band kernels' stream; the timed region "
+                                                  "runs without them, sweeps on two side streams: `value` is the product path)",
+                                          "ms_per_step": round(1e3 * clocked_elapsed / args.steps, 3),
+                                          "timed_region_ms_per_step": round(1e3 * elapsed / args.steps, 3)},
                     "chain": {"algorithmic_bytes_per_pair": bpp,
                               "achieved": round(value / world * bpp / 1e9, 1),
                               "frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 4)}}
@@ -879,6 +894,7 @@ def main():
         line = {
             "metric": "track-pairs/sec on N x N Serra09 Qmax (HPCP, T=2000)",
             "value": round(value, 1), "unit": "track-pairs/s", "n_gpus": world, "ranks_seen": ranks_seen, "collectives": (backend if collective else None),
+            "exchange": ((adist.exchange_in_use() + " (acoss_amd.dist.gather_tiles_device)") if collective else None),
             "rccl_version": rccl_version(collective, backend), "ranks": infos, "strong": strong, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -888,7 +904,7 @@ def main():
             "config": {"workload": "configs[2]: synthetic %d tracks x %d-frame HPCP (seed 1234), Serra09 Qmax "
                                    "(m=9, tau=1, kappa=0.095, OTI); the %d x %d pair grid in %d x %d tiles dealt to %d rank(s) "
                                    "by cost (acx_grid_plan); %d tiles = %d pairs per GPU per step, different tiles every "
-                                   "step; one all-gather of the tile scores per step"
+                                   "step; at N > 1 one exchange of the tile scores per step (the library's: gather to rank 0)"
                                    % (args.tracks, T_FRAMES, args.tracks, args.tracks, TILE, TILE, world, TILES_PER_STEP,
                                       int(pairs_per_step[0])),
                        "pairs_per_step": int(round(total_pairs / args.steps)), "frames_per_track": T_FRAMES,

@@ -352,3 +352,52 @@ def test_root_failure_reaches_every_rank(tmp_path):
     m1 = open(os.path.join(out, "rank1.txt")).read()
     assert m0 != "no exception" and m1 != "no exception", (m0, m1)
     assert m1.startswith("RuntimeError: rank 0 failed in a rank-0-only section"), m1
+
+
+def _worker_gather_refused(rank, ws, port, out, refuse):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=ws)
+    try:
+        from acoss_amd import dist as adist
+        real = dist.gather
+        if refuse == "raises":
+            def broken(*a, **k):
+                raise RuntimeError("this backend has no gather")
+            dist.gather = broken
+        elif refuse == "wrong":
+            def wrong(t, gather_list=None, dst=0, **k):          # arrives, but every buffer holds rank 0's values
+                real(t, gather_list=gather_list, dst=dst, **k)
+                if gather_list is not None:
+                    for g in gather_list[1:]:
+                        g.copy_(gather_list[0])
+            dist.gather = wrong
+        stride = 37
+        local = torch.arange(stride, dtype=torch.float32) + 1000.0 * rank
+        got = adist.gather_tiles_device(local, stride)
+        kind = adist.exchange_in_use()
+        ok = True
+        if rank == 0:
+            want = torch.cat([torch.arange(stride, dtype=torch.float32) + 1000.0 * r for r in range(ws)])
+            ok = torch.equal(got, want)
+        else:
+            ok = got is None
+        with open(os.path.join(out, "rank%d.txt" % rank), "w") as f:
+            f.write("%s %s" % (kind, ok))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("refuse,kind", [("no", "gather"), ("raises", "allgather"), ("wrong", "allgather")])
+def test_refused_gather_falls_back_to_allgather_on_every_rank(tmp_path, refuse, kind):
+    """The default exchange (torch.distributed.gather into views of one tensor) is probed once per process group on a few
+    floats; a gather that raises or delivers wrong values makes EVERY rank take the all-gather instead (agreed through an
+    all-reduce), and rank 0 still ends with every rank's buffer."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    mp.spawn(_worker_gather_refused, args=(3, _free_port(), out, refuse), nprocs=3, join=True)
+    for r in range(3):
+        assert open(os.path.join(out, "rank%d.txt" % r)).read() == "%s True" % kind
