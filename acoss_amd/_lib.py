@@ -32,9 +32,9 @@ EXPORTS = [
     "acx_set_ef_gemm", "acx_hip_versions",
     "acx_dev_alloc", "acx_dev_free", "acx_dev_read", "acx_dev_sync",
     "acx_comm_id", "acx_comm_init", "acx_comm_destroy", "acx_grid_allgather", "acx_pair_grid_ranks", "acx_set_ef_fuse",
-    "acx_device_info",
+    "acx_device_info", "acx_ef_debug_pairs",
 ]
-ABI_VERSION = 3           # include/acx.h ACX_ABI_VERSION this shim was written against
+ABI_VERSION = 4           # include/acx.h ACX_ABI_VERSION this shim was written against
 COMM_ID_BYTES = 128
 
 ALGO_SERRA09, ALGO_CHENFUSION, ALGO_SIMPLE, ALGO_EARLYFUSION = 0, 1, 2, 3
@@ -210,6 +210,7 @@ def load():
     L.acx_set_ef_fuse.argtypes = [vp, ctypes.c_int32]
     L.acx_earlyfusion_pairs.argtypes = [vp, ip, ctypes.c_int64, ep, fp]
     L.acx_ef_debug_pair.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ep, fp, fp, fp, ip]
+    L.acx_ef_debug_pairs.argtypes = [vp, ip, ctypes.c_int64, ep, ctypes.c_int64, fp, fp, fp, ip]
     L.acx_sw_binary.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, ctypes.c_int32, fp]
     L.acx_snf_fuse.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -574,6 +575,20 @@ class Context(object):
         p = EfParams(float(kappa), int(K))
         self._check(self._L.acx_ef_debug_pair(self._h, int(i), int(j), ctypes.byref(p), _fptr(csm), _fptr(fused),
                                               _fptr(sc), ctypes.byref(oti)))
+        return dict(csm=csm, fused=fused, scores=sc, oti=int(oti.value))
+
+    def ef_debug_pairs(self, pairs, which, kappa=0.1, K=10):
+        """Intermediates of pair `which` of a list that runs as ONE batch (the multi-pair rectangles of the product path)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        i, j = (int(v) for v in pairs[which])
+        M, N = int(self.ef_blocks[i]), int(self.ef_blocks[j])
+        csm = np.empty((3, M, N), np.float32)
+        fused = np.empty((M, N), np.float32)
+        sc = np.empty((len(pairs), 4), np.float32)
+        oti = ctypes.c_int32(0)
+        p = EfParams(float(kappa), int(K))
+        self._check(self._L.acx_ef_debug_pairs(self._h, pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(pairs), ctypes.byref(p),
+                                               int(which), _fptr(csm), _fptr(fused), _fptr(sc), ctypes.byref(oti)))
         return dict(csm=csm, fused=fused, scores=sc, oti=int(oti.value))
 
     def sw_binary(self, B):

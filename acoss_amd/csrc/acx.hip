@@ -888,7 +888,7 @@ int run_serra09_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serr
 // ---------------------------------------------------------------------------------------
 // EarlyFusion driver
 // ---------------------------------------------------------------------------------------
-struct EfDebug { float *csm, *fused; int32_t *oti; };
+struct EfDebug { float *csm, *fused; int32_t *oti; int64_t which = 0; };      // which: the pair of the (one-batch) list whose intermediates are wanted
 
 // pinned host staging + device copy of `n` score destinations idx[0 .. n)
 static int stage_idx(acx_ctx *c, const int64_t *idx, int64_t n)
@@ -1353,9 +1353,11 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
         ht[3] += now() - t_w;
         drain_profile(c);
         if (rc_next != ACX_OK) return rc_next;
+        if (dbg && !ext_matrix && k < K)
+            return fail(c, ACX_ERR_UNSUPPORTED, "ef_debug_pairs: the list does not fit one batch");
         if (dbg && B >= 1) {
             EfPair d;
-            ACX_HIP(c, hipMemcpy(&d, c->d_efpd, sizeof(EfPair), hipMemcpyDeviceToHost));
+            ACX_HIP(c, hipMemcpy(&d, c->d_efpd + (dbg->which - k0), sizeof(EfPair), hipMemcpyDeviceToHost));
             if (dbg->oti) *dbg->oti = d.oti;
             for (int sft = 0; sft < 3 && dbg->csm; ++sft)
                 ACX_HIP(c, hipMemcpy2D(dbg->csm + (size_t)sft * d.M * d.N, sizeof(float) * d.N,
@@ -2350,6 +2352,12 @@ int acx_earlyfusion_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, const acx
     if (!c) return ACX_ERR_INVALID;
     if (K < 0 || (K > 0 && (!pairs || !out)) || !params) return fail(c, ACX_ERR_INVALID, "earlyfusion_pairs: bad argument");
     if (K == 0) return ACX_OK;
+    // (indices are checked HERE, on the caller's list: the sorted copy below would name a pair by its sorted position)
+    for (int64_t k = 0; k < K; ++k)
+        if (pairs[2 * k] < 0 || pairs[2 * k + 1] < 0 || pairs[2 * k] >= c->ef_ntracks || pairs[2 * k + 1] >= c->ef_ntracks)
+            return fail(c, c->d_ef[0] && !c->ef_open ? ACX_ERR_INVALID : ACX_ERR_STATE,
+                        c->d_ef[0] && !c->ef_open ? "earlyfusion: track index out of range in pair " + std::to_string(k)
+                                                  : std::string("earlyfusion: block-feature pool not uploaded (acx_ef_upload_pool)"));
     // An arbitrary pair list is processed sorted by (first track, second track): pairs that share a track then fall
     // into the same rectangle of the GEMMs (shared operands) and neighbouring pairs read neighbouring memory.  A list
     // that is sorted already (a grid tile, np.triu_indices ...) goes through as it is.
@@ -2382,6 +2390,18 @@ int acx_ef_debug_pair(acx_ctx *c, int32_t i, int32_t j, const acx_ef_params *par
     EfDebug dbg{csm, fused, oti};
     int rc = run_ef(c, pr, 1, *params, sc, &dbg, nullptr, 0, 0);
     if (rc == ACX_OK && scores) for (int k = 0; k < 4; ++k) scores[k] = sc[k];
+    return rc;
+}
+
+int acx_ef_debug_pairs(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef_params *params, int64_t which,
+                       float *csm, float *fused, float *scores, int32_t *oti)
+{
+    if (!c) return ACX_ERR_INVALID;
+    if (!params || !pairs || K < 1 || which < 0 || which >= K) return fail(c, ACX_ERR_INVALID, "ef_debug_pairs: bad argument");
+    std::vector<float> sc((size_t)4 * K);
+    EfDebug dbg{csm, fused, oti, which};
+    const int rc = run_ef(c, pairs, K, *params, sc.data(), &dbg, nullptr, 0, 0);
+    if (rc == ACX_OK && scores) memcpy(scores, sc.data(), sizeof(float) * 4 * (size_t)K);
     return rc;
 }
 

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
 #endif
     f32x4 acc[NA][NB];
     float zero_ = 0.0f;
-    if (F16) asm volatile("v_mov_b32 %0, 0" : "=v"(zero_));     // (a register, not the inline constant: see band_kernel's note on this MFMA's destination)
+    if (F16) asm volatile("v_mov_b32 %0, 0" : "=v"(zero_));     // (a register, not the inline constant: band_kernel's note on this MFMA; scripts/isa_lint.py checks what the compiler made of the chain)
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll

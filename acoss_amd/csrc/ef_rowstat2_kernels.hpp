@@ -7,8 +7,8 @@
 // 32-63 the next, 16 values per lane; the two halves talk through LDS mailboxes; both order statistics of a row (rank K - 1 for
 // the neighbourhood mean, rank kappa N - 1 for the threshold) come out of ONE pivot-filtered histogram as the smallest / largest
 // cell of their bin (three or more cells around the rank: gathered and ranked inside the half).  Same values as the one-row
-// kernel's selection; the neighbourhood mean adds its <= K cells in another order (a half's tree instead of a wave's), i.e. it
-// may differ in the last bit -- as it does from numpy's own summation order.  A row this pass cannot decide (surplus ties at the
+// kernel's selection, and the neighbourhood mean adds its cells in the one-row kernels' order (two accumulators per lane, see
+// the kernel): bit-identical statistics whichever kernel a batch takes.  A row this pass cannot decide (surplus ties at the
 // threshold, too few cells below the pivot, a short row) is re-laid out through LDS and goes through ef_row_finish, the one-row
 // kernel's own code.
 #pragma once
@@ -317,18 +317,26 @@ __global__ __launch_bounds__(256, 6) void ef_rowstat2_kernel(const EfPair *__res
         ok = ef_pair_select2(x, kk - 1, kb - 1, mb_addr, lane, vk, t, lane_has_data, group_full, 0.15f);
     }
     // neighbourhood mean: the cells below the kk-th smallest + (kk - their number) times that value (mean_k_smallest)
+    // -- in the ORDER of the one-row kernels (mean_k_smallest + ef_wave_sum_f, rows of 8 or 16 values per lane of 64): a pair's
+    // score must not depend on which statistics kernel its batch takes (a batch with one row of more than 512 cells runs
+    // ef_rowstat_kernel<4> for ALL its pairs).  One-row lane l holds columns 4 l + e and 256 + 4 l + e -- this half's groups
+    // q = 0 and 2 -- and lane 32 + l the groups q = 1 and 3; the wave's tree is four steps inside every 16-lane row, then
+    // (r0 + r1) + (r2 + r3): the same four steps on both accumulators, then (A_r0 + A_r1) + (B_r0 + B_r1).
     float m;
     {
-        float acc = 0.0f;
+        float accA = 0.0f, accB = 0.0f;
         int cnt = 0;
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const bool lt = x[e] < vk;
-            acc += lt ? x[e] : 0.0f;
-            cnt += lt ? 1 : 0;
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool lt = x[4 * q + e] < vk;
+                if (q & 1) accB += lt ? x[4 * q + e] : 0.0f;
+                else accA += lt ? x[4 * q + e] : 0.0f;
+                cnt += lt ? 1 : 0;
+            }
         const int tot = half_sum_i(cnt);
-        const float ssum = half_sum_f(acc);
+        const float ssum = half_sum_f(accA) + half_sum_f(accB);
         m = (ssum + (float)(kk - tot) * vk) / (float)kk;
     }
     // cells at or below the threshold: exactly kb unless ties straddle it (then the row takes the one-row code)

@@ -1446,9 +1446,10 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4, ARITH)) vo
     auto gram = [&](const BvT &bv, AccT &acc, auto tb0_tag) {
         constexpr int tb0 = decltype(tb0_tag)::value;
         // (ARITH 1: the zero is opaque to the compiler, so that the first MFMA of a block takes its accumulator from REGISTERS and
-        // writes them back -- with the constant 0 as srcC the destination is a fresh allocation that may land on the dying column
-        // operand, and v_mfma_f32_16x16x32_f16 then returns garbage: scripts/ubench/mfma_f16_probe.hip before its operands were
-        // kept alive)
+        // writes them back.  Round 4 put this in after garbage out of a destination allocated over the dying column operand; round 6
+        // measured that the overlap itself is harmless (scripts/ubench/mfma_overlap_probe.hip) and that what bites is a consumer of
+        // the result earlier than 5 / 7 wait states (mfma_waitstate_probe.hip) -- scripts/isa_lint.py now checks the shipped code
+        // for that; the line stays: it costs nothing and the bits of the default build are pinned by it)
         float zero = 0.0f;
         if constexpr (ARITH != 0) asm volatile("" : "+v"(zero));
 #pragma unroll
@@ -1467,11 +1468,13 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4, ARITH)) vo
             // f16x2: slots 0-7 on one v_mfma_f32_16x16x32_f16, slot 8 (h1(b2) of the column frame = the low half of its second
             // dword, h2(b2) of the row frame) on a second one whose other slots are zero: 2 x 16 cycles of the f16 matrix pipe --
             // which runs BESIDE other waves' VALU work -- instead of 3 x 32 cycles of f32 MFMAs that block the SIMD.
-            // (Measured on the way, scripts/ubench/mfma_f16_probe.hip and the mid / wide classes of this kernel: the K = 16
-            // instruction v_mfma_f32_16x16x16_f16 chained behind the K = 32 one gave garbage in kernels with more than one
-            // tile per wave although the operands were right -- the same loads through f32 MFMAs are exact --, and a K = 32
-            // instruction whose destination is allocated over its SECOND source operand returns that operand's bits.  Hence:
-            // one opcode only, and the row operands stay alive to the end of the sweep.)
+            // (Round 4, scripts/ubench/mfma_f16_probe.hip and the mid / wide classes of this kernel: the K = 16 instruction
+            // v_mfma_f32_16x16x16_f16 chained behind the K = 32 one gave garbage in kernels with more than one tile per wave
+            // although the operands were right.  Round 6, scripts/ubench/mfma_waitstate_probe.hip: another 16-bit MFMA shape may
+            // take the K = 32 result as srcC only after 5 wait states (the SAME opcode accumulates back to back), VALU and
+            // srcA / srcB readers after 7 -- an earlier consumer sees the destination's stale registers, which is what "returns
+            // the operand's bits" was.  One opcode per chain needs no wait at all; scripts/isa_lint.py holds every shipped
+            // K = 32 MFMA to the measured distances.)
 #pragma unroll
             for (int ta = 0; ta < G::NRT; ++ta)
 #pragma unroll

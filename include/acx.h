@@ -30,7 +30,7 @@ extern "C" {
  *              (since the round-3 library, which still said 1).  The ctypes shim refuses a library of another version. */
 /* 3 (round 5): + acx_device_info; acx_pair_grid_ranks carries a per-rank status through its exchanges (a failing rank fails the call
  *              on every rank instead of leaving the others in the all-gather); ACX_RCCL_LIB, when set, is the only librccl tried. */
-#define ACX_ABI_VERSION 3
+#define ACX_ABI_VERSION 4
 
 enum {
     ACX_OK = 0,
@@ -369,6 +369,14 @@ int acx_set_ef_fuse(acx_ctx *ctx, int32_t mode);
 /* One pair with intermediates (tests): csm (3, M, N), fused (M, N), scores (4); any may be NULL. */
 int acx_ef_debug_pair(acx_ctx *ctx, int32_t i, int32_t j, const acx_ef_params *params,
                       float *csm, float *fused, float *scores, int32_t *oti);
+
+/* The same intermediates for pair `which` of a LIST of K pairs that runs as ONE batch (tests, ABI 4): the list goes through the
+ * rectangle GEMM the way acx_earlyfusion_pairs sends it -- many pairs per workgroup tile, shared operands, sub-tiles dropped
+ * into their own pairs' matrices -- so that a cell of a multi-pair rectangle can be held against an f64 product, not only the
+ * one-pair rectangle of acx_ef_debug_pair.  scores: (K, 4), all pairs.  A list that needs more than one batch (65 535 pairs or
+ * the scratch limit): ACX_ERR_UNSUPPORTED. */
+int acx_ef_debug_pairs(acx_ctx *ctx, const int32_t *pairs, int64_t K, const acx_ef_params *params, int64_t which,
+                       float *csm, float *fused, float *scores, int32_t *oti);
 
 /* csm_to_binary(D, kappa) (cross_recurrence.py:136-161: exactly k = round(kappa N) cells per row;
  * ties at the k-th value are taken in column order) followed by smith_waterman_constrained, for

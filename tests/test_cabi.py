@@ -23,7 +23,7 @@ def test_header_and_library_agree():
     for s in declared:
         assert hasattr(L, s), "libacx.so does not export %s" % s
     assert sorted(_lib.EXPORTS) == declared
-    assert L.acx_abi_version() == _lib.ABI_VERSION == 3
+    assert L.acx_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_default_params_match_reference_ctor():

@@ -432,7 +432,8 @@ def test_f16x2_gemm_mode(ctx):
         got = [ctx.earlyfusion_pairs(pr) for pr in lists]
         for g, w in zip(got, want):
             same = np.all(g == w, axis=1)
-            assert same.mean() >= 0.95, same.mean()
+            print("f16x2 vs bf16x3: pairs with all four scores identical: %.4f of %d, max |d| %.1f" % (same.mean(), len(g), np.max(np.abs(g - w))))
+            assert same.mean() >= 0.99, same.mean()
             assert np.max(np.abs(g - w)) <= 3.0
         # the pool scaled by powers of two: distances scale exactly, thresholds are ranks -> the mode's own scores again
         # (mfccs / ssms planes; chroma rows are normalised anyway)
@@ -451,6 +452,90 @@ def test_f16x2_gemm_mode(ctx):
         assert np.array_equal(pw[:, :2], want[0][:, :2])
     finally:
         ctx.set_ef_gemm("default")
+
+
+def test_every_gemm_instantiation_per_cell_in_multi_pair_rectangles(ctx):
+    """Every instantiation of ef_gemm_rect_bf16x3_kernel<CH, F16> (mfcc / ssm and chroma, three bf16 terms and two fp16 terms)
+    on rectangles that hold MANY pairs -- the product path's tiles: operands shared between the pairs of a track, sub-tiles
+    dropped into their own pair's matrix, track ends inside a workgroup tile -- cell by cell against f64 products, and bit for bit
+    against the one-pair rectangle of acx_ef_debug_pair.  (The fp16 / bf16 K = 32 MFMA returns garbage when its destination
+    registers overlap a dying source operand, tests/test_isa_lint.py: whether the compiler allocates that way depends on the
+    instantiation and on what surrounds the k loop, so each one is checked through the launch the product takes.)"""
+    rng = np.random.default_rng(61)
+    nbs = [1, 15, 16, 17, 33, 128, 129, 300, 47, 250, 64, 96] + [int(v) for v in rng.integers(20, 140, 12)]
+
+    def track(nb):
+        mf = rng.standard_normal((nb, 650)).astype(np.float32)
+        mf[:, :3] *= 30.0
+        ch = rng.random((nb, 480)).astype(np.float32) ** 3
+        return dict(mfccs=mf, ssms=(2 * rng.random((nb, 1225))).astype(np.float32), chromas=ch, chroma_med=rng.random(12) ** 2)
+    tracks = [track(nb) for nb in nbs]
+    n = len(tracks)
+    iu, ju = np.triu_indices(n, 1)
+    pairs = np.ascontiguousarray(np.stack([iu, ju], 1), np.int32)                    # 276 pairs: one rectangle of 24 x 24 tracks
+    pairs = np.concatenate([pairs, pairs[::7, ::-1]]).astype(np.int32)              # + some in the other orientation: a second rectangle
+    index_of = {(int(i), int(j)): k for k, (i, j) in enumerate(pairs)}
+    probes = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6), (6, 7), (7, 9), (8, 9), (4, 10), (10, 11), (0, 7), (12, 20), (15, 23), (7, 0)]
+    probes = [pq for pq in probes if pq in index_of]
+    assert len(probes) >= 13
+    try:
+        ctx.ef_upload_pool(tracks)
+        for mode in ("bf16x3", "f16x2"):
+            ctx.set_ef_gemm(mode)
+            listed = ctx.earlyfusion_pairs(pairs)
+            for (i, j) in probes:
+                d = ctx.ef_debug_pairs(pairs, index_of[(i, j)])
+                one = ctx.ef_debug_pair(i, j)
+                assert np.array_equal(d["scores"], listed), (mode, i, j)
+                assert d["oti"] == one["oti"]
+                assert np.array_equal(d["csm"], one["csm"]), (mode, i, j, "multi-pair rectangle != one-pair rectangle")
+                for k, s_ in enumerate(("mfccs", "ssms")):
+                    x64, y64 = tracks[i][s_].astype(np.float64), tracks[j][s_].astype(np.float64)
+                    scale = float(np.sum(x64 ** 2, 1).max() + np.sum(y64 ** 2, 1).max())
+                    true2 = np.maximum(0, np.sum(x64 ** 2, 1)[:, None] + np.sum(y64 ** 2, 1)[None, :] - 2 * x64.dot(y64.T))
+                    err = float(np.max(np.abs(d["csm"][k].astype(np.float64) ** 2 - true2))) / scale
+                    assert err <= 4e-6, (mode, s_, i, j, err)
+                X = tracks[i]["chromas"].astype(np.float64)
+                Y = tracks[j]["chromas"].astype(np.float64)
+                X = np.roll(X.reshape(len(X), 40, 12), d["oti"], axis=2).reshape(len(X), 480)
+                X /= np.linalg.norm(X, axis=1, keepdims=True)
+                Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+                e2 = float(np.max(np.abs(d["csm"][2] - (1.0 - X @ Y.T))))
+                assert e2 <= 2e-6, (mode, "chromas", i, j, e2)
+    finally:
+        ctx.set_ef_gemm("default")
+
+
+def test_batching_is_invisible_on_mixed_row_lengths(ctx):
+    """ADVICE r05: which row-statistics kernel a batch takes is decided by its LONGEST row (<= 512 cells: two rows per wave;
+    beyond: the one-row kernels for every pair of the batch) -- a pair's scores must not depend on what shares its batch.  A pool
+    that mixes tracks of <= 512 and > 512 blocks: the short pairs alone, the same pairs in a list with long ones, one pair per
+    batch, and the grid."""
+    from acoss_amd import synth, _lib
+    tracks = synth.earlyfusion_set(10, seed=31, nb_range=(200, 500)) + synth.earlyfusion_set(2, seed=32, nb_range=(520, 700))
+    rng = np.random.default_rng(8)
+    for key in ("mfccs", "ssms", "chromas"):                     # shared structure: alignments, thresholds that matter
+        for a, b in ((0, 1), (2, 10), (3, 4)):
+            m = 120
+            tracks[b][key][40:40 + m] = tracks[a][key][60:60 + m] + 0.02 * rng.standard_normal((m, tracks[a][key].shape[1])).astype(np.float32)
+    ctx.ef_upload_pool(tracks)
+    n = len(tracks)
+    iu, ju = np.triu_indices(n, 1)
+    allp = np.ascontiguousarray(np.stack([iu, ju], 1), np.int32)
+    short = allp[(allp[:, 0] < 10) & (allp[:, 1] < 10)]
+    alone = ctx.earlyfusion_pairs(short)                         # every row <= 512: the two-row kernel
+    mixed = ctx.earlyfusion_pairs(allp)                          # one batch with rows of > 512 cells: the one-row kernels
+    sel = (allp[:, 0] < 10) & (allp[:, 1] < 10)
+    assert np.array_equal(mixed[sel], alone)
+    ctx.set_scratch_limit(4 * 700 * 704 * 4 * 2)                 # a pair or two per batch
+    try:
+        assert np.array_equal(ctx.earlyfusion_pairs(allp), mixed)
+    finally:
+        ctx.set_scratch_limit(0)
+    planes = [np.zeros((n, n), np.float32) for _ in range(4)]
+    ctx.pair_grid(_lib.ALGO_EARLYFUSION, True, _lib.EfParams(0.1, 10), planes, mirror=False)
+    for e in range(4):
+        assert np.array_equal(planes[e][allp[:, 0], allp[:, 1]], mixed[:, e]), e
 
 
 def test_epilogue_sqrt(ctx):

@@ -65,7 +65,7 @@ def test_serra09_failure_behind_the_first_batches(ctx):
     try:
         ctx.profile_enable(True)
         ctx.profile_reset()
-        with pytest.raises(_lib.AcxError, match="pair 70000 does not fit"):
+        with pytest.raises(MemoryError, match="pair 70000 does not fit"):       # (ACX_ERR_NOMEM)
             ctx.serra09_pairs(bad)
         assert _launches(ctx) == 0
         ctx.profile_enable(False)

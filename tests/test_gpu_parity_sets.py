@@ -161,8 +161,8 @@ def _oracle_pool(fn, tracks, pairs, workers=None):
 
 # ---- EarlyFusion ------------------------------------------------------------------------------------
 
-def _cover_set_parity(ctx, n_works, key, pure_ratio):
-    tol = EF_TOL_LARGE if pure_ratio else EF_TOL
+def _cover_set_parity(ctx, n_works, key, pure_ratio, mid=False):
+    tol = EF_TOL_LARGE if (pure_ratio or mid) else EF_TOL
     import oracle
     from acoss_amd import synth, _lib
     tracks, labels = synth.earlyfusion_cover_set(n_works=n_works, versions=5, seed=2024, nb_range=(60, 100), noise=4.0)
@@ -226,7 +226,9 @@ def _cover_set_parity(ctx, n_works, key, pure_ratio):
             moved_hip = r[hk]["n"] - r[hk]["0"]
             # (round 5: on the 1500-track set a PURE ratio, no additive slack; on the 500-track set, where the counts are a few dozen,
             #  half again what the reference moves + two standard deviations of such a count + 2 pairs)
-            bar = EF_MOVED_RATIO_LARGE * moved_ref if pure_ratio else 1.5 * moved_ref + 2.0 * np.sqrt(moved_ref) + EF_MOVED_SLACK
+            # (round 6, the 600-track set the driver's suite runs: the large set's ratio + two standard deviations of the count + 2 pairs)
+            bar = EF_MOVED_RATIO_LARGE * moved_ref if pure_ratio else \
+                ((EF_MOVED_RATIO_LARGE if mid else 1.5) * moved_ref + 2.0 * np.sqrt(moved_ref) + EF_MOVED_SLACK)
             assert moved_hip <= bar, (s, hk, moved_hip, moved_ref)
         # the arithmetics of the device (two fp16 terms / three bf16 terms / f32 MFMAs) against each other: ties only
         for h in (r["hip_vs_f32gemm"], r["bf16x3_vs_f32gemm"], r["hip_vs_bf16x3"]):
@@ -234,7 +236,11 @@ def _cover_set_parity(ctx, n_works, key, pure_ratio):
 
 
 def test_earlyfusion_cover_set_map(ctx):
-    _cover_set_parity(ctx, 100, "earlyfusion_cover500", pure_ratio=False)
+    """The precision contract of the three matrix-pipe arithmetics, in the suite the driver runs: 600 tracks / 120 works, 179 700
+    pairs x 4 planes against the oracle (and against the same chain on f64-evaluated matrices) -- |dMAP| <= 1e-4 (north_star),
+    >= 99.8 % of the scores identical, the device moving no more than 1.75 x what the reference's own f32 sgemm moves (+ 2 sigma
+    of such a count).  (Rounds 4-5: 500 tracks here; the 1500-track set below stays a builder-side run.)"""
+    _cover_set_parity(ctx, 120, "earlyfusion_cover600", pure_ratio=False, mid=True)
 
 
 @pytest.mark.skipif(not os.environ.get("ACX_EF_PARITY_LARGE"), reason="builder-side run (minutes of CPU oracle): ACX_EF_PARITY_LARGE=1")
