@@ -25,6 +25,7 @@
 #include "simple_kernels.hpp"
 #include "ef_kernels.hpp"
 #include "ef_rowstat2_kernels.hpp"
+#include "ef_gemm_persist_kernels.hpp"
 #include "ef_prep_kernels.hpp"
 #include "grid.hpp"
 
@@ -128,6 +129,8 @@ struct acx_ctx {
     acx::EfSegWg *d_segw2 = nullptr;   size_t segw2_cap = 0;
     acx::EfSegWg *d_segw3 = nullptr;   size_t segw3_cap = 0;
     bool ef_rect_attr = false;
+    unsigned *d_efctr = nullptr;                       // tile counters of the persistent rectangle GEMMs (one per launch of a batch)
+    int n_cu = 0;
     int ef_split_fmt = 0;                             // what d_efs holds: 0 three bf16 terms, 1 two fp16 terms of x / d_efsc[row]
     float *d_efsc[3] = {nullptr, nullptr, nullptr};   // fmt 1: the power-of-two scale of every pool row (ef_rowscale_kernel)
     // scratch (grow-only)
@@ -1233,14 +1236,37 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
                             ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_bf16x3_kernel<1, 1>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_persist_kernel<0, 0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_persist_kernel<1, 0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_persist_kernel<0, 1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_persist_kernel<1, 1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipMalloc((void **)&c->d_efctr, 2 * sizeof(unsigned)));
                             c->ef_rect_attr = true;
                         }
+                        // round 6: ONE workgroup per CU walks the tiles (ef_gemm_persist_kernels.hpp); ACX_EF_PERSIST=0: one workgroup per tile
+                        const bool f16_ = c->ef_gemm == ACX_EF_GEMM_F16X2;
+                        static const bool persist = [] { const char *e = getenv("ACX_EF_PERSIST"); return !(e && e[0] == '0'); }();
+                        const auto pers_eucl = f16_ ? &acx::ef_gemm_rect_persist_kernel<0, 1> : &acx::ef_gemm_rect_persist_kernel<0, 0>;
+                        const auto pers_chroma = f16_ ? &acx::ef_gemm_rect_persist_kernel<1, 1> : &acx::ef_gemm_rect_persist_kernel<1, 0>;
+                        const int ncu = std::max(1, c->n_cu);
                         const bool f16 = c->ef_gemm == ACX_EF_GEMM_F16X2;
                         const auto rect_eucl = f16 ? &acx::ef_gemm_rect_bf16x3_kernel<0, 1> : &acx::ef_gemm_rect_bf16x3_kernel<0, 0>;
                         const auto rect_chroma = f16 ? &acx::ef_gemm_rect_bf16x3_kernel<1, 1> : &acx::ef_gemm_rect_bf16x3_kernel<1, 0>;
                         if (!seg.wgs2.empty()) {
                             if ((rc = ensure(c, c->d_segw2, c->segw2_cap, seg.wgs2.size())) != ACX_OK) return rc;
                             ACX_HIP(c, hipMemcpyAsync(c->d_segw2, seg.wgs2.data(), sizeof(acx::EfSegWg) * seg.wgs2.size(), hipMemcpyHostToDevice, c->stream));
+                            if (persist) {
+                                const int nt = (int)seg.wgs2.size();
+                                const unsigned grid = (unsigned)std::min<int64_t>(ncu, 2 * (int64_t)nt);
+                                ACX_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_efctr, (int)(2 * grid), 1, c->stream));
+                                hipLaunchKernelGGL(pers_eucl, dim3(grid), dim3(acx::EFR_THREADS), acx::EFR_LDS_BYTES, c->stream,
+                                                   c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd, c->d_rects, c->d_segw2, c->d_segr,
+                                                   c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1], c->d_efsc[0], c->d_efsc[1], nt, 2, c->d_efctr);
+                            } else
                             hipLaunchKernelGGL(rect_eucl,
                                                dim3((unsigned)seg.wgs2.size(), 1, 2), dim3(acx::EFR_THREADS),
                                                acx::EFR_LDS_BYTES, c->stream, c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd,
@@ -1253,6 +1279,15 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                             if (!seg.wgs3.empty()) {
                                 if ((rc = ensure(c, c->d_segw3, c->segw3_cap, seg.wgs3.size())) != ACX_OK) return rc;
                                 ACX_HIP(c, hipMemcpyAsync(c->d_segw3, seg.wgs3.data(), sizeof(acx::EfSegWg) * seg.wgs3.size(), hipMemcpyHostToDevice, c->stream));
+                                if (persist) {
+                                    const int nt = (int)seg.wgs3.size();
+                                    const unsigned grid = (unsigned)std::min(ncu, nt);
+                                    ACX_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(c->d_efctr + 1), (int)(2 * grid), 1, c->stream));
+                                    hipLaunchKernelGGL(pers_chroma, dim3(grid), dim3(acx::EFR_THREADS), acx::EFR_LDS_BYTES, c->stream,
+                                                       c->d_efs[2], c->d_efs[2], (const float *)nullptr, (const float *)nullptr, c->d_efpd, c->d_rects,
+                                                       c->d_segw3, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[2], c->ef_kp[2],
+                                                       c->d_efsc[2], c->d_efsc[2], nt, 1, c->d_efctr + 1);
+                                } else
                                 hipLaunchKernelGGL(rect_chroma,
                                                    dim3((unsigned)seg.wgs3.size(), 1, 1), dim3(acx::EFR_THREADS),
                                                    acx::EFR_LDS_BYTES, c->stream, c->d_efs[2], c->d_efs[2], (const float *)nullptr, (const float *)nullptr,
@@ -1467,6 +1502,7 @@ acx_ctx *acx_create(int device, int *err)
     acx_ctx *c = new acx_ctx();
     c->device = device;
     c->total_mem = prop.totalGlobalMem;
+    c->n_cu = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return bad(ACX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -1524,6 +1560,7 @@ void acx_destroy(acx_ctx *c)
     if (c->d_segw) (void)hipFree(c->d_segw);
     if (c->d_segw2) (void)hipFree(c->d_segw2);
     if (c->d_segw3) (void)hipFree(c->d_segw3);
+    if (c->d_efctr) (void)hipFree(c->d_efctr);
     if (c->qstream) (void)hipStreamDestroy(c->qstream);
     if (c->qstream2) (void)hipStreamDestroy(c->qstream2);
     if (c->q2_done) (void)hipEventDestroy(c->q2_done);

@@ -623,6 +623,9 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     auto gload_piece = [&](auto p_tag) {
         constexpr int p = decltype(p_tag)::value;
         if (F16 && p % 3 == 2) return;                 // (the third term does not exist)
+#ifdef ACX_EF_ABL_NOGLOAD      /* ... without its global loads (the staging registers keep what the prologue loaded), */
+        if (st[p].x != 0x12345u) return;
+#endif
         const unsigned short *src;
         if (p >= 6) src = bp;
         else if (!CH) src = p < 3 ? ap0 : ap1;
@@ -702,7 +705,11 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         constexpr int LASTP = F16 ? (P3 ? 8 : 11) : 18;                              // the slot of the chunk's barrier (behind its last staging piece and its last operand read)
         const unsigned short *a_ = aop + cur * EFR_A, *b_ = bop + cur * EFR_B;
         bf16x8 av[NA][3], bv[2][3];
+#ifdef ACX_EF_ABL_NOREAD       /* ... without the operand reads behind the chunk's first (all MFMAs on the prefetched registers) */
+        auto rdb = [&](int e, int b, int q) { bv[e][q] = bv[0][q]; (void)b; };
+#else
         auto rdb = [&](int e, int b, int q) { bv[e][q] = *reinterpret_cast<const bf16x8 *>(b_ + (q * EFR_COLS + 16 * b) * EFB_LP); };
+#endif
 #pragma unroll
         for (int a = 0; a < NA; ++a) { av[a][0] = pa0[a]; av[a][TP] = pa2[a]; }
         bv[0][TP] = pb2; bv[0][0] = pb0;
@@ -746,7 +753,9 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                     }
                 }
                 if (ST && slot == LASTP) {
+#ifndef ACX_EF_ABL_NOBARRIER   /* k-loop ablations (WRONG matrices; scripts/ab_build_acx.sh, profiles/r06_ef.md): the chunk without its barrier, */
                     __syncthreads();
+#endif
                     prefetch(cur ^ 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
