@@ -396,12 +396,15 @@ int ensure_f16pool(acx_ctx *c)
     if (total > 0) {
         unsigned *d_m = nullptr, h_m = 0u;
         ACX_HIP(c, hipMalloc((void **)&d_m, sizeof(unsigned)));
-        ACX_HIP(c, hipMemsetAsync(d_m, 0, sizeof(unsigned), c->stream));
-        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<int64_t>((total * acx::NBIN + 255) / 256, 4096)), dim3(256), 0, c->stream,
-                           c->d_frames, total * acx::NBIN, d_m);
-        ACX_HIP(c, hipMemcpyAsync(&h_m, d_m, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        ACX_HIP(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(d_m);
+        hipError_t em = hipMemsetAsync(d_m, 0, sizeof(unsigned), c->stream);
+        if (em == hipSuccess) {
+            hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<int64_t>((total * acx::NBIN + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                               c->d_frames, total * acx::NBIN, d_m);
+            em = hipMemcpyAsync(&h_m, d_m, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+        }
+        if (em == hipSuccess) em = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_m);                            // (on every path: a failed copy used to leak it)
+        ACX_HIP(c, em);
         float mx;
         memcpy(&mx, &h_m, sizeof(mx));
         if (!(mx >= 0.00390625f && mx <= 32768.0f))
@@ -1249,7 +1252,11 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                         }
                         // round 6: ONE workgroup per CU walks the tiles (ef_gemm_persist_kernels.hpp); ACX_EF_PERSIST=0: one workgroup per tile
                         const bool f16_ = c->ef_gemm == ACX_EF_GEMM_F16X2;
-                        static const bool persist = [] { const char *e = getenv("ACX_EF_PERSIST"); return !(e && e[0] == '0'); }();
+                        // (default: the two-term fp16 GEMMs, where it is 3.6 % of the GEMMs' time; the three-term bf16 build of the same
+                        //  kernel measures within noise of the one-tile kernel -- matrix pipe 0.69 busy either way -- and stays on that;
+                        //  ACX_EF_PERSIST=1 / 0 forces either for both)
+                        static const int persist_env = [] { const char *e = getenv("ACX_EF_PERSIST"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+                        const bool persist = persist_env < 0 ? f16_ : persist_env == 1;
                         const auto pers_eucl = f16_ ? &acx::ef_gemm_rect_persist_kernel<0, 1> : &acx::ef_gemm_rect_persist_kernel<0, 0>;
                         const auto pers_chroma = f16_ ? &acx::ef_gemm_rect_persist_kernel<1, 1> : &acx::ef_gemm_rect_persist_kernel<1, 0>;
                         const int ncu = std::max(1, c->n_cu);

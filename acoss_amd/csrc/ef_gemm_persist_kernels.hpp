@@ -260,6 +260,9 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             for (int g = 0; g < NG; ++g) {
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
+                    // (the builtins, not in-place inline asm: spelled out in place -- measured, profiles/r06_ef.md -- the f16x2 GEMMs take
+                    //  20.3-20.4 instead of 19.8 ms; the compiler's rotation of an accumulator through the MFMAs' destinations is not
+                    //  what the bf16x3 build of this kernel loses)
                     if (F16) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bv[b & 1][TB[g]]), __builtin_bit_cast(f16x8, av[a][TA[g]]), acc[a][b], 0, 0, 0);
                     else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[b & 1][TB[g]], av[a][TA[g]], acc[a][b], 0, 0, 0);
                 }
@@ -360,11 +363,19 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         // ---- epilogue of this tile.  First of all the next tile's first chunk goes on its way into the staging registers (dead since
         // the k loop's last loads) -- in front of this tile's stores in the memory pipeline, not behind them --, and one lane asks for
         // the index of the tile after next.
-        stage6(t_next);
-        if (nok) {
-            for9([&](auto p_tag) { gload_piece(p_tag); });
-            gload_advance();
-        }
+#ifndef ACX_EFP_GLOAD_UNIT
+#define ACX_EFP_GLOAD_UNIT (F16 ? -1 : 3)     /* bf16x3 (nine staging pieces, 36 registers): behind the epilogue's fourth unit, when half of the
+                                                 accumulators are dead -- at the head the kernel spills */
+#endif
+        constexpr int GLOAD_UNIT = ACX_EFP_GLOAD_UNIT;
+        auto next_chunk0 = [&]() {
+            stage6(t_next);
+            if (nok) {
+                for9([&](auto p_tag) { gload_piece(p_tag); });
+                gload_advance();
+            }
+        };
+        if (GLOAD_UNIT < 0) next_chunk0();
         if (tid == 0) pending = atomicAdd(counter, 1u);
         const float *nrm = s == 0 ? nrm0 : nrm1;
         const float *inv = (CH || s == 0) ? inv0 : inv1;
@@ -452,6 +463,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                         __builtin_nontemporal_store(w1, reinterpret_cast<f32x4 *>(cr + (int64_t)8 * cpitch[a][b]));
                     }
                 }
+                if (2 * a + b / 2 == GLOAD_UNIT) next_chunk0();
             }
         // hand the index of the tile after next round (wave 0 is done with its turning tile: word 0 is the mailbox)
         if (tid == 0) *mailbox = pending;

@@ -251,6 +251,9 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, ACX_SIMPLE_WAVES) void simple_kern
                     if (g == 0 && lane == L) nd = e;
                     dot = nd;
                     const double dist = (a2 + w) - 2.0 * dot;
+                    // (compare + two selects.  Round 6 measured the alternatives, profiles/r06_simple.md: fmin -- v_min_f64 behind two
+                    //  canonicalising v_max_f64 -- 16.85 instead of 15.75 ms per 262 k ordered pairs; a second copy of this loop for row
+                    //  group 0, to drop its per-step select from the other groups: 82 ms, the ring left the registers)
                     mn = dist < mn ? dist : mn;
                     if (more && lane == 63) E[b + eoff - 1] = dot;        // (slot of column b - 1, read above)
                 }
