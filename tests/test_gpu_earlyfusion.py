@@ -506,6 +506,56 @@ def test_every_gemm_instantiation_per_cell_in_multi_pair_rectangles(ctx):
         ctx.set_ef_gemm("default")
 
 
+def test_short_k_loops_of_small_feature_dims(ctx):
+    """Feature dimensions far below the reference's 650 / 1225 / 480: k loops of one to four 32-k chunks.  The persistent GEMM
+    (ef_gemm_persist_kernels.hpp) resolves its next tile behind the first four chunks of a k loop of at least seven; shorter loops take
+    the path that resolves it behind the loop -- no DA-TACOS-shaped set ever runs it.  Cells against f64 products, both 16-bit
+    arithmetics, many pairs per rectangle, several tiles per workgroup."""
+    rng = np.random.default_rng(77)
+    for dims in ((40, 100, 96), (20, 32, 96), (200, 230, 192)):
+        G = dims[2] // 12
+        nbs = [int(v) for v in rng.integers(20, 300, 14)] + [1, 16, 17]
+
+        def track(nb):
+            return dict(mfccs=rng.standard_normal((nb, dims[0])).astype(np.float32), ssms=(2 * rng.random((nb, dims[1]))).astype(np.float32),
+                        chromas=(rng.random((nb, dims[2])).astype(np.float32) ** 3 + 1e-3), chroma_med=rng.random(12) ** 2)
+        tracks = [track(nb) for nb in nbs]
+        n = len(tracks)
+        iu, ju = np.triu_indices(n, 1)
+        pairs = np.ascontiguousarray(np.stack([iu, ju], 1), np.int32)
+        try:
+            ctx.ef_upload_pool(tracks)
+            ref = None
+            for mode in ("f16x2", "bf16x3", "f32"):
+                ctx.set_ef_gemm(mode)
+                listed = ctx.earlyfusion_pairs(pairs)
+                if ref is None:
+                    ref = listed
+                else:                                           # (threshold ties may move a score between arithmetics)
+                    assert np.mean(np.all(listed == ref, axis=1)) >= 0.97 and np.max(np.abs(listed - ref)) <= 3.0, (dims, mode)
+                if mode == "f32":
+                    continue
+                for k in (0, 5, n + 3, len(pairs) - 1, len(pairs) // 2):
+                    i, j = (int(v) for v in pairs[k])
+                    d = ctx.ef_debug_pairs(pairs, k)
+                    assert np.array_equal(d["scores"], listed)
+                    for e, s_ in enumerate(("mfccs", "ssms")):
+                        x64, y64 = tracks[i][s_].astype(np.float64), tracks[j][s_].astype(np.float64)
+                        scale = float(np.sum(x64 ** 2, 1).max() + np.sum(y64 ** 2, 1).max())
+                        true2 = np.maximum(0, np.sum(x64 ** 2, 1)[:, None] + np.sum(y64 ** 2, 1)[None, :] - 2 * x64.dot(y64.T))
+                        err = float(np.max(np.abs(d["csm"][e].astype(np.float64) ** 2 - true2))) / scale
+                        assert err <= 4e-6, (dims, mode, s_, i, j, err)
+                    X = tracks[i]["chromas"].astype(np.float64)
+                    Y = tracks[j]["chromas"].astype(np.float64)
+                    X = np.roll(X.reshape(len(X), G, 12), d["oti"], axis=2).reshape(len(X), dims[2])
+                    X /= np.linalg.norm(X, axis=1, keepdims=True)
+                    Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+                    e2 = float(np.max(np.abs(d["csm"][2] - (1.0 - X @ Y.T))))
+                    assert e2 <= 2e-6, (dims, mode, "chromas", i, j, e2)
+        finally:
+            ctx.set_ef_gemm("default")
+
+
 def test_batching_is_invisible_on_mixed_row_lengths(ctx):
     """ADVICE r05: which row-statistics kernel a batch takes is decided by its LONGEST row (<= 512 cells: two rows per wave;
     beyond: the one-row kernels for every pair of the batch) -- a pair's scores must not depend on what shares its batch.  A pool
