@@ -1252,25 +1252,32 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
                             ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_dma_kernel<1>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_persist_dma_kernel<0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_persist_dma_kernel<1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
                             ACX_HIP(c, hipMalloc((void **)&c->d_efctr, 2 * sizeof(unsigned)));
                             c->ef_rect_attr = true;
                         }
-                        // round 6: ONE workgroup per CU walks the tiles (ef_gemm_persist_kernels.hpp); ACX_EF_PERSIST=0: one workgroup per tile
-                        const bool f16_ = c->ef_gemm == ACX_EF_GEMM_F16X2;
-                        // (default: the two-term fp16 GEMMs, where it is 3.6 % of the GEMMs' time; the three-term bf16 build of the same
-                        //  kernel measures within noise of the one-tile kernel -- matrix pipe 0.69 busy either way -- and stays on that;
-                        //  ACX_EF_PERSIST=1 / 0 forces either for both)
-                        static const int persist_env = [] { const char *e = getenv("ACX_EF_PERSIST"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
-                        // (experiment, profiles/r06_ef.md (b): the fp16 operands staged by LDS-DMA into three buffers, one workgroup per tile)
-                        static const bool dma_env = [] { const char *e = getenv("ACX_EF_DMA"); return e && e[0] == '1'; }();
-                        const bool use_dma = dma_env && f16_;
-                        const bool persist = !use_dma && (persist_env < 0 ? f16_ : persist_env == 1);
-                        const auto pers_eucl = f16_ ? &acx::ef_gemm_rect_persist_kernel<0, 1> : &acx::ef_gemm_rect_persist_kernel<0, 0>;
-                        const auto pers_chroma = f16_ ? &acx::ef_gemm_rect_persist_kernel<1, 1> : &acx::ef_gemm_rect_persist_kernel<1, 0>;
-                        const int ncu = std::max(1, c->n_cu);
+                        // Which kernel runs the three GEMMs (round 6, profiles/r06_ef.md):
+                        //   fp16 arithmetic (default):  ONE workgroup per CU walks the tiles, operands by LDS-DMA into three buffers
+                        //                               (ef_gemm_rect_persist_dma_kernel); ACX_EF_DMA=0: through the staging registers
+                        //                               (ef_gemm_rect_persist_kernel); ACX_EF_PERSIST=0: one workgroup per tile
+                        //   bf16x3:                     one workgroup per tile (the persistent build measures within noise of it: matrix
+                        //                               pipe 0.69 busy either way; its two operand buffers fill the LDS: no DMA variant);
+                        //                               ACX_EF_PERSIST=1: the persistent kernel
                         const bool f16 = c->ef_gemm == ACX_EF_GEMM_F16X2;
+                        static const int persist_env = [] { const char *e = getenv("ACX_EF_PERSIST"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+                        static const bool dma_env = [] { const char *e = getenv("ACX_EF_DMA"); return !(e && e[0] == '0'); }();
+                        const bool persist = persist_env < 0 ? f16 : persist_env == 1;
+                        const bool use_dma = dma_env && f16;
+                        const auto pers_eucl = use_dma ? &acx::ef_gemm_rect_persist_dma_kernel<0>
+                                               : (f16 ? &acx::ef_gemm_rect_persist_kernel<0, 1> : &acx::ef_gemm_rect_persist_kernel<0, 0>);
+                        const auto pers_chroma = use_dma ? &acx::ef_gemm_rect_persist_dma_kernel<1>
+                                                 : (f16 ? &acx::ef_gemm_rect_persist_kernel<1, 1> : &acx::ef_gemm_rect_persist_kernel<1, 0>);
                         const auto rect_eucl = use_dma ? &acx::ef_gemm_rect_dma_kernel<0> : (f16 ? &acx::ef_gemm_rect_bf16x3_kernel<0, 1> : &acx::ef_gemm_rect_bf16x3_kernel<0, 0>);
                         const auto rect_chroma = use_dma ? &acx::ef_gemm_rect_dma_kernel<1> : (f16 ? &acx::ef_gemm_rect_bf16x3_kernel<1, 1> : &acx::ef_gemm_rect_bf16x3_kernel<1, 0>);
+                        const int ncu = std::max(1, c->n_cu);
                         if (!seg.wgs2.empty()) {
                             if ((rc = ensure(c, c->d_segw2, c->segw2_cap, seg.wgs2.size())) != ACX_OK) return rc;
                             ACX_HIP(c, hipMemcpyAsync(c->d_segw2, seg.wgs2.data(), sizeof(acx::EfSegWg) * seg.wgs2.size(), hipMemcpyHostToDevice, c->stream));
