@@ -713,3 +713,48 @@ def test_exact_fuse_mode(ctx, golden):
     assert same >= 0.97 and np.max(np.abs(fast[:, 3] - exact[:, 3])) <= 2.0, (same, np.max(np.abs(fast[:, 3] - exact[:, 3])))
     with pytest.raises(ValueError):
         ctx.set_ef_fuse(7)
+
+
+_VARIANT_SNIPPET = r'''
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from acoss_amd import _lib, synth
+ctx = _lib.Context(0)
+tracks = synth.earlyfusion_set(40, seed=5, nb_range=(60, 330)) + synth.earlyfusion_set(2, seed=6, nb_range=(1, 17))
+ctx.ef_upload_pool(tracks)
+ctx.set_ef_gemm(%(mode)r)
+n = len(tracks)
+iu, ju = np.triu_indices(n, 1)
+pairs = np.ascontiguousarray(np.stack([iu, ju], 1), np.int32)
+rng = np.random.default_rng(1)
+extra = rng.integers(0, n, (500, 2)).astype(np.int32)
+out = np.concatenate([ctx.earlyfusion_pairs(pairs), ctx.earlyfusion_pairs(extra)])
+np.save(%(out)r, out)
+ctx.close()
+'''
+
+
+@pytest.mark.timeout(900)
+def test_gemm_kernel_variants_give_the_same_bits(tmp_path):
+    """The rectangle GEMMs exist as four kernels per arithmetic -- one workgroup per tile or a persistent workgroup per CU, operands through
+    the staging registers or (fp16 arithmetic) by LDS-DMA into three buffers -- chosen per process (ACX_EF_PERSIST, ACX_EF_DMA).  Same
+    tiles, same MFMAs in the same order: every variant must return the default's scores bit for bit, on a pair list that fills whole
+    grid rectangles, on random pairs (sparse rectangles, one pair per tile) and with tracks of 1-17 blocks (rims everywhere)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    results = {}
+    for mode, variants in (("f16x2", ({}, {"ACX_EF_DMA": "0"}, {"ACX_EF_PERSIST": "0"}, {"ACX_EF_PERSIST": "0", "ACX_EF_DMA": "0"})),
+                           ("bf16x3", ({}, {"ACX_EF_PERSIST": "1"}))):
+        for k, extra in enumerate(variants):
+            out = str(tmp_path / ("%s_%d.npy" % (mode, k)))
+            env = dict(os.environ)
+            env.pop("ACX_EF_DMA", None)
+            env.pop("ACX_EF_PERSIST", None)
+            env.update(extra)
+            subprocess.check_call([sys.executable, "-c", _VARIANT_SNIPPET % {"root": root, "mode": mode, "out": out}], env=env, timeout=300)
+            results[(mode, k)] = np.load(out)
+        for k in range(1, len(variants)):
+            assert np.array_equal(results[(mode, k)], results[(mode, 0)]), (mode, variants[k])
+    assert results[("f16x2", 0)].shape == results[("bf16x3", 0)].shape
