@@ -1252,6 +1252,10 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
                             ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_dma_kernel<1>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_dma2_kernel<0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_dma2_kernel<1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
                             ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_persist_dma_kernel<0>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
                             ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_persist_dma_kernel<1>),
@@ -1263,20 +1267,25 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                         //   fp16 arithmetic (default):  ONE workgroup per CU walks the tiles, operands by LDS-DMA into three buffers
                         //                               (ef_gemm_rect_persist_dma_kernel); ACX_EF_DMA=0: through the staging registers
                         //                               (ef_gemm_rect_persist_kernel); ACX_EF_PERSIST=0: one workgroup per tile
-                        //   bf16x3:                     one workgroup per tile (the persistent build measures within noise of it: matrix
-                        //                               pipe 0.69 busy either way; its two operand buffers fill the LDS: no DMA variant);
-                        //                               ACX_EF_PERSIST=1: the persistent kernel
+                        //   bf16x3:                     one workgroup per tile through the staging registers (round 5's kernel: the persistent
+                        //                               build and the DMA build -- two buffers -- both measure within noise of it, matrix
+                        //                               pipe 0.69 busy either way); ACX_EF_PERSIST=1 / ACX_EF_DMA=1: those builds
                         const bool f16 = c->ef_gemm == ACX_EF_GEMM_F16X2;
                         static const int persist_env = [] { const char *e = getenv("ACX_EF_PERSIST"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
-                        static const bool dma_env = [] { const char *e = getenv("ACX_EF_DMA"); return !(e && e[0] == '0'); }();
+                        static const int dma_env = [] { const char *e = getenv("ACX_EF_DMA"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
                         const bool persist = persist_env < 0 ? f16 : persist_env == 1;
-                        const bool use_dma = dma_env && f16;
+                        const bool use_dma = dma_env != 0 && f16;
                         const auto pers_eucl = use_dma ? &acx::ef_gemm_rect_persist_dma_kernel<0>
                                                : (f16 ? &acx::ef_gemm_rect_persist_kernel<0, 1> : &acx::ef_gemm_rect_persist_kernel<0, 0>);
                         const auto pers_chroma = use_dma ? &acx::ef_gemm_rect_persist_dma_kernel<1>
                                                  : (f16 ? &acx::ef_gemm_rect_persist_kernel<1, 1> : &acx::ef_gemm_rect_persist_kernel<1, 0>);
-                        const auto rect_eucl = use_dma ? &acx::ef_gemm_rect_dma_kernel<0> : (f16 ? &acx::ef_gemm_rect_bf16x3_kernel<0, 1> : &acx::ef_gemm_rect_bf16x3_kernel<0, 0>);
-                        const auto rect_chroma = use_dma ? &acx::ef_gemm_rect_dma_kernel<1> : (f16 ? &acx::ef_gemm_rect_bf16x3_kernel<1, 1> : &acx::ef_gemm_rect_bf16x3_kernel<1, 0>);
+                        // (bf16x3 by DMA into its two buffers, one workgroup per tile: only on request, ACX_EF_DMA=1 -- 31.5-31.7 against
+                        //  31.6 ms per 8128 pairs, profiles/r06_ef.md: that arithmetic runs at the matrix pipe's power budget)
+                        const bool use_dma2 = dma_env == 1 && !f16;
+                        const auto rect_eucl = use_dma ? &acx::ef_gemm_rect_dma_kernel<0> : (use_dma2 ? &acx::ef_gemm_rect_dma2_kernel<0>
+                                               : (f16 ? &acx::ef_gemm_rect_bf16x3_kernel<0, 1> : &acx::ef_gemm_rect_bf16x3_kernel<0, 0>));
+                        const auto rect_chroma = use_dma ? &acx::ef_gemm_rect_dma_kernel<1> : (use_dma2 ? &acx::ef_gemm_rect_dma2_kernel<1>
+                                                 : (f16 ? &acx::ef_gemm_rect_bf16x3_kernel<1, 1> : &acx::ef_gemm_rect_bf16x3_kernel<1, 0>));
                         const int ncu = std::max(1, c->n_cu);
                         if (!seg.wgs2.empty()) {
                             if ((rc = ensure(c, c->d_segw2, c->segw2_cap, seg.wgs2.size())) != ACX_OK) return rc;

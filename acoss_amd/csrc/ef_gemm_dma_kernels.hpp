@@ -321,6 +321,297 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
 }
 
 
+// ---- the three-term bf16 arithmetic (all 24 bits of every operand) by LDS-DMA: its two operand buffers are all the LDS there is (2 x 72 KB
+// + the turning tiles), so a chunk's nine pieces go into the buffer the PREVIOUS chunk was read from, behind that chunk's barrier -- one
+// chunk ahead instead of two; a bf16x3 chunk is 96 MFMAs per wave, twice the fp16 arithmetic's, and gives the DMA the same time to land.
+template <int CH>
+__global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ef_gemm_rect_dma2_kernel(
+    const unsigned short *__restrict__ split0, const unsigned short *__restrict__ split1, const float *__restrict__ nrm0,
+    const float *__restrict__ nrm1, const EfPair *__restrict__ pd, const EfSegRect *__restrict__ rects,
+    const EfSegWg *__restrict__ wgs, const EfSegGroup *__restrict__ rowg, const EfSegGroup *__restrict__ colg, const int32_t *__restrict__ pairtab,
+    float *__restrict__ scratch, int Kp0, int Kp1, const float *__restrict__ inv0, const float *__restrict__ inv1)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short efr_lds[];
+    unsigned short *As = efr_lds;                    // [buffer][term][row][32 k]
+    unsigned short *Bs = efr_lds + 2 * EFR_A;
+    const EfSegWg W = wgs[blockIdx.x];
+    const EfSegRect R = rects[W.rect];
+    const int ty = W.ty, tx = W.tx, ncg = W.pad;
+    const int s = CH ? 2 : (int)blockIdx.z;          // 0 mfcc, 1 ssm, 2 chroma
+    const int Kp = (CH || s == 0) ? Kp0 : Kp1;
+    const unsigned short *S = (CH || s == 0) ? split0 : split1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    constexpr int NA = 4, NB = 4, NT = 3;
+    const int gr0 = 16 * ty + NA * wr, gc0 = tx + NB * wc;
+    EfSegGroup GA[NA], GB[NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const bool in = gr0 + a < R.ng;
+        GA[a] = rowg[R.g0 + (in ? gr0 + a : 0)];
+        if (!in) GA[a].valid = 0;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const bool in = NB * wc + b < ncg;
+        GB[b] = colg[R.h0 + (in ? gc0 + b : tx)];
+        if (!in) GB[b].valid = 0;
+    }
+    int pidx[NA][NB];
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            int p = pairtab[R.ptab0 + GA[a].slot * R.ncols + GB[b].slot];
+            p = (GA[a].valid > 0 && GB[b].valid > 0) ? p : -1;
+            pidx[a][b] = __builtin_amdgcn_readfirstlane(p);
+            any = any || p >= 0;
+        }
+    f32x4 acc[NA][NB];
+    const float zero_ = 0.0f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{zero_, zero_, zero_, zero_};
+
+    // staging: lane 4 r + pos of a wave lands on position pos of row r of the wave's 16 rows; it fetches logical piece pos ^ swz(row)
+    const int srow = tid >> 2, pos = tid & 3;
+    const int sp = pos ^ ((0x78 >> (2 * ((srow >> 2) & 3))) & 3);
+    const int sg = wave, sr = srow & 15;
+    const int pieces = Kp / 8;
+    const unsigned short *ap0 = S, *ap1 = S, *bp = S + sp * 8;
+    int sp0 = sp, sp1 = sp;
+    {
+        int rslot = 0;
+        if (CH) rslot = colg[R.h0 + tx].slot;
+        auto roll_of = [&](const EfSegGroup &g) {
+            const int p = pairtab[R.ptab0 + g.slot * R.ncols + rslot];
+            int r = p >= 0 ? pd[p].oti : 0;
+            r = (sp - (pieces / 12) * r) % pieces;
+            return r < 0 ? r + pieces : r;
+        };
+        if (16 * ty + sg < R.ng) {
+            const EfSegGroup g = rowg[R.g0 + 16 * ty + sg];
+            if (sr < g.valid) { ap0 = S + (g.poolrow + sr) * NT * Kp; if (CH) sp0 = roll_of(g); }
+        }
+        if (16 * ty + 8 + sg < R.ng) {
+            const EfSegGroup g = rowg[R.g0 + 16 * ty + 8 + sg];
+            if (sr < g.valid) { ap1 = S + (g.poolrow + sr) * NT * Kp; if (CH) sp1 = roll_of(g); }
+        }
+        if (sg < ncg) {
+            const EfSegGroup g = colg[R.h0 + tx + sg];
+            if (sr < g.valid) bp = S + (g.poolrow + sr) * NT * Kp + sp * 8;
+        }
+        if (!CH) { ap0 += sp * 8; ap1 += sp * 8; }
+    }
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef __attribute__((address_space(1))) const void gbl_void_t;
+    // piece j of a chunk: 0-2 the three terms of A rows tid / 4, 3-5 of A rows 128 + tid / 4, 6-8 of B rows tid / 4
+    auto dma_piece = [&](int buf, auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        constexpr int t = j % 3, which = j / 3;
+        const unsigned short *src;
+        if (which == 2) src = bp;
+        else if (!CH) src = which == 0 ? ap0 : ap1;
+        else {
+            const int q = which == 0 ? sp0 : sp1;
+            src = (which == 0 ? ap0 : ap1) + (32 * NT) * (q >> 2) + 8 * (q & 3);
+        }
+        src += t * EFB_BK;
+        unsigned short *dst = which == 2 ? Bs + buf * EFR_B + (t * EFR_COLS + 16 * wave) * EFB_LP
+                                         : As + buf * EFR_A + (t * EFR_ROWS + 128 * which + 16 * wave) * EFB_LP;
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)dst, 16, 0, 0);
+    };
+    auto dma_advance = [&]() {
+        bp += NT * EFB_BK;
+        if (!CH) { ap0 += NT * EFB_BK; ap1 += NT * EFB_BK; }
+        else {
+            sp0 += 4; sp0 = sp0 >= pieces ? sp0 - pieces : sp0;
+            sp1 += 4; sp1 = sp1 >= pieces ? sp1 - pieces : sp1;
+        }
+    };
+    auto for9 = [&](auto &&f) {
+        f(std::integral_constant<int, 0>()); f(std::integral_constant<int, 1>()); f(std::integral_constant<int, 2>());
+        f(std::integral_constant<int, 3>()); f(std::integral_constant<int, 4>()); f(std::integral_constant<int, 5>());
+        f(std::integral_constant<int, 6>()); f(std::integral_constant<int, 7>()); f(std::integral_constant<int, 8>());
+    };
+    const int lks = lk ^ ((0x78 >> (2 * ((lr >> 2) & 3))) & 3);
+    const unsigned short *aop = As + (64 * wr + lr) * EFB_LP + 8 * lks;
+    const unsigned short *bop = Bs + (64 * wc + lr) * EFB_LP + 8 * lks;
+
+    bf16x8 pa0[NA], pa2[NA], pb0, pb2;               // prefetched: terms 0 and 2 of the four row sub-tiles and of column sub-tile 0 of the next chunk
+    auto prefetch = [&](int buf) {
+        const unsigned short *a_ = aop + buf * EFR_A, *b_ = bop + buf * EFR_B;
+        pb2 = *reinterpret_cast<const bf16x8 *>(b_ + (2 * EFR_COLS) * EFB_LP);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) pa0[a] = *reinterpret_cast<const bf16x8 *>(a_ + (16 * a) * EFB_LP);
+        pb0 = *reinterpret_cast<const bf16x8 *>(b_);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) pa2[a] = *reinterpret_cast<const bf16x8 *>(a_ + (2 * EFR_ROWS + 16 * a) * EFB_LP);
+    };
+    // one chunk out of buffer `cur`; ST: a next chunk exists -- its nine pieces go by DMA into the OTHER buffer behind slots 1 .. 9 (every
+    // wave is past the previous chunk's barrier, i.e. past its last read of that buffer), the wave waits for them (vmcnt(0): nothing
+    // younger is in flight) before this chunk's barrier behind slot 18, and reads them behind it.  Products in
+    // ef_gemm_rect_bf16x3_kernel<CH, 0>'s order: x1 y3, x3 y1, x2 y2, x1 y2, x2 y1, x1 y1.
+    auto chunk_mma = [&](int cur, auto st_tag) {
+        constexpr bool ST = decltype(st_tag)::value;
+        constexpr int NG = 6;
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int LASTP = 18;
+        const unsigned short *a_ = aop + cur * EFR_A, *b_ = bop + cur * EFR_B;
+        bf16x8 av[NA][3], bv[2][3];
+        auto rdb = [&](int e, int b, int q) { bv[e][q] = *reinterpret_cast<const bf16x8 *>(b_ + (q * EFR_COLS + 16 * b) * EFB_LP); };
+#pragma unroll
+        for (int a = 0; a < NA; ++a) { av[a][0] = pa0[a]; av[a][2] = pa2[a]; }
+        bv[0][2] = pb2; bv[0][0] = pb0;
+        rdb(0, 0, 1);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) av[a][1] = *reinterpret_cast<const bf16x8 *>(a_ + (EFR_ROWS + 16 * a) * EFB_LP);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[b & 1][TB[g]], av[a][TA[g]], acc[a][b], 0, 0, 0);
+                if (g == 1 && b + 1 < NB) { rdb((b + 1) & 1, b + 1, 2); rdb((b + 1) & 1, b + 1, 0); rdb((b + 1) & 1, b + 1, 1); }
+                const int slot = NG * b + g;
+                if (ST && slot >= 1 && slot <= 9) {
+                    switch (slot - 1) {
+                    case 0: dma_piece(cur ^ 1, std::integral_constant<int, 0>()); break;
+                    case 1: dma_piece(cur ^ 1, std::integral_constant<int, 1>()); break;
+                    case 2: dma_piece(cur ^ 1, std::integral_constant<int, 2>()); break;
+                    case 3: dma_piece(cur ^ 1, std::integral_constant<int, 3>()); break;
+                    case 4: dma_piece(cur ^ 1, std::integral_constant<int, 4>()); break;
+                    case 5: dma_piece(cur ^ 1, std::integral_constant<int, 5>()); break;
+                    case 6: dma_piece(cur ^ 1, std::integral_constant<int, 6>()); break;
+                    case 7: dma_piece(cur ^ 1, std::integral_constant<int, 7>()); break;
+                    default: dma_piece(cur ^ 1, std::integral_constant<int, 8>()); break;
+                    }
+                }
+                if (ST && slot == LASTP) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    prefetch(cur ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ST) dma_advance();
+    };
+    auto chunk_idle = [&](int cur, auto st_tag) {
+        constexpr bool ST = decltype(st_tag)::value;
+        if (ST) {
+            for9([&](auto j_tag) { dma_piece(cur ^ 1, j_tag); });
+            dma_advance();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    const int nk = Kp / EFB_BK;
+    // prologue: chunk 0 into buffer 0, complete and visible before the first read (chunk 1 follows behind chunk 0's first MFMAs)
+    for9([&](auto j_tag) { dma_piece(0, j_tag); });
+    dma_advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto sweep = [&](auto &&chunk) {
+        int kc = 0;
+        for (; kc + 1 < nk; ++kc) chunk(kc & 1, std::true_type());
+        chunk(kc & 1, std::false_type());
+    };
+    if (any) {
+        prefetch(0);
+        sweep(chunk_mma);
+    } else sweep(chunk_idle);
+
+    // ---- epilogue: ef_gemm_rect_bf16x3_kernel<CH, 0>'s
+    if (!any) return;
+    const float *nrm = s == 0 ? nrm0 : nrm1;
+    const int il = lr, jl = 4 * lk;
+    float nx[NA];
+    f32x4 ny[NB];
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    if (!CH) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) nx[a] = nrm[GA[a].poolrow + il];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) ny[b] = *reinterpret_cast<const f32x4u *>(nrm + GB[b].poolrow + jl);
+    }
+    int64_t cbase[NA][NB];
+    int cpitch[NA][NB], ctn[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const EfPair *P = pd + (pidx[a][b] < 0 ? 0 : pidx[a][b]);
+            const int pc = P->pitchC;
+            cbase[a][b] = P->offC + (int64_t)s * P->M * pc + (int64_t)GA[a].local0 * pc + GB[b].local0;
+            cpitch[a][b] = pc;
+            ctn[a][b] = P->ctN;
+        }
+    float *Tw = reinterpret_cast<float *>(efr_lds + 2 * (EFR_A + EFR_B)) + wave * (16 * EFR_TP);
+    auto value = [&](int a, int b, float (&v)[4]) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float dot = acc[a][b][reg];
+            if (CH) v[reg] = 1.0f - dot;
+            else {
+                float tq = (nx[a] + ny[b][reg]) - 2.0f * dot;
+                if (tq < 0.0f) tq = 0.0f;
+                v[reg] = ef_sqrt_nonneg(tq);
+            }
+        }
+    };
+    auto narrow = [&](int a, int b) {
+        if (pidx[a][b] < 0) return;
+        float v[4];
+        value(a, b, v);
+        float *cr = scratch + cbase[a][b] + (int64_t)il * cpitch[a][b] + jl;
+        if (GA[a].valid == 16 && GB[b].valid == 16) __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4 *>(cr));
+        else if (il < GA[a].valid) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (jl + reg < GB[b].valid) cr[reg] = v[reg];
+        }
+        if (ctn[a][b] && il < GA[a].valid) {
+            const EfPair P = pd[pidx[a][b]];
+            float *ct = scratch + ef_ct_off(P, s) + (size_t)(GB[b].local0 + jl) * P.pitchT + GA[a].local0 + il;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (jl + reg < GB[b].valid) ct[(size_t)reg * P.pitchT] = v[reg];
+        }
+    };
+    const int tr = lane >> 3, tc = 4 * (lane & 7);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; b += 2) {
+            const bool wide = pidx[a][b] >= 0 && pidx[a][b] == pidx[a][b + 1] && GA[a].valid == 16 && GB[b].valid == 16 &&
+                              GB[b + 1].valid == 16 && GB[b + 1].local0 == GB[b].local0 + 16 && !ctn[a][b];
+            if (!wide) { narrow(a, b); narrow(a, b + 1); continue; }
+            float v0[4], v1[4];
+            value(a, b, v0);
+            value(a, b + 1, v1);
+            const int wz = (il >> 1) & 7;
+            *reinterpret_cast<float4 *>(Tw + il * EFR_TP + 4 * (lk ^ wz)) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+            *reinterpret_cast<float4 *>(Tw + il * EFR_TP + 4 * ((4 + lk) ^ wz)) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(Tw + tr * EFR_TP + 4 * ((lane & 7) ^ ((tr >> 1) & 7)));
+            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(Tw + (8 + tr) * EFR_TP + 4 * ((lane & 7) ^ (((8 + tr) >> 1) & 7)));
+            float *cr = scratch + cbase[a][b] + (int64_t)tr * cpitch[a][b] + tc;
+            __builtin_nontemporal_store(w0, reinterpret_cast<f32x4 *>(cr));
+            __builtin_nontemporal_store(w1, reinterpret_cast<f32x4 *>(cr + (int64_t)8 * cpitch[a][b]));
+        }
+}
+
+
+
 // ---- the same staging inside the PERSISTENT workgroup of ef_gemm_persist_kernels.hpp (fp16 arithmetic): what round 6 ships as the default.
 // With the operands going straight to LDS a tile boundary shrinks to ONE barrier: at the head of a tile's epilogue the next tile's chunks 0
 // and 1 go by DMA into the two buffers the k loop's last two barriers have freed (the buffer after the last chunk's, and the one after

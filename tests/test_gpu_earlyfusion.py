@@ -746,7 +746,7 @@ def test_gemm_kernel_variants_give_the_same_bits(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     results = {}
     for mode, variants in (("f16x2", ({}, {"ACX_EF_DMA": "0"}, {"ACX_EF_PERSIST": "0"}, {"ACX_EF_PERSIST": "0", "ACX_EF_DMA": "0"})),
-                           ("bf16x3", ({}, {"ACX_EF_PERSIST": "1"}))):
+                           ("bf16x3", ({}, {"ACX_EF_PERSIST": "1"}, {"ACX_EF_DMA": "1"}))):
         for k, extra in enumerate(variants):
             out = str(tmp_path / ("%s_%d.npy" % (mode, k)))
             env = dict(os.environ)
