@@ -43,7 +43,7 @@ def other_source_sha16():
     """Hash of the kernel sources the companion legs run (scripts/make_traffic_other.py stamps its record with it)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("serra09_kernels.hpp", "serra09_band2_kernels.hpp", "acx_band.hip", "ef_kernels.hpp", "ef_rowstat2_kernels.hpp", "simple_kernels.hpp", "Makefile"):
+    for f in ("serra09_kernels.hpp", "serra09_band2_kernels.hpp", "acx_band.hip", "ef_kernels.hpp", "ef_gemm_persist_kernels.hpp", "ef_gemm_dma_kernels.hpp", "ef_rowstat2_kernels.hpp", "simple_kernels.hpp", "Makefile"):
         with open(os.path.join(ROOT, "acoss_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -427,8 +427,9 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
                                "acx_grid_run (scores scattered into a device buffer)" % (n, npairs, steps)},
         # all three cross-similarity GEMMs run on the 16-bit matrix pipe from two fp16 terms per value: three fp16 products
         # per f32-equivalent multiply-add are what the pipe executes, and what is priced against its dense peak
-        "roofline": {"bound": "mfma", "kernel": "ef_gemm_rect_bf16x3_kernel<0, 1> (mfcc / ssm) + <1, 1> (chroma): two fp16 terms per value "
-                                                "(ACX_EF_GEMM_F16X2, the default), 256 x 128 tiles over dense rectangles of pairs",
+        "roofline": {"bound": "mfma", "kernel": "ef_gemm_rect_persist_dma_kernel<0> (mfcc / ssm) + <1> (chroma): two fp16 terms per value "
+                                                "(ACX_EF_GEMM_F16X2, the default), 256 x 128 tiles over dense rectangles of pairs, one persistent "
+                                                "workgroup per CU, operands by LDS-DMA into three buffers (round 6)",
                      "achieved": round(3.0 * flops / ks / 1e12, 1), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(3.0 * flops / ks / 1e12 / BF16_MFMA_PEAK_TF, 4), "traffic": _traffic("earlyfusion")[0], "traffic_source": _traffic("earlyfusion")[1],
                      "flops": "executed fp16 flops = 3 x (x1 y2 + x2 y1 + x1 y1) the f32-equivalent 2 (650 + 1225 + 480) nb1 nb2 per pair (SURVEY 8d); dense fp16 peak = dense bf16 peak",
@@ -438,7 +439,9 @@ def earlyfusion_leg(ctx, steps=5, warmup=1, n=384, cpu_pairs=32):
         "bf16x3": {"value": round(npairs / dt_b, 1), "gemm_ms_per_step": round(prof_b["ef_gemm_kernel"]["ms"] / steps, 3),
                    "executed_tflops": round(6.0 * flops / (prof_b["ef_gemm_kernel"]["ms"] * 1e-3) / 1e12, 1),
                    "scores_identical_to_default_fraction": round(same_modes, 6),
-                   "note": "ACX_EF_GEMM_BF16X3 on the same tiles: three bf16 terms per value, six MFMAs per cell (round 3's default)"},
+                   "note": "ACX_EF_GEMM_BF16X3 on the same tiles: three bf16 terms per value (all 24 bits), six MFMAs per cell, "
+                           "ef_gemm_rect_bf16x3_kernel<., 0> (one workgroup per tile, staging registers: its persistent and DMA builds measure "
+                           "the same, profiles/r06_ef.md)"},
         "cpu_baseline": {"value": round(len(cp) / tcpu, 3), "unit": "track-pairs/s", "cores": 1, "kind": "port",
                          "sample": "first %d pairs of the first timed tile, numpy + C oracle, BLAS limited to one thread, %.1f s; "
                                    "%.4f of the 4 x %d scores identical to the GPU's, max |diff| %.3g%s"

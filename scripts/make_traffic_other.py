@@ -22,7 +22,8 @@ src = os.path.join(ROOT, "gpurun_out", "prof_ef_" + tag)
 # first prefix counts the launches.  serra09_covers: the two-rows-per-wave band kernels only (the T = 2000 launches of the f16x2
 # leg are band_kernel<9, 8, ...>); earlyfusion: the default two-term fp16 GEMMs, mfcc + ssm and chroma together (the bf16x3
 # comparison launches of the same leg are <., 0>).
-fam = {"serra09_covers": ["band2_kernel"], "earlyfusion": ["ef_gemm_rect_bf16x3_kernel<0, 1>", "ef_gemm_rect_bf16x3_kernel<1, 1>"],
+# (round 6: the default fp16 GEMMs are ef_gemm_rect_persist_dma_kernel<0> (mfcc + ssm) and <1> (chroma))
+fam = {"serra09_covers": ["band2_kernel"], "earlyfusion": ["ef_gemm_rect_persist_dma_kernel<0>", "ef_gemm_rect_persist_dma_kernel<1>"],
        "simple": ["simple_kernel"]}
 acc = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(lambda: defaultdict(int))
