@@ -27,6 +27,7 @@
 #include "ef_rowstat2_kernels.hpp"
 #include "ef_gemm_persist_kernels.hpp"
 #include "ef_gemm_dma_kernels.hpp"
+#include "ef_gemm_ws_kernels.hpp"
 #include "ef_prep_kernels.hpp"
 #include "grid.hpp"
 
@@ -928,12 +929,14 @@ struct SegBatch {
     std::vector<acx::EfSegWg> wgs;          // workgroup tiles of 8 x 8 groups (128 x 128 cells: ef_gemm_seg_f32_kernel)
     std::vector<acx::EfSegWg> wgs2;         // tiles of 16 x 8 groups (256 x 128 cells: ef_gemm_rect_bf16x3_kernel<0>): ty, first column group, groups
     std::vector<acx::EfSegWg> wgs3;         // the same for chroma (<1>): the columns of a tile stop at the end of their reference track
+    std::vector<acx::EfSegWg> wgs5, wgs6;   // tiles of 8 x 8 groups (128 x 128 cells: ef_gemm_rect_ws_kernel) in the same format: mfcc / ssm, chroma
 };
 void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_t> &efoff, int n_tracks, SegBatch &sb,
                     std::vector<int32_t> &qslot, std::vector<int32_t> &rslot)
 {
     sb.rowg.clear(); sb.colg.clear(); sb.rects.clear(); sb.ptab.clear(); sb.wgs.clear(); sb.wgs2.clear(); sb.wgs3.clear();
-    std::vector<uint8_t> mark, mark2, mark3;
+    sb.wgs5.clear(); sb.wgs6.clear();
+    std::vector<uint8_t> mark, mark2, mark3, mark6;
     std::vector<int32_t> cfirst;                  // chroma: first column chunk of every reference slot (+ one past the last)
     std::vector<std::pair<int32_t, int32_t>> cchunk;     // (first group, groups) of every column chunk
     std::vector<int32_t> gfirst_q, gfirst_r;      // first group of every slot (+ one past the last)
@@ -982,6 +985,7 @@ void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_
         cfirst.push_back((int32_t)cchunk.size());
         const int ncc = (int)cchunk.size();
         mark3.assign((size_t)tiles_y2 * ncc, 0);
+        mark6.assign((size_t)tiles_y * ncc, 0);
         for (const auto &m : members) {
             const int a = m.second / SEG_TRACKS, b = m.second % SEG_TRACKS;
             sb.ptab[(size_t)R.ptab0 + (size_t)a * R.ncols + b] = m.first;
@@ -994,6 +998,8 @@ void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_
                 }
             for (int ty = gfirst_q[a] / 16; ty <= (gfirst_q[a + 1] - 1) / 16; ++ty)
                 for (int ci = cfirst[b]; ci < cfirst[b + 1]; ++ci) mark3[(size_t)ty * ncc + ci] = 1;
+            for (int ty = gfirst_q[a] / 8; ty <= (gfirst_q[a + 1] - 1) / 8; ++ty)
+                for (int ci = cfirst[b]; ci < cfirst[b + 1]; ++ci) mark6[(size_t)ty * ncc + ci] = 1;
         }
         const int32_t rid = (int32_t)sb.rects.size();
         for (int ty = 0; ty < tiles_y; ++ty)
@@ -1005,6 +1011,12 @@ void ef_build_rects(const std::vector<acx::EfPair> &pd, const std::vector<int64_
         for (int ty = 0; ty < tiles_y2; ++ty)
             for (int ci = 0; ci < ncc; ++ci)
                 if (mark3[(size_t)ty * ncc + ci]) sb.wgs3.push_back(acx::EfSegWg{rid, ty, cchunk[(size_t)ci].first, cchunk[(size_t)ci].second});
+        for (int ty = 0; ty < tiles_y; ++ty)
+            for (int tx = 0; tx < tiles_x; ++tx)
+                if (mark[(size_t)ty * tiles_x + tx]) sb.wgs5.push_back(acx::EfSegWg{rid, ty, 8 * tx, std::min(8, R.nh - 8 * tx)});
+        for (int ty = 0; ty < tiles_y; ++ty)
+            for (int ci = 0; ci < ncc; ++ci)
+                if (mark6[(size_t)ty * ncc + ci]) sb.wgs6.push_back(acx::EfSegWg{rid, ty, cchunk[(size_t)ci].first, cchunk[(size_t)ci].second});
         sb.rects.push_back(R);
         for (int32_t t : qs) qslot[(size_t)t] = -1;
         for (int32_t t : rs) rslot[(size_t)t] = -1;
@@ -1252,6 +1264,10 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
                             ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_dma_kernel<1>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_ws_kernel<0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFW_LDS_BYTES));
+                            ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_ws_kernel<1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFW_LDS_BYTES));
                             ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_dma2_kernel<0>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, acx::EFR_LDS_BYTES));
                             ACX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(acx::ef_gemm_rect_dma2_kernel<1>),
@@ -1290,6 +1306,16 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                         if (!seg.wgs2.empty()) {
                             if ((rc = ensure(c, c->d_segw2, c->segw2_cap, seg.wgs2.size())) != ACX_OK) return rc;
                             ACX_HIP(c, hipMemcpyAsync(c->d_segw2, seg.wgs2.data(), sizeof(acx::EfSegWg) * seg.wgs2.size(), hipMemcpyHostToDevice, c->stream));
+                            static const bool ws_env = [] { const char *e = getenv("ACX_EF_WS"); return e && e[0] == '1'; }();
+                            if (ws_env && f16 && !seg.wgs5.empty()) {       // (experiment: wave-specialised workgroups, 128 x 128 tiles)
+                                if ((rc = ensure(c, c->d_segw2, c->segw2_cap, seg.wgs5.size())) != ACX_OK) return rc;
+                                ACX_HIP(c, hipMemcpyAsync(c->d_segw2, seg.wgs5.data(), sizeof(acx::EfSegWg) * seg.wgs5.size(), hipMemcpyHostToDevice, c->stream));
+                                const int nt = (int)seg.wgs5.size();
+                                const unsigned grid = (unsigned)std::min<int64_t>(ncu, 2 * (int64_t)nt);
+                                hipLaunchKernelGGL(acx::ef_gemm_rect_ws_kernel<0>, dim3(grid), dim3(acx::EFW_THREADS), acx::EFW_LDS_BYTES, c->stream,
+                                                   c->d_efs[0], c->d_efs[1], c->d_efn[0], c->d_efn[1], c->d_efpd, c->d_rects, c->d_segw2, c->d_segr,
+                                                   c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[0], c->ef_kp[1], c->d_efsc[0], c->d_efsc[1], nt, 2);
+                            } else
                             if (persist) {
                                 const int nt = (int)seg.wgs2.size();
                                 const unsigned grid = (unsigned)std::min<int64_t>(ncu, 2 * (int64_t)nt);
@@ -1310,6 +1336,17 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                             if (!seg.wgs3.empty()) {
                                 if ((rc = ensure(c, c->d_segw3, c->segw3_cap, seg.wgs3.size())) != ACX_OK) return rc;
                                 ACX_HIP(c, hipMemcpyAsync(c->d_segw3, seg.wgs3.data(), sizeof(acx::EfSegWg) * seg.wgs3.size(), hipMemcpyHostToDevice, c->stream));
+                                static const bool ws_env3 = [] { const char *e = getenv("ACX_EF_WS"); return e && e[0] == '1'; }();
+                                if (ws_env3 && f16 && !seg.wgs6.empty()) {
+                                    if ((rc = ensure(c, c->d_segw3, c->segw3_cap, seg.wgs6.size())) != ACX_OK) return rc;
+                                    ACX_HIP(c, hipMemcpyAsync(c->d_segw3, seg.wgs6.data(), sizeof(acx::EfSegWg) * seg.wgs6.size(), hipMemcpyHostToDevice, c->stream));
+                                    const int nt = (int)seg.wgs6.size();
+                                    const unsigned grid = (unsigned)std::min(ncu, nt);
+                                    hipLaunchKernelGGL(acx::ef_gemm_rect_ws_kernel<1>, dim3(grid), dim3(acx::EFW_THREADS), acx::EFW_LDS_BYTES, c->stream,
+                                                       c->d_efs[2], c->d_efs[2], (const float *)nullptr, (const float *)nullptr, c->d_efpd, c->d_rects,
+                                                       c->d_segw3, c->d_segr, c->d_segc, c->d_ptab, c->d_scratch, c->ef_kp[2], c->ef_kp[2],
+                                                       c->d_efsc[2], c->d_efsc[2], nt, 1);
+                                } else
                                 if (persist) {
                                     const int nt = (int)seg.wgs3.size();
                                     const unsigned grid = (unsigned)std::min(ncu, nt);

@@ -736,8 +736,9 @@ ctx.close()
 
 @pytest.mark.timeout(900)
 def test_gemm_kernel_variants_give_the_same_bits(tmp_path):
-    """The rectangle GEMMs exist as four kernels per arithmetic -- one workgroup per tile or a persistent workgroup per CU, operands through
-    the staging registers or (fp16 arithmetic) by LDS-DMA into three buffers -- chosen per process (ACX_EF_PERSIST, ACX_EF_DMA).  Same
+    """The rectangle GEMMs exist as several kernels per arithmetic -- one workgroup per tile or a persistent workgroup per CU, operands through
+    the staging registers or by LDS-DMA, and (fp16 arithmetic, an experiment) wave-specialised workgroups on 128 x 128 tiles -- chosen per
+    process (ACX_EF_PERSIST, ACX_EF_DMA, ACX_EF_WS).  Same
     tiles, same MFMAs in the same order: every variant must return the default's scores bit for bit, on a pair list that fills whole
     grid rectangles, on random pairs (sparse rectangles, one pair per tile) and with tracks of 1-17 blocks (rims everywhere)."""
     import os
@@ -745,13 +746,14 @@ def test_gemm_kernel_variants_give_the_same_bits(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     results = {}
-    for mode, variants in (("f16x2", ({}, {"ACX_EF_DMA": "0"}, {"ACX_EF_PERSIST": "0"}, {"ACX_EF_PERSIST": "0", "ACX_EF_DMA": "0"})),
+    for mode, variants in (("f16x2", ({}, {"ACX_EF_DMA": "0"}, {"ACX_EF_PERSIST": "0"}, {"ACX_EF_PERSIST": "0", "ACX_EF_DMA": "0"}, {"ACX_EF_WS": "1"})),
                            ("bf16x3", ({}, {"ACX_EF_PERSIST": "1"}, {"ACX_EF_DMA": "1"}))):
         for k, extra in enumerate(variants):
             out = str(tmp_path / ("%s_%d.npy" % (mode, k)))
             env = dict(os.environ)
             env.pop("ACX_EF_DMA", None)
             env.pop("ACX_EF_PERSIST", None)
+            env.pop("ACX_EF_WS", None)
             env.update(extra)
             subprocess.check_call([sys.executable, "-c", _VARIANT_SNIPPET % {"root": root, "mode": mode, "out": out}], env=env, timeout=300)
             results[(mode, k)] = np.load(out)
