@@ -130,6 +130,7 @@ struct acx_ctx {
     acx::EfSegWg *d_segw = nullptr;    size_t segw_cap = 0;
     acx::EfSegWg *d_segw2 = nullptr;   size_t segw2_cap = 0;
     acx::EfSegWg *d_segw3 = nullptr;   size_t segw3_cap = 0;
+    int launch_fail_stat = -1;                         // kernel family (KS_*) of the first failed launch since the last check
     bool ef_rect_attr = false;
     unsigned *d_efctr = nullptr;                       // tile counters of the persistent rectangle GEMMs (one per launch of a batch)
     int n_cu = 0;
@@ -209,9 +210,24 @@ struct ProfScope {
     }
     ~ProfScope()
     {
+        // a launch that failed inside this scope is attributed to the scope's kernel family, not just to the batch (hipPeekAtLastError:
+        // the batch's own check still sees and clears it)
+        if (c->launch_fail_stat < 0 && hipPeekAtLastError() != hipSuccess) c->launch_fail_stat = stat;
         if (c->prof) { (void)hipEventRecord(b, st); c->pending.push_back({a, b, stat, cells}); }
     }
 };
+
+// the batch's launch check: names the kernel family whose scope saw the failure first
+#define ACX_LAUNCHES_OK(ctx)                                                                                              \
+    do {                                                                                                                  \
+        const hipError_t e_ = hipGetLastError();                                                                          \
+        if (e_ != hipSuccess) {                                                                                           \
+            const int fs_ = (ctx)->launch_fail_stat;                                                                      \
+            (ctx)->launch_fail_stat = -1;                                                                                 \
+            return fail(ctx, ACX_ERR_HIP, std::string("kernel launch failed (") + (fs_ >= 0 ? (ctx)->stats[fs_].name : "outside the timed scopes") + \
+                                              "): " + hipGetErrorString(e_));                                             \
+        }                                                                                                                 \
+    } while (0)
 
 void drain_profile(acx_ctx *c)
 {
@@ -857,7 +873,7 @@ int run_serra09_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_serr
             else sweep(p.dmax != 0, S.d_out, qs);
             ACX_HIP(c, wait_err);
         }
-        ACX_HIP(c, hipGetLastError());
+        ACX_LAUNCHES_OK(c);
         if (dd) {
             hipLaunchKernelGGL(scatter_scores_kernel, dim3((B + 255) / 256), dim3(256), 0, qs,
                                S.d_out, S.d_idx, dd->base, B, w);
@@ -1436,7 +1452,7 @@ static int run_ef_impl(acx_ctx *c, const int32_t *pairs, int64_t K, const acx_ef
                 }
             }
         }
-        ACX_HIP(c, hipGetLastError());
+        ACX_LAUNCHES_OK(c);
         if (dd) {
             if ((rc = stage_idx(c, dd->idx + k0, B)) != ACX_OK) return rc;
             hipLaunchKernelGGL(scatter_scores_kernel, dim3((B + 255) / 256), dim3(256), 0, c->stream, c->d_out, c->d_idx, dd->base, B, 4);

@@ -623,9 +623,6 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     auto gload_piece = [&](auto p_tag) {
         constexpr int p = decltype(p_tag)::value;
         if (F16 && p % 3 == 2) return;                 // (the third term does not exist)
-#ifdef ACX_EF_ABL_NOGLOAD      /* ... without its global loads (the staging registers keep what the prologue loaded), */
-        if (st[p].x != 0x12345u) return;
-#endif
         const unsigned short *src;
         if (p >= 6) src = bp;
         else if (!CH) src = p < 3 ? ap0 : ap1;
@@ -753,7 +750,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                     }
                 }
                 if (ST && slot == LASTP) {
-#ifndef ACX_EF_ABL_NOBARRIER   /* k-loop ablations (WRONG matrices; scripts/ab_build_acx.sh, profiles/r06_ef.md): the chunk without its barrier, */
+#ifndef ACX_EF_ABL_NOBARRIER   /* k-loop ablations (WRONG matrices; scripts/ab_build_acx.sh, profiles/r06_ef.md): the chunk without its barrier */
                     __syncthreads();
 #endif
                     prefetch(cur ^ 1);
