@@ -580,7 +580,11 @@ class Context(object):
     def ef_debug_pairs(self, pairs, which, kappa=0.1, K=10):
         """Intermediates of pair `which` of a list that runs as ONE batch (the multi-pair rectangles of the product path)."""
         pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        if not 0 <= int(which) < len(pairs):
+            raise ValueError("ef_debug_pairs: `which` = %d is not a pair of the list (%d pairs)" % (which, len(pairs)))
         i, j = (int(v) for v in pairs[which])
+        if not (0 <= i < len(self.ef_blocks) and 0 <= j < len(self.ef_blocks)):
+            raise ValueError("ef_debug_pairs: track index out of range in pair %d" % which)
         M, N = int(self.ef_blocks[i]), int(self.ef_blocks[j])
         csm = np.empty((3, M, N), np.float32)
         fused = np.empty((M, N), np.float32)

@@ -191,6 +191,18 @@ def test_errors(ctx):
     with pytest.raises(ValueError):
         ctx.earlyfusion_pairs(np.array([[0, 2]], np.int32))
     assert ctx.earlyfusion_pairs(np.zeros((0, 2), np.int32)).shape == (0, 4)
+    # the multi-pair debug entry: pair `which` of a list that runs as ONE batch; a list that needs two is refused, loudly
+    pairs = np.array([[0, 1], [1, 0], [0, 0]], np.int32)
+    d = ctx.ef_debug_pairs(pairs, 1)
+    assert d["csm"].shape == (3, len(tracks[1]["mfccs"]), len(tracks[0]["mfccs"])) and np.array_equal(d["scores"], ctx.earlyfusion_pairs(pairs))
+    with pytest.raises(ValueError):
+        ctx.ef_debug_pairs(pairs, 3)
+    ctx.set_scratch_limit(4 * 30 * 64 * 4 * 2)             # room for two of the three pairs
+    try:
+        with pytest.raises(NotImplementedError, match="one batch"):
+            ctx.ef_debug_pairs(pairs, 0)
+    finally:
+        ctx.set_scratch_limit(0)
 
 
 def test_benchmark_end_to_end(tmp_path, monkeypatch):
