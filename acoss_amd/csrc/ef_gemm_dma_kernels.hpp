@@ -189,6 +189,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
                     prefetch(nxt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
         }
     };
     const int nk = Kp / EFB_BK;
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
     auto sweep = [&](auto &&chunk) {
         int kc = 0, cur = 0;
         auto inc = [](int b) { return b == 2 ? 0 : b + 1; };
@@ -497,6 +500,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
                     prefetch(cur ^ 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
         }
     };
     const int nk = Kp / EFB_BK;
@@ -521,6 +526,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
     auto sweep = [&](auto &&chunk) {
         int kc = 0;
         for (; kc + 1 < nk; ++kc) chunk(kc & 1, std::true_type());
@@ -862,6 +868,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
                     prefetch(nxt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -878,6 +885,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
         }
     };
 
@@ -906,6 +914,7 @@ __global__ __launch_bounds__(EFR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         // every wave's pieces of chunk 0 have landed (its own: see the epilogue), every wave is out of the previous tile's k loop
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
         if (!first) t_next = (int)__builtin_amdgcn_readfirstlane(*mailbox);
         float zero_ = 0.0f;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero_));

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(EFW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     auto bar = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");          // (the builtin is not a compiler-level memory barrier: nothing below may be hoisted above it)
     };
 
     if (wave < EFW_MW) {
