@@ -1,6 +1,7 @@
-"""Worker of tests/test_gpu_grid.py::test_two_ranks_share_one_gpu: launched under torch.distributed.run
-(gloo, every rank on GPU 0); runs the REAL Serra09 / ChenFusion classes over a synthetic cover set and
-stores rank 0's matrices."""
+"""Worker of tests/test_gpu_grid.py::test_two_ranks_share_one_gpu (gloo, every rank on GPU 0) and
+::test_two_gpus_exchange_over_rccl (ACX_TEST_BACKEND=nccl: rank r on GPU r, the tile exchange over RCCL): launched
+under torch.distributed.run; runs the REAL Serra09 / ChenFusion classes over a synthetic cover set and stores
+rank 0's matrices."""
 import os
 import sys
 
@@ -18,15 +19,21 @@ def main():
     from acoss_amd.algorithms.rqa_serra09 import Serra09
     from acoss_amd.algorithms.latefusion_chen import ChenFusion
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("ACX_TEST_BACKEND", "gloo")
+    dev = 0
     if world > 1:
-        dist.init_process_group("gloo")
+        if backend == "nccl":
+            import torch
+            dev = int(os.environ["LOCAL_RANK"])
+            torch.cuda.set_device(dev)
+        dist.init_process_group(backend)
     rank = dist.get_rank() if world > 1 else 0
     d = synth.cover_set(clique_sizes=[2] * 12 + [3, 3, 1, 1], seed=77, t_range=(60, 700))
     n = len(d["offsets"]) - 1
     tracks = [d["frames"][d["offsets"][i]:d["offsets"][i + 1]] for i in range(n)]
     res = {}
     for cls, name in ((Serra09, "serra09"), (ChenFusion, "chen")):
-        algo = cls("grid.csv", workdir + "/", shortname="w%d" % world, device=0)
+        algo = cls("grid.csv", workdir + "/", shortname="w%d" % world, device=dev)
         algo.set_pooled_features(tracks, d["labels"])
         algo.all_pairwise(symmetric=True)
         algo.normalize_by_length()
@@ -36,9 +43,14 @@ def main():
             if rank == 0:
                 res["%s_%s" % (name, key)] = np.array(algo.Ds[key])
         algo.cleanup_memmap()
+    if world > 1:
+        from acoss_amd import dist as adist
+        kind = adist.exchange_in_use()          # (every rank: the probe behind it is a collective the first time)
+        if rank == 0:
+            res["exchange"] = np.array(kind)    # which collective carried the tiles: "gather" unless the probe refused it
     np.savez(os.path.join(out, "world%d_rank%d.npz" % (world, rank)), **res)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[dev]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

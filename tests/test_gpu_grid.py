@@ -156,6 +156,39 @@ def test_two_ranks_share_one_gpu(tmp_path):
     assert float(one["serra09_main"].max()) > 10.0
 
 
+def test_two_gpus_exchange_over_rccl(tmp_path):
+    """Two ranks on TWO GPUs under the "nccl" backend: the tile exchange of the path (torch.distributed.gather, or the
+    all-gather the probe of acoss_amd/dist.py falls back to) really crosses xGMI.  Skipped on a box with one GPU --
+    every gpurun box of the build rounds; it is here for the first box that has two."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
+    from acoss_amd.featurestore import save_track
+    wd = str(tmp_path)
+    with open(os.path.join(wd, "grid.csv"), "w") as f:
+        f.write("work_id,track_id\n")
+        for k in range(32):
+            f.write("w%d,t%d\n" % (k, k))
+            save_track(os.path.join(wd, "w%d/t%d.h5" % (k, k)), {"label": "w%d" % k, "track_id": "t%d" % k})
+    out = os.path.join(wd, "out")
+    os.makedirs(out)
+    worker = os.path.join(ROOT, "tests", "_grid_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ACX_TEST_BACKEND="nccl")
+    env.pop("WORLD_SIZE", None)
+    subprocess.run([sys.executable, worker, wd, out], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, wd, out],
+                   check=True, env=env, timeout=900)
+    one = np.load(os.path.join(out, "world1_rank0.npz"))
+    two0 = np.load(os.path.join(out, "world2_rank0.npz"))
+    two1 = np.load(os.path.join(out, "world2_rank1.npz"))
+    assert str(two0["exchange"]) in ("gather", "allgather"), two0["exchange"]
+    for k in one.files:
+        assert np.array_equal(one[k], two0[k], equal_nan=True), k
+        if k.endswith("_stats"):
+            assert np.array_equal(one[k], two1[k], equal_nan=True), k
+
+
 def test_libacx_before_torch_in_one_process():
     """Import order must not matter: a process that creates its libacx context FIRST and imports torch later still
     gets a working torch.cuda (acoss_amd._lib preloads the HIP runtime PyTorch bundles, so both end up on the same
