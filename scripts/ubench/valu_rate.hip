@@ -69,6 +69,18 @@ __global__ __launch_bounds__(256) void k(float *out, int n, unsigned seed)
                 asm volatile("v_cvt_u32_f32 %0, %4\n v_and_or_b32 %1, %0, %2, %3\n v_lshl_add_u32 %2, %1, 2, %3\n v_add3_u32 %3, %0, %1, %2\n"
                              "v_cvt_u32_f32 %0, %5\n v_and_or_b32 %1, %0, %2, %3\n v_lshl_add_u32 %2, %1, 2, %3\n v_add3_u32 %3, %0, %1, %2\n"
                              : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(a0), "v"(a1));
+            } else if constexpr (OP == 12) {  // transcendental: exp2
+                asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
+                             "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if constexpr (OP == 13) {  // transcendental: reciprocal
+                asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                             "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if constexpr (OP == 14) {  // v_mul_f32
+                asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
             } else if constexpr (OP == 10) {  // ds_read_b32 conflict-free
                 unsigned la = (unsigned)(size_t)&hist[wave][0] + lane * 4;
                 unsigned t0, t1, t2, t3, t4, t5, t6, t7;
@@ -123,6 +135,9 @@ int main()
         run<7>("v_add_f32_dpp", d, w, ncu);
         run<8>("v_min3/max3_f32", d, w, ncu);
         run<9>("cvt/and_or/lshl_add/add3", d, w, ncu);
+        run<14>("v_mul_f32", d, w, ncu);
+        run<12>("v_exp_f32", d, w, ncu);
+        run<13>("v_rcp_f32", d, w, ncu);
         run<6>("ds_add_u32 random", d, w, ncu);
         run<10>("ds_read_b32", d, w, ncu);
         run<11>("ds_write_b32", d, w, ncu);
