@@ -251,10 +251,14 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, ACX_SIMPLE_WAVES) void simple_kern
                     if (g == 0 && lane == L) nd = e;
                     dot = nd;
                     const double dist = (a2 + w) - 2.0 * dot;
-                    // (compare + two selects.  Round 6 measured the alternatives, profiles/r06_simple.md: fmin -- v_min_f64 behind two
-                    //  canonicalising v_max_f64 -- 16.85 instead of 15.75 ms per 262 k ordered pairs; a second copy of this loop for row
-                    //  group 0, to drop its per-step select from the other groups: 82 ms, the ring left the registers)
-                    mn = dist < mn ? dist : mn;
+                    // The running minimum as ONE v_min_f64, written as the instruction: `dist < mn ? dist : mn` compiles to v_cmp_lt_f64 vcc +
+                    // two v_cndmask_b32 ..., vcc next to each other, and gfx950 takes ~10 cycles for the second of two ADJACENT selects on vcc
+                    // (scripts/ubench/cndmask_probe.hip, profiles/r06_cndmask_probe.txt: 17.5 cycles for the three, 4.2 for a v_min_f64);
+                    // __builtin_fmin puts two canonicalising v_max_f64 in front (16.85 instead of 15.75 ms per 262 k ordered pairs, measured).
+                    // Same value: neither operand is ever a NaN (the pool is checked for non-finite frames) and `x - y` never makes a -0.
+                    // (Also measured, profiles/r06_simple.md: a second copy of this loop for row group 0, to drop its per-step select from
+                    //  the other groups: 82 ms, the ring left the registers.)
+                    asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(dist), "v"(mn));
                     if (more && lane == 63) E[b + eoff - 1] = dot;        // (slot of column b - 1, read above)
                 }
             }
