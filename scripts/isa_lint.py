@@ -26,6 +26,13 @@ consumer that comes earlier than measured.  Consumers the probe did not measure 
 are held to the strictest measured figure of their kind.  Not covered: consumers behind a taken branch or a loop back-edge (the
 walk stops at the end of the block).
 
+A second rule (end of round 6; scripts/ubench/cndmask_probe.hip, profiles/r06_cndmask_probe.txt): of two ADJACENT v_cndmask_b32 ..., vcc
+the second costs ~10 cycles instead of 4, every further one ~19 (4 each with the mask in an SGPR pair, or with any instruction between
+them) -- hipcc emits the pair for every 64-bit select on a fresh comparison.  lint_selects() reports the runs per kernel and fails on
+  * a run of THREE or more in one of the path's hot kernels (HOT_KERNELS), and
+  * any run inside SiMPle's sweep (between the first and the last wave_shr DPP move of a simple_kernel -- the recurrence's neighbour
+    value, once per step: the running minimum was such a pair there, 7 % of the kernel, until it became one v_min_f64).
+
 usage: python scripts/isa_lint.py [path/to/libacx.so | listing.s ...]     exit status 1 when a violation is found
 """
 import json
@@ -108,7 +115,7 @@ def lint_text(text):
     kernel = "?"
     for ln in lines:
         if not ln.startswith(("\t", " ")):
-            lab = LABEL.match(ln.strip())
+            lab = LABEL.match(ln.split(";")[0].strip())
             if lab:
                 if not lab.group(1).startswith((".L", "BB")):
                     kernel = lab.group(1)
@@ -170,16 +177,74 @@ def lint_text(text):
     return checked, bad, stats
 
 
+HOT_KERNELS = re.compile(r"band_kernel|band2_kernel|qmax_bits_h16|sw_bits_h16|ef_rowstat|ef_colstat|ef_gemm_rect|simple_kernel")
+
+
+def lint_selects(text):
+    """(kernels seen, {kernel: {run length: count}}, violations) for runs of adjacent v_cndmask_b32 ..., vcc in a disassembly / -S listing."""
+    kernel, run, start = "?", 0, 0
+    runs, seen, bad = {}, set(), []
+    vmin = {}                                     # simple_kernel: instruction indices of its wave_shr DPP moves (the sweep lies between them)
+    pend = []                                     # (kernel, first instruction index, length)
+    n = 0
+
+    def close():
+        nonlocal run
+        if run >= 2:
+            runs.setdefault(kernel, {})
+            runs[kernel][run] = runs[kernel].get(run, 0) + 1
+            pend.append((kernel, start, run))
+        run = 0
+
+    for ln in text.split("\n"):
+        if not ln.startswith(("\t", " ")):
+            lab = LABEL.match(ln.split(";")[0].strip())
+            if lab:
+                close()
+                if not lab.group(1).startswith((".L", "BB")):
+                    kernel = lab.group(1)
+                    seen.add(kernel)
+                continue
+        p = _parse(ln)
+        if not p:
+            continue
+        n += 1
+        if p[0].startswith("v_mov_b32_dpp") and "wave_shr" in ln and "simple_kernel" in kernel:
+            vmin.setdefault(kernel, []).append(n)
+        if p[0].startswith("v_cndmask_b32") and p[1] and p[1][-1] == "vcc":
+            if run == 0:
+                start = n
+            run += 1
+        else:
+            close()
+    close()
+    for kern, at, length in pend:
+        if not HOT_KERNELS.search(kern):
+            continue
+        if length >= 3:
+            bad.append({"kernel": kern, "run": length, "reason": "three or more adjacent v_cndmask_b32 ..., vcc in a hot kernel (~19 cycles each from the third on)"})
+        elif "simple_kernel" in kern and len(vmin.get(kern, [])) >= 2 and vmin[kern][0] < at < vmin[kern][-1]:
+            bad.append({"kernel": kern, "run": length, "reason": "adjacent v_cndmask_b32 ..., vcc inside SiMPle's sweep (a 64-bit select on a fresh comparison: ~10 extra cycles per step)"})
+    return len(seen), runs, bad
+
+
 def lint_library(lib_path):
     checked, bad, dst_over = 0, [], 0
+    sel_bad, sel_runs, kernels = [], 0, 0
     objs = code_objects(lib_path)
     for co in objs:
-        n, b, st = lint_text(disassemble(co))
+        dis = disassemble(co)
+        n, b, st = lint_text(dis)
         checked += n
         bad += b
         dst_over += st["dst_over_srcA_or_srcB_harmless"]
+        k, runs, sb = lint_selects(dis)
+        kernels += k
+        sel_runs += sum(c for r in runs.values() for c in r.values())
+        sel_bad += sb
     return {"library": lib_path, "code_objects": len(objs), "mfma_checked": checked,
-            "dst_over_srcA_or_srcB_harmless": dst_over, "violations": bad}
+            "dst_over_srcA_or_srcB_harmless": dst_over, "violations": bad,
+            "kernels": kernels, "adjacent_select_runs": sel_runs, "select_violations": sel_bad}
 
 
 def main(argv):
@@ -187,13 +252,16 @@ def main(argv):
     rc = 0
     for p in paths:
         if p.endswith(".s"):
-            n, b, st = lint_text(open(p).read())
-            rec = {"listing": p, "mfma_checked": n, "violations": b}
+            txt = open(p).read()
+            n, b, st = lint_text(txt)
+            k, runs, sb = lint_selects(txt)
+            rec = {"listing": p, "mfma_checked": n, "violations": b, "kernels": k,
+                   "adjacent_select_runs": sum(c for r in runs.values() for c in r.values()), "select_violations": sb}
             rec.update(st)
         else:
             rec = lint_library(p)
         print(json.dumps(rec, indent=1))
-        if rec["violations"] or not rec["mfma_checked"]:
+        if rec["violations"] or rec["select_violations"] or not rec["mfma_checked"]:
             rc = 1
     return rc
 

@@ -6,7 +6,9 @@ K = 32 MFMAs, checked on the code objects that ship.
   * each measured rule is red one wait state too early and green at the measured distance (hand-written listings);
   * a real code object with a too-early consumer (inline asm, compiled here by hipcc) is red: the path the build takes --
     fat binary -> code object -> disassembly -> rule -- finds what it is there to find;
-  * a destination over srcA / srcB, which round 4 suspected and scripts/ubench/mfma_overlap_probe.hip cleared, is counted, not failed.
+  * a destination over srcA / srcB, which round 4 suspected and scripts/ubench/mfma_overlap_probe.hip cleared, is counted, not failed;
+  * the second rule -- adjacent v_cndmask_b32 ..., vcc (scripts/ubench/cndmask_probe.hip): three in a row in a hot kernel, or a pair
+    inside SiMPle's sweep, is red; the forms that cost nothing are green.
 """
 import os
 import subprocess
@@ -30,6 +32,7 @@ def test_shipped_library_is_green():
     rec = _lint().lint_library(lib)
     assert rec["code_objects"] == 2 and rec["mfma_checked"] >= 500, rec
     assert rec["violations"] == [], rec["violations"][:5]
+    assert rec["select_violations"] == [] and rec["kernels"] > 100, rec["select_violations"][:5]
 
 
 P = "\tv_mfma_f32_16x16x32_f16 v[56:59], v[40:43], v[44:47], 0\n"
@@ -116,3 +119,26 @@ def test_a_compiled_code_object_with_a_too_early_consumer(tmp_path, nop, red):
         assert len(rec["violations"]) == 1 and rec["violations"][0]["needs"] == 5 and rec["violations"][0]["wait_states"] == 3, rec
     else:
         assert rec["violations"] == [], rec
+
+
+SELECT = "\tv_cndmask_b32_e32 v%d, v%d, v%d, vcc\n"
+DPP = "\tv_mov_b32_dpp v20, v70 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+
+
+@pytest.mark.parametrize("kernel,body,n_bad", [
+    # three adjacent selects on vcc in a hot kernel: ~19 cycles for the third (profiles/r06_cndmask_probe.txt)
+    ("_ZN3acx12band2_kernelILi9ELi0ELb0ELi16ELi32EEEvPKf", "\tv_cmp_lt_f32_e32 vcc, v0, v1\n" + SELECT % (2, 2, 3) + SELECT % (4, 4, 5) + SELECT % (6, 6, 7), 1),
+    # ... a pair there is tolerated, and so are three with the mask in an SGPR pair or with an instruction between them
+    ("_ZN3acx12band2_kernelILi9ELi0ELb0ELi16ELi32EEEvPKf", "\tv_cmp_lt_f32_e32 vcc, v0, v1\n" + SELECT % (2, 2, 3) + SELECT % (4, 4, 5), 0),
+    ("_ZN3acx12band2_kernelILi9ELi0ELb0ELi16ELi32EEEvPKf", "\tv_cndmask_b32_e64 v2, v2, v3, s[2:3]\n" * 3, 0),
+    ("_ZN3acx12band2_kernelILi9ELi0ELb0ELi16ELi32EEEvPKf", (SELECT % (2, 2, 3) + "\tv_add_f32_e32 v9, v9, v8\n") * 3, 0),
+    # three in a kernel that is not on the path's hot list: counted, not failed
+    ("_ZN3acx14normtab_kernelILi6EEEvPKf", SELECT % (2, 2, 3) + SELECT % (4, 4, 5) + SELECT % (6, 6, 7), 0),
+    # SiMPle: a pair inside the sweep (between its wave_shr DPP moves) is what round 6 removed; outside the sweep it is tolerated
+    ("_ZN3acx13simple_kernelILi10EEEvPKd", DPP + "\tv_cmp_lt_f64_e32 vcc, v[20:21], v[62:63]\n" + SELECT % (63, 63, 21) + SELECT % (62, 62, 20) + DPP, 1),
+    ("_ZN3acx13simple_kernelILi10EEEvPKd", SELECT % (63, 63, 21) + SELECT % (62, 62, 20) + DPP + "\tv_min_f64 v[68:69], v[6:7], v[68:69]\n" + DPP, 0),
+])
+def test_adjacent_selects_on_vcc(kernel, body, n_bad):
+    L = _lint()
+    k, runs, bad = L.lint_selects(kernel + ":\n" + body + "\ts_endpgm\n")
+    assert k == 1 and len(bad) == n_bad, (runs, bad)
