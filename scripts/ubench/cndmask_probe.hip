@@ -25,6 +25,27 @@ __global__ __launch_bounds__(256) void k(float *out, int n)
                 if constexpr (N >= 2) asm volatile("v_cndmask_b32 %2, %2, %9, s[22:23]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s22", "s23");
                 if constexpr (N >= 4) asm volatile("v_cndmask_b32 %3, %3, %9, s[22:23]\n v_cndmask_b32 %4, %4, %9, s[22:23]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s22", "s23");
                 if constexpr (N >= 7) asm volatile("v_cndmask_b32 %5, %5, %9, s[22:23]\n v_cndmask_b32 %6, %6, %9, s[22:23]\n v_cndmask_b32 %7, %7, %9, s[22:23]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s22", "s23");
+            } else if constexpr (PAT == 3) {
+                // D: the recurrence bitmap's triple (band2_kernel): v_min_f32, v_cmp_le_f32 vcc, v_addc_co_u32 acc, vcc, acc, acc, vcc -- four of them
+                asm volatile("v_min_f32 %4, %0, %8\n v_cmp_le_f32 vcc, %1, %4\n v_addc_co_u32 %5, vcc, %5, %5, vcc\n"
+                             "v_min_f32 %4, %1, %8\n v_cmp_le_f32 vcc, %2, %4\n v_addc_co_u32 %5, vcc, %5, %5, vcc\n"
+                             "v_min_f32 %4, %2, %8\n v_cmp_le_f32 vcc, %3, %4\n v_addc_co_u32 %5, vcc, %5, %5, vcc\n"
+                             "v_min_f32 %4, %3, %8\n v_cmp_le_f32 vcc, %0, %4\n v_addc_co_u32 %5, vcc, %5, %5, vcc"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+            } else if constexpr (PAT == 4) {
+                // E: selects of CONSTANTS on vcc (the VOP3 form hipcc uses for `cond ? 1 : 0`), four adjacent
+                asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32_e64 %1, 0, 1, vcc\n v_cndmask_b32_e64 %2, 0, 1, vcc\n v_cndmask_b32_e64 %3, 0, 1, vcc\n v_cndmask_b32_e64 %4, 0, 1, vcc"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+            } else if constexpr (PAT == 5) {
+                // F: four comparisons into vcc, each with ONE select behind it (no adjacency)
+                asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %9, vcc\n"
+                             "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %9, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %9, vcc"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+            } else if constexpr (PAT == 6) {
+                // G: a DPP reduction chain as the selections run them: four DEPENDENT v_min_u32_dpp on one register
+                asm volatile("v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 1\n v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                             "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n s_nop 1\n v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n s_nop 1"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
             } else {
                 // C: one comparison, then select / add / select / add ... (N selects, N adds)
                 asm volatile("v_cmp_lt_f32 vcc, %0, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
@@ -38,7 +59,7 @@ __global__ __launch_bounds__(256) void k(float *out, int n)
 template <int PAT, int N>
 void run(float *d, int ncu, const char *name)
 {
-    const int w = 8, per = PAT == 2 ? 9 : 1 + N;
+    const int w = 8, per = PAT == 2 ? 9 : (PAT == 3 ? 12 : (PAT == 4 ? 5 : (PAT == 5 ? 8 : (PAT == 6 ? 8 : 1 + N))));
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     hipLaunchKernelGGL((k<PAT, N>), dim3(w * ncu), dim3(256), 0, 0, d, 8);
     (void)hipDeviceSynchronize();
@@ -63,5 +84,9 @@ int main()
     run<1, 4>(d, ncu, "v_cmp s[22:23] + 4 selects on it");
     run<1, 7>(d, ncu, "v_cmp s[22:23] + 7 selects on it");
     run<2, 4>(d, ncu, "v_cmp vcc + 4 x (select on vcc, v_add_f32)");
+    run<3, 4>(d, ncu, "4 x (v_min_f32, v_cmp_le_f32 vcc, v_addc_co_u32 on vcc)");
+    run<4, 4>(d, ncu, "v_cmp vcc + 4 x v_cndmask_b32_e64 v, 0, 1, vcc");
+    run<5, 4>(d, ncu, "4 x (v_cmp vcc, one select on vcc)");
+    run<6, 4>(d, ncu, "4 dependent v_min_u32_dpp, s_nop 1 behind each");
     return 0;
 }
