@@ -45,6 +45,9 @@ OPS = [
     ("v_permlane16_swap_b32", "v_permlane16_swap_b32 {r}, {r}", "u"), ("v_permlane32_swap_b32", "v_permlane32_swap_b32 {r}, {r}", "u"),
     ("v_pk_add_f32", "v_pk_add_f32 {r}, {r}, {b}", "d"), ("v_pk_fma_f32", "v_pk_fma_f32 {r}, {r}, {b}, {c}", "d"), ("v_pk_mov_b32", "v_pk_mov_b32 {r}, {r}, {b}", "d"),
     ("v_add_f64", "v_add_f64 {r}, {r}, {b}", "d"), ("v_mul_f64", "v_mul_f64 {r}, {r}, {b}", "d"), ("v_fma_f64", "v_fma_f64 {r}, {r}, {b}, {c}", "d"),
+    ("v_fmac_f64", "v_fmac_f64 {r}, {b}, {c}", "d"), ("v_fmac_f64 (an SGPR pair as a factor)", "v_fmac_f64 {r}, s[22:23], {c}", "d"),
+    ("v_fmac_f64, ONE dependent chain", "v_fmac_f64 %0, {b}, {c}", "d"), ("v_fmac_f32, ONE dependent chain", "v_fmac_f32 %0, {b}, {c}", "f"),
+    ("v_add_f64 (an SGPR pair as a term)", "v_add_f64 {r}, {r}, s[22:23]", "d"),
     ("v_min_f64", "v_min_f64 {r}, {r}, {b}", "d"), ("v_cmp_lt_f64 (vcc)", "v_cmp_lt_f64 vcc, {r}, {b}", "d"), ("v_lshlrev_b64", "v_lshlrev_b64 {r}, 1, {r}", "d"),
     ("v_lshl_add_u64", "v_lshl_add_u64 {r}, {r}, 1, {b}", "d"), ("v_mad_u64_u32", "v_mad_u64_u32 {r}, vcc, {b}, {c}, {r}", "dmix"),
     ("s_nop 0 (issue slot only)", "s_nop 0", "f"),
