@@ -8,6 +8,9 @@ import os
 OPS = [
     ("v_add_f32", "v_add_f32 {r}, {r}, {b}", "f"), ("v_sub_f32", "v_sub_f32 {r}, {r}, {b}", "f"), ("v_mul_f32", "v_mul_f32 {r}, {r}, {b}", "f"),
     ("v_fma_f32", "v_fma_f32 {r}, {r}, {b}, {c}", "f"), ("v_fmac_f32", "v_fmac_f32 {r}, {b}, {c}", "f"),
+    ("v_fma_f32 (inline constant + SGPR: the sweep's -2 xy + |x|^2)", "v_fma_f32 {r}, {r}, -2.0, s22", "f"),
+    ("v_add_f32 (an SGPR term)", "v_add_f32 {r}, s22, {r}", "f"), ("v_mul_f32 (a 32-bit literal)", "v_mul_f32 {r}, 0x3fb8aa3b, {r}", "f"),
+    ("v_max_f32 (inline 0: the clamp)", "v_max_f32 {r}, 0, {r}", "f"), ("v_add_u32 (a 32-bit literal)", "v_add_u32 {r}, 0x12345, {r}", "u"),
     ("v_min_f32", "v_min_f32 {r}, {r}, {b}", "f"), ("v_max_f32", "v_max_f32 {r}, {r}, {b}", "f"),
     ("v_med3_f32", "v_med3_f32 {r}, {r}, {b}, {c}", "f"), ("v_min3_f32", "v_min3_f32 {r}, {r}, {b}, {c}", "f"),
     ("v_exp_f32", "v_exp_f32 {r}, {r}", "f"), ("v_rcp_f32", "v_rcp_f32 {r}, {r}", "f"), ("v_sqrt_f32", "v_sqrt_f32 {r}, {r}", "f"),
