@@ -86,11 +86,16 @@ __device__ __forceinline__ unsigned long long simple_select_key(const unsigned l
 // track, so the waves of a workgroup -- and of its neighbours on the CU -- walk the SAME frames of B at
 // about the same time and share their scalar-cache misses.
 constexpr int SIMPLE_WPB = 4;
-template <int L>
-#ifndef ACX_SIMPLE_WAVES
-#define ACX_SIMPLE_WAVES 1
+// Waves per SIMD the kernel is compiled for: seven (72 registers) up to the reference's own subsequence length, L = 10 -- 71 registers,
+// nothing spilled: 14.46 -> 13.81 ms per 262 k ordered pairs against the six waves of the compiler's own choice (74 registers); eight
+// spill (21.4 ms), and from L = 12 on the ring (2 L registers) spills at seven.  -DACX_SIMPLE_WAVES=N overrides (A/B builds).
+#ifdef ACX_SIMPLE_WAVES
+constexpr int simple_waves(int) { return ACX_SIMPLE_WAVES; }
+#else
+constexpr int simple_waves(int l) { return l <= 10 ? 7 : 1; }
 #endif
-__global__ __launch_bounds__(64 * SIMPLE_WPB, ACX_SIMPLE_WAVES) void simple_kernel(const double *__restrict__ pool,
+template <int L>
+__global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kernel(const double *__restrict__ pool,
                                                                  const int64_t *__restrict__ toff,
                                                                  const double *__restrict__ prof,
                                                                  const double *__restrict__ wn,
