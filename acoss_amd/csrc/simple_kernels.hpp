@@ -152,16 +152,30 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
         return acc;
     };
 
-    // ---- row 0 in full: top[b] = sum_k <A[k], B'[b + k]>  (lanes over b), kept in E (slots b + ngroups) for group 0
-    for (int b = lane; b < mb; b += 64) {
-        double acc = 0.0;
+    // ---- row 0 in full: top[b] = sum_k <A[k], B'[b + k]>  (lanes over b), kept in E (slots b + ngroups_) as the "row before" of the
+    // first group; row 0's own profile value -- the smallest of its distances -- is taken here and the groups start at row 1 (inside
+    // group 0 the row cost every step of every group a 64-bit select: "row 0 takes the stored value")
+    {
+        unsigned long long k0 = 0xffffffffffffffffull;
+        const double a2_0 = wa[0];
+        for (int b = lane; b < mb; b += 64) {
+            double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < L; ++k) {
-            double ak[12];
-            load_a(k, ak);                                   // wave-uniform address: scalar loads
-            acc += dot12(ak, gb + (size_t)(b + k) * 12);
+            for (int k = 0; k < L; ++k) {
+                double ak[12];
+                load_a(k, ak);                                   // wave-uniform address: scalar loads
+                acc += dot12(ak, gb + (size_t)(b + k) * 12);
+            }
+            E[b + ngroups_] = acc;
+            const unsigned long long kd = f64_key((a2_0 + wb[b]) - 2.0 * acc);
+            k0 = kd < k0 ? kd : k0;
         }
-        E[b + ngroups_] = acc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(k0, o);
+            k0 = other < k0 ? other : k0;
+        }
+        if (lane == 0) mp[0] = k0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -172,10 +186,10 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
     // lanes up (one 64-bit lane permute, consumed L steps later: its latency is free) and keeps the L it has
     // received in a register ring; the leaving frame of B is never loaded again.  The first L lanes of a group
     // have nobody below them: they only feed -- they repeat the last L rows of the previous group (group 0: the
-    // rows -L .. -1 that do not exist; row 0 never uses the recurrence).
+    // rows 1 - L .. 0; the frames they multiply, A[0 .. L - 1], exist).
     constexpr int STRIDE = 64 - L;
     static_assert(L >= 1 && L <= 16, "feeder lanes");
-    const int ngroups = (ma + STRIDE - 1) / STRIDE;
+    const int ngroups = (ma - 1 + STRIDE - 1) / STRIDE;             // rows 1 .. ma - 1 (<= ngroups_, which sizes E)
     const int up_src = ((lane - L) & 63) << 2;                     // ds_bpermute address of the lane L below
     auto shift_up_L = [&](double v) {
         const long long bits = __double_as_longlong(v);
@@ -184,12 +198,12 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
         return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
     };
     for (int g = 0; g < ngroups; ++g) {
-        const int a = STRIDE * g + lane - L;                    // this lane's row (feeders: a row of the group before, or < 0)
+        const int a = STRIDE * g + 1 + lane - L;                // this lane's row (feeders: a row of the group before, or <= 0)
         const bool valid = lane >= L && a < ma;
         const int ac = a < 0 ? 0 : (a > ma - 1 ? ma - 1 : a);   // clamp: results of feeder / idle lanes are dropped
         int fa = a + L - 1;                                     // frame entering the window of row a
         fa = fa < 0 ? 0 : (fa > na - 1 ? na - 1 : fa);
-        const int eoff = ngroups - g;                           // this group reads column c of its predecessor at E[c + eoff]
+        const int eoff = ngroups_ - g;                          // this group reads column c of its predecessor at E[c + eoff]
         const bool more = g + 1 < ngroups;
         double An[12];
         load_a(fa, An);
@@ -204,7 +218,6 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
                 dot += dot12(ak, gb + (size_t)k * 12);
             }
         }
-        if (g == 0 && lane == L) dot = E[eoff];
         double mn = (a2 + wb[0]) - 2.0 * dot;
         if (more && lane == 63) E[eoff - 1] = dot;
         // ring[b % L] = the product leaving at step b.  Steps 1 .. L need the products that "entered" at steps
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
                         const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(bits_ >> 32), 0x138, 0xf, 0xf, true);
                         prev = __longlong_as_double(((long long)hi_ << 32) | (unsigned int)lo_);
                     }
-                    const double e = E[b - 1 + (g == 0 ? 1 : 0) + eoff];   // group 0: row 0's own value top[b]; else dot[a - 1][b - 1] of the last lane
+                    const double e = E[b - 1 + eoff];                      // dot[a - 1][b - 1] of the group before's last lane (group 0: of row 0)
                     double gnew = 0.0;
 #pragma unroll
                     for (int c = 0; c < 12; ++c) gnew = __builtin_fma(An[c], bn[(1 + j) & 1][c], gnew);
@@ -252,9 +265,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
                     const double gold = ring[(1 + j) % L];          // entered the window of row a - L at step b - L
                     ring[(1 + j) % L] = shift_up_L(gnew);           // leaves the window of this row at step b + L
                     if (lane == L) prev = e;
-                    double nd = (prev - gold) + gnew;
-                    if (g == 0 && lane == L) nd = e;
-                    dot = nd;
+                    dot = (prev - gold) + gnew;
                     const double dist = (a2 + w) - 2.0 * dot;
                     // The running minimum as ONE v_min_f64, written as the instruction: `dist < mn ? dist : mn` compiles to v_cmp_lt_f64 vcc +
                     // two v_cndmask_b32 ..., vcc next to each other, and gfx950 takes ~10 cycles for the second of two ADJACENT selects on vcc
