@@ -190,6 +190,10 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
     constexpr int STRIDE = 64 - L;
     static_assert(L >= 1 && L <= 16, "feeder lanes");
     const int ngroups = (ma - 1 + STRIDE - 1) / STRIDE;             // rows 1 .. ma - 1 (<= ngroups_, which sizes E)
+    // The lanes are ROTATED: the group's first row sits in physical lane 0, its feeders in the top L lanes (`vl`, the position in the
+    // group, = lane + L mod 64).  The value a row takes from the row before it -- one lane down, a DPP wave_shr:1 -- has no source in
+    // lane 0, which therefore KEEPS what the destination held: the last row of the group before (E), read into it.  No select.
+    const int vl = (lane + L) & 63;
     const int up_src = ((lane - L) & 63) << 2;                     // ds_bpermute address of the lane L below
     auto shift_up_L = [&](double v) {
         const long long bits = __double_as_longlong(v);
@@ -198,8 +202,8 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
         return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
     };
     for (int g = 0; g < ngroups; ++g) {
-        const int a = STRIDE * g + 1 + lane - L;                // this lane's row (feeders: a row of the group before, or <= 0)
-        const bool valid = lane >= L && a < ma;
+        const int a = STRIDE * g + 1 + vl - L;                  // this lane's row (feeders: a row of the group before, or <= 0)
+        const bool valid = vl >= L && a < ma;
         const int ac = a < 0 ? 0 : (a > ma - 1 ? ma - 1 : a);   // clamp: results of feeder / idle lanes are dropped
         int fa = a + L - 1;                                     // frame entering the window of row a
         fa = fa < 0 ? 0 : (fa > na - 1 ? na - 1 : fa);
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
             }
         }
         double mn = (a2 + wb[0]) - 2.0 * dot;
-        if (more && lane == 63) E[eoff - 1] = dot;
+        if (more && vl == 63) E[eoff - 1] = dot;
         // ring[b % L] = the product leaving at step b.  Steps 1 .. L need the products that "entered" at steps
         // 1 - L .. 0, i.e. with the frames B'[0 .. L - 1]: computed here, before the sweep.
         double ring[L];
@@ -242,17 +246,17 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
                 const int b = b0 + j;                               // b % L == (1 + j) % L, b % 2 == (1 + j) % 2
                 if (b < mb) {                                       // wave-uniform
                     const double w = wb[b];
-                    // dot[a - 1][b - 1] of the neighbour lane: two DPP wave_shr:1 moves (lane 0, a feeder lane whose value is never
-                    // used, reads 0) -- this value is the loop-carried dependency of the sweep; as a 64-bit __shfl_up it was two
-                    // ds_bpermute_b32 round trips per step in that chain
+                    // dot[a - 1][b - 1]: of the neighbour lane by two DPP wave_shr:1 moves; lane 0 -- the group's first row -- keeps the
+                    // destination's old contents, the last row of the group before (E).  This value is the loop-carried dependency of the
+                    // sweep; as a 64-bit __shfl_up it was two ds_bpermute_b32 round trips per step in that chain
+                    const double e = E[b - 1 + eoff];                      // dot[a - 1][b - 1] of the group before's last lane (group 0: of row 0)
                     double prev;
                     {
-                        const long long bits_ = __double_as_longlong(dot);
-                        const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(bits_ & 0xffffffffll), 0x138, 0xf, 0xf, true);
-                        const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(bits_ >> 32), 0x138, 0xf, 0xf, true);
+                        const long long bits_ = __double_as_longlong(dot), ebits_ = __double_as_longlong(e);
+                        const int lo_ = __builtin_amdgcn_update_dpp((int)(ebits_ & 0xffffffffll), (int)(bits_ & 0xffffffffll), 0x138, 0xf, 0xf, false);
+                        const int hi_ = __builtin_amdgcn_update_dpp((int)(ebits_ >> 32), (int)(bits_ >> 32), 0x138, 0xf, 0xf, false);
                         prev = __longlong_as_double(((long long)hi_ << 32) | (unsigned int)lo_);
                     }
-                    const double e = E[b - 1 + eoff];                      // dot[a - 1][b - 1] of the group before's last lane (group 0: of row 0)
                     double gnew = 0.0;
 #pragma unroll
                     for (int c = 0; c < 12; ++c) gnew = __builtin_fma(An[c], bn[(1 + j) & 1][c], gnew);
@@ -264,9 +268,10 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
                     }
                     const double gold = ring[(1 + j) % L];          // entered the window of row a - L at step b - L
                     ring[(1 + j) % L] = shift_up_L(gnew);           // leaves the window of this row at step b + L
-                    if (lane == L) prev = e;
                     dot = (prev - gold) + gnew;
-                    const double dist = (a2 + w) - 2.0 * dot;
+                    // (a2 + w) - 2 dot as ONE fused instruction: 2 dot is exact, so the fma rounds the same exact difference the
+                    // subtraction rounded -- same bits, an instruction less per step
+                    const double dist = __builtin_fma(-2.0, dot, a2 + w);
                     // The running minimum as ONE v_min_f64, written as the instruction: `dist < mn ? dist : mn` compiles to v_cmp_lt_f64 vcc +
                     // two v_cndmask_b32 ..., vcc next to each other, and gfx950 takes ~10 cycles for the second of two ADJACENT selects on vcc
                     // (scripts/ubench/cndmask_probe.hip, profiles/r06_cndmask_probe.txt: 17.5 cycles for the three, 4.2 for a v_min_f64);
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
                     // (Also measured, profiles/r06_simple.md: a second copy of this loop for row group 0, to drop its per-step select from
                     //  the other groups: 82 ms, the ring left the registers.)
                     asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(dist), "v"(mn));
-                    if (more && lane == 63) E[b + eoff - 1] = dot;        // (slot of column b - 1, read above)
+                    if (more && vl == 63) E[b + eoff - 1] = dot;        // (slot of column b - 1, read above)
                 }
             }
         }
