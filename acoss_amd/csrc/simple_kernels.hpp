@@ -240,16 +240,27 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
                 for (int c = 0; c < 12; ++c) bn[(1 + q) & 1][c] = pn[c];
             }
         constexpr int UN = (L % 2 == 0) ? L : 2 * L;            // steps per unrolled round: ring slot and register set are static
+        typedef __attribute__((address_space(3))) double lds_f64;
+        typedef __attribute__((address_space(3))) void lds_void_;
+        double w2[2] = {0.0, 0.0};
+        static_assert(UN % 2 == 0, "window norms in pairs");
         for (int b0 = 1; b0 < mb; b0 += UN) {
+            // E's slots of this round through ONE vector register (the slot of column b0 - 1 + eoff; the steps add immediates): the
+            // address came out of a scalar register into a fresh vector register for every read and every write of every step
+            unsigned rbase = (unsigned)(uintptr_t)(lds_void_ *)(E + (b0 - 1 + eoff));
+            asm volatile("" : "+v"(rbase));
 #pragma unroll
             for (int j = 0; j < UN; ++j) {
                 const int b = b0 + j;                               // b % L == (1 + j) % L, b % 2 == (1 + j) % 2
                 if (b < mb) {                                       // wave-uniform
-                    const double w = wb[b];
+                    // the columns' window norms two at a time (one scalar load and one address per two steps; for L >= 2 the slot behind a
+                    // track's last column lies inside the track's own range of the table)
+                    if (L >= 2 ? j % 2 == 0 : true) { w2[j % 2] = wb[b]; if (L >= 2) w2[1] = wb[b + 1]; }
+                    const double w = w2[j % 2];
                     // dot[a - 1][b - 1]: of the neighbour lane by two DPP wave_shr:1 moves; lane 0 -- the group's first row -- keeps the
                     // destination's old contents, the last row of the group before (E).  This value is the loop-carried dependency of the
                     // sweep; as a 64-bit __shfl_up it was two ds_bpermute_b32 round trips per step in that chain
-                    const double e = E[b - 1 + eoff];                      // dot[a - 1][b - 1] of the group before's last lane (group 0: of row 0)
+                    const double e = *(const lds_f64 *)(rbase + 8u * j);   // E[b - 1 + eoff]: dot[a - 1][b - 1] of the group before's last lane (group 0: of row 0)
                     double prev;
                     {
                         const long long bits_ = __double_as_longlong(dot), ebits_ = __double_as_longlong(e);
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
                     // (Also measured, profiles/r06_simple.md: a second copy of this loop for row group 0, to drop its per-step select from
                     //  the other groups: 82 ms, the ring left the registers.)
                     asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(dist), "v"(mn));
-                    if (more && vl == 63) E[b + eoff - 1] = dot;        // (slot of column b - 1, read above)
+                    if (more && vl == 63) *(lds_f64 *)(rbase + 8u * j) = dot;  // E[b + eoff - 1] (slot of column b - 1, read above)
                 }
             }
         }
