@@ -244,7 +244,10 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
         typedef __attribute__((address_space(3))) void lds_void_;
         double w2[2] = {0.0, 0.0};
         static_assert(UN % 2 == 0, "window norms in pairs");
-        for (int b0 = 1; b0 < mb; b0 += UN) {
+        // A round of UN steps.  FULL: every step of it exists and so does the frame two steps behind its last one -- ONE basic block, no
+        // compare-and-branch per step; the last round(s) of a sweep keep the per-step tests.
+        auto round = [&](int b0, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
             // E's slots of this round through ONE vector register (the slot of column b0 - 1 + eoff; the steps add immediates): the
             // address came out of a scalar register into a fresh vector register for every read and every write of every step
             unsigned rbase = (unsigned)(uintptr_t)(lds_void_ *)(E + (b0 - 1 + eoff));
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
 #pragma unroll
             for (int j = 0; j < UN; ++j) {
                 const int b = b0 + j;                               // b % L == (1 + j) % L, b % 2 == (1 + j) % 2
-                if (b < mb) {                                       // wave-uniform
+                if (FULL || b < mb) {                               // wave-uniform
                     // the columns' window norms two at a time (one scalar load and one address per two steps; for L >= 2 the slot behind a
                     // track's last column lies inside the track's own range of the table)
                     if (L >= 2 ? j % 2 == 0 : true) { w2[j % 2] = wb[b]; if (L >= 2) w2[1] = wb[b + 1]; }
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
 #pragma unroll
                     for (int c = 0; c < 12; ++c) gnew = __builtin_fma(An[c], bn[(1 + j) & 1][c], gnew);
                     asm volatile("" : "+v"(gnew));                  // this register set is dead from here: it takes the frame of step b + 2
-                    if (b + 2 < mb) {
+                    if (FULL || b + 2 < mb) {
                         const double *pn = gb + (size_t)(b + 1 + L) * 12;
 #pragma unroll
                         for (int c = 0; c < 12; ++c) bn[(1 + j) & 1][c] = pn[c];
@@ -294,7 +297,10 @@ __global__ __launch_bounds__(64 * SIMPLE_WPB, simple_waves(L)) void simple_kerne
                     if (more && vl == 63) *(lds_f64 *)(rbase + 8u * j) = dot;  // E[b + eoff - 1] (slot of column b - 1, read above)
                 }
             }
-        }
+        };
+        int b0 = 1;
+        for (; b0 + UN + 1 < mb; b0 += UN) round(b0, std::true_type());
+        for (; b0 < mb; b0 += UN) round(b0, std::false_type());
         if (valid) mp[a] = f64_key(mn);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
