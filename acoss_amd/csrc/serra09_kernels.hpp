@@ -1547,15 +1547,19 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4, ARITH)) vo
     BvT bvbuf[SINGLE_BV ? 1 : 2];
     f32x4 halo[G::NRT][HB];
     if (wave * cpw < ntiles) load_operands(wave * cpw, bvbuf[0], std::integral_constant<int, 0>());
+    // FULL (the wide class, when every one of the wave's NSTEP tiles exists -- all waves of a band at T = 2000): the same steps without
+    // their wave-uniform tests, i.e. ONE basic block for the whole sweep of the wave instead of one per tile
+    auto sweep = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
     static_for<0, NSTEP>([&](auto st_tag) {
         constexpr int st = decltype(st_tag)::value;
         constexpr int tb0 = st == 0 ? 0 : HB;            // first block this step computes
         const int tile = tile_of(st);
-        if (st < cpw && tile < ntiles) {      // wave-uniform
+        if (FULL || (st < cpw && tile < ntiles)) {      // wave-uniform
             float yv[BAND];
             load_norms(tile, yv);
             if constexpr (!SINGLE_BV) {
-                if (st + 1 < NSTEP && st + 1 < cpw && tile + 1 < ntiles)
+                if (st + 1 < NSTEP && (FULL || (st + 1 < cpw && tile + 1 < ntiles)))
                     load_operands(tile + 1, bvbuf[(st + 1) & 1], std::integral_constant<int, HB>());
             }
             if constexpr (st > 0) {
@@ -1570,7 +1574,7 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4, ARITH)) vo
                 AccT acc;
                 gram(bvbuf[SINGLE_BV ? 0 : (st & 1)], acc, std::integral_constant<int, tb0>());
                 if constexpr (SINGLE_BV) {
-                    if (st + 1 < NSTEP && st + 1 < cpw && tile + 1 < ntiles)
+                    if (st + 1 < NSTEP && (FULL || (st + 1 < cpw && tile + 1 < ntiles)))
                         load_operands(tile + 1, bvbuf[0], std::integral_constant<int, HB>());
                 }
                 store_gram(acc, std::integral_constant<int, tb0>());
@@ -1591,6 +1595,11 @@ __global__ __launch_bounds__(BAND_THREADS, band_waves_per_simd(M, V4, ARITH)) vo
             for (int a = 0; a < BAND; ++a) xv[a][st] = PADV;
         }
     });
+    };
+    if constexpr (V4 >= 8 && !WD2) {
+        if (cpw == NSTEP && tile_of(NSTEP - 1) < ntiles) sweep(std::true_type());      // (wave-uniform)
+        else sweep(std::false_type());
+    } else sweep(std::false_type());
     if constexpr (ARITH != 0) {
         // (the row operands outlive every MFMA that reads them: an empty statement that also takes the last tile's cells cannot
         // be scheduled before the last Gram, so no MFMA destination can be allocated over ah8 / ah9)
